@@ -1,0 +1,894 @@
+// glu_hip.hip -- implementation of the C ABI in include/glu_hip.h (gfx950 only, no CPU fallback).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#define GLU_HIP_BUILD 1
+#include "glu_hip.h"
+#include "radix_sort_kernels.hpp"
+#include "scan_reduce_kernels.hpp"
+
+using namespace glu_hip;
+
+// ------------------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------------------
+namespace
+{
+thread_local std::string g_last_error;
+
+glu_status fail(glu_status code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                                  \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        hipError_t e_ = (expr);                                                                                        \
+        if (e_ != hipSuccess)                                                                                          \
+            return fail(e_ == hipErrorOutOfMemory ? GLU_ERROR_OUT_OF_MEMORY : GLU_ERROR_DEVICE, "%s failed: %s", #expr, \
+                        hipGetErrorString(e_));                                                                        \
+    } while (0)
+
+#define GLU_TRY(expr)                                                                                                  \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        glu_status s_ = (expr);                                                                                        \
+        if (s_ != GLU_OK) return s_;                                                                                   \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------------------
+// device / queue state (one device per process)
+// ------------------------------------------------------------------------------------------------------------
+struct Device
+{
+    std::mutex mutex;
+    bool ready = false;
+    int requested = -1;
+    int id = 0;
+    int num_cus = 256;
+    hipStream_t queue = nullptr;
+    hipDeviceProp_t props;
+};
+Device g_dev;
+
+glu_status ensure_device()
+{
+    std::lock_guard<std::mutex> lock(g_dev.mutex);
+    if (g_dev.ready) return GLU_OK;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0)
+        return fail(GLU_ERROR_NO_DEVICE,
+                    "no HIP device visible (%s): libglu_hip has no CPU fallback, an MI355X (gfx950) is required",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+    int id = 0;
+    if (g_dev.requested >= 0)
+        id = g_dev.requested;
+    else
+        HIP_TRY(hipGetDevice(&id));
+    if (id >= count) return fail(GLU_ERROR_INVALID_ARGUMENT, "device %d does not exist (%d visible)", id, count);
+    HIP_TRY(hipSetDevice(id));
+    HIP_TRY(hipGetDeviceProperties(&g_dev.props, id));
+    if (strncmp(g_dev.props.gcnArchName, "gfx950", 6) != 0)
+        return fail(GLU_ERROR_NO_DEVICE, "device %d is %s; libglu_hip is built for gfx950 only", id,
+                    g_dev.props.gcnArchName);
+    g_dev.id = id;
+    g_dev.num_cus = g_dev.props.multiProcessorCount > 0 ? g_dev.props.multiProcessorCount : 256;
+    HIP_TRY(hipStreamCreateWithFlags(&g_dev.queue, hipStreamNonBlocking));
+    g_dev.ready = true;
+    return GLU_OK;
+}
+
+inline hipStream_t pick_stream(void* stream) { return stream ? (hipStream_t) stream : g_dev.queue; }
+
+// ------------------------------------------------------------------------------------------------------------
+// buffers
+// ------------------------------------------------------------------------------------------------------------
+struct Buffer
+{
+    void* ptr = nullptr;
+    size_t size = 0;
+    bool owned = true;
+};
+std::mutex g_buf_mutex;
+std::unordered_map<glu_buffer, Buffer> g_buffers;
+glu_buffer g_next_buffer = 1;
+
+glu_status lookup(glu_buffer h, Buffer& out, const char* what)
+{
+    if (h == 0) return fail(GLU_ERROR_INVALID_ARGUMENT, "Invalid %s", what);
+    std::lock_guard<std::mutex> lock(g_buf_mutex);
+    auto it = g_buffers.find(h);
+    if (it == g_buffers.end()) return fail(GLU_ERROR_INVALID_ARGUMENT, "Invalid %s (unknown handle %u)", what, h);
+    out = it->second;
+    return GLU_OK;
+}
+
+glu_buffer register_buffer(const Buffer& b)
+{
+    std::lock_guard<std::mutex> lock(g_buf_mutex);
+    glu_buffer h = g_next_buffer++;
+    if (g_next_buffer == 0) g_next_buffer = 1;
+    g_buffers[h] = b;
+    return h;
+}
+
+// grow-only device allocation owned by an operator object
+struct Scratch
+{
+    void* ptr = nullptr;
+    size_t size = 0;
+    glu_status reserve(size_t bytes)
+    {
+        if (bytes <= size) return GLU_OK;
+        if (ptr) HIP_TRY(hipFree(ptr));
+        ptr = nullptr;
+        size = 0;
+        HIP_TRY(hipMalloc(&ptr, bytes));
+        size = bytes;
+        if (getenv("GLU_VERBOSE")) fprintf(stderr, "[glu_hip] scratch reallocated to: %zu\n", bytes);
+        return GLU_OK;
+    }
+    void release()
+    {
+        if (ptr) (void) hipFree(ptr);
+        ptr = nullptr;
+        size = 0;
+    }
+};
+} // namespace
+
+// ------------------------------------------------------------------------------------------------------------
+// library / device
+// ------------------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* glu_last_error(void) { return g_last_error.c_str(); }
+const char* glu_version(void) { return "glu_hip 0.1.0 gfx950"; }
+
+glu_status glu_device_count(int* count)
+{
+    if (!count) return fail(GLU_ERROR_INVALID_ARGUMENT, "count is NULL");
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) c = 0;
+    *count = c;
+    return GLU_OK;
+}
+
+glu_status glu_set_device(int device)
+{
+    {
+        std::lock_guard<std::mutex> lock(g_dev.mutex);
+        if (g_dev.ready)
+        {
+            if (device == g_dev.id) return GLU_OK;
+            return fail(GLU_ERROR_INVALID_STATE, "device already initialised to %d (one device per process)", g_dev.id);
+        }
+        g_dev.requested = device;
+    }
+    return ensure_device();
+}
+
+glu_status glu_device_info(char* out, size_t out_size)
+{
+    GLU_TRY(ensure_device());
+    if (!out || out_size == 0) return fail(GLU_ERROR_INVALID_ARGUMENT, "out is NULL");
+    snprintf(out, out_size, "%s (%s), %d CUs, %.1f GiB, device %d", g_dev.props.name, g_dev.props.gcnArchName,
+             g_dev.num_cus, (double) g_dev.props.totalGlobalMem / (1024.0 * 1024.0 * 1024.0), g_dev.id);
+    return GLU_OK;
+}
+
+glu_status glu_device_synchronize(void)
+{
+    GLU_TRY(ensure_device());
+    HIP_TRY(hipStreamSynchronize(g_dev.queue));
+    return GLU_OK;
+}
+
+glu_status glu_queue(void** stream)
+{
+    GLU_TRY(ensure_device());
+    if (!stream) return fail(GLU_ERROR_INVALID_ARGUMENT, "stream is NULL");
+    *stream = (void*) g_dev.queue;
+    return GLU_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// buffers
+// ------------------------------------------------------------------------------------------------------------
+glu_status glu_buffer_create(size_t size, glu_buffer* out)
+{
+    GLU_TRY(ensure_device());
+    if (!out) return fail(GLU_ERROR_INVALID_ARGUMENT, "out is NULL");
+    Buffer b;
+    b.size = size;
+    if (size > 0) HIP_TRY(hipMalloc(&b.ptr, size));
+    *out = register_buffer(b);
+    return GLU_OK;
+}
+
+glu_status glu_buffer_create_with_data(const void* data, size_t size, glu_buffer* out)
+{
+    if (!data) return fail(GLU_ERROR_INVALID_ARGUMENT, "data is NULL");
+    if (size == 0) return fail(GLU_ERROR_INVALID_ARGUMENT, "size is 0");
+    GLU_TRY(glu_buffer_create(size, out));
+    return glu_buffer_write(*out, data, size, 0);
+}
+
+glu_status glu_buffer_wrap(void* device_ptr, size_t size, glu_buffer* out)
+{
+    GLU_TRY(ensure_device());
+    if (!out) return fail(GLU_ERROR_INVALID_ARGUMENT, "out is NULL");
+    if (!device_ptr && size > 0) return fail(GLU_ERROR_INVALID_ARGUMENT, "device_ptr is NULL");
+    Buffer b;
+    b.ptr = device_ptr;
+    b.size = size;
+    b.owned = false;
+    *out = register_buffer(b);
+    return GLU_OK;
+}
+
+glu_status glu_buffer_destroy(glu_buffer buffer)
+{
+    if (buffer == 0) return GLU_OK;
+    Buffer b;
+    {
+        std::lock_guard<std::mutex> lock(g_buf_mutex);
+        auto it = g_buffers.find(buffer);
+        if (it == g_buffers.end()) return fail(GLU_ERROR_INVALID_ARGUMENT, "unknown buffer handle %u", buffer);
+        b = it->second;
+        g_buffers.erase(it);
+    }
+    if (b.owned && b.ptr)
+    {
+        // queued work may still use it: free after the queue drains (hipFree synchronises the device anyway)
+        HIP_TRY(hipStreamSynchronize(g_dev.queue));
+        HIP_TRY(hipFree(b.ptr));
+    }
+    return GLU_OK;
+}
+
+glu_status glu_buffer_size(glu_buffer buffer, size_t* size)
+{
+    Buffer b;
+    GLU_TRY(lookup(buffer, b, "buffer"));
+    if (!size) return fail(GLU_ERROR_INVALID_ARGUMENT, "size is NULL");
+    *size = b.size;
+    return GLU_OK;
+}
+
+glu_status glu_buffer_device_ptr(glu_buffer buffer, void** device_ptr)
+{
+    Buffer b;
+    GLU_TRY(lookup(buffer, b, "buffer"));
+    if (!device_ptr) return fail(GLU_ERROR_INVALID_ARGUMENT, "device_ptr is NULL");
+    *device_ptr = b.ptr;
+    return GLU_OK;
+}
+
+glu_status glu_buffer_write(glu_buffer buffer, const void* data, size_t size, size_t offset)
+{
+    Buffer b;
+    GLU_TRY(lookup(buffer, b, "buffer"));
+    if (size == 0) return GLU_OK;
+    if (!data) return fail(GLU_ERROR_INVALID_ARGUMENT, "data is NULL");
+    if (offset > b.size || size > b.size - offset)
+        return fail(GLU_ERROR_INVALID_ARGUMENT, "write of %zu bytes at %zu exceeds buffer size %zu", size, offset, b.size);
+    // pageable host memory: the copy is staged before the call returns, ordered on the queue
+    HIP_TRY(hipMemcpyAsync((char*) b.ptr + offset, data, size, hipMemcpyHostToDevice, g_dev.queue));
+    HIP_TRY(hipStreamSynchronize(g_dev.queue));
+    return GLU_OK;
+}
+
+glu_status glu_buffer_read(glu_buffer buffer, void* data, size_t size, size_t offset)
+{
+    Buffer b;
+    GLU_TRY(lookup(buffer, b, "buffer"));
+    if (size == 0) return GLU_OK;
+    if (!data) return fail(GLU_ERROR_INVALID_ARGUMENT, "data is NULL");
+    if (offset > b.size || size > b.size - offset)
+        return fail(GLU_ERROR_INVALID_ARGUMENT, "read of %zu bytes at %zu exceeds buffer size %zu", size, offset, b.size);
+    HIP_TRY(hipMemcpyAsync(data, (const char*) b.ptr + offset, size, hipMemcpyDeviceToHost, g_dev.queue));
+    HIP_TRY(hipStreamSynchronize(g_dev.queue));
+    return GLU_OK;
+}
+
+glu_status glu_buffer_fill_u32(glu_buffer buffer, uint32_t value)
+{
+    Buffer b;
+    GLU_TRY(lookup(buffer, b, "buffer"));
+    if (b.size / 4 > 0) HIP_TRY(hipMemsetD32Async((hipDeviceptr_t) b.ptr, (int) value, b.size / 4, g_dev.queue));
+    return GLU_OK;
+}
+
+glu_status glu_buffer_copy(glu_buffer src, glu_buffer dst, size_t size, size_t src_offset, size_t dst_offset)
+{
+    Buffer s, d;
+    GLU_TRY(lookup(src, s, "source buffer"));
+    GLU_TRY(lookup(dst, d, "destination buffer"));
+    if (src_offset > s.size || size > s.size - src_offset || dst_offset > d.size || size > d.size - dst_offset)
+        return fail(GLU_ERROR_INVALID_ARGUMENT, "copy of %zu bytes out of range", size);
+    if (size > 0)
+        HIP_TRY(hipMemcpyAsync((char*) d.ptr + dst_offset, (const char*) s.ptr + src_offset, size,
+                               hipMemcpyDeviceToDevice, g_dev.queue));
+    return GLU_OK;
+}
+
+} // extern "C"
+
+// ------------------------------------------------------------------------------------------------------------
+// radix sort
+// ------------------------------------------------------------------------------------------------------------
+namespace
+{
+constexpr int kSortThreads = 256;
+constexpr int kSortKpt = 16;
+constexpr int kSortTile = kSortThreads * kSortKpt;
+constexpr int kSortBlocksPerCu = 4;
+constexpr int kMaxRadix = 256;
+}
+
+struct glu_radix_sort_s
+{
+    Scratch keys;   // one key scratch array (ping-pong partner of the caller's buffer)
+    Scratch vals;
+    Scratch table;  // [RADIX][num_blocks] digit counts -> scanned offsets, + RADIX digit totals
+    uint32_t digit_bits = 8;
+    uint32_t max_blocks = 0;
+};
+
+namespace
+{
+uint32_t sort_num_blocks(const glu_radix_sort_s* s, size_t count)
+{
+    uint64_t tiles = (count + kSortTile - 1) / kSortTile;
+    uint64_t cap = s->max_blocks ? s->max_blocks : (uint64_t) g_dev.num_cus * kSortBlocksPerCu;
+    return (uint32_t) std::max<uint64_t>(1, std::min<uint64_t>(tiles, cap));
+}
+
+glu_status sort_prepare(glu_radix_sort_s* s, size_t count, size_t key_size)
+{
+    if (count <= 1) return GLU_OK;
+    GLU_TRY(s->keys.reserve(count * key_size));
+    GLU_TRY(s->vals.reserve(count * sizeof(uint32_t)));
+    uint64_t cap = (uint64_t) g_dev.num_cus * kSortBlocksPerCu;
+    GLU_TRY(s->table.reserve((kMaxRadix * cap + kMaxRadix) * sizeof(uint32_t)));
+    return GLU_OK;
+}
+
+template<typename KeyT, int BITS>
+glu_status launch_pass(glu_radix_sort_s* s, const KeyT* src_k, const uint32_t* src_v, KeyT* dst_k, uint32_t* dst_v,
+                       size_t count, uint32_t shift, uint32_t bits, uint32_t* histogram_out, hipStream_t stream)
+{
+    constexpr int RADIX = 1 << BITS;
+    const uint32_t nb = sort_num_blocks(s, count);
+    const uint32_t tiles = (uint32_t) ((count + kSortTile - 1) / kSortTile);
+    const uint32_t mask = (1u << bits) - 1;
+    uint32_t* table = (uint32_t*) s->table.ptr;
+    uint32_t* totals = table + (size_t) RADIX * nb;
+
+    hipLaunchKernelGGL((radix_count_kernel<KeyT, BITS, kSortThreads, kSortTile>), dim3(nb), dim3(kSortThreads), 0,
+                       stream, src_k, table, (uint32_t) count, shift, mask, tiles);
+    hipLaunchKernelGGL((radix_row_scan_kernel<256>), dim3(RADIX), dim3(256), 0, stream, table, totals, nb);
+    if (histogram_out)
+        HIP_TRY(hipMemcpyAsync(histogram_out, totals, ((size_t) 1 << bits) * sizeof(uint32_t), hipMemcpyDeviceToDevice,
+                               stream));
+    using Smem = ScatterSmem<KeyT, BITS, kSortThreads, kSortKpt>;
+    hipLaunchKernelGGL((radix_scatter_kernel<KeyT, BITS, kSortThreads, kSortKpt>), dim3(nb), dim3(kSortThreads),
+                       sizeof(Smem), stream, src_k, src_v, dst_k, dst_v, table, totals, (uint32_t) count, shift, mask,
+                       tiles);
+    HIP_TRY(hipGetLastError());
+    return GLU_OK;
+}
+
+template<typename KeyT>
+glu_status dispatch_pass(glu_radix_sort_s* s, const KeyT* src_k, const uint32_t* src_v, KeyT* dst_k, uint32_t* dst_v,
+                         size_t count, uint32_t shift, uint32_t bits, uint32_t* histogram_out, hipStream_t stream)
+{
+    if (bits <= 4) return launch_pass<KeyT, 4>(s, src_k, src_v, dst_k, dst_v, count, shift, bits, histogram_out, stream);
+    return launch_pass<KeyT, 8>(s, src_k, src_v, dst_k, dst_v, count, shift, bits, histogram_out, stream);
+}
+
+template<typename KeyT>
+glu_status sort_run(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t count, size_t num_steps, hipStream_t stream)
+{
+    constexpr size_t kMaxSteps = sizeof(KeyT) * 2; // 4-bit steps: 8 for 32-bit keys (RadixSort.hpp:289,332)
+    if (count <= 1) return GLU_OK;                  // RadixSort.hpp:278-279
+    if (count > 0xFFFF0000ull) return fail(GLU_ERROR_INVALID_ARGUMENT, "count %zu does not fit 32-bit indexing", count);
+    if (((uintptr_t) keys % 16) != 0 || ((uintptr_t) vals % 16) != 0)
+        return fail(GLU_ERROR_INVALID_ARGUMENT, "key/value arrays must be 16-byte aligned");
+    GLU_TRY(sort_prepare(s, count, sizeof(KeyT))); // RadixSort.hpp:281 (no-op when prepared)
+
+    const size_t steps = (num_steps == 0 || num_steps > kMaxSteps) ? kMaxSteps : num_steps;
+    uint32_t total_bits = (uint32_t) steps * 4;
+
+    KeyT* kbuf[2] = {keys, (KeyT*) s->keys.ptr};
+    uint32_t* vbuf[2] = {vals, (uint32_t*) s->vals.ptr};
+    int cur = 0;
+    uint32_t shift = 0;
+    while (shift < total_bits)
+    {
+        uint32_t bits = std::min<uint32_t>(s->digit_bits, total_bits - shift);
+        GLU_TRY(dispatch_pass<KeyT>(s, kbuf[cur], vbuf[cur], kbuf[cur ^ 1], vbuf[cur ^ 1], count, shift, bits, nullptr,
+                                    stream));
+        cur ^= 1;
+        shift += bits;
+    }
+    if (cur == 1)
+    {
+        // odd number of passes: the reference would leave the result in its private scratch (documented
+        // deviation in glu_hip.h) -- bring it home
+        HIP_TRY(hipMemcpyAsync(keys, kbuf[1], count * sizeof(KeyT), hipMemcpyDeviceToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(vals, vbuf[1], count * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
+    }
+    return GLU_OK;
+}
+} // namespace
+
+extern "C" {
+
+glu_status glu_radix_sort_create(glu_radix_sort* out)
+{
+    GLU_TRY(ensure_device());
+    if (!out) return fail(GLU_ERROR_INVALID_ARGUMENT, "out is NULL");
+    glu_radix_sort_s* s = new glu_radix_sort_s();
+    if (const char* e = getenv("GLU_HIP_DIGIT_BITS"))
+    {
+        int b = atoi(e);
+        if (b == 4 || b == 8) s->digit_bits = (uint32_t) b;
+    }
+    if (const char* e = getenv("GLU_HIP_SORT_BLOCKS"))
+    {
+        int b = atoi(e);
+        if (b > 0 && b <= g_dev.num_cus * kSortBlocksPerCu) s->max_blocks = (uint32_t) b;
+    }
+    *out = s;
+    return GLU_OK;
+}
+
+glu_status glu_radix_sort_destroy(glu_radix_sort sort)
+{
+    if (!sort) return GLU_OK;
+    (void) hipStreamSynchronize(g_dev.queue);
+    sort->keys.release();
+    sort->vals.release();
+    sort->table.release();
+    delete sort;
+    return GLU_OK;
+}
+
+glu_status glu_radix_sort_prepare(glu_radix_sort sort, size_t count)
+{
+    if (!sort) return fail(GLU_ERROR_INVALID_ARGUMENT, "sort is NULL");
+    return sort_prepare(sort, count, sizeof(uint32_t));
+}
+
+glu_status glu_radix_sort_prepare_u64(glu_radix_sort sort, size_t count)
+{
+    if (!sort) return fail(GLU_ERROR_INVALID_ARGUMENT, "sort is NULL");
+    return sort_prepare(sort, count, sizeof(uint64_t));
+}
+
+glu_status glu_radix_sort_run_ptr(glu_radix_sort sort, uint32_t* keys, uint32_t* vals, size_t count, size_t num_steps,
+                                  void* stream)
+{
+    if (!sort) return fail(GLU_ERROR_INVALID_ARGUMENT, "sort is NULL");
+    if (!keys) return fail(GLU_ERROR_INVALID_ARGUMENT, "Invalid key buffer");
+    if (!vals) return fail(GLU_ERROR_INVALID_ARGUMENT, "Invalid value buffer");
+    return sort_run<uint32_t>(sort, keys, vals, count, num_steps, pick_stream(stream));
+}
+
+glu_status glu_radix_sort_run_u64_ptr(glu_radix_sort sort, uint64_t* keys, uint32_t* vals, size_t count,
+                                      size_t num_steps, void* stream)
+{
+    if (!sort) return fail(GLU_ERROR_INVALID_ARGUMENT, "sort is NULL");
+    if (!keys) return fail(GLU_ERROR_INVALID_ARGUMENT, "Invalid key buffer");
+    if (!vals) return fail(GLU_ERROR_INVALID_ARGUMENT, "Invalid value buffer");
+    return sort_run<uint64_t>(sort, keys, vals, count, num_steps, pick_stream(stream));
+}
+
+glu_status glu_radix_sort_run(glu_radix_sort sort, glu_buffer key_buffer, glu_buffer val_buffer, size_t count,
+                              size_t num_steps)
+{
+    if (!sort) return fail(GLU_ERROR_INVALID_ARGUMENT, "sort is NULL");
+    Buffer k, v;
+    GLU_TRY(lookup(key_buffer, k, "key buffer"));   // RadixSort.hpp:275
+    GLU_TRY(lookup(val_buffer, v, "value buffer")); // RadixSort.hpp:276
+    if (count > 1 && (k.size / sizeof(uint32_t) < count || v.size / sizeof(uint32_t) < count))
+        return fail(GLU_ERROR_INVALID_ARGUMENT, "count %zu exceeds the key/value buffer size", count);
+    return sort_run<uint32_t>(sort, (uint32_t*) k.ptr, (uint32_t*) v.ptr, count, num_steps, g_dev.queue);
+}
+
+glu_status glu_radix_sort_run_u64(glu_radix_sort sort, glu_buffer key_buffer, glu_buffer val_buffer, size_t count,
+                                  size_t num_steps)
+{
+    if (!sort) return fail(GLU_ERROR_INVALID_ARGUMENT, "sort is NULL");
+    Buffer k, v;
+    GLU_TRY(lookup(key_buffer, k, "key buffer"));
+    GLU_TRY(lookup(val_buffer, v, "value buffer"));
+    if (count > 1 && (k.size / sizeof(uint64_t) < count || v.size / sizeof(uint32_t) < count))
+        return fail(GLU_ERROR_INVALID_ARGUMENT, "count %zu exceeds the key/value buffer size", count);
+    return sort_run<uint64_t>(sort, (uint64_t*) k.ptr, (uint32_t*) v.ptr, count, num_steps, g_dev.queue);
+}
+
+glu_status glu_radix_sort_partition_ptr(glu_radix_sort sort, const uint32_t* src_keys, const uint32_t* src_vals,
+                                        uint32_t* dst_keys, uint32_t* dst_vals, size_t count, uint32_t shift,
+                                        uint32_t bits, uint32_t* digit_histogram, void* stream)
+{
+    if (!sort) return fail(GLU_ERROR_INVALID_ARGUMENT, "sort is NULL");
+    if (!src_keys || !src_vals || !dst_keys || !dst_vals) return fail(GLU_ERROR_INVALID_ARGUMENT, "NULL array");
+    if (src_keys == dst_keys || src_vals == dst_vals)
+        return fail(GLU_ERROR_INVALID_ARGUMENT, "partition needs distinct source and destination");
+    if (bits < 1 || bits > 8 || shift + bits > 32) return fail(GLU_ERROR_INVALID_ARGUMENT, "bad digit: shift %u bits %u", shift, bits);
+    if (count > 0xFFFF0000ull) return fail(GLU_ERROR_INVALID_ARGUMENT, "count %zu does not fit 32-bit indexing", count);
+    if (((uintptr_t) src_keys % 16) != 0) return fail(GLU_ERROR_INVALID_ARGUMENT, "key array must be 16-byte aligned");
+    hipStream_t st = pick_stream(stream);
+    if (count == 0)
+    {
+        if (digit_histogram) HIP_TRY(hipMemsetAsync(digit_histogram, 0, ((size_t) 1 << bits) * 4, st));
+        return GLU_OK;
+    }
+    // table only (no key/val scratch needed)
+    uint64_t cap = (uint64_t) g_dev.num_cus * kSortBlocksPerCu;
+    GLU_TRY(sort->table.reserve((kMaxRadix * cap + kMaxRadix) * sizeof(uint32_t)));
+    return dispatch_pass<uint32_t>(sort, src_keys, src_vals, dst_keys, dst_vals, count, shift, bits, digit_histogram, st);
+}
+
+glu_status glu_radix_sort_set_digit_bits(glu_radix_sort sort, uint32_t bits)
+{
+    if (!sort) return fail(GLU_ERROR_INVALID_ARGUMENT, "sort is NULL");
+    if (bits != 4 && bits != 8) return fail(GLU_ERROR_INVALID_ARGUMENT, "digit bits must be 4 or 8 (got %u)", bits);
+    sort->digit_bits = bits;
+    return GLU_OK;
+}
+
+glu_status glu_radix_sort_get_digit_bits(glu_radix_sort sort, uint32_t* bits)
+{
+    if (!sort || !bits) return fail(GLU_ERROR_INVALID_ARGUMENT, "NULL argument");
+    *bits = sort->digit_bits;
+    return GLU_OK;
+}
+
+glu_status glu_radix_sort_scratch_size(glu_radix_sort sort, size_t* bytes)
+{
+    if (!sort || !bytes) return fail(GLU_ERROR_INVALID_ARGUMENT, "NULL argument");
+    *bytes = sort->keys.size + sort->vals.size + sort->table.size;
+    return GLU_OK;
+}
+
+} // extern "C"
+
+// ------------------------------------------------------------------------------------------------------------
+// scan / reduce: data-type dispatch
+// ------------------------------------------------------------------------------------------------------------
+namespace
+{
+size_t data_type_size(glu_data_type t)
+{
+    switch (t)
+    {
+    case GLU_DATA_TYPE_FLOAT: case GLU_DATA_TYPE_INT: case GLU_DATA_TYPE_UINT: return 4;
+    case GLU_DATA_TYPE_DOUBLE: case GLU_DATA_TYPE_VEC2: case GLU_DATA_TYPE_UVEC2: case GLU_DATA_TYPE_IVEC2: return 8;
+    case GLU_DATA_TYPE_VEC4: case GLU_DATA_TYPE_UVEC4: case GLU_DATA_TYPE_IVEC4: case GLU_DATA_TYPE_DVEC2: return 16;
+    case GLU_DATA_TYPE_DVEC4: return 32;
+    default: return 0;
+    }
+}
+
+// calls f.template operator()<S, N>() for the scalar type / component count of `t`
+template<typename F>
+glu_status dispatch_type(glu_data_type t, F&& f)
+{
+    switch (t)
+    {
+    case GLU_DATA_TYPE_FLOAT: return f.template operator()<float, 1>();
+    case GLU_DATA_TYPE_DOUBLE: return f.template operator()<double, 1>();
+    case GLU_DATA_TYPE_INT: return f.template operator()<int32_t, 1>();
+    case GLU_DATA_TYPE_UINT: return f.template operator()<uint32_t, 1>();
+    case GLU_DATA_TYPE_VEC2: return f.template operator()<float, 2>();
+    case GLU_DATA_TYPE_VEC4: return f.template operator()<float, 4>();
+    case GLU_DATA_TYPE_DVEC2: return f.template operator()<double, 2>();
+    case GLU_DATA_TYPE_DVEC4: return f.template operator()<double, 4>();
+    case GLU_DATA_TYPE_UVEC2: return f.template operator()<uint32_t, 2>();
+    case GLU_DATA_TYPE_UVEC4: return f.template operator()<uint32_t, 4>();
+    case GLU_DATA_TYPE_IVEC2: return f.template operator()<int32_t, 2>();
+    case GLU_DATA_TYPE_IVEC4: return f.template operator()<int32_t, 4>();
+    default: return fail(GLU_ERROR_INVALID_ARGUMENT, "Invalid data type: %d", (int) t);
+    }
+}
+} // namespace
+
+struct glu_scan_s
+{
+    glu_data_type type;
+    Scratch sums;
+};
+
+struct glu_reduce_s
+{
+    glu_data_type type;
+    glu_reduce_operator op;
+    Scratch partials;
+};
+
+namespace
+{
+constexpr int kReduceMaxBlocks = 2048;
+
+// number of chunk-sum elements over all recursion levels
+template<typename T>
+size_t scan_scratch_elems(size_t count, size_t partitions)
+{
+    size_t total = 0;
+    size_t c = count;
+    while (c > (size_t) ScanCfg<T>::CHUNK)
+    {
+        c = (c + ScanCfg<T>::CHUNK - 1) / ScanCfg<T>::CHUNK;
+        total += c * partitions;
+    }
+    return total;
+}
+
+template<typename S, int N>
+glu_status scan_level(Elem<S, N>* data, size_t count, size_t partitions, Elem<S, N>* scratch, hipStream_t stream)
+{
+    using T = Elem<S, N>;
+    using C = ScanCfg<T>;
+    const size_t chunks = (count + C::CHUNK - 1) / C::CHUNK;
+    if (chunks * partitions > 0x7FFFFFFFull) return fail(GLU_ERROR_INVALID_ARGUMENT, "scan too large");
+    const bool aligned = ((uintptr_t) data % 16 == 0) && (partitions == 1 || (count * sizeof(T)) % 16 == 0);
+    const dim3 grid((uint32_t) (chunks * partitions));
+    if (chunks == 1)
+    {
+        if (aligned)
+            hipLaunchKernelGGL((scan_chunks_kernel<S, N, true>), grid, dim3(C::THREADS), 0, stream, data, (const T*) nullptr, (uint64_t) count, 1u);
+        else
+            hipLaunchKernelGGL((scan_chunks_kernel<S, N, false>), grid, dim3(C::THREADS), 0, stream, data, (const T*) nullptr, (uint64_t) count, 1u);
+        HIP_TRY(hipGetLastError());
+        return GLU_OK;
+    }
+    T* sums = scratch;
+    if (aligned)
+        hipLaunchKernelGGL((scan_chunk_sums_kernel<S, N, true>), grid, dim3(C::THREADS), 0, stream, (const T*) data, sums, (uint64_t) count, (uint32_t) chunks);
+    else
+        hipLaunchKernelGGL((scan_chunk_sums_kernel<S, N, false>), grid, dim3(C::THREADS), 0, stream, (const T*) data, sums, (uint64_t) count, (uint32_t) chunks);
+    GLU_TRY((scan_level<S, N>(sums, chunks, partitions, scratch + chunks * partitions, stream)));
+    if (aligned)
+        hipLaunchKernelGGL((scan_chunks_kernel<S, N, true>), grid, dim3(C::THREADS), 0, stream, data, (const T*) sums, (uint64_t) count, (uint32_t) chunks);
+    else
+        hipLaunchKernelGGL((scan_chunks_kernel<S, N, false>), grid, dim3(C::THREADS), 0, stream, data, (const T*) sums, (uint64_t) count, (uint32_t) chunks);
+    HIP_TRY(hipGetLastError());
+    return GLU_OK;
+}
+
+struct ScanRunner
+{
+    glu_scan_s* scan;
+    void* data;
+    size_t count, partitions;
+    hipStream_t stream;
+    bool size_only;
+    template<typename S, int N>
+    glu_status operator()()
+    {
+        using T = Elem<S, N>;
+        size_t need = scan_scratch_elems<T>(count, partitions) * sizeof(T);
+        if (need) GLU_TRY(scan->sums.reserve(need));
+        if (size_only) return GLU_OK;
+        return scan_level<S, N>((T*) data, count, partitions, (T*) scan->sums.ptr, stream);
+    }
+};
+
+template<int OP, typename S, int N>
+glu_status reduce_launch(glu_reduce_s* r, Elem<S, N>* data, size_t count, hipStream_t stream)
+{
+    using T = Elem<S, N>;
+    const bool aligned = ((uintptr_t) data % 16) == 0;
+    const size_t vec = (aligned && sizeof(T) < 16) ? 16 / sizeof(T) : 1;
+    const size_t packs = count / vec;
+    size_t blocks = std::max<size_t>(1, std::min<size_t>(packs / (256 * 4), (size_t) kReduceMaxBlocks));
+    T* partials = (T*) r->partials.ptr;
+    if (blocks == 1)
+    {
+        if (aligned) hipLaunchKernelGGL((reduce_kernel<OP, S, N, true>), dim3(1), dim3(256), 0, stream, (const T*) data, data, (uint64_t) count);
+        else hipLaunchKernelGGL((reduce_kernel<OP, S, N, false>), dim3(1), dim3(256), 0, stream, (const T*) data, data, (uint64_t) count);
+    }
+    else
+    {
+        if (aligned) hipLaunchKernelGGL((reduce_kernel<OP, S, N, true>), dim3((uint32_t) blocks), dim3(256), 0, stream, (const T*) data, partials, (uint64_t) count);
+        else hipLaunchKernelGGL((reduce_kernel<OP, S, N, false>), dim3((uint32_t) blocks), dim3(256), 0, stream, (const T*) data, partials, (uint64_t) count);
+        hipLaunchKernelGGL((reduce_kernel<OP, S, N, true>), dim3(1), dim3(256), 0, stream, (const T*) partials, data, (uint64_t) blocks);
+    }
+    HIP_TRY(hipGetLastError());
+    return GLU_OK;
+}
+
+struct ReduceRunner
+{
+    glu_reduce_s* red;
+    void* data;
+    size_t count;
+    hipStream_t stream;
+    template<typename S, int N>
+    glu_status operator()()
+    {
+        using T = Elem<S, N>;
+        switch (red->op)
+        {
+        case GLU_REDUCE_SUM: return reduce_launch<OP_SUM, S, N>(red, (T*) data, count, stream);
+        case GLU_REDUCE_MUL: return reduce_launch<OP_MUL, S, N>(red, (T*) data, count, stream);
+        case GLU_REDUCE_MIN: return reduce_launch<OP_MIN, S, N>(red, (T*) data, count, stream);
+        case GLU_REDUCE_MAX: return reduce_launch<OP_MAX, S, N>(red, (T*) data, count, stream);
+        default: return fail(GLU_ERROR_INVALID_ARGUMENT, "Invalid reduction operator: %d", (int) red->op);
+        }
+    }
+};
+} // namespace
+
+extern "C" {
+
+glu_status glu_scan_create(glu_data_type data_type, glu_scan* out)
+{
+    GLU_TRY(ensure_device());
+    if (!out) return fail(GLU_ERROR_INVALID_ARGUMENT, "out is NULL");
+    if ((int) data_type < 0 || data_type >= GLU_DATA_TYPE_COUNT_)
+        return fail(GLU_ERROR_INVALID_ARGUMENT, "Invalid data type: %d", (int) data_type);
+    glu_scan_s* s = new glu_scan_s();
+    s->type = data_type;
+    *out = s;
+    return GLU_OK;
+}
+
+glu_status glu_scan_destroy(glu_scan scan)
+{
+    if (!scan) return GLU_OK;
+    (void) hipStreamSynchronize(g_dev.queue);
+    scan->sums.release();
+    delete scan;
+    return GLU_OK;
+}
+
+glu_status glu_scan_prepare(glu_scan scan, size_t count, size_t num_partitions)
+{
+    if (!scan) return fail(GLU_ERROR_INVALID_ARGUMENT, "scan is NULL");
+    if (count == 0 || num_partitions == 0) return GLU_OK;
+    ScanRunner r{scan, nullptr, count, num_partitions, nullptr, true};
+    return dispatch_type(scan->type, r);
+}
+
+glu_status glu_scan_run_ptr(glu_scan scan, void* data, size_t count, size_t num_partitions, void* stream)
+{
+    if (!scan) return fail(GLU_ERROR_INVALID_ARGUMENT, "scan is NULL");
+    if (!data) return fail(GLU_ERROR_INVALID_ARGUMENT, "Invalid buffer");
+    if (count == 0) return fail(GLU_ERROR_INVALID_ARGUMENT, "Count must be greater than zero");
+    if (num_partitions < 1) return fail(GLU_ERROR_INVALID_ARGUMENT, "Num of partitions must be >= 1");
+    if (((uintptr_t) data % data_type_size(scan->type)) != 0)
+        return fail(GLU_ERROR_INVALID_ARGUMENT, "data is not aligned to its element size");
+    ScanRunner r{scan, data, count, num_partitions, pick_stream(stream), false};
+    return dispatch_type(scan->type, r);
+}
+
+glu_status glu_scan_run(glu_scan scan, glu_buffer buffer, size_t count, size_t num_partitions)
+{
+    if (!scan) return fail(GLU_ERROR_INVALID_ARGUMENT, "scan is NULL");
+    Buffer b;
+    GLU_TRY(lookup(buffer, b, "buffer"));                                                         // BlellochScan.hpp:132
+    if (count == 0) return fail(GLU_ERROR_INVALID_ARGUMENT, "Count must be greater than zero");    // :133
+    if ((count & (count - 1)) != 0) return fail(GLU_ERROR_INVALID_ARGUMENT, "Count must be a power of 2"); // :134
+    if (num_partitions < 1) return fail(GLU_ERROR_INVALID_ARGUMENT, "Num of partitions must be >= 1");      // :135
+    const size_t es = data_type_size(scan->type);
+    if (count > b.size / es / num_partitions)
+        return fail(GLU_ERROR_INVALID_ARGUMENT, "count * num_partitions exceeds the buffer size");
+    return glu_scan_run_ptr(scan, b.ptr, count, num_partitions, nullptr);
+}
+
+glu_status glu_reduce_create(glu_data_type data_type, glu_reduce_operator op, glu_reduce* out)
+{
+    GLU_TRY(ensure_device());
+    if (!out) return fail(GLU_ERROR_INVALID_ARGUMENT, "out is NULL");
+    if ((int) data_type < 0 || data_type >= GLU_DATA_TYPE_COUNT_)
+        return fail(GLU_ERROR_INVALID_ARGUMENT, "Invalid data type: %d", (int) data_type);
+    if ((int) op < 0 || op >= GLU_REDUCE_COUNT_)
+        return fail(GLU_ERROR_INVALID_ARGUMENT, "Invalid reduction operator: %d", (int) op); // Reduce.hpp:94-97
+    glu_reduce_s* r = new glu_reduce_s();
+    r->type = data_type;
+    r->op = op;
+    glu_status st = r->partials.reserve((size_t) kReduceMaxBlocks * 32);
+    if (st != GLU_OK)
+    {
+        delete r;
+        return st;
+    }
+    *out = r;
+    return GLU_OK;
+}
+
+glu_status glu_reduce_destroy(glu_reduce reduce)
+{
+    if (!reduce) return GLU_OK;
+    (void) hipStreamSynchronize(g_dev.queue);
+    reduce->partials.release();
+    delete reduce;
+    return GLU_OK;
+}
+
+glu_status glu_reduce_run_ptr(glu_reduce reduce, void* data, size_t count, void* stream)
+{
+    if (!reduce) return fail(GLU_ERROR_INVALID_ARGUMENT, "reduce is NULL");
+    if (!data) return fail(GLU_ERROR_INVALID_ARGUMENT, "Invalid buffer");
+    if (count == 0) return fail(GLU_ERROR_INVALID_ARGUMENT, "Count must be greater than zero");
+    if (((uintptr_t) data % std::min<size_t>(16, data_type_size(reduce->type))) != 0)
+        return fail(GLU_ERROR_INVALID_ARGUMENT, "data is not aligned to its element size");
+    ReduceRunner r{reduce, data, count, pick_stream(stream)};
+    return dispatch_type(reduce->type, r);
+}
+
+glu_status glu_reduce_run(glu_reduce reduce, glu_buffer buffer, size_t count)
+{
+    if (!reduce) return fail(GLU_ERROR_INVALID_ARGUMENT, "reduce is NULL");
+    Buffer b;
+    GLU_TRY(lookup(buffer, b, "buffer"));                                                      // Reduce.hpp:113
+    if (count == 0) return fail(GLU_ERROR_INVALID_ARGUMENT, "Count must be greater than zero"); // Reduce.hpp:114
+    if (count > b.size / data_type_size(reduce->type))
+        return fail(GLU_ERROR_INVALID_ARGUMENT, "count exceeds the buffer size");
+    return glu_reduce_run_ptr(reduce, b.ptr, count, nullptr);
+}
+
+} // extern "C"
+
+// ------------------------------------------------------------------------------------------------------------
+// timer
+// ------------------------------------------------------------------------------------------------------------
+struct glu_timer_s
+{
+    hipEvent_t start, stop;
+};
+
+extern "C" {
+
+glu_status glu_timer_begin(glu_timer* out)
+{
+    GLU_TRY(ensure_device());
+    if (!out) return fail(GLU_ERROR_INVALID_ARGUMENT, "out is NULL");
+    glu_timer_s* t = new glu_timer_s();
+    if (hipEventCreate(&t->start) != hipSuccess || hipEventCreate(&t->stop) != hipSuccess)
+    {
+        delete t;
+        return fail(GLU_ERROR_DEVICE, "hipEventCreate failed");
+    }
+    HIP_TRY(hipEventRecord(t->start, g_dev.queue));
+    *out = t;
+    return GLU_OK;
+}
+
+glu_status glu_timer_end(glu_timer timer, uint64_t* elapsed_ns)
+{
+    if (!timer) return fail(GLU_ERROR_INVALID_ARGUMENT, "timer is NULL");
+    HIP_TRY(hipEventRecord(timer->stop, g_dev.queue));
+    HIP_TRY(hipEventSynchronize(timer->stop));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, timer->start, timer->stop));
+    if (elapsed_ns) *elapsed_ns = (uint64_t) ((double) ms * 1.0e6);
+    (void) hipEventDestroy(timer->start);
+    (void) hipEventDestroy(timer->stop);
+    delete timer;
+    return GLU_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,352 @@
+// scan_reduce_kernels.hpp -- gfx950 kernels behind glu::BlellochScan and glu::Reduce.
+//
+//   exclusive scan  <- upsweep/downsweep shaders (reference glu/BlellochScan.hpp:13-76): same result
+//                      (in-place exclusive `+` scan of adjacent partitions), computed as
+//                      chunk sums -> scan of the chunk sums (recursive) -> chunk scan with carry-in,
+//                      i.e. 3 launches for 2^28 elements instead of 2*log2(count) dispatches.
+//   reduce          <- reduction shader (reference glu/Reduce.hpp:11-38): data[0] = op over data[0..count),
+//                      wave64 shuffles + LDS, two launches; no subgroup-size-32 assumption.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace glu_hip
+{
+constexpr int kW = 64;
+
+// ---- element types: scalar S or N-component vector of S, std430 strides (4/8/16/32 B) ---------------------
+template<typename S, int N>
+struct alignas((sizeof(S) * N >= 16) ? 16 : sizeof(S) * N) Elem
+{
+    S c[N];
+};
+
+enum OpKind
+{
+    OP_SUM = 0,
+    OP_MUL = 1,
+    OP_MIN = 2,
+    OP_MAX = 3
+};
+
+template<typename S>
+struct ScalarOps
+{
+    using U = S;
+    static __device__ __forceinline__ S sum(S a, S b) { return a + b; }
+    static __device__ __forceinline__ S mul(S a, S b) { return a * b; }
+    static __device__ __forceinline__ S mn(S a, S b) { return a < b ? a : b; }
+    static __device__ __forceinline__ S mx(S a, S b) { return a > b ? a : b; }
+};
+template<>
+struct ScalarOps<int32_t>
+{ // GLSL int arithmetic wraps; do it unsigned to keep C++ well-defined
+    static __device__ __forceinline__ int32_t sum(int32_t a, int32_t b) { return (int32_t) ((uint32_t) a + (uint32_t) b); }
+    static __device__ __forceinline__ int32_t mul(int32_t a, int32_t b) { return (int32_t) ((uint32_t) a * (uint32_t) b); }
+    static __device__ __forceinline__ int32_t mn(int32_t a, int32_t b) { return a < b ? a : b; }
+    static __device__ __forceinline__ int32_t mx(int32_t a, int32_t b) { return a > b ? a : b; }
+};
+
+template<int OP, typename S, int N>
+__device__ __forceinline__ Elem<S, N> combine(const Elem<S, N>& a, const Elem<S, N>& b)
+{
+    Elem<S, N> r;
+#pragma unroll
+    for (int i = 0; i < N; i++)
+    {
+        if (OP == OP_SUM) r.c[i] = ScalarOps<S>::sum(a.c[i], b.c[i]);
+        else if (OP == OP_MUL) r.c[i] = ScalarOps<S>::mul(a.c[i], b.c[i]);
+        else if (OP == OP_MIN) r.c[i] = ScalarOps<S>::mn(a.c[i], b.c[i]);
+        else r.c[i] = ScalarOps<S>::mx(a.c[i], b.c[i]);
+    }
+    return r;
+}
+
+template<typename S, int N>
+__device__ __forceinline__ Elem<S, N> zero_elem()
+{
+    Elem<S, N> r;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.c[i] = (S) 0;
+    return r;
+}
+
+// cross-lane moves of an arbitrary Elem, one dword at a time
+template<typename T>
+__device__ __forceinline__ T shfl_up_t(const T& v, int delta)
+{
+    constexpr int W = sizeof(T) / 4;
+    union { T t; uint32_t w[W]; } in, out;
+    in.t = v;
+#pragma unroll
+    for (int i = 0; i < W; i++) out.w[i] = __shfl_up(in.w[i], delta, kW);
+    return out.t;
+}
+template<typename T>
+__device__ __forceinline__ T shfl_down_t(const T& v, int delta)
+{
+    constexpr int W = sizeof(T) / 4;
+    union { T t; uint32_t w[W]; } in, out;
+    in.t = v;
+#pragma unroll
+    for (int i = 0; i < W; i++) out.w[i] = __shfl_down(in.w[i], delta, kW);
+    return out.t;
+}
+template<typename T>
+__device__ __forceinline__ T shfl_t(const T& v, int src)
+{
+    constexpr int W = sizeof(T) / 4;
+    union { T t; uint32_t w[W]; } in, out;
+    in.t = v;
+#pragma unroll
+    for (int i = 0; i < W; i++) out.w[i] = __shfl(in.w[i], src, kW);
+    return out.t;
+}
+
+// ---- scan -------------------------------------------------------------------------------------------------
+// A chunk = THREADS * GROUPS * VEC elements.  Inside a wave the layout is "group-major, then lane, then the VEC
+// elements of a 16-byte vector", so every load/store instruction of a wave is one contiguous 1 KiB.
+template<typename T>
+struct ScanCfg
+{
+    static constexpr int THREADS = 256;
+    static constexpr int WAVES = THREADS / kW;
+    static constexpr int VEC = sizeof(T) >= 16 ? 1 : 16 / (int) sizeof(T);
+    static constexpr int GROUPS = 4;
+    static constexpr int WAVE_ELEMS = kW * GROUPS * VEC;
+    static constexpr int CHUNK = WAVES * WAVE_ELEMS;
+};
+
+template<typename T, int VEC>
+struct alignas(sizeof(T) * VEC >= 16 ? 16 : sizeof(T) * VEC) Pack
+{
+    T v[VEC];
+};
+
+// Loads the calling wave's elements of one chunk.  `base` points at the chunk start, `valid` = elements of the
+// chunk that exist (the rest read as zero).
+template<typename S, int N, bool ALIGNED>
+__device__ __forceinline__ void scan_load(const Elem<S, N>* base, uint32_t valid, uint32_t wave, uint32_t lane,
+                                          Elem<S, N> (&x)[ScanCfg<Elem<S, N>>::GROUPS][ScanCfg<Elem<S, N>>::VEC])
+{
+    using T = Elem<S, N>;
+    using C = ScanCfg<T>;
+#pragma unroll
+    for (int g = 0; g < C::GROUPS; g++)
+    {
+        const uint32_t e0 = wave * C::WAVE_ELEMS + (g * kW + lane) * C::VEC;
+        if (ALIGNED && e0 + C::VEC <= valid)
+        {
+            Pack<T, C::VEC> p = *reinterpret_cast<const Pack<T, C::VEC>*>(base + e0);
+#pragma unroll
+            for (int k = 0; k < C::VEC; k++) x[g][k] = p.v[k];
+        }
+        else
+        {
+#pragma unroll
+            for (int k = 0; k < C::VEC; k++) x[g][k] = (e0 + k < valid) ? base[e0 + k] : zero_elem<S, N>();
+        }
+    }
+}
+
+// sums[partition * chunks + chunk] = sum of the chunk
+template<typename S, int N, bool ALIGNED>
+__global__ __launch_bounds__(256) void scan_chunk_sums_kernel(const Elem<S, N>* __restrict__ data,
+                                                              Elem<S, N>* __restrict__ sums, uint64_t count,
+                                                              uint32_t chunks)
+{
+    using T = Elem<S, N>;
+    using C = ScanCfg<T>;
+    __shared__ T wsum[C::WAVES];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t chunk = blockIdx.x % chunks, part = blockIdx.x / chunks; // grid = partitions * chunks
+    const uint64_t cbeg = (uint64_t) chunk * C::CHUNK;
+    const uint32_t valid = (count - cbeg) < (uint64_t) C::CHUNK ? (uint32_t) (count - cbeg) : (uint32_t) C::CHUNK;
+    const T* base = data + (uint64_t) part * count + cbeg;
+
+    T x[C::GROUPS][C::VEC];
+    scan_load<S, N, ALIGNED>(base, valid, wave, lane, x);
+    T acc = zero_elem<S, N>();
+#pragma unroll
+    for (int g = 0; g < C::GROUPS; g++)
+#pragma unroll
+        for (int k = 0; k < C::VEC; k++) acc = combine<OP_SUM>(acc, x[g][k]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc = combine<OP_SUM>(acc, shfl_down_t(acc, off));
+    if (lane == 0) wsum[wave] = acc;
+    __syncthreads();
+    if (tid == 0)
+    {
+        T t = wsum[0];
+#pragma unroll
+        for (int w = 1; w < C::WAVES; w++) t = combine<OP_SUM>(t, wsum[w]);
+        sums[(uint64_t) part * chunks + chunk] = t;
+    }
+}
+
+// In-place exclusive scan of every chunk, plus carry[partition * chunks + chunk] when carry != nullptr.
+template<typename S, int N, bool ALIGNED>
+__global__ __launch_bounds__(256) void scan_chunks_kernel(Elem<S, N>* __restrict__ data,
+                                                          const Elem<S, N>* __restrict__ carry, uint64_t count,
+                                                          uint32_t chunks)
+{
+    using T = Elem<S, N>;
+    using C = ScanCfg<T>;
+    __shared__ T wsum[C::WAVES];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t chunk = blockIdx.x % chunks, part = blockIdx.x / chunks; // grid = partitions * chunks
+    const uint64_t cbeg = (uint64_t) chunk * C::CHUNK;
+    const uint32_t valid = (count - cbeg) < (uint64_t) C::CHUNK ? (uint32_t) (count - cbeg) : (uint32_t) C::CHUNK;
+    T* base = data + (uint64_t) part * count + cbeg;
+
+    T x[C::GROUPS][C::VEC];
+    scan_load<S, N, ALIGNED>(base, valid, wave, lane, x);
+
+    // per group: lane-local exclusive over the VEC elements, then a wave scan of the lane sums
+    T gexcl[C::GROUPS]; // exclusive prefix of this lane inside its group
+    T gtot[C::GROUPS];  // group totals (wave-uniform)
+#pragma unroll
+    for (int g = 0; g < C::GROUPS; g++)
+    {
+        T lsum = x[g][0];
+#pragma unroll
+        for (int k = 1; k < C::VEC; k++) lsum = combine<OP_SUM>(lsum, x[g][k]);
+        T incl = lsum;
+#pragma unroll
+        for (int off = 1; off < kW; off <<= 1)
+        {
+            T t = shfl_up_t(incl, off);
+            if (lane >= (uint32_t) off) incl = combine<OP_SUM>(t, incl);
+        }
+        gtot[g] = shfl_t(incl, kW - 1);
+        T up = shfl_up_t(incl, 1);
+        gexcl[g] = lane == 0 ? zero_elem<S, N>() : up;
+    }
+    T wave_total = gtot[0];
+#pragma unroll
+    for (int g = 1; g < C::GROUPS; g++) wave_total = combine<OP_SUM>(wave_total, gtot[g]);
+    if (lane == 0) wsum[wave] = wave_total;
+    __syncthreads();
+
+    T run = carry ? carry[(uint64_t) part * chunks + chunk] : zero_elem<S, N>();
+#pragma unroll
+    for (int w = 0; w < C::WAVES; w++)
+        if ((uint32_t) w < wave) run = combine<OP_SUM>(run, wsum[w]);
+
+#pragma unroll
+    for (int g = 0; g < C::GROUPS; g++)
+    {
+        T acc = combine<OP_SUM>(run, gexcl[g]);
+        Pack<T, C::VEC> p;
+#pragma unroll
+        for (int k = 0; k < C::VEC; k++)
+        {
+            p.v[k] = acc;
+            acc = combine<OP_SUM>(acc, x[g][k]);
+        }
+        const uint32_t e0 = wave * C::WAVE_ELEMS + (g * kW + lane) * C::VEC;
+        if (ALIGNED && e0 + C::VEC <= valid)
+        {
+            *reinterpret_cast<Pack<T, C::VEC>*>(base + e0) = p;
+        }
+        else
+        {
+#pragma unroll
+            for (int k = 0; k < C::VEC; k++)
+                if (e0 + k < valid) base[e0 + k] = p.v[k];
+        }
+        run = combine<OP_SUM>(run, gtot[g]);
+    }
+}
+
+// ---- reduce -----------------------------------------------------------------------------------------------
+template<int OP, typename S, int N>
+__device__ __forceinline__ Elem<S, N> block_reduce(Elem<S, N> acc, bool has, Elem<S, N>* wtmp, uint32_t* whas,
+                                                   uint32_t tid, bool& out_has)
+{
+    // lanes without any element are skipped (no identity element needed for min/max/mul)
+    using T = Elem<S, N>;
+    const uint32_t lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+    {
+        T o = shfl_down_t(acc, off);
+        int oh = __shfl_down((int) has, off, kW);
+        bool other_ok = (lane + off < (uint32_t) kW) && oh;
+        if (other_ok) acc = has ? combine<OP>(acc, o) : o;
+        has = has || other_ok;
+    }
+    if (lane == 0)
+    {
+        wtmp[wave] = acc;
+        whas[wave] = has;
+    }
+    __syncthreads();
+    T r = wtmp[0];
+    bool rh = whas[0];
+    const uint32_t nw = blockDim.x / kW;
+    for (uint32_t w = 1; w < nw; w++)
+    {
+        if (whas[w])
+        {
+            r = rh ? combine<OP>(r, wtmp[w]) : wtmp[w];
+            rh = true;
+        }
+    }
+    out_has = rh;
+    return r;
+}
+
+// out[b] = op over workgroup b's grid-strided share of in[0..count).  Launch with gridDim.x <= max(1, packs / 256)
+// so that every workgroup owns at least one element; with gridDim.x == 1 the result lands in out[0] (out may
+// alias in: every read happens before the single write).
+template<int OP, typename S, int N, bool ALIGNED>
+__global__ __launch_bounds__(256) void reduce_kernel(const Elem<S, N>* __restrict__ in, Elem<S, N>* __restrict__ out,
+                                                     uint64_t count)
+{
+    using T = Elem<S, N>;
+    constexpr int VEC = (ALIGNED && sizeof(T) < 16) ? 16 / (int) sizeof(T) : 1;
+    constexpr int UNROLL = 4;
+    using P = Pack<T, VEC>;
+    __shared__ T wtmp[4];
+    __shared__ uint32_t whas[4];
+    const uint32_t tid = threadIdx.x;
+    T acc = zero_elem<S, N>();
+    bool has = false;
+    auto fold = [&](const T& v) {
+        acc = has ? combine<OP>(acc, v) : v;
+        has = true;
+    };
+
+    const uint64_t npacks = count / VEC;
+    const P* pin = reinterpret_cast<const P*>(in);
+    const uint64_t stride = (uint64_t) gridDim.x * blockDim.x;
+    uint64_t i = (uint64_t) blockIdx.x * blockDim.x + tid;
+    for (; i + (UNROLL - 1) * stride < npacks; i += UNROLL * stride)
+    {
+        P v[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) v[u] = pin[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++)
+#pragma unroll
+            for (int k = 0; k < VEC; k++) fold(v[u].v[k]);
+    }
+    for (; i < npacks; i += stride)
+    {
+        P v = pin[i];
+#pragma unroll
+        for (int k = 0; k < VEC; k++) fold(v.v[k]);
+    }
+    if (VEC > 1 && blockIdx.x == 0)
+    {
+        const uint64_t t = npacks * VEC + tid; // < VEC leftover elements
+        if (t < count) fold(in[t]);
+    }
+    bool rh;
+    T r = block_reduce<OP>(acc, has, wtmp, whas, tid, rh);
+    if (tid == 0 && rh) out[blockIdx.x] = r;
+}
+
+} // namespace glu_hip

@@ -1,0 +1,314 @@
+"""ctypes binding of libglu_hip.so (include/glu_hip.h) -- used by the tests, bench.py and the
+multi-GPU driver.  The C++17 headers in ../glu/ are the drop-in surface for the reference's users; this
+module is the thinnest possible Python view of the same C ABI.
+
+There is no CPU fallback: importing works anywhere (so that symbol/ABI tests run without a GPU), but every
+compute call returns GLU_ERROR_NO_DEVICE without an MI355X and raises GluError.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG_DIR, "lib", "libglu_hip.so")
+
+# glu/data_types.hpp:8-22 and glu/Reduce.hpp:42-48 (same numeric values)
+DataType_Float, DataType_Double, DataType_Int, DataType_Uint, DataType_Vec2, DataType_Vec4, DataType_DVec2, \
+    DataType_DVec4, DataType_UVec2, DataType_UVec4, DataType_IVec2, DataType_IVec4 = range(12)
+ReduceOperator_Sum, ReduceOperator_Mul, ReduceOperator_Min, ReduceOperator_Max = range(4)
+
+GLU_OK = 0
+GLU_ERROR_INVALID_ARGUMENT = 1
+GLU_ERROR_INVALID_STATE = 2
+GLU_ERROR_OUT_OF_MEMORY = 3
+GLU_ERROR_DEVICE = 4
+GLU_ERROR_NO_DEVICE = 5
+
+# every symbol include/glu_hip.h declares: (name, restype, argtypes)
+_u32, _u64, _sz, _int, _vp = ctypes.c_uint32, ctypes.c_uint64, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p
+_P = ctypes.POINTER
+SYMBOLS = [
+    ("glu_last_error", ctypes.c_char_p, []),
+    ("glu_version", ctypes.c_char_p, []),
+    ("glu_device_count", _int, [_P(_int)]),
+    ("glu_set_device", _int, [_int]),
+    ("glu_device_info", _int, [ctypes.c_char_p, _sz]),
+    ("glu_device_synchronize", _int, []),
+    ("glu_queue", _int, [_P(_vp)]),
+    ("glu_buffer_create", _int, [_sz, _P(_u32)]),
+    ("glu_buffer_create_with_data", _int, [_vp, _sz, _P(_u32)]),
+    ("glu_buffer_wrap", _int, [_vp, _sz, _P(_u32)]),
+    ("glu_buffer_destroy", _int, [_u32]),
+    ("glu_buffer_size", _int, [_u32, _P(_sz)]),
+    ("glu_buffer_device_ptr", _int, [_u32, _P(_vp)]),
+    ("glu_buffer_write", _int, [_u32, _vp, _sz, _sz]),
+    ("glu_buffer_read", _int, [_u32, _vp, _sz, _sz]),
+    ("glu_buffer_fill_u32", _int, [_u32, _u32]),
+    ("glu_buffer_copy", _int, [_u32, _u32, _sz, _sz, _sz]),
+    ("glu_radix_sort_create", _int, [_P(_vp)]),
+    ("glu_radix_sort_destroy", _int, [_vp]),
+    ("glu_radix_sort_prepare", _int, [_vp, _sz]),
+    ("glu_radix_sort_prepare_u64", _int, [_vp, _sz]),
+    ("glu_radix_sort_run", _int, [_vp, _u32, _u32, _sz, _sz]),
+    ("glu_radix_sort_run_ptr", _int, [_vp, _vp, _vp, _sz, _sz, _vp]),
+    ("glu_radix_sort_run_u64", _int, [_vp, _u32, _u32, _sz, _sz]),
+    ("glu_radix_sort_run_u64_ptr", _int, [_vp, _vp, _vp, _sz, _sz, _vp]),
+    ("glu_radix_sort_partition_ptr", _int, [_vp, _vp, _vp, _vp, _vp, _sz, _u32, _u32, _vp, _vp]),
+    ("glu_radix_sort_set_digit_bits", _int, [_vp, _u32]),
+    ("glu_radix_sort_get_digit_bits", _int, [_vp, _P(_u32)]),
+    ("glu_radix_sort_scratch_size", _int, [_vp, _P(_sz)]),
+    ("glu_scan_create", _int, [_int, _P(_vp)]),
+    ("glu_scan_destroy", _int, [_vp]),
+    ("glu_scan_prepare", _int, [_vp, _sz, _sz]),
+    ("glu_scan_run", _int, [_vp, _u32, _sz, _sz]),
+    ("glu_scan_run_ptr", _int, [_vp, _vp, _sz, _sz, _vp]),
+    ("glu_reduce_create", _int, [_int, _int, _P(_vp)]),
+    ("glu_reduce_destroy", _int, [_vp]),
+    ("glu_reduce_run", _int, [_vp, _u32, _sz]),
+    ("glu_reduce_run_ptr", _int, [_vp, _vp, _sz, _vp]),
+    ("glu_timer_begin", _int, [_P(_vp)]),
+    ("glu_timer_end", _int, [_vp, _P(_u64)]),
+]
+
+_lib = None
+
+
+class GluError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__("glu_hip status %d: %s" % (status, message))
+        self.status = status
+        self.message = message
+
+
+def lib():
+    """Loads libglu_hip.so (built by __graft_entry__.build() / make -C gl-radix-sort_amd/csrc)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(there is no CPU fallback)" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(status):
+    if status != GLU_OK:
+        raise GluError(status, lib().glu_last_error().decode())
+
+
+def device_count():
+    c = _int(0)
+    check(lib().glu_device_count(ctypes.byref(c)))
+    return c.value
+
+
+def set_device(i):
+    check(lib().glu_set_device(i))
+
+
+def device_info():
+    buf = ctypes.create_string_buffer(256)
+    check(lib().glu_device_info(buf, 256))
+    return buf.value.decode()
+
+
+def synchronize():
+    check(lib().glu_device_synchronize())
+
+
+def queue():
+    s = _vp()
+    check(lib().glu_queue(ctypes.byref(s)))
+    return s.value
+
+
+class ShaderStorageBuffer:
+    """Python mirror of glu::ShaderStorageBuffer (reference glu/gl_utils.hpp:146-246) over the C ABI."""
+
+    def __init__(self, data=None, size=0):
+        self._h = _u32(0)
+        self._size = 0
+        if data is not None:
+            a = np.ascontiguousarray(data)
+            if a.nbytes == 0:
+                raise GluError(GLU_ERROR_INVALID_ARGUMENT, "empty data")
+            check(lib().glu_buffer_create_with_data(a.ctypes.data_as(_vp), a.nbytes, ctypes.byref(self._h)))
+            self._size = a.nbytes
+        elif size > 0:
+            self.resize(size)
+
+    @classmethod
+    def wrap(cls, device_ptr, size):
+        b = cls()
+        check(lib().glu_buffer_wrap(_vp(device_ptr), size, ctypes.byref(b._h)))
+        b._size = size
+        return b
+
+    def handle(self):
+        return self._h.value
+
+    def size(self):
+        return self._size
+
+    def device_ptr(self):
+        p = _vp()
+        check(lib().glu_buffer_device_ptr(self._h, ctypes.byref(p)))
+        return p.value
+
+    def resize(self, size, keep_data=False):
+        if size == self._size:
+            return
+        new = _u32(0)
+        check(lib().glu_buffer_create(size, ctypes.byref(new)))
+        if keep_data and self._h.value:
+            check(lib().glu_buffer_copy(self._h, new, min(self._size, size), 0, 0))
+        if self._h.value:
+            check(lib().glu_buffer_destroy(self._h))
+        self._h, self._size = new, size
+
+    def clear(self, value=0):
+        check(lib().glu_buffer_fill_u32(self._h, value))
+
+    def write_data(self, data):
+        a = np.ascontiguousarray(data)
+        check(lib().glu_buffer_write(self._h, a.ctypes.data_as(_vp), a.nbytes, 0))
+
+    def get_data(self, dtype):
+        dt = np.dtype(dtype)
+        if self._size % dt.itemsize:
+            raise GluError(GLU_ERROR_INVALID_ARGUMENT, "Size %d isn't a multiple of %d" % (self._size, dt.itemsize))
+        out = np.empty(self._size // dt.itemsize, dtype=dt)
+        if self._size:
+            check(lib().glu_buffer_read(self._h, out.ctypes.data_as(_vp), self._size, 0))
+        return out
+
+    def destroy(self):
+        if self._h.value and _lib is not None:
+            _lib.glu_buffer_destroy(self._h)
+        self._h = _u32(0)
+        self._size = 0
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+class RadixSort:
+    """glu::RadixSort (reference glu/RadixSort.hpp:186-354) over the C ABI."""
+
+    def __init__(self, digit_bits=None):
+        self._h = _vp()
+        check(lib().glu_radix_sort_create(ctypes.byref(self._h)))
+        if digit_bits is not None:
+            check(lib().glu_radix_sort_set_digit_bits(self._h, digit_bits))
+
+    @property
+    def digit_bits(self):
+        b = _u32(0)
+        check(lib().glu_radix_sort_get_digit_bits(self._h, ctypes.byref(b)))
+        return b.value
+
+    def prepare_internal_buffers(self, count, key_bytes=4):
+        fn = lib().glu_radix_sort_prepare if key_bytes == 4 else lib().glu_radix_sort_prepare_u64
+        check(fn(self._h, count))
+
+    def scratch_size(self):
+        s = _sz(0)
+        check(lib().glu_radix_sort_scratch_size(self._h, ctypes.byref(s)))
+        return s.value
+
+    def __call__(self, key_buffer, val_buffer, count, num_steps=0, key_bytes=4):
+        kb = key_buffer.handle() if isinstance(key_buffer, ShaderStorageBuffer) else key_buffer
+        vb = val_buffer.handle() if isinstance(val_buffer, ShaderStorageBuffer) else val_buffer
+        fn = lib().glu_radix_sort_run if key_bytes == 4 else lib().glu_radix_sort_run_u64
+        check(fn(self._h, kb, vb, count, num_steps))
+
+    def run_ptr(self, keys_ptr, vals_ptr, count, num_steps=0, stream=None, key_bytes=4):
+        fn = lib().glu_radix_sort_run_ptr if key_bytes == 4 else lib().glu_radix_sort_run_u64_ptr
+        check(fn(self._h, _vp(keys_ptr), _vp(vals_ptr), count, num_steps, _vp(stream)))
+
+    def partition_ptr(self, src_keys, src_vals, dst_keys, dst_vals, count, shift, bits, histogram_ptr=None,
+                      stream=None):
+        check(lib().glu_radix_sort_partition_ptr(self._h, _vp(src_keys), _vp(src_vals), _vp(dst_keys), _vp(dst_vals),
+                                                 count, shift, bits, _vp(histogram_ptr), _vp(stream)))
+
+    def destroy(self):
+        if self._h and _lib is not None:
+            _lib.glu_radix_sort_destroy(self._h)
+        self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+class BlellochScan:
+    """glu::BlellochScan (reference glu/BlellochScan.hpp:80-191) over the C ABI."""
+
+    def __init__(self, data_type):
+        self._h = _vp()
+        check(lib().glu_scan_create(data_type, ctypes.byref(self._h)))
+
+    def __call__(self, buffer, count, num_partitions=1):
+        b = buffer.handle() if isinstance(buffer, ShaderStorageBuffer) else buffer
+        check(lib().glu_scan_run(self._h, b, count, num_partitions))
+
+    def run_ptr(self, data_ptr, count, num_partitions=1, stream=None):
+        check(lib().glu_scan_run_ptr(self._h, _vp(data_ptr), count, num_partitions, _vp(stream)))
+
+    def destroy(self):
+        if self._h and _lib is not None:
+            _lib.glu_scan_destroy(self._h)
+        self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+class Reduce:
+    """glu::Reduce (reference glu/Reduce.hpp:51-136) over the C ABI."""
+
+    def __init__(self, data_type, operator_):
+        self._h = _vp()
+        check(lib().glu_reduce_create(data_type, operator_, ctypes.byref(self._h)))
+
+    def __call__(self, buffer, count):
+        b = buffer.handle() if isinstance(buffer, ShaderStorageBuffer) else buffer
+        check(lib().glu_reduce_run(self._h, b, count))
+
+    def run_ptr(self, data_ptr, count, stream=None):
+        check(lib().glu_reduce_run_ptr(self._h, _vp(data_ptr), count, _vp(stream)))
+
+    def destroy(self):
+        if self._h and _lib is not None:
+            _lib.glu_reduce_destroy(self._h)
+        self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+def measure_elapsed_time(callback):
+    """glu::measure_gl_elapsed_time (reference glu/gl_utils.hpp:249-265): nanoseconds of device time."""
+    t = _vp()
+    check(lib().glu_timer_begin(ctypes.byref(t)))
+    callback()
+    ns = _u64(0)
+    check(lib().glu_timer_end(t, ctypes.byref(ns)))
+    return ns.value

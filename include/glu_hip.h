@@ -1,0 +1,200 @@
+/*
+ * glu_hip.h -- C ABI of libglu_hip.so: MI355X (gfx950) radix sort / exclusive scan / reduce.
+ *
+ * This is the drop-in boundary for the hot path of loryruta/gl-radix-sort (reference @ v2).  The reference
+ * has no FFI layer: its operators are header-only C++ classes (namespace glu) that record OpenGL compute
+ * dispatches against GLuint buffer names.  The functions below are what those classes need from the device
+ * side; the C++17 headers in gl-radix-sort_amd/glu/ re-create the reference's classes on top of them, and any
+ * other host language binds the same symbols (INTEGRATION.md shows the bindings).
+ *
+ * Conventions
+ *   - every function returns glu_status (0 = GLU_OK); nothing here prints or calls exit() -- the
+ *     print-and-exit(1) convention of glu/errors.hpp:8-18 lives in the C++ headers above this ABI;
+ *   - glu_last_error() returns a thread-local message for the last non-zero status;
+ *   - buffers are named by 32-bit handles exactly like GLuint buffer names: 0 is "no buffer"
+ *     (checked the way glu/RadixSort.hpp:275-276 checks it);
+ *   - all handle-based calls enqueue on one in-order queue per process (a HIP stream owned by the
+ *     library, the analogue of the thread's GL command queue) and return without waiting for the GPU,
+ *     like the reference's operator() (glu/RadixSort.hpp:273-334 never blocks).  glu_buffer_read() and
+ *     glu_device_synchronize() wait.  *_ptr entry points take raw device pointers plus a caller stream
+ *     (a hipStream_t passed as void*; NULL = the library queue);
+ *   - no function allocates device memory inside a sort/scan/reduce call once the matching
+ *     *_prepare() has been called with a count at least as large (glu/RadixSort.hpp:237-271:
+ *     grow-only scratch).
+ *   - not thread-safe per handle; distinct handles may be used from distinct threads.
+ */
+#ifndef GLU_HIP_H
+#define GLU_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(GLU_HIP_BUILD)
+#define GLU_API __attribute__((visibility("default")))
+#else
+#define GLU_API
+#endif
+
+typedef int glu_status;
+enum
+{
+    GLU_OK = 0,
+    GLU_ERROR_INVALID_ARGUMENT = 1, /* what GLU_CHECK_ARGUMENT rejects in the reference */
+    GLU_ERROR_INVALID_STATE = 2,    /* what GLU_CHECK_STATE rejects */
+    GLU_ERROR_OUT_OF_MEMORY = 3,
+    GLU_ERROR_DEVICE = 4,           /* a HIP runtime call failed; message has the hipError string */
+    GLU_ERROR_NO_DEVICE = 5         /* no gfx950 GPU visible: there is NO CPU fallback */
+};
+
+/* glu/data_types.hpp:8-22 -- same numeric values */
+typedef enum glu_data_type
+{
+    GLU_DATA_TYPE_FLOAT = 0,
+    GLU_DATA_TYPE_DOUBLE,
+    GLU_DATA_TYPE_INT,
+    GLU_DATA_TYPE_UINT,
+    GLU_DATA_TYPE_VEC2,
+    GLU_DATA_TYPE_VEC4,
+    GLU_DATA_TYPE_DVEC2,
+    GLU_DATA_TYPE_DVEC4,
+    GLU_DATA_TYPE_UVEC2,
+    GLU_DATA_TYPE_UVEC4,
+    GLU_DATA_TYPE_IVEC2,
+    GLU_DATA_TYPE_IVEC4,
+    GLU_DATA_TYPE_COUNT_
+} glu_data_type;
+
+/* glu/Reduce.hpp:42-48 -- same numeric values */
+typedef enum glu_reduce_operator
+{
+    GLU_REDUCE_SUM = 0,
+    GLU_REDUCE_MUL,
+    GLU_REDUCE_MIN,
+    GLU_REDUCE_MAX,
+    GLU_REDUCE_COUNT_
+} glu_reduce_operator;
+
+typedef unsigned int glu_buffer; /* replaces GLuint buffer names (glu/gl_utils.hpp:149) */
+typedef struct glu_radix_sort_s* glu_radix_sort;
+typedef struct glu_scan_s* glu_scan;
+typedef struct glu_reduce_s* glu_reduce;
+typedef struct glu_timer_s* glu_timer;
+
+/* ---- library / device ---------------------------------------------------------------------------- */
+
+/* Thread-local text for the last failing call on this thread ("" if none). */
+GLU_API const char* glu_last_error(void);
+/* "glu_hip <version> gfx950" */
+GLU_API const char* glu_version(void);
+/* Number of visible HIP devices (0 is not an error here). */
+GLU_API glu_status glu_device_count(int* count);
+/* Select the device the library queue lives on (default: the current HIP device, normally 0).  Must be
+ * called before the first buffer / operator is created; one device per process (one process per GPU). */
+GLU_API glu_status glu_set_device(int device);
+/* Human readable device line: name, gcnArchName, CU count, memory. */
+GLU_API glu_status glu_device_info(char* out, size_t out_size);
+/* Block until everything enqueued on the library queue has finished (the glFinish analogue). */
+GLU_API glu_status glu_device_synchronize(void);
+/* The library queue as a hipStream_t (void*), for callers that want to enqueue their own work in order. */
+GLU_API glu_status glu_queue(void** stream);
+
+/* ---- buffers: replaces glu::ShaderStorageBuffer's GL calls (glu/gl_utils.hpp:146-246) ------------- */
+
+/* glCreateBuffers + glBufferStorage(size, NULL)      (gl_utils.hpp:203-205).  size may be 0. */
+GLU_API glu_status glu_buffer_create(size_t size, glu_buffer* out);
+/* glBufferStorage(size, data)                          (gl_utils.hpp:165-167) */
+GLU_API glu_status glu_buffer_create_with_data(const void* data, size_t size, glu_buffer* out);
+/* Name an existing device allocation (e.g. a torch tensor's data_ptr()); not owned, never freed. */
+GLU_API glu_status glu_buffer_wrap(void* device_ptr, size_t size, glu_buffer* out);
+/* glDeleteBuffers                                      (gl_utils.hpp:186-187).  0 is ignored. */
+GLU_API glu_status glu_buffer_destroy(glu_buffer buffer);
+GLU_API glu_status glu_buffer_size(glu_buffer buffer, size_t* size);
+GLU_API glu_status glu_buffer_device_ptr(glu_buffer buffer, void** device_ptr);
+/* glBufferSubData(offset, size, data)                  (gl_utils.hpp:221-227) */
+GLU_API glu_status glu_buffer_write(glu_buffer buffer, const void* data, size_t size, size_t offset);
+/* glGetBufferSubData(offset, size, data); waits        (gl_utils.hpp:229-238) */
+GLU_API glu_status glu_buffer_read(glu_buffer buffer, void* data, size_t size, size_t offset);
+/* glClearBufferData(GL_R32UI, value): whole buffer     (gl_utils.hpp:215-219) */
+GLU_API glu_status glu_buffer_fill_u32(glu_buffer buffer, uint32_t value);
+/* glCopyBufferSubData                                  (gl_utils.hpp:13-22) */
+GLU_API glu_status glu_buffer_copy(glu_buffer src, glu_buffer dst, size_t size, size_t src_offset, size_t dst_offset);
+
+/* ---- radix sort: replaces glu::RadixSort (glu/RadixSort.hpp:186-354) ------------------------------ */
+
+/* RadixSort::RadixSort()                               (RadixSort.hpp:205-233) */
+GLU_API glu_status glu_radix_sort_create(glu_radix_sort* out);
+GLU_API glu_status glu_radix_sort_destroy(glu_radix_sort sort);
+/* RadixSort::prepare_internal_buffers(count)           (RadixSort.hpp:237-271): grow-only scratch for
+ * `count` pairs with 32-bit keys. */
+GLU_API glu_status glu_radix_sort_prepare(glu_radix_sort sort, size_t count);
+/* Same for 64-bit keys (BASELINE.json config 5). */
+GLU_API glu_status glu_radix_sort_prepare_u64(glu_radix_sort sort, size_t count);
+/* RadixSort::operator()(key_buffer, val_buffer, count, num_steps)   (RadixSort.hpp:273-334).
+ * Stable ascending sort of `count` (uint32 key, uint32 val) pairs by the low 4*num_steps key bits
+ * (num_steps == 0 or > 8: all 32 bits).  count <= 1 returns immediately (:278).  count must be < 2^32.
+ * Deliberate deviation: the result is always left in key_buffer / val_buffer; the
+ * reference leaves it in its private scratch buffers when num_steps is odd. */
+GLU_API glu_status glu_radix_sort_run(glu_radix_sort sort, glu_buffer key_buffer, glu_buffer val_buffer, size_t count,
+                                      size_t num_steps);
+/* Raw-pointer form of the same call; `stream` is a hipStream_t or NULL. */
+GLU_API glu_status glu_radix_sort_run_ptr(glu_radix_sort sort, uint32_t* keys, uint32_t* vals, size_t count,
+                                          size_t num_steps, void* stream);
+/* 64-bit keys + 32-bit payload, num_steps 4-bit digits (0 or > 16: all 64 bits). */
+GLU_API glu_status glu_radix_sort_run_u64(glu_radix_sort sort, glu_buffer key_buffer, glu_buffer val_buffer,
+                                          size_t count, size_t num_steps);
+GLU_API glu_status glu_radix_sort_run_u64_ptr(glu_radix_sort sort, uint64_t* keys, uint32_t* vals, size_t count,
+                                              size_t num_steps, void* stream);
+/* One stable counting pass on the digit (key >> shift) & ((1 << bits) - 1), 1 <= bits <= 8, from src to dst
+ * (distinct buffers).  This is the partition step of the multi-GPU sort (top-8-bit buckets).  If
+ * digit_histogram != NULL it receives the 1 << bits digit totals (device memory, uint32). */
+GLU_API glu_status glu_radix_sort_partition_ptr(glu_radix_sort sort, const uint32_t* src_keys, const uint32_t* src_vals,
+                                                uint32_t* dst_keys, uint32_t* dst_vals, size_t count, uint32_t shift,
+                                                uint32_t bits, uint32_t* digit_histogram, void* stream);
+/* Digit width (bits per counting pass) the sort uses internally: 4 (the reference's pass structure: 8 passes
+ * for 32-bit keys) or 8 (4 passes).  The sorted result is identical; see DESIGN.md. */
+GLU_API glu_status glu_radix_sort_set_digit_bits(glu_radix_sort sort, uint32_t bits);
+GLU_API glu_status glu_radix_sort_get_digit_bits(glu_radix_sort sort, uint32_t* bits);
+/* Bytes of scratch currently owned by the sort object (keys + vals + tables). */
+GLU_API glu_status glu_radix_sort_scratch_size(glu_radix_sort sort, size_t* bytes);
+
+/* ---- exclusive scan: replaces glu::BlellochScan (glu/BlellochScan.hpp:80-191) ---------------------- */
+
+/* BlellochScan::BlellochScan(data_type)                (BlellochScan.hpp:91-121) */
+GLU_API glu_status glu_scan_create(glu_data_type data_type, glu_scan* out);
+GLU_API glu_status glu_scan_destroy(glu_scan scan);
+/* Optional: pre-size the internal block-sum scratch for count * num_partitions elements. */
+GLU_API glu_status glu_scan_prepare(glu_scan scan, size_t count, size_t num_partitions);
+/* BlellochScan::operator()(buffer, count, num_partitions)   (BlellochScan.hpp:130-139): in-place exclusive
+ * `+` scan (identity 0) of num_partitions adjacent partitions of `count` elements each.  The reference's
+ * argument checks are kept (:132-135): buffer != 0, count > 0, count a power of two, num_partitions >= 1. */
+GLU_API glu_status glu_scan_run(glu_scan scan, glu_buffer buffer, size_t count, size_t num_partitions);
+/* Raw-pointer form; additionally accepts any count > 0 (no power-of-two requirement). */
+GLU_API glu_status glu_scan_run_ptr(glu_scan scan, void* data, size_t count, size_t num_partitions, void* stream);
+
+/* ---- reduce: replaces glu::Reduce (glu/Reduce.hpp:51-136) ----------------------------------------- */
+
+/* Reduce::Reduce(data_type, operator)                  (Reduce.hpp:62-107) */
+GLU_API glu_status glu_reduce_create(glu_data_type data_type, glu_reduce_operator op, glu_reduce* out);
+GLU_API glu_status glu_reduce_destroy(glu_reduce reduce);
+/* Reduce::operator()(buffer, count)                    (Reduce.hpp:111-135): data[0] = op over data[0..count),
+ * component-wise for vector types.  Elements other than data[0] are left untouched (the reference clobbers
+ * some of them; only data[0] is contract).  Checks kept (:113-114): buffer != 0, count > 0. */
+GLU_API glu_status glu_reduce_run(glu_reduce reduce, glu_buffer buffer, size_t count);
+GLU_API glu_status glu_reduce_run_ptr(glu_reduce reduce, void* data, size_t count, void* stream);
+
+/* ---- timing: replaces glu::measure_gl_elapsed_time (glu/gl_utils.hpp:249-265) ---------------------- */
+
+/* glGenQueries + glBeginQuery(GL_TIME_ELAPSED) on the library queue. */
+GLU_API glu_status glu_timer_begin(glu_timer* out);
+/* glEndQuery + glGetQueryObjectui64v(GL_QUERY_RESULT): waits, returns nanoseconds, frees the timer. */
+GLU_API glu_status glu_timer_end(glu_timer timer, uint64_t* elapsed_ns);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* GLU_HIP_H */
