@@ -1,0 +1,321 @@
+"""bench.py -- Mkeys/s of the hot path (glu::RadixSort::operator(), reference glu/RadixSort.hpp:273-334) on MI355X.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one full sort of one batch of synthetic unsorted input that is already resident in HBM.
+  N = 1   BASELINE.json configs[2]: 2^28 uniform-random uint32 keys + uint32 values (vals = iota), in place in the
+          caller's two arrays, scratch pre-allocated (the reference's benchmark does the same,
+          test/radix_sort_tests.cpp:187).  Every step sorts its own pristine copy of the input, so no restore copy
+          sits inside the timed region.
+  N > 1   BASELINE.json configs[3]: 2^27 pairs per GPU (2^30 at N = 8), rank r holds slice r; top-8-bit bucket
+          partition -> one all-to-all (RCCL over xGMI) -> local sort (gl-radix-sort_amd/glu_hip/dist.py).
+Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (the scatter pass) from HIP-event timings
+taken inside the timed region; `cpu_baseline` is std::sort on the host cores over a bounded sample.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "gl-radix-sort_amd"))
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s)
+KEY_BYTES, VAL_BYTES = 4, 4
+
+
+def parse_args():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=10)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--log2-keys", type=int, default=None, help="pairs per GPU = 2^this (default 28 at N=1, 27 at N>1)")
+    p.add_argument("--digit-bits", type=int, default=None, help="4 or 8 (default: library default)")
+    p.add_argument("--keys", default="uniform", choices=["uniform", "zero"],
+                   help="uniform = headline; zero = the reference README's benchmark input")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-sample-log2", type=int, default=25)
+    p.add_argument("--no-verify", action="store_true")
+    return p.parse_args()
+
+
+def make_input(torch, n, kind, seed, device, index_base=0):
+    """keys: uniform over the full [0, 2^32) (bit 31 set half of the time), vals: global index mod 2^32;
+    both held as int32 bit patterns."""
+    g = torch.Generator(device=device)
+    g.manual_seed(0x5EED + seed)
+    if kind == "zero":
+        keys = torch.zeros(n, dtype=torch.int32, device=device)
+    else:
+        keys = torch.randint(-2**31, 2**31, (n,), dtype=torch.int32, device=device, generator=g)
+    vals = (torch.arange(n, dtype=torch.int64, device=device) + index_base).to(torch.int32)
+    return keys, vals
+
+
+def verify_sorted(torch, keys0, out_k, out_v, vals_are_local_iota):
+    """GPU-side checks: keys ascending as unsigned; (with vals = local iota) out_k[i] == keys0[out_v[i]] and
+    equal keys keep ascending values (stability)."""
+    flipped = out_k ^ (-2**31)  # unsigned order == signed order of key ^ 0x80000000
+    ok = bool((flipped[1:] >= flipped[:-1]).all())
+    if vals_are_local_iota:
+        idx = out_v.to(torch.int64) & 0xFFFFFFFF
+        ok = ok and bool((keys0[idx] == out_k).all())
+        eq = out_k[1:] == out_k[:-1]
+        ok = ok and bool((idx[1:][eq] > idx[:-1][eq]).all())
+    return ok
+
+
+def cpu_baseline(sample_log2):
+    """std::sort of (key, val) structs by key on the host cores (oracle/cpu_sort_baseline.cpp), bounded sample."""
+    import numpy as np
+
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    lib_path = os.path.join(ROOT, "oracle", "libglu_cpu_baseline.so")
+    if not os.path.exists(lib_path):
+        import subprocess
+
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s"])
+    L = ctypes.CDLL(lib_path)
+    L.glu_cpu_sort_pairs.restype = ctypes.c_double
+    L.glu_cpu_sort_pairs.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int]
+    L.glu_cpu_hardware_threads.restype = ctypes.c_uint
+    cores = int(L.glu_cpu_hardware_threads()) or (os.cpu_count() or 1)
+    try:
+        cores = min(cores, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    n = 1 << sample_log2
+    rng = np.random.default_rng(0x5EED)
+    keys = rng.integers(0, 2**32, n, dtype=np.uint32)
+    vals = np.arange(n, dtype=np.uint32)
+    k1, v1 = keys.copy(), vals.copy()
+    t1 = L.glu_cpu_sort_pairs(k1.ctypes.data, v1.ctypes.data, n, 1)
+    kp, vp = keys.copy(), vals.copy()
+    tp = L.glu_cpu_sort_pairs(kp.ctypes.data, vp.ctypes.data, n, cores)
+    assert (k1[1:] >= k1[:-1]).all() and (kp == k1).all()
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except Exception:
+        pass
+    return {
+        "value": round(n / tp / 1e6, 2), "unit": "Mkeys/s", "cores": cores, "kind": "port",
+        "sample": "std::sort (__gnu_parallel::sort on %d threads) of 2^%d uniform uint32 key+val structs by key; "
+                  "same generator family as the GPU workload" % (cores, sample_log2),
+        "single_thread_value": round(n / t1 / 1e6, 2), "cpu_model": model,
+        "reference_published": "53.4 Mkeys/s (RTX 2060 SUPER, all-zero keys, reference README.md:133)",
+    }
+
+
+def load_traffic(workload_key):
+    """HBM bytes per scatter launch from committed rocprofv3 PMC passes (profiles/traffic_*.json), if they were
+    collected for this exact workload; otherwise null."""
+    try:
+        best = None
+        pdir = os.path.join(ROOT, "profiles")
+        for f in sorted(os.listdir(pdir)):
+            if f.startswith("traffic_") and f.endswith(".json"):
+                d = json.load(open(os.path.join(pdir, f)))
+                if d.get("workload_key") == workload_key:
+                    best = d
+        return best
+    except Exception:
+        return None
+
+
+def main():
+    args = parse_args()
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+                         "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: libglu_hip has no CPU fallback")
+
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    import glu_hip as G
+
+    G.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=device)
+
+    log2n = args.log2_keys if args.log2_keys is not None else (28 if world == 1 else 27)
+    n = 1 << log2n
+    K, W = args.steps, args.warmup
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    result = {}
+    if world == 1:
+        sorter = G.RadixSort(digit_bits=args.digit_bits)
+        sorter.prepare_internal_buffers(n)
+        keys0, vals0 = make_input(torch, n, args.keys, 0, device)
+        # one pristine copy per step so that nothing but the sort runs inside the timed region
+        free_bytes = torch.cuda.mem_get_info()[0]
+        copies = K + W
+        restore_in_region = False
+        if copies * n * 8 > free_bytes * 0.8:
+            copies = max(1, int(free_bytes * 0.8) // (n * 8))
+            restore_in_region = True
+        sets = [(keys0.clone(), vals0.clone()) for _ in range(copies)]
+
+        def step(i):
+            k, v = sets[i % copies]
+            if restore_in_region and i >= copies:
+                k.copy_(keys0)
+                v.copy_(vals0)
+            sorter.run_ptr(k.data_ptr(), v.data_ptr(), n, 0, stream)
+
+        for i in range(W):
+            step(i)
+        barrier()
+        sorter.set_profiling(True)
+        t0 = time.perf_counter()
+        for i in range(W, W + K):
+            step(i)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        prof = sorter.read_profile()
+        sorter.set_profiling(False)
+        bits = sorter.digit_bits
+        units = n * K
+        verified = None
+        if not args.no_verify:
+            k, v = sets[(W + K - 1) % copies]
+            verified = verify_sorted(torch, keys0, k, v, True)
+        # roofline of the dominant kernel: the scatter pass reads key+val and writes key+val of every pair
+        passes = max(int(prof["passes"]), 1)
+        scatter_ms = prof["scatter_ms"] / passes
+        alg_bytes = n * 2 * (KEY_BYTES + VAL_BYTES)
+        achieved = alg_bytes / (scatter_ms * 1e-3) / 1e9 if scatter_ms > 0 else 0.0
+        workload_key = "radix_sort_u32_pairs_2^%d_%s_bits%d" % (log2n, args.keys, bits)
+        traffic = load_traffic(workload_key)
+        passes_per_sort = passes // K
+        bytes_per_pair_moved = passes_per_sort * (3 * KEY_BYTES + 2 * VAL_BYTES)
+        result.update({
+            "roofline": {
+                "bound": "hbm", "kernel": "radix_scatter_kernel<u32,%d>" % bits,
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                "traffic": traffic["hbm_bytes_per_launch"] if traffic else None,
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "avg_launch_ms": round(scatter_ms, 4),
+                "launches_timed": passes,
+                "count_kernel_avg_ms": round(prof["count_ms"] / passes, 4),
+                "scan_kernel_avg_ms": round(prof["scan_ms"] / passes, 4),
+            },
+            "whole_sort": {
+                "passes": passes_per_sort, "digit_bits": bits,
+                "bytes_per_pair_moved": bytes_per_pair_moved,
+                "achieved_GBps_own_bytes": round(units * bytes_per_pair_moved / elapsed / 1e9, 1),
+                "frac_of_peak_own_bytes": round(units * bytes_per_pair_moved / elapsed / 1e9 / HBM_PEAK_GBPS, 4),
+                "achieved_GBps_at_160B_per_pair": round(units * 160 / elapsed / 1e9, 1),
+                "frac_of_peak_at_160B_per_pair": round(units * 160 / elapsed / 1e9 / HBM_PEAK_GBPS, 4),
+            },
+            "verified": verified,
+            "restore_copies_in_timed_region": restore_in_region,
+        })
+        workload = "2^%d uint32 key + uint32 val pairs, %s keys, vals=iota, in-place stable LSD radix sort, 1x MI355X" % (
+            log2n, "uniform-random full-range" if args.keys == "uniform" else "all-zero")
+        parallelism = "single"
+    else:
+        from glu_hip import dist as D
+
+        ops = D.HipLocalOps(digit_bits=args.digit_bits)
+        dsort = D.DistributedRadixSort(local_ops=ops)
+        keys0, vals0 = make_input(torch, n, args.keys, rank, device, index_base=rank * n)
+        for i in range(W):
+            dsort.sort(keys0, vals0)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(K):
+            rk, rv, cnt = dsort.sort(keys0, vals0)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        units = n * world * K
+        verified = None
+        if not args.no_verify:
+            flipped = rk ^ (-2**31)
+            ok = bool((flipped[1:] >= flipped[:-1]).all())
+            # rank boundaries: my last key <= next rank's first key; counts add up
+            first = flipped[:1].to(torch.int64) if cnt > 0 else torch.full((1,), 2**40, device=device)
+            last = flipped[-1:].to(torch.int64) if cnt > 0 else torch.full((1,), -2**40, device=device)
+            edges = torch.stack([first, last]).reshape(1, 2)
+            gathered = [torch.zeros_like(edges) for _ in range(world)]
+            dist.all_gather(gathered, edges)
+            total = torch.tensor([cnt], dtype=torch.int64, device=device)
+            dist.all_reduce(total)
+            if rank == 0:
+                prev_last = None
+                for e in gathered:
+                    f, l = int(e[0, 0]), int(e[0, 1])
+                    if f > l:
+                        continue  # empty shard
+                    if prev_last is not None and f < prev_last:
+                        ok = False
+                    prev_last = l
+            ok = ok and int(total.item()) == n * world
+            flag = torch.tensor([1 if ok else 0], device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            verified = bool(flag.item())
+        result["verified"] = verified
+        result["shard_pairs_rank0"] = int(cnt)
+        workload = ("2^%d uint32 key+val pairs per GPU (%d GPUs, 2^%.2f total), uniform-random keys; top-8-bit bucket "
+                    "partition + one RCCL all-to-all over xGMI + local sort") % (log2n, world, log2n + __import__("math").log2(world))
+        parallelism = "bucket-sharded x%d (1 all-to-all)" % world
+
+    # max over ranks
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        line = {
+            "metric": "Mkeys/s sorting 2^28 uint32 key+val; % HBM roofline; 1/2/4/8 GPU",
+            "value": round(units / elapsed / 1e6, 1),
+            "unit": "Mkeys/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": round(elapsed / K * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic",
+            "config": {"workload": workload, "pairs_per_gpu": n, "key_distribution": args.keys,
+                       "parallelism": parallelism, "device": G.device_info()},
+        }
+        line.update(result)
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_sample_log2)
+        print(json.dumps(line), flush=True)
+
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -351,6 +351,25 @@ struct glu_radix_sort_s
     Scratch table;  // [RADIX][num_blocks] digit counts -> scanned offsets, + RADIX digit totals
     uint32_t digit_bits = 8;
     uint32_t max_blocks = 0;
+    // optional per-kernel timing: 4 events per pass (before count, after count, after scan, after scatter)
+    bool profiling = false;
+    std::vector<hipEvent_t> events;
+    size_t events_used = 0;
+    hipEvent_t next_event()
+    {
+        if (events_used == events.size())
+        {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return nullptr;
+            events.push_back(e);
+        }
+        return events[events_used++];
+    }
+    void mark(hipStream_t stream)
+    {
+        if (!profiling) return;
+        if (hipEvent_t e = next_event()) (void) hipEventRecord(e, stream);
+    }
 };
 
 namespace
@@ -383,9 +402,12 @@ glu_status launch_pass(glu_radix_sort_s* s, const KeyT* src_k, const uint32_t* s
     uint32_t* table = (uint32_t*) s->table.ptr;
     uint32_t* totals = table + (size_t) RADIX * nb;
 
+    s->mark(stream);
     hipLaunchKernelGGL((radix_count_kernel<KeyT, BITS, kSortThreads, kSortTile>), dim3(nb), dim3(kSortThreads), 0,
                        stream, src_k, table, (uint32_t) count, shift, mask, tiles);
+    s->mark(stream);
     hipLaunchKernelGGL((radix_row_scan_kernel<256>), dim3(RADIX), dim3(256), 0, stream, table, totals, nb);
+    s->mark(stream);
     if (histogram_out)
         HIP_TRY(hipMemcpyAsync(histogram_out, totals, ((size_t) 1 << bits) * sizeof(uint32_t), hipMemcpyDeviceToDevice,
                                stream));
@@ -393,6 +415,7 @@ glu_status launch_pass(glu_radix_sort_s* s, const KeyT* src_k, const uint32_t* s
     hipLaunchKernelGGL((radix_scatter_kernel<KeyT, BITS, kSortThreads, kSortKpt>), dim3(nb), dim3(kSortThreads),
                        sizeof(Smem), stream, src_k, src_v, dst_k, dst_v, table, totals, (uint32_t) count, shift, mask,
                        tiles);
+    s->mark(stream);
     HIP_TRY(hipGetLastError());
     return GLU_OK;
 }
@@ -469,6 +492,7 @@ glu_status glu_radix_sort_destroy(glu_radix_sort sort)
     sort->keys.release();
     sort->vals.release();
     sort->table.release();
+    for (hipEvent_t e : sort->events) (void) hipEventDestroy(e);
     delete sort;
     return GLU_OK;
 }
@@ -562,6 +586,36 @@ glu_status glu_radix_sort_get_digit_bits(glu_radix_sort sort, uint32_t* bits)
 {
     if (!sort || !bits) return fail(GLU_ERROR_INVALID_ARGUMENT, "NULL argument");
     *bits = sort->digit_bits;
+    return GLU_OK;
+}
+
+glu_status glu_radix_sort_set_profiling(glu_radix_sort sort, int enable)
+{
+    if (!sort) return fail(GLU_ERROR_INVALID_ARGUMENT, "sort is NULL");
+    sort->profiling = enable != 0;
+    if (!enable) sort->events_used = 0;
+    return GLU_OK;
+}
+
+glu_status glu_radix_sort_read_profile(glu_radix_sort sort, double* count_ms, double* scan_ms, double* scatter_ms,
+                                       uint64_t* passes)
+{
+    if (!sort) return fail(GLU_ERROR_INVALID_ARGUMENT, "sort is NULL");
+    double acc[3] = {0, 0, 0};
+    const size_t n = sort->events_used / 4;
+    if (n > 0) HIP_TRY(hipEventSynchronize(sort->events[n * 4 - 1]));
+    for (size_t p = 0; p < n; p++)
+        for (int k = 0; k < 3; k++)
+        {
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, sort->events[p * 4 + k], sort->events[p * 4 + k + 1]));
+            acc[k] += ms;
+        }
+    sort->events_used = 0;
+    if (count_ms) *count_ms = acc[0];
+    if (scan_ms) *scan_ms = acc[1];
+    if (scatter_ms) *scatter_ms = acc[2];
+    if (passes) *passes = n;
     return GLU_OK;
 }
 

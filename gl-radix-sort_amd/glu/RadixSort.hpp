@@ -1,0 +1,71 @@
+// glu/RadixSort.hpp -- glu::RadixSort on MI355X (drop-in for reference glu/RadixSort.hpp:186-354).
+#ifndef GLU_RADIXSORT_HPP
+#define GLU_RADIXSORT_HPP
+
+#include <cstdint>
+
+#include "BlellochScan.hpp"
+#include "hip_utils.hpp"
+
+namespace glu
+{
+    /// Stable LSD radix sort of (uint32 key, uint32 value) pairs, ascending by key, in place in the caller's
+    /// two buffers.  `radix_sort(keys, vals, count)` only enqueues GPU work (reference semantics); reading a
+    /// buffer back waits for it.
+    class RadixSort
+    {
+    public:
+        explicit RadixSort() { GLU_CHECK_STATUS(glu_radix_sort_create(&m_impl)); }
+
+        RadixSort(const RadixSort&) = delete;
+        RadixSort& operator=(const RadixSort&) = delete;
+
+        ~RadixSort() { glu_radix_sort_destroy(m_impl); }
+
+        /// Allocates (grow-only) the internal scratch for `count` pairs, so that a following sort of at most
+        /// `count` pairs allocates nothing.
+        void prepare_internal_buffers(size_t count) { GLU_CHECK_STATUS(glu_radix_sort_prepare(m_impl, count)); }
+
+        /// @param num_steps number of 4-bit digits to sort by, starting from the least significant;
+        ///        0 (default) or more than 8 = all 32 bits.
+        /// Unlike the reference, the result is in key_buffer / val_buffer for every num_steps (the reference
+        /// leaves it in a private scratch buffer when num_steps is odd).
+        void operator()(GLuint key_buffer, GLuint val_buffer, size_t count, size_t num_steps = 0)
+        {
+            GLU_CHECK_ARGUMENT(key_buffer, "Invalid key buffer");
+            GLU_CHECK_ARGUMENT(val_buffer, "Invalid value buffer");
+            if (count <= 1) return;
+            GLU_CHECK_STATUS(glu_radix_sort_run(m_impl, key_buffer, val_buffer, count, num_steps));
+        }
+
+        /// Native form: raw device pointers + hipStream_t (nullptr = the library queue).
+        void operator()(uint32_t* device_keys, uint32_t* device_vals, size_t count, size_t num_steps, void* stream)
+        {
+            GLU_CHECK_STATUS(glu_radix_sort_run_ptr(m_impl, device_keys, device_vals, count, num_steps, stream));
+        }
+
+        /// 64-bit keys with 32-bit values (not in the reference); num_steps counts 4-bit digits, 0 = all 64 bits.
+        void sort_u64(GLuint key_buffer, GLuint val_buffer, size_t count, size_t num_steps = 0)
+        {
+            GLU_CHECK_ARGUMENT(key_buffer, "Invalid key buffer");
+            GLU_CHECK_ARGUMENT(val_buffer, "Invalid value buffer");
+            if (count <= 1) return;
+            GLU_CHECK_STATUS(glu_radix_sort_run_u64(m_impl, key_buffer, val_buffer, count, num_steps));
+        }
+        void prepare_internal_buffers_u64(size_t count) { GLU_CHECK_STATUS(glu_radix_sort_prepare_u64(m_impl, count)); }
+
+        /// Bits per counting pass: 4 = the reference's pass structure (8 passes), 8 = 4 passes; same output.
+        void set_digit_bits(uint32_t bits) { GLU_CHECK_STATUS(glu_radix_sort_set_digit_bits(m_impl, bits)); }
+        [[nodiscard]] uint32_t digit_bits() const
+        {
+            uint32_t bits = 0;
+            GLU_CHECK_STATUS(glu_radix_sort_get_digit_bits(m_impl, &bits));
+            return bits;
+        }
+
+    private:
+        glu_radix_sort m_impl = nullptr;
+    };
+} // namespace glu
+
+#endif // GLU_RADIXSORT_HPP

@@ -58,6 +58,8 @@ SYMBOLS = [
     ("glu_radix_sort_set_digit_bits", _int, [_vp, _u32]),
     ("glu_radix_sort_get_digit_bits", _int, [_vp, _P(_u32)]),
     ("glu_radix_sort_scratch_size", _int, [_vp, _P(_sz)]),
+    ("glu_radix_sort_set_profiling", _int, [_vp, _int]),
+    ("glu_radix_sort_read_profile", _int, [_vp, _P(ctypes.c_double), _P(ctypes.c_double), _P(ctypes.c_double), _P(_u64)]),
     ("glu_scan_create", _int, [_int, _P(_vp)]),
     ("glu_scan_destroy", _int, [_vp]),
     ("glu_scan_prepare", _int, [_vp, _sz, _sz]),
@@ -224,6 +226,17 @@ class RadixSort:
         s = _sz(0)
         check(lib().glu_radix_sort_scratch_size(self._h, ctypes.byref(s)))
         return s.value
+
+    def set_profiling(self, enable):
+        check(lib().glu_radix_sort_set_profiling(self._h, 1 if enable else 0))
+
+    def read_profile(self):
+        """{count_ms, scan_ms, scatter_ms, passes}: summed device time per kernel class since the last read."""
+        c, s, x = ctypes.c_double(0), ctypes.c_double(0), ctypes.c_double(0)
+        n = _u64(0)
+        check(lib().glu_radix_sort_read_profile(self._h, ctypes.byref(c), ctypes.byref(s), ctypes.byref(x),
+                                                ctypes.byref(n)))
+        return {"count_ms": c.value, "scan_ms": s.value, "scatter_ms": x.value, "passes": n.value}
 
     def __call__(self, key_buffer, val_buffer, count, num_steps=0, key_bytes=4):
         kb = key_buffer.handle() if isinstance(key_buffer, ShaderStorageBuffer) else key_buffer

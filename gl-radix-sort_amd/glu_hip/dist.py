@@ -1,0 +1,189 @@
+"""Multi-GPU radix sort: one process per GPU, one all-to-all over xGMI on the top key bits, then local sorts.
+
+The reference (loryruta/gl-radix-sort) is single-device; this is the sharded form BASELINE.json config 4 asks
+for.  Rank r holds slice r of the global array.  Steps:
+
+  1. each rank: stable partition of its slice by the top-8-bit bucket (one counting pass of the local sort
+     kernels, glu_radix_sort_partition_ptr) + the 256-bin bucket histogram;
+  2. all-gather of the R x 256 histogram -> every rank derives the same contiguous bucket -> rank assignment;
+  3. one all-to-all of keys and one of values (RCCL: all_to_all_single with split sizes), receive segments
+     ordered by source rank;
+  4. each rank: full local stable sort of what it received.
+
+The concatenation of the rank outputs in rank order equals the single-device stable sort: a bucket is never
+split across ranks, equal keys share a bucket, the local partition and the local sort are stable and receive
+segments keep (source rank, source index) order.
+
+The planning functions are pure numpy so the rank logic is testable on CPU with simulated ranks; the device
+work goes through `local_ops` (HipLocalOps: libglu_hip.so on torch device memory; there is no CPU version in
+the product -- the CPU tests inject an oracle-backed stand-in).
+"""
+import numpy as np
+
+TOP_BITS = 8
+NUM_BUCKETS = 1 << TOP_BITS
+
+
+def plan_bucket_to_rank(bucket_totals, world_size):
+    """Contiguous, monotone bucket -> rank map balancing the element counts.
+
+    bucket_totals: [NUM_BUCKETS] global counts.  Rank r gets buckets [cut[r], cut[r+1]) where cut[r] is the
+    bucket boundary whose prefix count is nearest to r * N / R.  A bucket is never split (a single hot bucket
+    bounds the balance).  Returns int64 array [NUM_BUCKETS] of rank ids.
+    """
+    totals = np.asarray(bucket_totals, dtype=np.int64)
+    assert totals.shape == (NUM_BUCKETS,)
+    n = int(totals.sum())
+    prefix = np.concatenate([[0], np.cumsum(totals)])  # prefix[b] = elements in buckets < b
+    cuts = [0]
+    for r in range(1, world_size):
+        target = (n * r) // world_size
+        b = int(np.searchsorted(prefix, target, side="left"))
+        # choose the nearer boundary of b-1 / b
+        if b > 0 and abs(int(prefix[b - 1]) - target) <= abs(int(prefix[min(b, NUM_BUCKETS)]) - target):
+            b -= 1
+        b = max(b, cuts[-1])
+        cuts.append(min(b, NUM_BUCKETS))
+    cuts.append(NUM_BUCKETS)
+    out = np.empty(NUM_BUCKETS, dtype=np.int64)
+    for r in range(world_size):
+        out[cuts[r]:cuts[r + 1]] = r
+    return out
+
+
+def split_counts(all_hist, bucket_to_rank, rank):
+    """all_hist: [R, NUM_BUCKETS] per-rank bucket histograms.  Returns (send_counts[R], recv_counts[R]) for
+    `rank`: send_counts[d] = my elements whose bucket belongs to rank d; recv_counts[s] = rank s's elements
+    whose bucket belongs to me."""
+    all_hist = np.asarray(all_hist, dtype=np.int64)
+    world = all_hist.shape[0]
+    owner = np.asarray(bucket_to_rank)
+    send = np.array([int(all_hist[rank][owner == d].sum()) for d in range(world)], dtype=np.int64)
+    recv = np.array([int(all_hist[s][owner == rank].sum()) for s in range(world)], dtype=np.int64)
+    return send, recv
+
+
+class HipLocalOps:
+    """Device work of one rank on torch tensors (int32 views of the uint32 data) through libglu_hip.so."""
+
+    def __init__(self, digit_bits=None):
+        import torch
+        from . import RadixSort
+
+        if not torch.cuda.is_available():
+            raise RuntimeError("HipLocalOps needs an MI355X: there is no CPU fallback")
+        self.torch = torch
+        self.sorter = RadixSort(digit_bits=digit_bits)
+
+    def _stream(self):
+        return self.torch.cuda.current_stream().cuda_stream
+
+    def prepare(self, count):
+        self.sorter.prepare_internal_buffers(count)
+
+    def partition(self, keys, vals, out_keys, out_vals, hist):
+        """Stable partition by (key >> 24); hist: int32[256] device tensor."""
+        n = keys.numel()
+        self.sorter.partition_ptr(keys.data_ptr(), vals.data_ptr(), out_keys.data_ptr(), out_vals.data_ptr(), n,
+                                  32 - TOP_BITS, TOP_BITS, hist.data_ptr(), self._stream())
+
+    def sort(self, keys, vals, count):
+        self.sorter.run_ptr(keys.data_ptr(), vals.data_ptr(), count, 0, self._stream())
+
+
+class DistributedRadixSort:
+    """sort(keys, vals) -> (sorted_keys, sorted_vals, count): this rank's shard of the globally sorted array
+    (shard sizes vary with the data).  keys / vals: 1-D int32 torch tensors holding uint32 bit patterns."""
+
+    def __init__(self, group=None, local_ops=None, capacity_factor=1.25):
+        import torch
+        import torch.distributed as dist
+
+        self.torch, self.dist, self.group = torch, dist, group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.ops = local_ops if local_ops is not None else HipLocalOps()
+        self.capacity_factor = capacity_factor
+        self._bufs = None
+        self.last_plan = None
+
+    def _buffers(self, n_local, device, need_recv=0):
+        cap = max(int(n_local * self.capacity_factor) + 4096, need_recv)
+        b = self._bufs
+        if b is None or b["n_local"] < n_local or b["cap"] < cap or b["device"] != device:
+            t = self.torch
+            b = {
+                "n_local": n_local, "cap": cap, "device": device,
+                "part_k": t.empty(max(n_local, 1), dtype=t.int32, device=device),
+                "part_v": t.empty(max(n_local, 1), dtype=t.int32, device=device),
+                "recv_k": t.empty(cap, dtype=t.int32, device=device),
+                "recv_v": t.empty(cap, dtype=t.int32, device=device),
+                "hist": t.zeros(NUM_BUCKETS, dtype=t.int32, device=device),
+                "all_hist": t.zeros(self.world * NUM_BUCKETS, dtype=t.int32, device=device),
+            }
+            self._bufs = b
+            if hasattr(self.ops, "prepare"):
+                self.ops.prepare(cap)
+        return b
+
+    def _all_to_all(self, out, inp, recv_counts, send_counts):
+        dist = self.dist
+        backend = dist.get_backend(self.group)
+        if backend == "gloo":
+            # gloo has no all_to_all_single: same exchange as pairwise send/recv (CPU tests only)
+            reqs = []
+            so = np.concatenate([[0], np.cumsum(send_counts)])
+            ro = np.concatenate([[0], np.cumsum(recv_counts)])
+            for peer in range(self.world):
+                if peer == self.rank:
+                    out[ro[peer]:ro[peer + 1]].copy_(inp[so[peer]:so[peer + 1]])
+                    continue
+                if send_counts[peer]:
+                    reqs.append(dist.isend(inp[so[peer]:so[peer + 1]].contiguous(), peer, group=self.group))
+                if recv_counts[peer]:
+                    reqs.append(dist.irecv(out[ro[peer]:ro[peer + 1]], peer, group=self.group))
+            for r in reqs:
+                r.wait()
+        else:
+            dist.all_to_all_single(out, inp, [int(c) for c in recv_counts], [int(c) for c in send_counts],
+                                   group=self.group)
+
+    def sort(self, keys, vals):
+        t, dist = self.torch, self.dist
+        n_local = keys.numel()
+        b = self._buffers(n_local, keys.device)
+
+        # 1. local stable partition by top-8-bit bucket + histogram
+        self.ops.partition(keys, vals, b["part_k"], b["part_v"], b["hist"])
+
+        # 2. everyone learns every rank's histogram (R x 256 int32: latency-bound, tiny)
+        dist.all_gather_into_tensor(b["all_hist"], b["hist"], group=self.group)
+        all_hist = b["all_hist"].cpu().numpy().reshape(self.world, NUM_BUCKETS).astype(np.int64)
+
+        # 3. identical plan on every rank
+        owner = plan_bucket_to_rank(all_hist.sum(axis=0), self.world)
+        send_counts, recv_counts = split_counts(all_hist, owner, self.rank)
+        n_recv = int(recv_counts.sum())
+        if n_recv > b["cap"]:
+            b = self._grow_recv(b, n_recv)
+        self.last_plan = {"owner": owner, "send": send_counts, "recv": recv_counts}
+
+        # 4. one exchange for keys, one for values; receive segments ordered by source rank
+        recv_k = b["recv_k"][:n_recv]
+        recv_v = b["recv_v"][:n_recv]
+        self._all_to_all(recv_k, b["part_k"][:n_local], recv_counts, send_counts)
+        self._all_to_all(recv_v, b["part_v"][:n_local], recv_counts, send_counts)
+
+        # 5. local stable sort of the received pairs
+        self.ops.sort(recv_k, recv_v, n_recv)
+        return recv_k, recv_v, n_recv
+
+    def _grow_recv(self, b, n_recv):
+        t = self.torch
+        cap = int(n_recv * 1.1) + 4096
+        b["recv_k"] = t.empty(cap, dtype=t.int32, device=b["device"])
+        b["recv_v"] = t.empty(cap, dtype=t.int32, device=b["device"])
+        b["cap"] = cap
+        if hasattr(self.ops, "prepare"):
+            self.ops.prepare(cap)
+        return b

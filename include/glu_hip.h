@@ -160,6 +160,13 @@ GLU_API glu_status glu_radix_sort_set_digit_bits(glu_radix_sort sort, uint32_t b
 GLU_API glu_status glu_radix_sort_get_digit_bits(glu_radix_sort sort, uint32_t* bits);
 /* Bytes of scratch currently owned by the sort object (keys + vals + tables). */
 GLU_API glu_status glu_radix_sort_scratch_size(glu_radix_sort sort, size_t* bytes);
+/* Per-kernel device timing (the measure_gl_elapsed_time idea, glu/gl_utils.hpp:249-265, at kernel granularity):
+ * while enabled, every counting pass records HIP events on its stream around the count, scan and scatter
+ * kernels.  glu_radix_sort_read_profile waits for the recorded work, returns the summed device milliseconds
+ * per kernel class and the number of passes since the previous read, and resets the accumulation. */
+GLU_API glu_status glu_radix_sort_set_profiling(glu_radix_sort sort, int enable);
+GLU_API glu_status glu_radix_sort_read_profile(glu_radix_sort sort, double* count_ms, double* scan_ms,
+                                               double* scatter_ms, uint64_t* passes);
 
 /* ---- exclusive scan: replaces glu::BlellochScan (glu/BlellochScan.hpp:80-191) ---------------------- */
 

@@ -1,0 +1,159 @@
+// C++ API tests of glu::RadixSort -- the reference's cases (reference test/radix_sort_tests.cpp:88-158: same
+// sizes, seed and key ranges, same sorted + permutation assertions) plus what the reference leaves unpinned:
+// value order (stability), key bit 31, num_steps, tiny counts.
+#include <algorithm>
+#include <cinttypes>
+#include <numeric>
+#include <unordered_map>
+#include <vector>
+
+#include "glu/RadixSort.hpp"
+#include "util/Random.hpp"
+#include "util/mini_test.hpp"
+
+using namespace glu;
+
+namespace
+{
+    template<typename T>
+    std::unordered_map<T, size_t> value_histogram(const std::vector<T>& v)
+    {
+        std::unordered_map<T, size_t> h;
+        for (const T& x : v) ++h[x];
+        return h;
+    }
+
+    template<typename T>
+    void check_permutation(const std::vector<T>& a, const std::vector<T>& b)
+    {
+        CHECK(a.size() == b.size());
+        CHECK(value_histogram(a) == value_histogram(b));
+    }
+
+    template<typename T>
+    void check_sorted(const std::vector<T>& v)
+    {
+        CHECK(std::is_sorted(v.begin(), v.end()));
+    }
+
+    /// keys sorted + permutation, as the reference asserts
+    void run_reference_case(size_t n, GLuint min, GLuint max)
+    {
+        Random random(1);
+        std::vector<GLuint> keys = random.sample_int_vector<GLuint>(n, min, max);
+        std::vector<GLuint> vals(n);
+
+        ShaderStorageBuffer key_buffer(keys);
+        ShaderStorageBuffer val_buffer(vals);
+
+        RadixSort radix_sort;
+        radix_sort(key_buffer.handle(), val_buffer.handle(), keys.size());
+
+        std::vector<GLuint> sorted_keys = key_buffer.get_data<GLuint>();
+        check_permutation(keys, sorted_keys);
+        check_sorted(sorted_keys);
+    }
+
+    /// full contract: identical to std::stable_sort of the pairs by (masked) key
+    void run_stability_case(std::vector<GLuint> keys, size_t num_steps, uint32_t digit_bits)
+    {
+        const size_t n = keys.size();
+        std::vector<GLuint> vals(n);
+        std::iota(vals.begin(), vals.end(), 0u);
+
+        std::vector<GLuint> order(vals);
+        const uint32_t mask = (num_steps == 0 || num_steps >= 8) ? 0xFFFFFFFFu : ((1u << (4 * num_steps)) - 1u);
+        std::stable_sort(order.begin(), order.end(), [&](GLuint a, GLuint b) { return (keys[a] & mask) < (keys[b] & mask); });
+
+        ShaderStorageBuffer key_buffer(n ? n * sizeof(GLuint) : 4), val_buffer(n ? n * sizeof(GLuint) : 4);
+        if (n)
+        {
+            key_buffer.write_data(keys.data(), n * sizeof(GLuint));
+            val_buffer.write_data(vals.data(), n * sizeof(GLuint));
+        }
+        RadixSort radix_sort;
+        radix_sort.set_digit_bits(digit_bits);
+        radix_sort(key_buffer.handle(), val_buffer.handle(), n, num_steps);
+
+        std::vector<GLuint> out_keys = key_buffer.get_data<GLuint>();
+        std::vector<GLuint> out_vals = val_buffer.get_data<GLuint>();
+        bool same = true;
+        for (size_t i = 0; i < n; i++) same = same && out_vals[i] == order[i] && out_keys[i] == keys[order[i]];
+        CHECK(same);
+    }
+} // namespace
+
+TEST_CASE("RadixSort-128-256-512-1024")
+{
+    for (size_t n : {128, 256, 512, 1024}) run_reference_case(n, 0, UINT32_MAX);
+}
+
+TEST_CASE("RadixSort-2048")
+{
+    run_reference_case(2048, 0, 10);
+}
+
+TEST_CASE("RadixSort-multiple-sizes")
+{
+    for (size_t n : {10993, 14978, 16243, 18985, 23857, 27865, 33363, 41298, 45821, 47487})
+        run_reference_case(n, 0, UINT32_MAX);
+}
+
+TEST_CASE("RadixSort-stable-full-32-bit")
+{
+    std::mt19937 gen(0x5EED);
+    for (uint32_t bits : {4u, 8u})
+        for (size_t n : {0, 1, 2, 3, 1023, 1024, 1025, 4096, 4097, 65537, 1 << 20})
+        {
+            std::vector<GLuint> keys(n);
+            for (auto& k : keys) k = gen(); // sets bit 31
+            run_stability_case(keys, 0, bits);
+        }
+}
+
+TEST_CASE("RadixSort-stable-duplicates")
+{
+    Random random(7);
+    for (uint32_t bits : {4u, 8u})
+    {
+        run_stability_case(random.sample_int_vector<GLuint>(50000, 0, 10), 0, bits);
+        run_stability_case(std::vector<GLuint>(30000, 0u), 0, bits);           // the reference's benchmark input
+        run_stability_case(std::vector<GLuint>(30000, 0xFFFFFFFFu), 0, bits);
+        std::vector<GLuint> asc(20000), desc(20000);
+        std::iota(asc.begin(), asc.end(), 0u);
+        for (size_t i = 0; i < desc.size(); i++) desc[i] = GLuint(desc.size() - i) * 77777u;
+        run_stability_case(asc, 0, bits);
+        run_stability_case(desc, 0, bits);
+    }
+}
+
+TEST_CASE("RadixSort-num-steps")
+{
+    std::mt19937 gen(99);
+    std::vector<GLuint> keys(30011);
+    for (auto& k : keys) k = gen();
+    for (uint32_t bits : {4u, 8u})
+        for (size_t steps = 1; steps <= 9; steps++) run_stability_case(keys, steps, bits);
+}
+
+TEST_CASE("RadixSort-reuse-and-prepare")
+{
+    RadixSort radix_sort;
+    radix_sort.prepare_internal_buffers(100000);
+    std::mt19937 gen(5);
+    for (size_t n : {100000, 5000, 77777})
+    {
+        std::vector<GLuint> keys(n), vals(n);
+        for (auto& k : keys) k = gen();
+        std::iota(vals.begin(), vals.end(), 0u);
+        ShaderStorageBuffer kb(keys), vb(vals);
+        radix_sort(kb.handle(), vb.handle(), n);
+        std::vector<GLuint> sk = kb.get_data<GLuint>(), sv = vb.get_data<GLuint>();
+        check_sorted(sk);
+        bool paired = true;
+        for (size_t i = 0; i < n; i++) paired = paired && keys[sv[i]] == sk[i];
+        CHECK(paired);
+    }
+}
+
+int main(int argc, char** argv) { return mini_test::run(argc, argv); }

@@ -1,0 +1,152 @@
+"""CPU tests of the multi-GPU path (gl-radix-sort_amd/glu_hip/dist.py): the planning functions with simulated
+ranks, and the full exchange with two real processes over gloo.  The per-rank device work is replaced by an
+oracle-backed stand-in here (test infrastructure); on the GPU box HipLocalOps does it through libglu_hip.so."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+import oracle as O
+from glu_hip import dist as D
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class OracleLocalOps:
+    """numpy/oracle stand-in for HipLocalOps (same interface), CPU tensors."""
+
+    def partition(self, keys, vals, out_keys, out_vals, hist):
+        k = keys.numpy().view(np.uint32)
+        v = vals.numpy().view(np.uint32)
+        b = (k >> 24).astype(np.int64)
+        order = np.argsort(b, kind="stable")
+        out_keys.numpy().view(np.uint32)[:k.size] = k[order]
+        out_vals.numpy().view(np.uint32)[:k.size] = v[order]
+        hist.numpy()[:] = np.bincount(b, minlength=256).astype(np.int32)
+
+    def sort(self, keys, vals, count):
+        k, v = O.stable_sort_pairs(keys.numpy().view(np.uint32)[:count], vals.numpy().view(np.uint32)[:count])
+        keys.numpy().view(np.uint32)[:count] = k
+        vals.numpy().view(np.uint32)[:count] = v
+
+
+def make_keys(kind, n, seed):
+    rng = np.random.default_rng(seed)
+    if kind == "uniform":
+        return rng.integers(0, 2**32, n, dtype=np.uint32)
+    if kind == "dups":
+        return (rng.integers(0, 50, n, dtype=np.uint32) << 22) | rng.integers(0, 3, n, dtype=np.uint32)
+    if kind == "hot":  # one hot bucket + sprinkles
+        k = np.full(n, 0x7F000000, dtype=np.uint32) | rng.integers(0, 4, n, dtype=np.uint32)
+        k[::5] = rng.integers(0, 2**32, k[::5].size, dtype=np.uint32)
+        return k
+    return np.zeros(n, dtype=np.uint32)
+
+
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+def test_plan_is_contiguous_monotone_and_balanced(world):
+    rng = np.random.default_rng(world)
+    totals = rng.integers(1000, 2000, 256)
+    owner = D.plan_bucket_to_rank(totals, world)
+    assert owner[0] == 0 and owner[-1] == world - 1
+    assert (np.diff(owner) >= 0).all() and set(owner.tolist()) == set(range(world))
+    per_rank = np.array([totals[owner == r].sum() for r in range(world)])
+    assert per_rank.max() <= totals.sum() / world + totals.max()
+    # uniform buckets -> bucket b belongs to rank b * R / 256
+    owner = D.plan_bucket_to_rank(np.full(256, 1 << 19), world)
+    assert (owner == (np.arange(256) * world) // 256).all()
+
+
+def test_plan_skew_never_splits_a_bucket():
+    totals = np.zeros(256, dtype=np.int64)
+    totals[77] = 10**6
+    totals[3] = 5
+    owner = D.plan_bucket_to_rank(totals, 8)
+    assert (np.diff(owner) >= 0).all()
+    assert len(set(owner[totals > 0].tolist())) <= 2
+
+
+@pytest.mark.parametrize("kind", ["uniform", "dups", "hot", "zero"])
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_simulated_ranks_equal_single_device_stable_sort(kind, world):
+    """Pure-function simulation of R ranks: partition -> plan -> exchange (source-rank order) -> local stable sort."""
+    n_local = 5000
+    shards = [make_keys(kind, n_local + 17 * r, 100 + r) for r in range(world)]
+    offs = np.concatenate([[0], np.cumsum([s.size for s in shards])])
+    vals = [np.arange(offs[r], offs[r + 1], dtype=np.uint32) for r in range(world)]
+    parts, hists = [], []
+    for r in range(world):
+        b = (shards[r] >> 24).astype(np.int64)
+        order = np.argsort(b, kind="stable")
+        parts.append((shards[r][order], vals[r][order]))
+        hists.append(np.bincount(b, minlength=256))
+    all_hist = np.stack(hists)
+    owner = D.plan_bucket_to_rank(all_hist.sum(0), world)
+    out_k, out_v = [], []
+    for me in range(world):
+        seg_k, seg_v = [], []
+        for src in range(world):
+            send, _ = D.split_counts(all_hist, owner, src)
+            so = np.concatenate([[0], np.cumsum(send)])
+            seg_k.append(parts[src][0][so[me]:so[me + 1]])
+            seg_v.append(parts[src][1][so[me]:so[me + 1]])
+        _, recv = D.split_counts(all_hist, owner, me)
+        assert [s.size for s in seg_k] == recv.tolist()
+        k, v = O.stable_sort_pairs(np.concatenate(seg_k), np.concatenate(seg_v))
+        out_k.append(k)
+        out_v.append(v)
+    ek, ev = O.stable_sort_pairs(np.concatenate(shards), np.concatenate(vals))
+    assert (np.concatenate(out_k) == ek).all() and (np.concatenate(out_v) == ev).all()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, kind, n_local, q):
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        keys = make_keys(kind, n_local + 13 * rank, 7 + rank)
+        base = sum(n_local + 13 * r for r in range(rank))
+        vals = np.arange(base, base + keys.size, dtype=np.uint32)
+        sorter = D.DistributedRadixSort(local_ops=OracleLocalOps())
+        kt = torch.from_numpy(keys.view(np.int32).copy())
+        vt = torch.from_numpy(vals.view(np.int32).copy())
+        rk, rv, cnt = sorter.sort(kt, vt)
+        q.put((rank, rk.numpy().view(np.uint32)[:cnt].copy(), rv.numpy().view(np.uint32)[:cnt].copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["uniform", "dups", "hot"])
+def test_two_process_gloo_sort_matches_oracle(kind):
+    import torch.multiprocessing as mp
+
+    world, n_local = 2, 20000
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, n_local, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    all_keys = np.concatenate([make_keys(kind, n_local + 13 * r, 7 + r) for r in range(world)])
+    all_vals = np.arange(all_keys.size, dtype=np.uint32)
+    ek, ev = O.stable_sort_pairs(all_keys, all_vals)
+    gk = np.concatenate([r[1] for r in results])
+    gv = np.concatenate([r[2] for r in results])
+    assert (gk == ek).all() and (gv == ev).all()

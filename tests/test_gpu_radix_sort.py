@@ -1,0 +1,233 @@
+"""GPU parity tests of the hot path (glu::RadixSort::operator(), reference glu/RadixSort.hpp:273-334), called
+through the C ABI of libglu_hip.so and compared bit-for-bit with the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle as O
+from conftest import fnv1a64
+
+pytestmark = pytest.mark.gpu
+
+DIGIT_BITS = [4, 8]
+
+
+@pytest.fixture(scope="module")
+def G(built):
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    print(built.device_info())
+    return built
+
+
+def gpu_sort(G, keys, vals, num_steps=0, bits=8, key_bytes=4):
+    sorter = G.RadixSort(digit_bits=bits)
+    kb, vb = G.ShaderStorageBuffer(keys), G.ShaderStorageBuffer(vals)
+    sorter(kb, vb, keys.size, num_steps, key_bytes=key_bytes)
+    return kb.get_data(keys.dtype), vb.get_data(np.uint32)
+
+
+def test_native_library_is_loaded(G):
+    G.RadixSort()
+    maps = open("/proc/self/maps").read()
+    assert "libglu_hip.so" in maps
+
+
+@pytest.mark.parametrize("bits", DIGIT_BITS)
+def test_reference_test_inputs_match_literal_oracle(G, golden, bits):
+    """The reference's own test inputs (radix_sort_tests.cpp:88-158) with vals = iota: keys AND values must equal
+    the literal restatement of the GLSL algorithm; checksums must equal the committed golden ones."""
+    sums = {(c["n"], c["max"]): c for c in golden["checksums"]["cases"]}
+    for c in golden["reference"]["radix_sort_tests"]["cases"]:
+        n = c["n"]
+        keys = O.minstd_sample(1, n, c["min"], c["max"])
+        vals = np.arange(n, dtype=np.uint32)
+        gk, gv = gpu_sort(G, keys, vals, bits=bits)
+        ref = O.radix_sort_reference(keys, vals)
+        assert (gk == ref["result_keys"]).all() and (gv == ref["result_vals"]).all(), n
+        s = sums[(n, c["max"])]
+        assert fnv1a64(gk) == s["sorted_keys_fnv1a64"] and fnv1a64(gv) == s["sorted_vals_fnv1a64"]
+        # the reference's assertions
+        assert (np.diff(gk.astype(np.int64)) >= 0).all() and (np.sort(keys) == gk).all()
+        # the reference's dummy all-zero values
+        gk0, gv0 = gpu_sort(G, keys, np.zeros(n, dtype=np.uint32), bits=bits)
+        assert (gk0 == gk).all() and not gv0.any()
+
+
+@pytest.mark.parametrize("bits", DIGIT_BITS)
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 63, 64, 65, 255, 256, 257, 1023, 1024, 1025, 4095, 4096, 4097, 8191, 8192,
+                               8193, 100000, (1 << 20), (1 << 20) + 1, 3 * 4096 * 1024 + 77])
+def test_sizes_full_32_bit_keys(G, bits, n):
+    rng = np.random.default_rng(n + bits)
+    keys = rng.integers(0, 2**32, n, dtype=np.uint32)
+    vals = rng.integers(0, 2**32, n, dtype=np.uint32)
+    if n <= 1:
+        kb, vb = G.ShaderStorageBuffer(size=4), G.ShaderStorageBuffer(size=4)
+        G.RadixSort(digit_bits=bits)(kb, vb, n)  # early-out, RadixSort.hpp:278
+        return
+    gk, gv = gpu_sort(G, keys, vals, bits=bits)
+    ek, ev = O.stable_sort_pairs(keys, vals)
+    assert (gk == ek).all() and (gv == ev).all()
+
+
+@pytest.mark.parametrize("bits", DIGIT_BITS)
+@pytest.mark.parametrize("kind", ["zero", "ones", "few", "sorted", "reversed", "low_bits", "high_bits", "two_values"])
+def test_key_distributions_are_stable(G, bits, kind):
+    n = 300007
+    rng = np.random.default_rng(3)
+    keys = {
+        "zero": np.zeros(n, dtype=np.uint32),
+        "ones": np.full(n, 0xFFFFFFFF, dtype=np.uint32),
+        "few": rng.integers(0, 10, n, dtype=np.uint32),
+        "sorted": np.sort(rng.integers(0, 2**32, n, dtype=np.uint32)),
+        "reversed": np.sort(rng.integers(0, 2**32, n, dtype=np.uint32))[::-1].copy(),
+        "low_bits": rng.integers(0, 16, n, dtype=np.uint32),
+        "high_bits": rng.integers(0, 16, n, dtype=np.uint32) << 28,
+        "two_values": np.where(rng.integers(0, 2, n) == 0, 0x80000000, 0x7FFFFFFF).astype(np.uint32),
+    }[kind]
+    vals = np.arange(n, dtype=np.uint32)
+    gk, gv = gpu_sort(G, keys, vals, bits=bits)
+    ek, ev = O.stable_sort_pairs(keys, vals)
+    assert (gk == ek).all() and (gv == ev).all()
+
+
+@pytest.mark.parametrize("bits", DIGIT_BITS)
+@pytest.mark.parametrize("steps", [1, 2, 3, 4, 5, 6, 7, 8, 9, 1000])
+def test_num_steps(G, bits, steps):
+    """Low 4*num_steps bits only (RadixSort.hpp:289,303,331-332).  The sorted pairs equal what the reference
+    produces (wherever it leaves them); they are always returned in the caller's buffers (documented deviation)."""
+    n = 30011
+    keys = O.minstd_sample(1, n, 0, 0xFFFFFFFF) ^ np.uint32(0x80000000)
+    vals = np.arange(n, dtype=np.uint32)
+    gk, gv = gpu_sort(G, keys, vals, num_steps=steps, bits=bits)
+    ref = O.radix_sort_reference(keys, vals, num_steps=steps)
+    assert (gk == ref["result_keys"]).all() and (gv == ref["result_vals"]).all()
+
+
+def test_prepare_then_no_growth_and_reuse(G):
+    sorter = G.RadixSort()
+    sorter.prepare_internal_buffers(1 << 20)
+    size0 = sorter.scratch_size()
+    assert size0 >= 2 * 4 * (1 << 20)
+    rng = np.random.default_rng(0)
+    for n in (1 << 20, 1000, 77777):
+        keys = rng.integers(0, 2**32, n, dtype=np.uint32)
+        vals = np.arange(n, dtype=np.uint32)
+        kb, vb = G.ShaderStorageBuffer(keys), G.ShaderStorageBuffer(vals)
+        sorter(kb, vb, n)
+        ek, ev = O.stable_sort_pairs(keys, vals)
+        assert (kb.get_data(np.uint32) == ek).all() and (vb.get_data(np.uint32) == ev).all()
+        assert sorter.scratch_size() == size0  # grow-only, RadixSort.hpp:237-271
+
+
+def test_argument_checks(G):
+    sorter = G.RadixSort()
+    kb = G.ShaderStorageBuffer(np.arange(10, dtype=np.uint32))
+    with pytest.raises(G.GluError) as e:
+        sorter(0, kb, 10)
+    assert "Invalid key buffer" in e.value.message  # RadixSort.hpp:275
+    with pytest.raises(G.GluError) as e:
+        sorter(kb, 0, 10)
+    assert "Invalid value buffer" in e.value.message  # RadixSort.hpp:276
+    with pytest.raises(G.GluError):
+        sorter(kb, kb, 11)  # larger than the buffers
+    with pytest.raises(G.GluError):
+        G.RadixSort(digit_bits=5)
+
+
+@pytest.mark.parametrize("bits", DIGIT_BITS)
+@pytest.mark.parametrize("n", [2, 4097, 250000])
+def test_u64_keys(G, bits, n):
+    rng = np.random.default_rng(n)
+    keys = rng.integers(0, 2**64, n, dtype=np.uint64)
+    keys[::3] = keys[0]
+    vals = np.arange(n, dtype=np.uint32)
+    gk, gv = gpu_sort(G, keys, vals, bits=bits, key_bytes=8)
+    ek, ev = O.stable_sort_pairs(keys, vals)
+    assert (gk == ek).all() and (gv == ev).all()
+    gk, gv = gpu_sort(G, keys, vals, num_steps=5, bits=bits, key_bytes=8)
+    ek, ev = O.stable_sort_pairs(keys, vals, key_bits=20)
+    assert (gk == ek).all() and (gv == ev).all()
+
+
+def test_raw_pointer_entry_on_torch_memory(G):
+    import torch
+
+    n = 123457
+    rng = np.random.default_rng(1)
+    keys = rng.integers(0, 2**32, n, dtype=np.uint32)
+    vals = np.arange(n, dtype=np.uint32)
+    kt = torch.from_numpy(keys.view(np.int32)).cuda()
+    vt = torch.from_numpy(vals.view(np.int32)).cuda()
+    sorter = G.RadixSort()
+    sorter.run_ptr(kt.data_ptr(), vt.data_ptr(), n, 0, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    ek, ev = O.stable_sort_pairs(keys, vals)
+    assert (kt.cpu().numpy().view(np.uint32) == ek).all() and (vt.cpu().numpy().view(np.uint32) == ev).all()
+
+
+@pytest.mark.parametrize("shift,bits", [(24, 8), (28, 4), (0, 8), (13, 5), (31, 1)])
+def test_partition_pass_and_histogram(G, shift, bits):
+    import torch
+
+    n = 200003
+    rng = np.random.default_rng(shift)
+    keys = rng.integers(0, 2**32, n, dtype=np.uint32)
+    vals = np.arange(n, dtype=np.uint32)
+    kt = torch.from_numpy(keys.view(np.int32)).cuda()
+    vt = torch.from_numpy(vals.view(np.int32)).cuda()
+    ok, ov = torch.empty_like(kt), torch.empty_like(vt)
+    hist = torch.zeros(1 << bits, dtype=torch.int32, device="cuda")
+    sorter = G.RadixSort()
+    sorter.partition_ptr(kt.data_ptr(), vt.data_ptr(), ok.data_ptr(), ov.data_ptr(), n, shift, bits, hist.data_ptr(),
+                         torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    d = ((keys >> shift) & ((1 << bits) - 1)).astype(np.int64)
+    order = np.argsort(d, kind="stable")
+    assert (ok.cpu().numpy().view(np.uint32) == keys[order]).all()
+    assert (ov.cpu().numpy().view(np.uint32) == vals[order]).all()
+    assert (hist.cpu().numpy() == np.bincount(d, minlength=1 << bits)).all()
+
+
+def _check_sorted_properties(keys, gk, gv):
+    """Size-independent properties that pin the stable sort exactly when vals = iota:
+    keys ascending; gk[i] == keys[gv[i]]; gv is a permutation; gv ascending inside runs of equal keys."""
+    assert (gk[1:] >= gk[:-1]).all()
+    assert (keys[gv] == gk).all()
+    seen = np.zeros(keys.size, dtype=bool)
+    seen[gv] = True
+    assert seen.all()
+    eq = gk[1:] == gk[:-1]
+    assert (gv[1:][eq] > gv[:-1][eq]).all()
+
+
+@pytest.mark.parametrize("bits", DIGIT_BITS)
+def test_full_size_2_28_properties(G, bits):
+    """BASELINE.json config 3: N = 2^28 uint32 key + val, uniform random full-range keys."""
+    n = 1 << 28
+    rng = np.random.default_rng(0x5EED)
+    keys = rng.integers(0, 2**32, n, dtype=np.uint32)
+    vals = np.arange(n, dtype=np.uint32)
+    gk, gv = gpu_sort(G, keys, vals, bits=bits)
+    _check_sorted_properties(keys, gk, gv)
+
+
+def test_full_size_2_28_duplicate_heavy(G):
+    n = 1 << 28
+    rng = np.random.default_rng(11)
+    keys = rng.integers(0, 1000, n, dtype=np.uint32) * np.uint32(4294967)
+    vals = np.arange(n, dtype=np.uint32)
+    gk, gv = gpu_sort(G, keys, vals)
+    _check_sorted_properties(keys, gk, gv)
+
+
+def test_full_size_2_28_u64(G):
+    """BASELINE.json config 5: N = 2^28 uint64 keys + uint32 payload."""
+    n = 1 << 28
+    rng = np.random.default_rng(5)
+    keys = rng.integers(0, 2**64, n, dtype=np.uint64)
+    vals = np.arange(n, dtype=np.uint32)
+    gk, gv = gpu_sort(G, keys, vals, key_bytes=8)
+    _check_sorted_properties(keys, gk, gv)
