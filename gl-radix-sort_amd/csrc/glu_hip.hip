@@ -337,11 +337,29 @@ glu_status glu_buffer_copy(glu_buffer src, glu_buffer dst, size_t size, size_t s
 // ------------------------------------------------------------------------------------------------------------
 namespace
 {
-constexpr int kSortThreads = 256;
-constexpr int kSortKpt = 16;
-constexpr int kSortTile = kSortThreads * kSortKpt;
-constexpr int kSortBlocksPerCu = 4;
 constexpr int kMaxRadix = 256;
+constexpr int kMaxBlocksPerCu = 4;
+
+// Launch geometry of one counting pass.  "Large" = one 1024-thread workgroup per CU with the biggest tile LDS
+// allows (long per-digit runs, fewest partial 64-byte blocks); "small" = 256-thread workgroups, 4 per CU, for inputs
+// that cannot give every CU a large tile.  Measured on MI355X, 2^28 pairs (tools/scatter_bench.hip):
+//   8-bit digits: 1024 x 12 + carry 1.17 ms/pass vs 256 x 16 1.95 ms;  4-bit digits: 1024 x 16 0.90-0.95 ms vs 1.03 ms.
+template<int THREADS_, int KPT_, int BLOCKS_PER_CU_, bool CARRY_>
+struct Geometry
+{
+    static constexpr int THREADS = THREADS_, KPT = KPT_, BLOCKS_PER_CU = BLOCKS_PER_CU_, TILE = THREADS_ * KPT_;
+    static constexpr bool CARRY = CARRY_;
+};
+template<typename KeyT, int BITS, bool LARGE>
+struct GeometryFor;
+template<> struct GeometryFor<uint32_t, 8, true> : Geometry<1024, 12, 1, true> {};
+template<> struct GeometryFor<uint32_t, 4, true> : Geometry<1024, 12, 1, false> {};
+template<> struct GeometryFor<uint32_t, 8, false> : Geometry<256, 16, 3, false> {};
+template<> struct GeometryFor<uint32_t, 4, false> : Geometry<256, 16, 3, false> {};
+template<> struct GeometryFor<uint64_t, 8, true> : Geometry<1024, 8, 1, false> {};
+template<> struct GeometryFor<uint64_t, 4, true> : Geometry<1024, 8, 1, false> {};
+template<> struct GeometryFor<uint64_t, 8, false> : Geometry<256, 8, 4, false> {};
+template<> struct GeometryFor<uint64_t, 4, false> : Geometry<256, 8, 4, false> {};
 }
 
 struct glu_radix_sort_s
@@ -350,7 +368,8 @@ struct glu_radix_sort_s
     Scratch vals;
     Scratch table;  // [RADIX][num_blocks] digit counts -> scanned offsets, + RADIX digit totals
     uint32_t digit_bits = 8;
-    uint32_t max_blocks = 0;
+    uint32_t max_blocks = 0;   // GLU_HIP_SORT_BLOCKS: cap on the number of workgroups (tuning)
+    bool force_small = false;  // GLU_HIP_SORT_SMALL=1: always use the small-tile geometry (tests / tuning)
     // optional per-kernel timing: 4 events per pass (before count, after count, after scan, after scatter)
     bool profiling = false;
     std::vector<hipEvent_t> events;
@@ -374,58 +393,72 @@ struct glu_radix_sort_s
 
 namespace
 {
-uint32_t sort_num_blocks(const glu_radix_sort_s* s, size_t count)
-{
-    uint64_t tiles = (count + kSortTile - 1) / kSortTile;
-    uint64_t cap = s->max_blocks ? s->max_blocks : (uint64_t) g_dev.num_cus * kSortBlocksPerCu;
-    return (uint32_t) std::max<uint64_t>(1, std::min<uint64_t>(tiles, cap));
-}
-
 glu_status sort_prepare(glu_radix_sort_s* s, size_t count, size_t key_size)
 {
     if (count <= 1) return GLU_OK;
     GLU_TRY(s->keys.reserve(count * key_size));
     GLU_TRY(s->vals.reserve(count * sizeof(uint32_t)));
-    uint64_t cap = (uint64_t) g_dev.num_cus * kSortBlocksPerCu;
+    uint64_t cap = (uint64_t) g_dev.num_cus * kMaxBlocksPerCu;
     GLU_TRY(s->table.reserve((kMaxRadix * cap + kMaxRadix) * sizeof(uint32_t)));
     return GLU_OK;
 }
 
-template<typename KeyT, int BITS>
+template<typename KeyT, int BITS, bool LARGE>
 glu_status launch_pass(glu_radix_sort_s* s, const KeyT* src_k, const uint32_t* src_v, KeyT* dst_k, uint32_t* dst_v,
                        size_t count, uint32_t shift, uint32_t bits, uint32_t* histogram_out, hipStream_t stream)
 {
+    using G = GeometryFor<KeyT, BITS, LARGE>;
     constexpr int RADIX = 1 << BITS;
-    const uint32_t nb = sort_num_blocks(s, count);
-    const uint32_t tiles = (uint32_t) ((count + kSortTile - 1) / kSortTile);
+    const uint32_t tiles = (uint32_t) ((count + G::TILE - 1) / G::TILE);
+    uint64_t cap = (uint64_t) g_dev.num_cus * G::BLOCKS_PER_CU;
+    if (s->max_blocks) cap = std::min<uint64_t>(cap, s->max_blocks);
+    const uint32_t nb = (uint32_t) std::max<uint64_t>(1, std::min<uint64_t>(tiles, cap));
     const uint32_t mask = (1u << bits) - 1;
     uint32_t* table = (uint32_t*) s->table.ptr;
     uint32_t* totals = table + (size_t) RADIX * nb;
 
+    using Smem = ScatterSmem<KeyT, BITS, G::THREADS, G::KPT, G::CARRY>;
+    auto scatter = radix_scatter_kernel<KeyT, BITS, G::THREADS, G::KPT, G::CARRY, 0, false, G::BLOCKS_PER_CU * G::THREADS / 256>;
+    static bool lds_opt_in = false; // per instantiation: allow > 64 KiB of dynamic LDS
+    if (!lds_opt_in)
+    {
+        HIP_TRY(hipFuncSetAttribute((const void*) scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sizeof(Smem)));
+        lds_opt_in = true;
+    }
+
     s->mark(stream);
-    hipLaunchKernelGGL((radix_count_kernel<KeyT, BITS, kSortThreads, kSortTile>), dim3(nb), dim3(kSortThreads), 0,
-                       stream, src_k, table, (uint32_t) count, shift, mask, tiles);
+    hipLaunchKernelGGL((radix_count_kernel<KeyT, BITS, G::THREADS, G::TILE>), dim3(nb), dim3(G::THREADS), 0, stream,
+                       src_k, table, (uint32_t) count, shift, mask, tiles);
     s->mark(stream);
     hipLaunchKernelGGL((radix_row_scan_kernel<256>), dim3(RADIX), dim3(256), 0, stream, table, totals, nb);
     s->mark(stream);
     if (histogram_out)
         HIP_TRY(hipMemcpyAsync(histogram_out, totals, ((size_t) 1 << bits) * sizeof(uint32_t), hipMemcpyDeviceToDevice,
                                stream));
-    using Smem = ScatterSmem<KeyT, BITS, kSortThreads, kSortKpt>;
-    hipLaunchKernelGGL((radix_scatter_kernel<KeyT, BITS, kSortThreads, kSortKpt>), dim3(nb), dim3(kSortThreads),
-                       sizeof(Smem), stream, src_k, src_v, dst_k, dst_v, table, totals, (uint32_t) count, shift, mask,
-                       tiles);
+    hipLaunchKernelGGL(scatter, dim3(nb), dim3(G::THREADS), sizeof(Smem), stream, src_k, src_v, dst_k, dst_v,
+                       (const uint32_t*) table, (const uint32_t*) totals, (uint32_t) count, shift, mask, tiles,
+                       (unsigned long long*) nullptr);
     s->mark(stream);
     HIP_TRY(hipGetLastError());
     return GLU_OK;
+}
+
+template<typename KeyT, int BITS>
+glu_status launch_pass_sized(glu_radix_sort_s* s, const KeyT* src_k, const uint32_t* src_v, KeyT* dst_k, uint32_t* dst_v,
+                             size_t count, uint32_t shift, uint32_t bits, uint32_t* histogram_out, hipStream_t stream)
+{
+    // large geometry once every CU gets at least one large tile
+    const bool large = count >= (size_t) g_dev.num_cus * GeometryFor<KeyT, BITS, true>::TILE && !s->force_small;
+    if (large) return launch_pass<KeyT, BITS, true>(s, src_k, src_v, dst_k, dst_v, count, shift, bits, histogram_out, stream);
+    return launch_pass<KeyT, BITS, false>(s, src_k, src_v, dst_k, dst_v, count, shift, bits, histogram_out, stream);
 }
 
 template<typename KeyT>
 glu_status dispatch_pass(glu_radix_sort_s* s, const KeyT* src_k, const uint32_t* src_v, KeyT* dst_k, uint32_t* dst_v,
                          size_t count, uint32_t shift, uint32_t bits, uint32_t* histogram_out, hipStream_t stream)
 {
-    if (bits <= 4) return launch_pass<KeyT, 4>(s, src_k, src_v, dst_k, dst_v, count, shift, bits, histogram_out, stream);
-    return launch_pass<KeyT, 8>(s, src_k, src_v, dst_k, dst_v, count, shift, bits, histogram_out, stream);
+    if (bits <= 4) return launch_pass_sized<KeyT, 4>(s, src_k, src_v, dst_k, dst_v, count, shift, bits, histogram_out, stream);
+    return launch_pass_sized<KeyT, 8>(s, src_k, src_v, dst_k, dst_v, count, shift, bits, histogram_out, stream);
 }
 
 template<typename KeyT>
@@ -479,8 +512,9 @@ glu_status glu_radix_sort_create(glu_radix_sort* out)
     if (const char* e = getenv("GLU_HIP_SORT_BLOCKS"))
     {
         int b = atoi(e);
-        if (b > 0 && b <= g_dev.num_cus * kSortBlocksPerCu) s->max_blocks = (uint32_t) b;
+        if (b > 0) s->max_blocks = (uint32_t) b;
     }
+    if (const char* e = getenv("GLU_HIP_SORT_SMALL")) s->force_small = atoi(e) != 0;
     *out = s;
     return GLU_OK;
 }
@@ -569,7 +603,7 @@ glu_status glu_radix_sort_partition_ptr(glu_radix_sort sort, const uint32_t* src
         return GLU_OK;
     }
     // table only (no key/val scratch needed)
-    uint64_t cap = (uint64_t) g_dev.num_cus * kSortBlocksPerCu;
+    uint64_t cap = (uint64_t) g_dev.num_cus * kMaxBlocksPerCu;
     GLU_TRY(sort->table.reserve((kMaxRadix * cap + kMaxRadix) * sizeof(uint32_t)));
     return dispatch_pass<uint32_t>(sort, src_keys, src_vals, dst_keys, dst_vals, count, shift, bits, digit_histogram, st);
 }

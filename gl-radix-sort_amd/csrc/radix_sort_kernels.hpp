@@ -167,32 +167,93 @@ __global__ __launch_bounds__(THREADS) void radix_row_scan_kernel(uint32_t* __res
 // ---------------------------------------------------------------------------------------------------------
 // K4: stable scatter of (key, val) by one digit.
 // ---------------------------------------------------------------------------------------------------------
-template<typename KeyT, int BITS, int THREADS, int KPT>
+
+// LDS arrays of (key, val) pairs.  32-bit keys travel with their value as one 8-byte element (one ds_write_b64 /
+// ds_read_b64 per pair); 64-bit keys use two arrays.
+template<typename KeyT, int COUNT>
+struct PairArray;
+
+template<int COUNT>
+struct PairArray<uint32_t, COUNT>
+{
+    uint2 kv[COUNT];
+    __device__ __forceinline__ void put(uint32_t pos, uint32_t k, uint32_t v) { kv[pos] = make_uint2(k, v); }
+    __device__ __forceinline__ void get(uint32_t pos, uint32_t& k, uint32_t& v) const
+    {
+        const uint2 e = kv[pos];
+        k = e.x;
+        v = e.y;
+    }
+};
+
+template<int COUNT>
+struct PairArray<uint64_t, COUNT>
+{
+    uint64_t keys[COUNT];
+    uint32_t vals[COUNT];
+    __device__ __forceinline__ void put(uint32_t pos, uint64_t k, uint32_t v)
+    {
+        keys[pos] = k;
+        vals[pos] = v;
+    }
+    __device__ __forceinline__ void get(uint32_t pos, uint64_t& k, uint32_t& v) const
+    {
+        k = keys[pos];
+        v = vals[pos];
+    }
+};
+
+constexpr int kBlockElems = 16; // 64-byte write block of 4-byte elements: the granule the carry keeps whole
+
+template<typename KeyT, int BITS, int THREADS, int KPT, bool CARRY>
 struct ScatterSmem
 {
     static constexpr int RADIX = 1 << BITS;
     static constexpr int WAVES = THREADS / kWave;
     static constexpr int TILE = THREADS * KPT;
-    KeyT keys[TILE];
-    uint32_t vals[TILE];
-    uint32_t wcnt[WAVES][RADIX]; // wave-private running digit counters -> wave/digit start positions
-    uint32_t gdelta[RADIX];      // global index = local position + gdelta[digit]
+    PairArray<KeyT, TILE> stage;                                 // the tile in ranked order
+    PairArray<KeyT, CARRY ? RADIX * kBlockElems : 1> carry;      // per digit: elements of a not yet complete 64-B block
+    uint32_t wcnt[WAVES][RADIX]; // wave-private running digit counters -> first ranked position of (wave, digit)
+    uint32_t tstart[RADIX];      // first ranked position of each digit in the tile
+    uint32_t gdelta[RADIX];      // global index = ranked position + gdelta[digit]
+    uint32_t wend[RADIX];        // CARRY: elements with global index >= wend[digit] go to the carry, not to memory
+    uint32_t flush_lo[RADIX];    // CARRY: carried elements [flush_lo, flush_hi) of the digit are written this tile
+    uint32_t flush_hi[RADIX];
     uint32_t scan_tmp[WAVES];
 };
 
-template<typename KeyT, int BITS, int THREADS, int KPT>
-__global__ __launch_bounds__(THREADS) void radix_scatter_kernel(
+// Per tile: load keys + values (wave-striped) -> rank inside each wave (ballot match + wave-private LDS counters)
+// -> one block-wide exclusive scan of the [digit][wave] counters -> stage (key, val) in LDS in ranked order ->
+// write out with consecutive threads on consecutive ranked positions.
+//
+// CARRY: a digit's run of one tile rarely ends on a 64-byte boundary, and a partially written 64-byte block that is
+// completed a whole tile period later costs the memory system a fill read + a second write (measured: +50 % fetch
+// traffic with 256 digits).  With CARRY the tail of every run (the elements past the last 64-byte boundary) stays
+// in LDS and is written, together with the head of the digit's next run, when its block is complete -- the only
+// partial blocks left are at the two ends of a workgroup's range.
+//
+// ABLATE (tuning builds only, results are wrong for != 0): 1 = write every tile back linearly (prices the
+// scattered stores).  STAMPS (diagnostic builds): wave 0 of every workgroup adds the s_memtime cycles of each
+// phase to stamps[0..7].
+template<typename KeyT, int BITS, int THREADS, int KPT, bool CARRY = true, int ABLATE = 0, bool STAMPS = false,
+         int MIN_WAVES_PER_SIMD = 1>
+__global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_kernel(
     const KeyT* __restrict__ src_keys, const uint32_t* __restrict__ src_vals, KeyT* __restrict__ dst_keys,
     uint32_t* __restrict__ dst_vals, const uint32_t* __restrict__ table, const uint32_t* __restrict__ totals,
-    uint32_t n, uint32_t shift, uint32_t mask, uint32_t tiles_total)
+    uint32_t n, uint32_t shift, uint32_t mask, uint32_t tiles_total, unsigned long long* stamps = nullptr)
 {
-    using Smem = ScatterSmem<KeyT, BITS, THREADS, KPT>;
+    using Smem = ScatterSmem<KeyT, BITS, THREADS, KPT, CARRY>;
     constexpr int RADIX = Smem::RADIX;
     constexpr int WAVES = Smem::WAVES;
     constexpr int TILE = Smem::TILE;
     constexpr int WAVE_TILE = kWave * KPT;
+    constexpr int WQ = WAVES / 4;              // threads per digit in the offset scan (4 waves each)
+    constexpr int SCAN_THREADS = RADIX * WQ;   // threads taking part in the offset scan
+    constexpr int SCAN_WAVES = (SCAN_THREADS + kWave - 1) / kWave;
+    constexpr uint32_t BLK = kBlockElems;
     const uint32_t MASK = mask; // <= RADIX - 1
-    static_assert(RADIX <= THREADS, "one thread per digit in the offset phase");
+    static_assert(WAVES % 4 == 0, "offset scan handles 4 waves per thread");
+    static_assert(SCAN_THREADS <= THREADS && RADIX <= THREADS, "offset phase needs RADIX * WAVES / 4 threads");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Smem& s = *reinterpret_cast<Smem*>(smem_raw);
@@ -202,7 +263,7 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_kernel(
 
     // ---- prologue: this workgroup's global base for every digit:
     //      exclusive scan of the digit totals (RadixSort.hpp:148-152) + this block's scanned table entry (:176)
-    uint32_t digit_base = 0; // valid in threads tid < RADIX
+    uint32_t digit_base = 0; // valid in threads tid < RADIX: global index of the digit's next element
     {
         uint32_t t = tid < RADIX ? totals[tid] : 0;
         uint32_t wtotal;
@@ -215,22 +276,60 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_kernel(
             if ((uint32_t) w < wave) woff += s.scan_tmp[w];
         if (tid < RADIX) digit_base = woff + excl + table[(size_t) tid * nb + b];
     }
+    uint32_t carry_start = digit_base; // CARRY: elements [carry_start, digit_base) of the digit are held in s.carry
     for (int i = tid; i < WAVES * RADIX; i += THREADS) (&s.wcnt[0][0])[i] = 0;
     __syncthreads();
 
     uint32_t first, last;
     block_tile_range(b, nb, tiles_total, first, last);
 
+    // wave-striped layout: item i of lane l of wave w is element w*WAVE_TILE + i*64 + l of the tile, so that
+    // "item-major, then lane" order inside a wave is memory order -> ranks are stable
+    const uint32_t wave_off = wave * WAVE_TILE + lane;
+
+    unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = 0;
+    auto stamp = [&](int slot) {
+        if (STAMPS)
+        {
+            unsigned long long t = __builtin_amdgcn_s_memtime();
+            acc[slot] += t - tprev;
+            tprev = t;
+        }
+    };
+
+    // writes the carried elements [flush_lo, flush_hi) of every digit: thread (digit, slot) pairs, 16 consecutive
+    // lanes per digit
+    auto flush_carry = [&]() {
+#pragma unroll
+        for (int j = 0; j < (RADIX * (int) BLK + THREADS - 1) / THREADS; j++)
+        {
+            const uint32_t e = j * THREADS + tid;
+            const uint32_t d = e / BLK, slot = e % BLK;
+            if (RADIX * BLK % THREADS != 0 && e >= RADIX * BLK) break;
+            const uint32_t lo = s.flush_lo[d], hi = s.flush_hi[d];
+            const uint32_t g = (lo & ~(BLK - 1)) + slot;
+            if (g >= lo && g < hi)
+            {
+                KeyT k;
+                uint32_t v;
+                s.carry.get(e, k, v);
+                dst_keys[g] = k;
+                dst_vals[g] = v;
+            }
+        }
+    };
+
     for (uint32_t tile = first; tile < last; tile++)
     {
         const uint64_t tile_base = (uint64_t) tile * TILE;
-        const uint32_t tile_valid = (n - tile_base) < (uint64_t) TILE ? (uint32_t) (n - tile_base) : (uint32_t) TILE;
+        const uint64_t rem = (uint64_t) n - tile_base;
+        const uint32_t tile_valid = rem < (uint64_t) TILE ? (uint32_t) rem : (uint32_t) TILE;
+        if (STAMPS) tprev = __builtin_amdgcn_s_memtime();
 
-        // ---- load: wave-striped (item i of lane l of wave w is element w*WAVE_TILE + i*64 + l), so that
-        //      "item-major, then lane" order inside a wave is memory order -> ranks are stable
+        // ---- load
         KeyT key[KPT];
         uint32_t val[KPT];
-        const uint32_t wave_off = wave * WAVE_TILE + lane;
         if (tile_valid == (uint32_t) TILE)
         {
 #pragma unroll
@@ -243,101 +342,178 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_kernel(
 #pragma unroll
             for (int i = 0; i < KPT; i++)
             {
-                uint32_t p = wave_off + i * kWave;
-                bool ok = p < tile_valid;
+                const uint32_t p = wave_off + i * kWave;
+                const bool ok = p < tile_valid;
                 key[i] = ok ? src_keys[tile_base + p] : (KeyT) ~(KeyT) 0; // pad: last digit, ranks after all real keys
                 val[i] = ok ? src_vals[tile_base + p] : 0u;
             }
         }
+        if (STAMPS)
+        {
+            stamp(0); // issue
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            stamp(1); // load latency (diagnostic builds wait here; production waits at first use)
+        }
 
-        // ---- rank inside the wave: peers = lanes holding the same digit (match-any via one ballot per bit)
+        // ---- rank inside the wave
         uint32_t rank[KPT];
         uint32_t* my_cnt = s.wcnt[wave];
 #pragma unroll
         for (int i = 0; i < KPT; i++)
         {
             const uint32_t d = digit_of<KeyT>(key[i], shift, MASK);
-            uint64_t peers = ~0ull;
+            uint32_t* const cnt = my_cnt + d;
+            const uint32_t prev = *cnt; // issued first: its LDS latency hides under the ballots below
+            // peers = lanes whose digit equals mine.  Per digit bit: sel = 0 / ~0 (v_bfe_i32), m = ballot(bit set),
+            // peers &= ~(m ^ sel) -- one v_bitop3_b32 per 32-bit half (truth table 0x90: a & ~(b ^ c)).
+            uint32_t plo = ~0u, phi = ~0u;
 #pragma unroll
             for (int bit = 0; bit < BITS; bit++)
             {
-                const bool set = (d >> bit) & 1u;
-                const uint64_t m = __ballot(set);
-                peers &= set ? m : ~m;
+                const int32_t sel = __builtin_amdgcn_sbfe((int32_t) d, bit, 1);
+                const uint64_t m = __ballot(sel < 0);
+                plo = __builtin_amdgcn_bitop3_b32(plo, (uint32_t) m, (uint32_t) sel, 0x90);
+                phi = __builtin_amdgcn_bitop3_b32(phi, (uint32_t) (m >> 32), (uint32_t) sel, 0x90);
             }
-            const uint32_t lower = __builtin_amdgcn_mbcnt_hi((uint32_t) (peers >> 32),
-                                                             __builtin_amdgcn_mbcnt_lo((uint32_t) peers, 0u));
-            const uint32_t total = (uint32_t) __popcll(peers);
-            const uint32_t prev = my_cnt[d];
+            const uint32_t lower = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
+            const uint32_t total = (uint32_t) __popc(plo) + (uint32_t) __popc(phi);
             rank[i] = prev + lower;
-            __builtin_amdgcn_wave_barrier();
-            if (lower + 1 == total) my_cnt[d] = prev + total; // highest peer lane publishes the new count
-            __builtin_amdgcn_wave_barrier();
+            // every peer stores the same new count to the same address (no exec-mask juggling for a leader lane)
+            *cnt = prev + total;
         }
+        stamp(2); // rank
         __syncthreads();
+        stamp(3); // barrier after rank
 
-        // ---- tile offsets: thread d owns digit d
+        // ---- offsets: exclusive scan of the counters in (digit, wave) order = first ranked position of every
+        //      (wave, digit) group.  Thread t < RADIX * WAVES/4 owns digit t / (WAVES/4), waves 4*(t % (WAVES/4)) .. +3.
         {
-            uint32_t wexcl[WAVES];
-            uint32_t dsum = 0;
-            if (tid < RADIX)
+            const uint32_t sd = tid / WQ, sw = (tid % WQ) * 4;
+            uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+            if (tid < SCAN_THREADS)
             {
-#pragma unroll
-                for (int w = 0; w < WAVES; w++)
-                {
-                    wexcl[w] = dsum;
-                    dsum += s.wcnt[w][tid];
-                }
+                c0 = s.wcnt[sw + 0][sd];
+                c1 = s.wcnt[sw + 1][sd];
+                c2 = s.wcnt[sw + 2][sd];
+                c3 = s.wcnt[sw + 3][sd];
             }
-            uint32_t wtotal;
-            uint32_t excl = wave_exclusive_sum(dsum, lane, wtotal);
-            if (RADIX > kWave)
+            uint32_t excl = 0;
+            if (wave < SCAN_WAVES) // wave-uniform
             {
-                if (lane == 0) s.scan_tmp[wave] = wtotal;
+                uint32_t wtotal;
+                excl = wave_exclusive_sum(c0 + c1 + c2 + c3, lane, wtotal);
+                if (SCAN_WAVES > 1 && lane == 0) s.scan_tmp[wave] = wtotal;
+            }
+            if (SCAN_WAVES > 1)
+            {
                 __syncthreads();
 #pragma unroll
-                for (int w = 0; w < WAVES; w++)
+                for (int w = 0; w < SCAN_WAVES - 1; w++)
                     if ((uint32_t) w < wave) excl += s.scan_tmp[w];
             }
-            if (tid < RADIX)
+            if (tid < SCAN_THREADS)
             {
-                // excl = first local position of digit `tid` in the ranked tile
-#pragma unroll
-                for (int w = 0; w < WAVES; w++) s.wcnt[w][tid] = excl + wexcl[w];
-                s.gdelta[tid] = digit_base - excl;
-                // pads were counted in the last digit only; they never reach memory and the last digit's base
-                // is not used after the final tile
-                digit_base += dsum;
+                s.wcnt[sw + 0][sd] = excl;
+                s.wcnt[sw + 1][sd] = excl + c0;
+                s.wcnt[sw + 2][sd] = excl + c0 + c1;
+                s.wcnt[sw + 3][sd] = excl + c0 + c1 + c2;
+                if (sw == 0) s.tstart[sd] = excl;
             }
         }
         __syncthreads();
+        stamp(4); // offsets
 
+        // ---- thread d: where digit d of this tile goes, advance the running base
+        if (tid < RADIX)
+        {
+            const uint32_t ts = s.tstart[tid];
+            const uint32_t te = tid + 1 < RADIX ? s.tstart[tid + 1] : (uint32_t) TILE;
+            uint32_t len = te - ts;
+            // pads (last, partial tile only) were ranked at the end of the highest used digit: not real elements
+            if (tid == MASK) len -= (uint32_t) TILE - tile_valid;
+            s.gdelta[tid] = digit_base - ts;
+            if (CARRY)
+            {
+                const uint32_t end = digit_base + len;
+                const uint32_t aligned_end = end & ~(BLK - 1);
+                if (aligned_end > carry_start)
+                {
+                    // the run reaches past a 64-byte boundary: the carried elements are completed -> write them,
+                    // write the run up to its last boundary, carry its tail
+                    s.flush_lo[tid] = carry_start;
+                    s.flush_hi[tid] = digit_base;
+                    s.wend[tid] = aligned_end;
+                    carry_start = aligned_end;
+                }
+                else
+                {
+                    // still inside the same 64-byte block: everything joins the carry
+                    s.flush_lo[tid] = 0;
+                    s.flush_hi[tid] = 0;
+                    s.wend[tid] = digit_base;
+                }
+            }
+            digit_base += len;
+        }
         // ---- stage in ranked order
 #pragma unroll
         for (int i = 0; i < KPT; i++)
         {
             const uint32_t d = digit_of<KeyT>(key[i], shift, MASK);
-            const uint32_t pos = my_cnt[d] + rank[i];
-            s.keys[pos] = key[i];
-            s.vals[pos] = val[i];
+            s.stage.put(my_cnt[d] + rank[i], key[i], val[i]);
         }
         __syncthreads();
+        stamp(5); // stage + barrier
 
-        // ---- write out: consecutive threads -> consecutive local positions -> (per digit) consecutive addresses
+        if (CARRY)
+        {
+            flush_carry(); // old carry out before the write-out below refills the slots
+            __syncthreads();
+        }
+
+        // ---- write out: consecutive threads -> consecutive ranked positions -> (per digit) consecutive addresses
 #pragma unroll
         for (int i = 0; i < KPT; i++)
         {
             const uint32_t p = i * THREADS + tid;
             if (p < tile_valid)
             {
-                const KeyT k = s.keys[p];
-                const uint32_t g = p + s.gdelta[digit_of<KeyT>(k, shift, MASK)];
+                KeyT k;
+                uint32_t v;
+                s.stage.get(p, k, v);
+                const uint32_t wd = digit_of<KeyT>(k, shift, MASK);
+                uint32_t g = p + s.gdelta[wd];
+                if (CARRY && g >= s.wend[wd])
+                {
+                    s.carry.put(wd * BLK + (g & (BLK - 1)), k, v);
+                    continue;
+                }
+                if (ABLATE == 1) g = (uint32_t) tile_base + p;
                 dst_keys[g] = k;
-                dst_vals[g] = s.vals[p];
+                dst_vals[g] = v;
             }
         }
         for (int i = tid; i < WAVES * RADIX; i += THREADS) (&s.wcnt[0][0])[i] = 0;
+        stamp(6); // write-out issue
         __syncthreads();
+        stamp(7); // final barrier
+    }
+
+    if (CARRY)
+    {
+        // what is still carried at the end of this workgroup's range: the (partial) last block of every digit
+        if (tid < RADIX)
+        {
+            s.flush_lo[tid] = carry_start;
+            s.flush_hi[tid] = digit_base;
+        }
+        __syncthreads();
+        flush_carry();
+    }
+    if (STAMPS && tid == 0 && stamps)
+    {
+#pragma unroll
+        for (int i = 0; i < 8; i++) atomicAdd(&stamps[i], acc[i]);
     }
 }
 

@@ -94,6 +94,49 @@ def test_key_distributions_are_stable(G, bits, kind):
 
 
 @pytest.mark.parametrize("bits", DIGIT_BITS)
+@pytest.mark.parametrize("kind", ["zero", "few", "sorted", "high_bits", "mixed_runs"])
+def test_key_distributions_large_tile_geometry(G, bits, kind):
+    """Same, at a size that uses the 1024-thread / large-tile kernels (and, for 8-bit digits, the carry of partial
+    64-byte blocks across tiles): runs of every length, from one element to whole tiles, must stay stable."""
+    n = 5 * (1 << 20) + 12345
+    rng = np.random.default_rng(17)
+    if kind == "zero":
+        keys = np.zeros(n, dtype=np.uint32)
+    elif kind == "few":
+        keys = rng.integers(0, 7, n, dtype=np.uint32) * np.uint32(0x01010101)
+    elif kind == "sorted":
+        keys = np.sort(rng.integers(0, 2**32, n, dtype=np.uint32))
+    elif kind == "high_bits":
+        keys = rng.integers(0, 256, n, dtype=np.uint32) << 24
+    else:
+        # long stretches of one digit interleaved with uniform stretches: run lengths 1 .. tile size
+        keys = rng.integers(0, 2**32, n, dtype=np.uint32)
+        for start in range(0, n, 200000):
+            keys[start:start + 70000] = keys[start]
+    vals = np.arange(n, dtype=np.uint32)
+    gk, gv = gpu_sort(G, keys, vals, bits=bits)
+    ek, ev = O.stable_sort_pairs(keys, vals)
+    assert (gk == ek).all() and (gv == ev).all()
+
+
+def test_small_geometry_forced_matches(G, monkeypatch):
+    """GLU_HIP_SORT_SMALL=1 forces the 256-thread kernels at any size; both geometries give identical output."""
+    n = 4 * (1 << 20) + 99
+    rng = np.random.default_rng(23)
+    keys = rng.integers(0, 2**32, n, dtype=np.uint32)
+    vals = np.arange(n, dtype=np.uint32)
+    ek, ev = O.stable_sort_pairs(keys, vals)
+    monkeypatch.setenv("GLU_HIP_SORT_SMALL", "1")
+    for bits in DIGIT_BITS:
+        gk, gv = gpu_sort(G, keys, vals, bits=bits)
+        assert (gk == ek).all() and (gv == ev).all()
+    monkeypatch.delenv("GLU_HIP_SORT_SMALL")
+    for bits in DIGIT_BITS:
+        gk, gv = gpu_sort(G, keys, vals, bits=bits)
+        assert (gk == ek).all() and (gv == ev).all()
+
+
+@pytest.mark.parametrize("bits", DIGIT_BITS)
 @pytest.mark.parametrize("steps", [1, 2, 3, 4, 5, 6, 7, 8, 9, 1000])
 def test_num_steps(G, bits, steps):
     """Low 4*num_steps bits only (RadixSort.hpp:289,303,331-332).  The sorted pairs equal what the reference
@@ -138,7 +181,7 @@ def test_argument_checks(G):
 
 
 @pytest.mark.parametrize("bits", DIGIT_BITS)
-@pytest.mark.parametrize("n", [2, 4097, 250000])
+@pytest.mark.parametrize("n", [2, 4097, 250000, 3000001])
 def test_u64_keys(G, bits, n):
     rng = np.random.default_rng(n)
     keys = rng.integers(0, 2**64, n, dtype=np.uint64)
@@ -168,11 +211,11 @@ def test_raw_pointer_entry_on_torch_memory(G):
     assert (kt.cpu().numpy().view(np.uint32) == ek).all() and (vt.cpu().numpy().view(np.uint32) == ev).all()
 
 
+@pytest.mark.parametrize("n", [200003, 4 * (1 << 20) + 5])
 @pytest.mark.parametrize("shift,bits", [(24, 8), (28, 4), (0, 8), (13, 5), (31, 1)])
-def test_partition_pass_and_histogram(G, shift, bits):
+def test_partition_pass_and_histogram(G, shift, bits, n):
     import torch
 
-    n = 200003
     rng = np.random.default_rng(shift)
     keys = rng.integers(0, 2**32, n, dtype=np.uint32)
     vals = np.arange(n, dtype=np.uint32)

@@ -1,0 +1,253 @@
+// scatter_bench.hip -- tuning harness for the radix-sort kernels (not part of the product).
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -I gl-radix-sort_amd/csrc -o tools/scatter_bench tools/scatter_bench.hip
+//   ./tools/scatter_bench [log2n]
+// Times one counting pass (count + row scan + scatter) for several geometries, next to a plain copy kernel.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "radix_sort_kernels.hpp"
+
+using namespace glu_hip;
+
+#define CK(x)                                                                                                          \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        hipError_t e = (x);                                                                                            \
+        if (e != hipSuccess)                                                                                           \
+        {                                                                                                              \
+            printf("%s failed: %s\n", #x, hipGetErrorString(e));                                                       \
+            exit(1);                                                                                                   \
+        }                                                                                                              \
+    } while (0)
+
+__global__ void fill_kernel(uint32_t* keys, uint32_t* vals, size_t n, int zero)
+{
+    size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x;
+    size_t stride = (size_t) gridDim.x * blockDim.x;
+    for (; i < n; i += stride)
+    {
+        uint64_t x = i * 0x9E3779B97F4A7C15ull + 0x1234567;
+        x ^= x >> 31; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 29; x *= 0x94D049BB133111EBull; x ^= x >> 32;
+        keys[i] = zero ? 0u : (uint32_t) x;
+        vals[i] = (uint32_t) i;
+    }
+}
+
+__global__ void copy_kernel(const uint4* __restrict__ a, const uint4* __restrict__ b, uint4* __restrict__ c,
+                            uint4* __restrict__ d, size_t nvec)
+{
+    size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x;
+    size_t stride = (size_t) gridDim.x * blockDim.x;
+    for (; i < nvec; i += stride)
+    {
+        c[i] = a[i];
+        d[i] = b[i];
+    }
+}
+
+// copy with selectable access widths (bytes per lane) to see what narrow accesses cost
+template<int LW, int SW>
+__global__ __launch_bounds__(1024) void copy_width_kernel(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b,
+                                                          uint32_t* __restrict__ c, uint32_t* __restrict__ d, size_t n)
+{
+    // each thread moves 16 consecutive dwords of a and of b per iteration
+    const size_t chunk = (size_t) blockDim.x * 16;
+    for (size_t base = (size_t) blockIdx.x * chunk; base < n; base += (size_t) gridDim.x * chunk)
+    {
+        uint32_t ra[16], rb[16];
+        if (LW == 16)
+        {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+            {
+                uint4 x = *reinterpret_cast<const uint4*>(a + base + (j * blockDim.x + threadIdx.x) * 4);
+                uint4 y = *reinterpret_cast<const uint4*>(b + base + (j * blockDim.x + threadIdx.x) * 4);
+                ra[4 * j] = x.x; ra[4 * j + 1] = x.y; ra[4 * j + 2] = x.z; ra[4 * j + 3] = x.w;
+                rb[4 * j] = y.x; rb[4 * j + 1] = y.y; rb[4 * j + 2] = y.z; rb[4 * j + 3] = y.w;
+            }
+        }
+        else
+        {
+#pragma unroll
+            for (int j = 0; j < 16; j++)
+            {
+                ra[j] = a[base + j * blockDim.x + threadIdx.x];
+                rb[j] = b[base + j * blockDim.x + threadIdx.x];
+            }
+        }
+        if (SW == 16)
+        {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+            {
+                *reinterpret_cast<uint4*>(c + base + (j * blockDim.x + threadIdx.x) * 4) = make_uint4(ra[4 * j], ra[4 * j + 1], ra[4 * j + 2], ra[4 * j + 3]);
+                *reinterpret_cast<uint4*>(d + base + (j * blockDim.x + threadIdx.x) * 4) = make_uint4(rb[4 * j], rb[4 * j + 1], rb[4 * j + 2], rb[4 * j + 3]);
+            }
+        }
+        else
+        {
+#pragma unroll
+            for (int j = 0; j < 16; j++)
+            {
+                c[base + j * blockDim.x + threadIdx.x] = ra[j];
+                d[base + j * blockDim.x + threadIdx.x] = rb[j];
+            }
+        }
+    }
+}
+
+__global__ void check_kernel(const uint32_t* keys, const uint32_t* vals, const uint32_t* src_keys, size_t n,
+                             uint32_t shift, uint32_t mask, unsigned long long* bad)
+{
+    size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x;
+    size_t stride = (size_t) gridDim.x * blockDim.x;
+    unsigned long long b = 0;
+    for (; i + 1 < n; i += stride)
+    {
+        uint32_t d0 = (keys[i] >> shift) & mask, d1 = (keys[i + 1] >> shift) & mask;
+        if (d0 > d1) b++;
+        if (d0 == d1 && vals[i] > vals[i + 1]) b++; // stable: vals = iota on input
+        if (src_keys[vals[i]] != keys[i]) b++;
+    }
+    if (b) atomicAdd(bad, b);
+}
+
+struct Ctx
+{
+    uint32_t *keys, *vals, *keys2, *vals2, *table;
+    unsigned long long* bad;
+    size_t n;
+    int cus;
+    hipEvent_t ev[4];
+};
+
+template<typename F>
+float time_min(Ctx& c, int reps, F&& f)
+{
+    float best = 1e30f;
+    for (int r = 0; r < reps; r++)
+    {
+        CK(hipEventRecord(c.ev[0]));
+        f();
+        CK(hipEventRecord(c.ev[1]));
+        CK(hipEventSynchronize(c.ev[1]));
+        float ms;
+        CK(hipEventElapsedTime(&ms, c.ev[0], c.ev[1]));
+        best = std::min(best, ms);
+    }
+    return best;
+}
+
+template<int BITS, int THREADS, int KPT, bool CARRY = true, int ABLATE = 0>
+void run_variant(Ctx& c, int blocks_per_cu, uint32_t shift, uint32_t mask_override = 0)
+{
+    constexpr int RADIX = 1 << BITS;
+    constexpr int TILE = THREADS * KPT;
+    using Smem = ScatterSmem<uint32_t, BITS, THREADS, KPT, CARRY>;
+    const uint32_t tiles = (uint32_t) ((c.n + TILE - 1) / TILE);
+    const uint32_t nb = std::min<uint32_t>(tiles, (uint32_t) (c.cus * blocks_per_cu));
+    uint32_t* totals = c.table + (size_t) RADIX * nb;
+    const uint32_t mask = mask_override ? mask_override : RADIX - 1;
+    if (mask_override) printf("mask %u: ", mask);
+    auto scatter = radix_scatter_kernel<uint32_t, BITS, THREADS, KPT, CARRY, ABLATE, false>;
+    auto scatter_st = radix_scatter_kernel<uint32_t, BITS, THREADS, KPT, CARRY, ABLATE, true>;
+    CK(hipFuncSetAttribute((const void*) scatter_st, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sizeof(Smem)));
+    CK(hipFuncSetAttribute((const void*) scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sizeof(Smem)));
+
+    float t_count = time_min(c, 5, [&] {
+        hipLaunchKernelGGL((radix_count_kernel<uint32_t, BITS, THREADS, TILE>), dim3(nb), dim3(THREADS), 0, 0, c.keys, c.table,
+                           (uint32_t) c.n, shift, mask, tiles);
+    });
+    float t_scan = time_min(c, 1, [&] {
+        hipLaunchKernelGGL((radix_row_scan_kernel<256>), dim3(RADIX), dim3(256), 0, 0, c.table, totals, nb);
+    });
+    float t_scatter = time_min(c, 5, [&] {
+        hipLaunchKernelGGL(scatter, dim3(nb), dim3(THREADS), sizeof(Smem), 0, c.keys, c.vals, c.keys2, c.vals2, c.table,
+                           totals, (uint32_t) c.n, shift, mask, tiles, (unsigned long long*) nullptr);
+    });
+    CK(hipGetLastError());
+    unsigned long long* st;
+    CK(hipMalloc(&st, 64));
+    CK(hipMemset(st, 0, 64));
+    hipLaunchKernelGGL(scatter_st, dim3(nb), dim3(THREADS), sizeof(Smem), 0, c.keys, c.vals, c.keys2, c.vals2, c.table,
+                       totals, (uint32_t) c.n, shift, mask, tiles, st);
+    unsigned long long hst[8];
+    CK(hipMemcpy(hst, st, 64, hipMemcpyDeviceToHost));
+    CK(hipFree(st));
+    CK(hipMemset(c.bad, 0, 8));
+    hipLaunchKernelGGL(check_kernel, dim3(4096), dim3(256), 0, 0, c.keys2, c.vals2, c.keys, c.n, shift, mask, c.bad);
+    unsigned long long bad = 0;
+    CK(hipMemcpy(&bad, c.bad, 8, hipMemcpyDeviceToHost));
+    if (ABLATE) printf("ABLATE %d: ", ABLATE);
+    printf(CARRY ? "carry " : "plain ");
+    printf("bits %d threads %4d kpt %2d tile %5d lds %6zu blk/cu %d nb %5u | count %.3f ms (%.0f GB/s) scan %.3f | scatter %.3f ms "
+           "(%.0f GB/s) | pass %.3f ms %s\n",
+           BITS, THREADS, KPT, TILE, sizeof(Smem), blocks_per_cu, nb, t_count, c.n * 4.0 / t_count / 1e6, t_scan, t_scatter,
+           c.n * 16.0 / t_scatter / 1e6, t_count + t_scan + t_scatter, bad ? "WRONG" : "ok");
+    {
+        double per_tile = 1.0 / (double) tiles; // cycles per tile (100 MHz s_memtime ticks? -> printed raw)
+        const char* names[8] = {"issue", "loadwait", "rank", "bar1", "offsets", "stage", "wout", "bar_end"};
+        printf("    stamps/tile:");
+        for (int i = 0; i < 8; i++) printf(" %s %.0f", names[i], hst[i] * per_tile);
+        printf("\n");
+    }
+    fflush(stdout);
+}
+
+int main(int argc, char** argv)
+{
+    int log2n = argc > 1 ? atoi(argv[1]) : 28;
+    int zero = argc > 2 ? atoi(argv[2]) : 0;
+    Ctx c;
+    c.n = (size_t) 1 << log2n;
+    hipDeviceProp_t p;
+    CK(hipGetDeviceProperties(&p, 0));
+    c.cus = p.multiProcessorCount;
+    printf("%s %s CUs %d, N = 2^%d %s\n", p.name, p.gcnArchName, c.cus, log2n, zero ? "(zero keys)" : "");
+    CK(hipMalloc(&c.keys, c.n * 4));
+    CK(hipMalloc(&c.vals, c.n * 4));
+    CK(hipMalloc(&c.keys2, c.n * 4));
+    CK(hipMalloc(&c.vals2, c.n * 4));
+    CK(hipMalloc(&c.table, (256 * 8192 + 256) * 4));
+    CK(hipMalloc(&c.bad, 8));
+    for (int i = 0; i < 4; i++) CK(hipEventCreate(&c.ev[i]));
+    hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, c.keys, c.vals, c.n, zero);
+    CK(hipDeviceSynchronize());
+
+    for (int g : {2048, 4096, 8192})
+    {
+        float t = time_min(c, 5, [&] {
+            hipLaunchKernelGGL(copy_kernel, dim3(g), dim3(256), 0, 0, (const uint4*) c.keys, (const uint4*) c.vals,
+                               (uint4*) c.keys2, (uint4*) c.vals2, c.n / 4);
+        });
+        printf("copy (2 streams in, 2 out) grid %d: %.3f ms (%.0f GB/s)\n", g, t, c.n * 16.0 / t / 1e6);
+    }
+
+    auto cw = [&](auto kern, const char* name, int g, int th) {
+        float t = time_min(c, 5, [&] { hipLaunchKernelGGL(kern, dim3(g), dim3(th), 0, 0, c.keys, c.vals, c.keys2, c.vals2, c.n); });
+        printf("copy %s grid %d x %d: %.3f ms (%.0f GB/s)\n", name, g, th, t, c.n * 16.0 / t / 1e6);
+    };
+    cw(copy_width_kernel<16, 16>, "ld16 st16", 256, 1024);
+    cw(copy_width_kernel<4, 4>, "ld4  st4 ", 256, 1024);
+    const uint32_t shift = 8; // any digit of uniform keys
+    if (argc > 3)
+    { // short list for counter collection (rocprofv3 --pmc)
+        run_variant<8, 1024, 12, true>(c, 1, shift);
+        run_variant<8, 1024, 12, false>(c, 1, shift);
+        run_variant<4, 1024, 16, true>(c, 1, shift);
+        return 0;
+    }
+    run_variant<8, 1024, 12, true>(c, 1, shift);
+    run_variant<8, 1024, 12, true>(c, 1, shift, 127);
+    run_variant<8, 1024, 12, true>(c, 1, shift, 63);
+    run_variant<8, 1024, 12, true>(c, 1, shift, 15);
+    run_variant<8, 1024, 12, false>(c, 1, shift, 15);
+    run_variant<8, 1024, 12, true>(c, 1, shift, 3);
+    run_variant<4, 1024, 16, false>(c, 1, shift);
+    run_variant<4, 1024, 12, false>(c, 1, shift);
+    return 0;
+}
