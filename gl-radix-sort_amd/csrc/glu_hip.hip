@@ -706,6 +706,11 @@ struct glu_scan_s
 {
     glu_data_type type;
     Scratch sums;
+    // chained (single-pass) scan state for 4-byte element types: one 64-bit word per chunk + a ticket counter
+    Scratch chain;
+    Scratch ticket;
+    uint32_t epoch = 0;
+    bool chained = true; // GLU_HIP_SCAN_CHAINED=0 falls back to reduce-then-scan
 };
 
 struct glu_reduce_s
@@ -731,6 +736,41 @@ size_t scan_scratch_elems(size_t count, size_t partitions)
         total += c * partitions;
     }
     return total;
+}
+
+// single-pass chained scan (4-byte element types, more than one chunk per partition)
+template<typename S, int N>
+glu_status scan_chained(glu_scan_s* scan, Elem<S, N>* data, size_t count, size_t partitions, hipStream_t stream)
+{
+    using T = Elem<S, N>;
+    using C = ScanCfg<T, kChainGroups>;
+    const size_t chunks = (count + C::CHUNK - 1) / C::CHUNK;
+    const size_t words = chunks * partitions;
+    if (scan->chain.size < words * sizeof(unsigned long long))
+    {
+        GLU_TRY(scan->chain.reserve(words * sizeof(unsigned long long)));
+        HIP_TRY(hipMemsetAsync(scan->chain.ptr, 0, scan->chain.size, stream)); // epoch 0 = never ready
+        scan->epoch = 0;
+    }
+    GLU_TRY(scan->ticket.reserve(256));
+    if (++scan->epoch >= (1u << 30))
+    {
+        HIP_TRY(hipMemsetAsync(scan->chain.ptr, 0, scan->chain.size, stream));
+        scan->epoch = 1;
+    }
+    HIP_TRY(hipMemsetAsync(scan->ticket.ptr, 0, 16, stream));
+    const bool aligned = ((uintptr_t) data % 16 == 0) && (partitions == 1 || (count * sizeof(T)) % 16 == 0);
+    const dim3 grid((uint32_t) words);
+    if (aligned)
+        hipLaunchKernelGGL((scan_chunks_kernel<S, N, true, true>), grid, dim3(C::THREADS), 0, stream, data, (const T*) nullptr,
+                           (uint64_t) count, (uint32_t) chunks, (unsigned long long*) scan->chain.ptr,
+                           (uint32_t*) scan->ticket.ptr, scan->epoch);
+    else
+        hipLaunchKernelGGL((scan_chunks_kernel<S, N, false, true>), grid, dim3(C::THREADS), 0, stream, data, (const T*) nullptr,
+                           (uint64_t) count, (uint32_t) chunks, (unsigned long long*) scan->chain.ptr,
+                           (uint32_t*) scan->ticket.ptr, scan->epoch);
+    HIP_TRY(hipGetLastError());
+    return GLU_OK;
 }
 
 template<typename S, int N>
@@ -776,6 +816,25 @@ struct ScanRunner
     glu_status operator()()
     {
         using T = Elem<S, N>;
+        if constexpr (sizeof(T) == 4)
+        {
+            const size_t chunks = (count + ScanCfg<T, kChainGroups>::CHUNK - 1) / ScanCfg<T, kChainGroups>::CHUNK;
+            if (scan->chained && chunks > 1 && chunks * partitions <= 0x7FFFFFFFull)
+            {
+                if (size_only)
+                {
+                    GLU_TRY(scan->ticket.reserve(256));
+                    if (scan->chain.size < chunks * partitions * 8)
+                    {
+                        GLU_TRY(scan->chain.reserve(chunks * partitions * 8));
+                        HIP_TRY(hipMemset(scan->chain.ptr, 0, scan->chain.size));
+                        scan->epoch = 0;
+                    }
+                    return GLU_OK;
+                }
+                return scan_chained<S, N>(scan, (T*) data, count, partitions, stream);
+            }
+        }
         size_t need = scan_scratch_elems<T>(count, partitions) * sizeof(T);
         if (need) GLU_TRY(scan->sums.reserve(need));
         if (size_only) return GLU_OK;
@@ -839,6 +898,7 @@ glu_status glu_scan_create(glu_data_type data_type, glu_scan* out)
         return fail(GLU_ERROR_INVALID_ARGUMENT, "Invalid data type: %d", (int) data_type);
     glu_scan_s* s = new glu_scan_s();
     s->type = data_type;
+    if (const char* e = getenv("GLU_HIP_SCAN_CHAINED")) s->chained = atoi(e) != 0;
     *out = s;
     return GLU_OK;
 }
@@ -848,6 +908,8 @@ glu_status glu_scan_destroy(glu_scan scan)
     if (!scan) return GLU_OK;
     (void) hipStreamSynchronize(g_dev.queue);
     scan->sums.release();
+    scan->chain.release();
+    scan->ticket.release();
     delete scan;
     return GLU_OK;
 }

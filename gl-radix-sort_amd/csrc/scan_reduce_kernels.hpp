@@ -107,13 +107,16 @@ __device__ __forceinline__ T shfl_t(const T& v, int src)
 // ---- scan -------------------------------------------------------------------------------------------------
 // A chunk = THREADS * GROUPS * VEC elements.  Inside a wave the layout is "group-major, then lane, then the VEC
 // elements of a 16-byte vector", so every load/store instruction of a wave is one contiguous 1 KiB.
-template<typename T>
+// GROUPS_ = 4: 4096 4-byte elements per chunk (reduce-then-scan path); the chained path uses 16 (16384 elements, 64 KiB
+// per workgroup) so that the single ticket counter sees ~16 K atomics for 2^28 elements instead of 65 K (one global
+// counter sustains only ~90 returning atomics per microsecond on MI355X).
+template<typename T, int GROUPS_ = 4>
 struct ScanCfg
 {
     static constexpr int THREADS = 256;
     static constexpr int WAVES = THREADS / kW;
     static constexpr int VEC = sizeof(T) >= 16 ? 1 : 16 / (int) sizeof(T);
-    static constexpr int GROUPS = 4;
+    static constexpr int GROUPS = GROUPS_;
     static constexpr int WAVE_ELEMS = kW * GROUPS * VEC;
     static constexpr int CHUNK = WAVES * WAVE_ELEMS;
 };
@@ -126,12 +129,12 @@ struct alignas(sizeof(T) * VEC >= 16 ? 16 : sizeof(T) * VEC) Pack
 
 // Loads the calling wave's elements of one chunk.  `base` points at the chunk start, `valid` = elements of the
 // chunk that exist (the rest read as zero).
-template<typename S, int N, bool ALIGNED>
+template<typename S, int N, bool ALIGNED, int GROUPS = 4>
 __device__ __forceinline__ void scan_load(const Elem<S, N>* base, uint32_t valid, uint32_t wave, uint32_t lane,
-                                          Elem<S, N> (&x)[ScanCfg<Elem<S, N>>::GROUPS][ScanCfg<Elem<S, N>>::VEC])
+                                          Elem<S, N> (&x)[GROUPS][ScanCfg<Elem<S, N>>::VEC])
 {
     using T = Elem<S, N>;
-    using C = ScanCfg<T>;
+    using C = ScanCfg<T, GROUPS>;
 #pragma unroll
     for (int g = 0; g < C::GROUPS; g++)
     {
@@ -185,23 +188,51 @@ __global__ __launch_bounds__(256) void scan_chunk_sums_kernel(const Elem<S, N>* 
     }
 }
 
-// In-place exclusive scan of every chunk, plus carry[partition * chunks + chunk] when carry != nullptr.
-template<typename S, int N, bool ALIGNED>
+// ---- chained scan state (single-pass "decoupled look-back") ---------------------------------------------------
+// One 64-bit word per chunk, written and read with agent-scope relaxed atomics (one aligned 8-byte store: the data IS
+// the flag, no separate release/acquire needed): [63:34] epoch of the launch, [33:32] 1 = chunk total, 2 = inclusive
+// prefix up to and including the chunk, [31:0] the 4-byte value.  Words of older epochs read as "not ready", so the
+// array is zeroed once at allocation, never per launch.
+constexpr uint64_t kChainLocal = 1, kChainGlobal = 2;
+__device__ __forceinline__ uint64_t chain_pack(uint32_t epoch, uint64_t flag, uint32_t value)
+{
+    return ((uint64_t) epoch << 34) | (flag << 32) | value;
+}
+constexpr int kChainGroups = 16;              // 16-byte load groups per thread in the chained kernel
+constexpr uint32_t kChainSpinLimit = 1u << 24; // polls before the kernel gives up loudly (trap) instead of hanging
+
+// In-place exclusive scan of every chunk.
+//   CHAINED = false: carry-in from carry[partition * chunks + chunk] (nullptr = 0): the reduce-then-scan path.
+//   CHAINED = true (4-byte element types): single pass.  Chunks are taken in ticket order (so every chunk a
+//   workgroup waits for is already running), each publishes its total, looks back over its predecessors' words for
+//   the carry-in, then publishes its inclusive prefix.  8 B/element of HBM traffic instead of 12.
+template<typename S, int N, bool ALIGNED, bool CHAINED = false>
 __global__ __launch_bounds__(256) void scan_chunks_kernel(Elem<S, N>* __restrict__ data,
                                                           const Elem<S, N>* __restrict__ carry, uint64_t count,
-                                                          uint32_t chunks)
+                                                          uint32_t chunks, unsigned long long* __restrict__ chain = nullptr,
+                                                          uint32_t* __restrict__ ticket = nullptr, uint32_t epoch = 0)
 {
     using T = Elem<S, N>;
-    using C = ScanCfg<T>;
+    using C = ScanCfg<T, CHAINED ? kChainGroups : 4>;
+    static_assert(!CHAINED || sizeof(T) == 4, "chained scan packs the value into 32 bits");
     __shared__ T wsum[C::WAVES];
+    __shared__ uint32_t s_ticket;
+    __shared__ T s_prefix;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t chunk = blockIdx.x % chunks, part = blockIdx.x / chunks; // grid = partitions * chunks
+    uint32_t linear = blockIdx.x;
+    if (CHAINED)
+    {
+        if (tid == 0) s_ticket = atomicAdd(ticket, 1u);
+        __syncthreads();
+        linear = s_ticket;
+    }
+    const uint32_t chunk = linear % chunks, part = linear / chunks; // grid = partitions * chunks
     const uint64_t cbeg = (uint64_t) chunk * C::CHUNK;
     const uint32_t valid = (count - cbeg) < (uint64_t) C::CHUNK ? (uint32_t) (count - cbeg) : (uint32_t) C::CHUNK;
     T* base = data + (uint64_t) part * count + cbeg;
 
     T x[C::GROUPS][C::VEC];
-    scan_load<S, N, ALIGNED>(base, valid, wave, lane, x);
+    scan_load<S, N, ALIGNED, C::GROUPS>(base, valid, wave, lane, x);
 
     // per group: lane-local exclusive over the VEC elements, then a wave scan of the lane sums
     T gexcl[C::GROUPS]; // exclusive prefix of this lane inside its group
@@ -229,7 +260,80 @@ __global__ __launch_bounds__(256) void scan_chunks_kernel(Elem<S, N>* __restrict
     if (lane == 0) wsum[wave] = wave_total;
     __syncthreads();
 
-    T run = carry ? carry[(uint64_t) part * chunks + chunk] : zero_elem<S, N>();
+    T run = zero_elem<S, N>();
+    if (CHAINED)
+    {
+        if (wave == 0)
+        {
+            T total = wsum[0];
+#pragma unroll
+            for (int w = 1; w < C::WAVES; w++) total = combine<OP_SUM>(total, wsum[w]);
+            union { T t; uint32_t u; } cv;
+            unsigned long long* words = chain + (uint64_t) part * chunks;
+            T prefix = zero_elem<S, N>();
+            if (chunk == 0)
+            {
+                cv.t = total;
+                if (lane == 0)
+                    __hip_atomic_store(&words[0], chain_pack(epoch, kChainGlobal, cv.u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            else
+            {
+                cv.t = total;
+                if (lane == 0)
+                    __hip_atomic_store(&words[chunk], chain_pack(epoch, kChainLocal, cv.u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // look back: lane l examines chunk (look - l); the window moves 64 chunks at a time
+                int look = (int) chunk - 1;
+                uint32_t spins = 0;
+                for (;;)
+                {
+                    const int idx = look - (int) lane;
+                    uint64_t w = chain_pack(epoch, kChainGlobal, 0u); // before the partition's first chunk: prefix 0
+                    if (idx >= 0) w = __hip_atomic_load(&words[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint64_t flag = (w >> 32) & 3u;
+                    const bool ready = (uint32_t) (w >> 34) == epoch && flag != 0;
+                    const uint64_t ready_mask = __ballot(ready);
+                    const uint64_t global_mask = __ballot(ready && flag == kChainGlobal);
+                    uint64_t need = ~0ull; // lanes whose values are summed this round
+                    bool done = false;
+                    if (global_mask != 0)
+                    {
+                        const int g = __builtin_ctzll(global_mask); // nearest predecessor with an inclusive prefix
+                        need = g == 63 ? ~0ull : ((1ull << (g + 1)) - 1);
+                        done = true;
+                    }
+                    if ((ready_mask & need) == need)
+                    {
+                        union { T t; uint32_t u; } v;
+                        v.u = (uint32_t) w;
+                        T part_sum = ((need >> lane) & 1ull) ? v.t : zero_elem<S, N>();
+#pragma unroll
+                        for (int off = 32; off > 0; off >>= 1) part_sum = combine<OP_SUM>(part_sum, shfl_down_t(part_sum, off));
+                        part_sum = shfl_t(part_sum, 0);
+                        prefix = combine<OP_SUM>(part_sum, prefix);
+                        if (done) break;
+                        look -= kW;
+                        spins = 0;
+                    }
+                    else
+                    {
+                        if (++spins > kChainSpinLimit) __builtin_trap(); // fail loudly, never hang
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                }
+                cv.t = combine<OP_SUM>(prefix, total);
+                if (lane == 0)
+                    __hip_atomic_store(&words[chunk], chain_pack(epoch, kChainGlobal, cv.u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (lane == 0) s_prefix = prefix;
+        }
+        __syncthreads();
+        run = s_prefix;
+    }
+    else if (carry)
+    {
+        run = carry[(uint64_t) part * chunks + chunk];
+    }
 #pragma unroll
     for (int w = 0; w < C::WAVES; w++)
         if ((uint32_t) w < wave) run = combine<OP_SUM>(run, wsum[w]);

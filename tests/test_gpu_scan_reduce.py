@@ -62,6 +62,31 @@ def test_scan_non_power_of_two_through_raw_pointer_entry(G, count):
     assert (b.get_data(np.uint32) == O.exclusive_scan_u32(d, count, parts)).all()
 
 
+@pytest.mark.parametrize("chained", ["1", "0"])
+def test_scan_chained_and_reduce_then_scan_paths_agree(G, monkeypatch, chained):
+    """4-byte types use the single-pass chained scan (decoupled look-back) by default; GLU_HIP_SCAN_CHAINED=0 selects the
+    3-launch reduce-then-scan path that the wider types always use.  Both must equal the oracle."""
+    monkeypatch.setenv("GLU_HIP_SCAN_CHAINED", chained)
+    rng = np.random.default_rng(int(chained))
+    for dt, npdt in ((G.DataType_Uint, np.uint32), (G.DataType_Int, np.int32), (G.DataType_Float, np.float32)):
+        scan = G.BlellochScan(dt)
+        for count, parts in ((1 << 13, 5), (1 << 20, 3), (1 << 25 if npdt != np.float32 else 1 << 22, 1), (16384 * 65 + 7, 2)):
+            raw = rng.integers(0, 4, count * parts)
+            d = (raw * (0.5 if npdt == np.float32 else 1)).astype(npdt)  # float partial sums stay exact
+            b = G.ShaderStorageBuffer(d)
+            scan.run_ptr(b.device_ptr(), count, parts)
+            got = b.get_data(npdt).reshape(parts, count)
+            x = d.reshape(parts, count)
+            exp = np.zeros_like(x)
+            exp[:, 1:] = np.cumsum(x.astype(np.float64 if npdt == np.float32 else np.int64), axis=1)[:, :-1].astype(npdt)
+            assert (got == exp).all(), (dt, count, parts)
+        for rep in range(3):  # epochs: the chain words of earlier launches must read as "not ready"
+            d = rng.integers(0, 2**32, 1 << 22, dtype=np.uint32)
+            b = G.ShaderStorageBuffer(d)
+            G.BlellochScan(G.DataType_Uint)(b, 1 << 22)
+            assert (b.get_data(np.uint32) == O.exclusive_scan_u32(d, 1 << 22)).all()
+
+
 def test_scan_argument_checks(G):
     scan = G.BlellochScan(G.DataType_Uint)
     b = G.ShaderStorageBuffer(np.arange(16, dtype=np.uint32))
