@@ -39,6 +39,8 @@ def parse_args():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample-log2", type=int, default=25)
     p.add_argument("--no-verify", action="store_true")
+    p.add_argument("--force-dist", action="store_true",
+                   help="run the multi-GPU code path (partition + all-to-all + local sort) even with one rank")
     return p.parse_args()
 
 
@@ -150,15 +152,23 @@ def main():
 
     G.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=device)
+        if "MASTER_ADDR" not in os.environ:
+            os.environ["MASTER_ADDR"] = "127.0.0.1"
+            os.environ.setdefault("MASTER_PORT", "29577")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     log2n = args.log2_keys if args.log2_keys is not None else (28 if world == 1 else 27)
     n = 1 << log2n
     K, W = args.steps, args.warmup
-    stream = torch.cuda.current_stream().cuda_stream
+    # everything runs on one explicit torch stream: the handle of torch's default stream is 0, which the C ABI
+    # reads as "use the library's own queue"
+    work_stream = torch.cuda.Stream(device=device)
+    torch.cuda.set_stream(work_stream)
+    stream = work_stream.cuda_stream
+    assert stream != 0
 
     def barrier():
         if dist is not None:
@@ -166,7 +176,7 @@ def main():
         torch.cuda.synchronize()
 
     result = {}
-    if world == 1:
+    if world == 1 and not args.force_dist:
         sorter = G.RadixSort(digit_bits=args.digit_bits)
         sorter.prepare_internal_buffers(n)
         keys0, vals0 = make_input(torch, n, args.keys, 0, device)
@@ -308,7 +318,7 @@ def main():
                        "parallelism": parallelism, "device": G.device_info()},
         }
         line.update(result)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.force_dist and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_sample_log2)
         print(json.dumps(line), flush=True)
 

@@ -95,25 +95,30 @@ __global__ __launch_bounds__(THREADS) void radix_count_kernel(const KeyT* __rest
     using VecT = typename std::conditional<sizeof(KeyT) == 4, uint4, ulonglong2>::type;
     const uint64_t nvec = (end - begin) / VEC;
     const VecT* vkeys = reinterpret_cast<const VecT*>(keys + begin); // begin % TILE == 0 and keys is 16-B aligned
-    uint64_t vbase = 0;
-    for (; vbase + 2 * THREADS <= nvec; vbase += 2 * THREADS) // block-uniform trip count
-    {
-        VecT a = vkeys[vbase + tid];
-        VecT b = vkeys[vbase + tid + THREADS];
+    auto tally_vec = [&](const VecT& a) {
         if constexpr (sizeof(KeyT) == 4)
         {
             tally(digit_of<uint32_t>(a.x, shift, MASK)); tally(digit_of<uint32_t>(a.y, shift, MASK));
             tally(digit_of<uint32_t>(a.z, shift, MASK)); tally(digit_of<uint32_t>(a.w, shift, MASK));
-            tally(digit_of<uint32_t>(b.x, shift, MASK)); tally(digit_of<uint32_t>(b.y, shift, MASK));
-            tally(digit_of<uint32_t>(b.z, shift, MASK)); tally(digit_of<uint32_t>(b.w, shift, MASK));
         }
         else
         {
             tally(digit_of<uint64_t>(a.x, shift, MASK)); tally(digit_of<uint64_t>(a.y, shift, MASK));
-            tally(digit_of<uint64_t>(b.x, shift, MASK)); tally(digit_of<uint64_t>(b.y, shift, MASK));
         }
+    };
+    uint64_t vbase = 0;
+    for (; vbase + 4 * THREADS <= nvec; vbase += 4 * THREADS) // block-uniform trip count, 4 x 16 B in flight per lane
+    {
+        VecT a = vkeys[vbase + tid];
+        VecT b = vkeys[vbase + tid + THREADS];
+        VecT c = vkeys[vbase + tid + 2 * THREADS];
+        VecT d = vkeys[vbase + tid + 3 * THREADS];
+        tally_vec(a);
+        tally_vec(b);
+        tally_vec(c);
+        tally_vec(d);
     }
-    // tail (< 2 * THREADS vectors + a partial vector): plain per-key atomics, lanes may be inactive
+    // tail (< 4 * THREADS vectors + a partial vector): plain per-key atomics, lanes may be inactive
     for (uint64_t i = begin + vbase * VEC + tid; i < end; i += THREADS)
         atomicAdd(&my_hist[digit_of<KeyT>(keys[i], shift, MASK)], 1u);
     __syncthreads();

@@ -76,7 +76,12 @@ class HipLocalOps:
         self.sorter = RadixSort(digit_bits=digit_bits)
 
     def _stream(self):
-        return self.torch.cuda.current_stream().cuda_stream
+        # NOTE: the handle of torch's default stream is 0, which the C ABI reads as "use the library queue";
+        # DistributedRadixSort therefore always runs inside its own (non-default) torch stream.
+        h = self.torch.cuda.current_stream().cuda_stream
+        if h == 0:
+            raise RuntimeError("HipLocalOps must run under a non-default torch stream (torch.cuda.stream(...))")
+        return h
 
     def prepare(self, count):
         self.sorter.prepare_internal_buffers(count)
@@ -106,6 +111,7 @@ class DistributedRadixSort:
         self.capacity_factor = capacity_factor
         self._bufs = None
         self.last_plan = None
+        self._stream = None
 
     def _buffers(self, n_local, device, need_recv=0):
         cap = max(int(n_local * self.capacity_factor) + 4096, need_recv)
@@ -149,6 +155,21 @@ class DistributedRadixSort:
                                    group=self.group)
 
     def sort(self, keys, vals):
+        """Runs on a private torch stream (ordered after the caller's current stream on entry, and the caller's
+        stream waits for it on exit), so the raw-pointer kernels, the RCCL calls and torch ops share one queue."""
+        if not keys.is_cuda:
+            return self._sort(keys, vals)
+        t = self.torch
+        if self._stream is None:
+            self._stream = t.cuda.Stream(device=keys.device)
+        caller = t.cuda.current_stream(keys.device)
+        self._stream.wait_stream(caller)
+        with t.cuda.stream(self._stream):
+            out = self._sort(keys, vals)
+        caller.wait_stream(self._stream)
+        return out
+
+    def _sort(self, keys, vals):
         t, dist = self.torch, self.dist
         n_local = keys.numel()
         b = self._buffers(n_local, keys.device)

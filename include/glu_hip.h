@@ -17,7 +17,8 @@
  *     library, the analogue of the thread's GL command queue) and return without waiting for the GPU,
  *     like the reference's operator() (glu/RadixSort.hpp:273-334 never blocks).  glu_buffer_read() and
  *     glu_device_synchronize() wait.  *_ptr entry points take raw device pointers plus a caller stream
- *     (a hipStream_t passed as void*; NULL = the library queue);
+ *     (a hipStream_t passed as void*; NULL = the library queue -- to target HIP's null stream pass the
+ *     hipStreamLegacy / hipStreamPerThread handle, not 0);
  *   - no function allocates device memory inside a sort/scan/reduce call once the matching
  *     *_prepare() has been called with a count at least as large (glu/RadixSort.hpp:237-271:
  *     grow-only scratch).

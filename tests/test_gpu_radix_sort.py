@@ -205,10 +205,14 @@ def test_raw_pointer_entry_on_torch_memory(G):
     kt = torch.from_numpy(keys.view(np.int32)).cuda()
     vt = torch.from_numpy(vals.view(np.int32)).cuda()
     sorter = G.RadixSort()
-    sorter.run_ptr(kt.data_ptr(), vt.data_ptr(), n, 0, torch.cuda.current_stream().cuda_stream)
-    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):  # a caller-owned stream (handle != 0; 0 would mean "the library queue")
+        assert side.cuda_stream != 0
+        sorter.run_ptr(kt.data_ptr(), vt.data_ptr(), n, 0, side.cuda_stream)
+        out_k, out_v = kt.cpu(), vt.cpu()  # ordered on the same stream: no device-wide sync needed
     ek, ev = O.stable_sort_pairs(keys, vals)
-    assert (kt.cpu().numpy().view(np.uint32) == ek).all() and (vt.cpu().numpy().view(np.uint32) == ev).all()
+    assert (out_k.numpy().view(np.uint32) == ek).all() and (out_v.numpy().view(np.uint32) == ev).all()
 
 
 @pytest.mark.parametrize("n", [200003, 4 * (1 << 20) + 5])
@@ -224,9 +228,9 @@ def test_partition_pass_and_histogram(G, shift, bits, n):
     ok, ov = torch.empty_like(kt), torch.empty_like(vt)
     hist = torch.zeros(1 << bits, dtype=torch.int32, device="cuda")
     sorter = G.RadixSort()
-    sorter.partition_ptr(kt.data_ptr(), vt.data_ptr(), ok.data_ptr(), ov.data_ptr(), n, shift, bits, hist.data_ptr(),
-                         torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
+    sorter.partition_ptr(kt.data_ptr(), vt.data_ptr(), ok.data_ptr(), ov.data_ptr(), n, shift, bits, hist.data_ptr(), None)
+    G.synchronize()  # stream None = the library queue
     d = ((keys >> shift) & ((1 << bits) - 1)).astype(np.int64)
     order = np.argsort(d, kind="stable")
     assert (ok.cpu().numpy().view(np.uint32) == keys[order]).all()
