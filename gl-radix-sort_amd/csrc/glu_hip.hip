@@ -356,7 +356,7 @@ template<> struct GeometryFor<uint32_t, 8, true> : Geometry<1024, 12, 1, true> {
 template<> struct GeometryFor<uint32_t, 4, true> : Geometry<1024, 12, 1, false> {};
 template<> struct GeometryFor<uint32_t, 8, false> : Geometry<256, 16, 3, false> {};
 template<> struct GeometryFor<uint32_t, 4, false> : Geometry<256, 16, 3, false> {};
-template<> struct GeometryFor<uint64_t, 8, true> : Geometry<1024, 8, 1, false> {};
+template<> struct GeometryFor<uint64_t, 8, true> : Geometry<512, 16, 1, true> {};
 template<> struct GeometryFor<uint64_t, 4, true> : Geometry<1024, 8, 1, false> {};
 template<> struct GeometryFor<uint64_t, 8, false> : Geometry<256, 8, 4, false> {};
 template<> struct GeometryFor<uint64_t, 4, false> : Geometry<256, 8, 4, false> {};
@@ -427,7 +427,10 @@ glu_status launch_pass(glu_radix_sort_s* s, const KeyT* src_k, const uint32_t* s
     }
 
     s->mark(stream);
-    hipLaunchKernelGGL((radix_count_kernel<KeyT, BITS, G::THREADS, G::TILE>), dim3(nb), dim3(G::THREADS), 0, stream,
+    // the count kernel only shares TILE and the grid with the scatter kernel; 1024 threads keep enough loads in flight
+    // when there is one workgroup per CU
+    constexpr int COUNT_THREADS = LARGE ? 1024 : G::THREADS;
+    hipLaunchKernelGGL((radix_count_kernel<KeyT, BITS, COUNT_THREADS, G::TILE>), dim3(nb), dim3(COUNT_THREADS), 0, stream,
                        src_k, table, (uint32_t) count, shift, mask, tiles);
     s->mark(stream);
     hipLaunchKernelGGL((radix_row_scan_kernel<256>), dim3(RADIX), dim3(256), 0, stream, table, totals, nb);

@@ -210,13 +210,15 @@ struct PairArray<uint64_t, COUNT>
 
 constexpr int kBlockElems = 16; // 64-byte write block of 4-byte elements: the granule the carry keeps whole
 
-template<typename KeyT, int BITS, int THREADS, int KPT, bool CARRY>
+template<typename KeyT, int BITS, int THREADS, int KPT, bool CARRY, int ROUNDS = 1>
 struct ScatterSmem
 {
     static constexpr int RADIX = 1 << BITS;
     static constexpr int WAVES = THREADS / kWave;
     static constexpr int TILE = THREADS * KPT;
-    PairArray<KeyT, TILE> stage;                                 // the tile in ranked order
+    static constexpr int STAGE = TILE / ROUNDS;                  // ranked positions staged per round
+    static_assert(KPT % ROUNDS == 0, "a round writes out KPT / ROUNDS positions per thread");
+    PairArray<KeyT, STAGE> stage;                                // one round of the tile in ranked order
     PairArray<KeyT, CARRY ? RADIX * kBlockElems : 1> carry;      // per digit: elements of a not yet complete 64-B block
     uint32_t wcnt[WAVES][RADIX]; // wave-private running digit counters -> first ranked position of (wave, digit)
     uint32_t tstart[RADIX];      // first ranked position of each digit in the tile
@@ -240,14 +242,22 @@ struct ScatterSmem
 // ABLATE (tuning builds only, results are wrong for != 0): 1 = write every tile back linearly (prices the
 // scattered stores).  STAMPS (diagnostic builds): wave 0 of every workgroup adds the s_memtime cycles of each
 // phase to stamps[0..7].
+//
+// ROUNDS > 1: the tile is ROUNDS times larger than the LDS staging area.  Keys, values and ranked positions stay in
+// registers; round r stages and writes out the ranked positions [r * STAGE, (r + 1) * STAGE).  A digit's run per tile
+// (TILE / RADIX elements) gets ROUNDS times longer for the same LDS, which is what the 64-byte-granular scattered
+// writes of wide digits need.  EXPERIMENTAL, not used by the library: with 1024 threads x 24 keys hipcc 7.2 spills
+// ~145 dwords per lane (it also hoists lane-constant shuffle addresses out of the tile loop) and the kernel runs 4x
+// slower; it needs the values to be loaded per round instead of being held in registers.
 template<typename KeyT, int BITS, int THREADS, int KPT, bool CARRY = true, int ABLATE = 0, bool STAMPS = false,
-         int MIN_WAVES_PER_SIMD = 1>
+         int MIN_WAVES_PER_SIMD = 1, int ROUNDS = 1>
 __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_kernel(
     const KeyT* __restrict__ src_keys, const uint32_t* __restrict__ src_vals, KeyT* __restrict__ dst_keys,
     uint32_t* __restrict__ dst_vals, const uint32_t* __restrict__ table, const uint32_t* __restrict__ totals,
     uint32_t n, uint32_t shift, uint32_t mask, uint32_t tiles_total, unsigned long long* stamps = nullptr)
 {
-    using Smem = ScatterSmem<KeyT, BITS, THREADS, KPT, CARRY>;
+    using Smem = ScatterSmem<KeyT, BITS, THREADS, KPT, CARRY, ROUNDS>;
+    constexpr int STAGE = Smem::STAGE;
     constexpr int RADIX = Smem::RADIX;
     constexpr int WAVES = Smem::WAVES;
     constexpr int TILE = Smem::TILE;
@@ -460,43 +470,56 @@ __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_ker
             }
             digit_base += len;
         }
-        // ---- stage in ranked order
+        // ---- ranked position of every item (rank[] becomes the position inside the tile)
 #pragma unroll
         for (int i = 0; i < KPT; i++)
         {
-            const uint32_t d = digit_of<KeyT>(key[i], shift, MASK);
-            s.stage.put(my_cnt[d] + rank[i], key[i], val[i]);
-        }
-        __syncthreads();
-        stamp(5); // stage + barrier
-
-        if (CARRY)
-        {
-            flush_carry(); // old carry out before the write-out below refills the slots
-            __syncthreads();
+            rank[i] += my_cnt[digit_of<KeyT>(key[i], shift, MASK)];
         }
 
-        // ---- write out: consecutive threads -> consecutive ranked positions -> (per digit) consecutive addresses
 #pragma unroll
-        for (int i = 0; i < KPT; i++)
+        for (int r = 0; r < ROUNDS; r++)
         {
-            const uint32_t p = i * THREADS + tid;
-            if (p < tile_valid)
+            // ---- stage the ranked positions [r * STAGE, (r + 1) * STAGE)
+#pragma unroll
+            for (int i = 0; i < KPT; i++)
             {
-                KeyT k;
-                uint32_t v;
-                s.stage.get(p, k, v);
-                const uint32_t wd = digit_of<KeyT>(k, shift, MASK);
-                uint32_t g = p + s.gdelta[wd];
-                if (CARRY && g >= s.wend[wd])
-                {
-                    s.carry.put(wd * BLK + (g & (BLK - 1)), k, v);
-                    continue;
+                const uint32_t pos = rank[i] - (uint32_t) (r * STAGE);
+                if (ROUNDS == 1 || pos < (uint32_t) STAGE) s.stage.put(pos, key[i], val[i]);
                 }
-                if (ABLATE == 1) g = (uint32_t) tile_base + p;
-                dst_keys[g] = k;
-                dst_vals[g] = v;
+            __syncthreads();
+            if (r == 0) stamp(5); // stage + barrier
+
+            if (CARRY && r == 0)
+            {
+                flush_carry(); // old carry out before the write-out below refills the slots
+                __syncthreads();
             }
+
+            // ---- write out: consecutive threads -> consecutive ranked positions -> (per digit) consecutive addresses
+#pragma unroll
+            for (int i = 0; i < KPT / ROUNDS; i++)
+            {
+                const uint32_t q = i * THREADS + tid;       // position inside the staging area
+                const uint32_t p = r * STAGE + q;           // ranked position inside the tile
+                if (p < tile_valid)
+                {
+                    KeyT k;
+                    uint32_t v;
+                    s.stage.get(q, k, v);
+                    const uint32_t wd = digit_of<KeyT>(k, shift, MASK);
+                    uint32_t g = p + s.gdelta[wd];
+                    if (CARRY && g >= s.wend[wd])
+                    {
+                        s.carry.put(wd * BLK + (g & (BLK - 1)), k, v);
+                        continue;
+                    }
+                    if (ABLATE == 1) g = (uint32_t) tile_base + p;
+                    dst_keys[g] = k;
+                    dst_vals[g] = v;
+                }
+            }
+            if (r + 1 < ROUNDS) __syncthreads(); // the next round overwrites the staging area
         }
         for (int i = tid; i < WAVES * RADIX; i += THREADS) (&s.wcnt[0][0])[i] = 0;
         stamp(6); // write-out issue

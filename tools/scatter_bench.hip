@@ -142,19 +142,19 @@ float time_min(Ctx& c, int reps, F&& f)
     return best;
 }
 
-template<int BITS, int THREADS, int KPT, bool CARRY = true, int ABLATE = 0>
+template<int BITS, int THREADS, int KPT, bool CARRY = true, int ABLATE = 0, int ROUNDS = 1>
 void run_variant(Ctx& c, int blocks_per_cu, uint32_t shift, uint32_t mask_override = 0)
 {
     constexpr int RADIX = 1 << BITS;
     constexpr int TILE = THREADS * KPT;
-    using Smem = ScatterSmem<uint32_t, BITS, THREADS, KPT, CARRY>;
+    using Smem = ScatterSmem<uint32_t, BITS, THREADS, KPT, CARRY, ROUNDS>;
     const uint32_t tiles = (uint32_t) ((c.n + TILE - 1) / TILE);
     const uint32_t nb = std::min<uint32_t>(tiles, (uint32_t) (c.cus * blocks_per_cu));
     uint32_t* totals = c.table + (size_t) RADIX * nb;
     const uint32_t mask = mask_override ? mask_override : RADIX - 1;
     if (mask_override) printf("mask %u: ", mask);
-    auto scatter = radix_scatter_kernel<uint32_t, BITS, THREADS, KPT, CARRY, ABLATE, false>;
-    auto scatter_st = radix_scatter_kernel<uint32_t, BITS, THREADS, KPT, CARRY, ABLATE, true>;
+    auto scatter = radix_scatter_kernel<uint32_t, BITS, THREADS, KPT, CARRY, ABLATE, false, 1, ROUNDS>;
+    auto scatter_st = radix_scatter_kernel<uint32_t, BITS, THREADS, KPT, CARRY, ABLATE, true, 1, ROUNDS>;
     CK(hipFuncSetAttribute((const void*) scatter_st, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sizeof(Smem)));
     CK(hipFuncSetAttribute((const void*) scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sizeof(Smem)));
 
@@ -184,6 +184,7 @@ void run_variant(Ctx& c, int blocks_per_cu, uint32_t shift, uint32_t mask_overri
     CK(hipMemcpy(&bad, c.bad, 8, hipMemcpyDeviceToHost));
     if (ABLATE) printf("ABLATE %d: ", ABLATE);
     printf(CARRY ? "carry " : "plain ");
+    if (ROUNDS > 1) printf("rounds %d ", ROUNDS);
     printf("bits %d threads %4d kpt %2d tile %5d lds %6zu blk/cu %d nb %5u | count %.3f ms (%.0f GB/s) scan %.3f | scatter %.3f ms "
            "(%.0f GB/s) | pass %.3f ms %s\n",
            BITS, THREADS, KPT, TILE, sizeof(Smem), blocks_per_cu, nb, t_count, c.n * 4.0 / t_count / 1e6, t_scan, t_scatter,
@@ -242,12 +243,12 @@ int main(int argc, char** argv)
         return 0;
     }
     run_variant<8, 1024, 12, true>(c, 1, shift);
-    run_variant<8, 1024, 12, true>(c, 1, shift, 127);
-    run_variant<8, 1024, 12, true>(c, 1, shift, 63);
-    run_variant<8, 1024, 12, true>(c, 1, shift, 15);
-    run_variant<8, 1024, 12, false>(c, 1, shift, 15);
-    run_variant<8, 1024, 12, true>(c, 1, shift, 3);
-    run_variant<4, 1024, 16, false>(c, 1, shift);
+    run_variant<8, 1024, 24, true, 0, 2>(c, 1, shift);
+    run_variant<8, 512, 48, true, 0, 2>(c, 1, shift);
+    run_variant<8, 512, 24, true, 0, 1>(c, 1, shift);
+    run_variant<8, 512, 72, true, 0, 3>(c, 1, shift);
     run_variant<4, 1024, 12, false>(c, 1, shift);
+    run_variant<4, 1024, 24, false, 0, 2>(c, 1, shift);
+    run_variant<8, 1024, 12, true>(c, 1, shift);
     return 0;
 }
