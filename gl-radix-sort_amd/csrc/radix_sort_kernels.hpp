@@ -93,8 +93,11 @@ __global__ __launch_bounds__(THREADS) void radix_count_kernel(const KeyT* __rest
 
     constexpr int VEC = 16 / sizeof(KeyT); // 16-byte loads
     using VecT = typename std::conditional<sizeof(KeyT) == 4, uint4, ulonglong2>::type;
-    const uint64_t nvec = (end - begin) / VEC;
-    const VecT* vkeys = reinterpret_cast<const VecT*>(keys + begin); // begin % TILE == 0 and keys is 16-B aligned
+    // 16-byte loads need a 16-byte aligned array (begin is a multiple of TILE); an unaligned array (a sub-range handed
+    // in by the caller) takes the element-wise tail loop for everything
+    const bool vec_ok = (reinterpret_cast<uintptr_t>(keys) & 15u) == 0;
+    const uint64_t nvec = vec_ok ? (end - begin) / VEC : 0;
+    const VecT* vkeys = reinterpret_cast<const VecT*>(keys + begin);
     auto tally_vec = [&](const VecT& a) {
         if constexpr (sizeof(KeyT) == 4)
         {
@@ -119,8 +122,16 @@ __global__ __launch_bounds__(THREADS) void radix_count_kernel(const KeyT* __rest
         tally_vec(d);
     }
     // tail (< 4 * THREADS vectors + a partial vector): plain per-key atomics, lanes may be inactive
-    for (uint64_t i = begin + vbase * VEC + tid; i < end; i += THREADS)
-        atomicAdd(&my_hist[digit_of<KeyT>(keys[i], shift, MASK)], 1u);
+    uint64_t i = begin + vbase * VEC + tid;
+    for (; i + 7ull * THREADS < end; i += 8ull * THREADS) // 8 loads in flight per lane
+    {
+        KeyT k[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) k[j] = keys[i + (uint64_t) j * THREADS];
+#pragma unroll
+        for (int j = 0; j < 8; j++) atomicAdd(&my_hist[digit_of<KeyT>(k[j], shift, MASK)], 1u);
+    }
+    for (; i < end; i += THREADS) atomicAdd(&my_hist[digit_of<KeyT>(keys[i], shift, MASK)], 1u);
     __syncthreads();
 
     for (int d = tid; d < RADIX; d += THREADS)
@@ -250,7 +261,7 @@ struct ScatterSmem
 // ~145 dwords per lane (it also hoists lane-constant shuffle addresses out of the tile loop) and the kernel runs 4x
 // slower; it needs the values to be loaded per round instead of being held in registers.
 template<typename KeyT, int BITS, int THREADS, int KPT, bool CARRY = true, int ABLATE = 0, bool STAMPS = false,
-         int MIN_WAVES_PER_SIMD = 1, int ROUNDS = 1>
+         int MIN_WAVES_PER_SIMD = 1, int ROUNDS = 1, bool PREFETCH = false>
 __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_kernel(
     const KeyT* __restrict__ src_keys, const uint32_t* __restrict__ src_vals, KeyT* __restrict__ dst_keys,
     uint32_t* __restrict__ dst_vals, const uint32_t* __restrict__ table, const uint32_t* __restrict__ totals,
@@ -335,22 +346,18 @@ __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_ker
         }
     };
 
-    for (uint32_t tile = first; tile < last; tile++)
-    {
-        const uint64_t tile_base = (uint64_t) tile * TILE;
-        const uint64_t rem = (uint64_t) n - tile_base;
-        const uint32_t tile_valid = rem < (uint64_t) TILE ? (uint32_t) rem : (uint32_t) TILE;
-        if (STAMPS) tprev = __builtin_amdgcn_s_memtime();
-
-        // ---- load
-        KeyT key[KPT];
-        uint32_t val[KPT];
-        if (tile_valid == (uint32_t) TILE)
+    // loads one tile into registers (wave-striped); positions past the end of the array read as pads
+    KeyT key[KPT];
+    uint32_t val[KPT];
+    auto load_tile = [&](uint32_t t) {
+        const uint64_t base = (uint64_t) t * TILE;
+        const uint64_t left = (uint64_t) n - base;
+        if (left >= (uint64_t) TILE)
         {
 #pragma unroll
-            for (int i = 0; i < KPT; i++) key[i] = src_keys[tile_base + wave_off + i * kWave];
+            for (int i = 0; i < KPT; i++) key[i] = src_keys[base + wave_off + i * kWave];
 #pragma unroll
-            for (int i = 0; i < KPT; i++) val[i] = src_vals[tile_base + wave_off + i * kWave];
+            for (int i = 0; i < KPT; i++) val[i] = src_vals[base + wave_off + i * kWave];
         }
         else
         {
@@ -358,11 +365,23 @@ __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_ker
             for (int i = 0; i < KPT; i++)
             {
                 const uint32_t p = wave_off + i * kWave;
-                const bool ok = p < tile_valid;
-                key[i] = ok ? src_keys[tile_base + p] : (KeyT) ~(KeyT) 0; // pad: last digit, ranks after all real keys
-                val[i] = ok ? src_vals[tile_base + p] : 0u;
+                const bool ok = p < (uint32_t) left;
+                key[i] = ok ? src_keys[base + p] : (KeyT) ~(KeyT) 0; // pad: last digit, ranks after all real keys
+                val[i] = ok ? src_vals[base + p] : 0u;
             }
         }
+    };
+    if (PREFETCH && first < last) load_tile(first);
+
+    for (uint32_t tile = first; tile < last; tile++)
+    {
+        const uint64_t tile_base = (uint64_t) tile * TILE;
+        const uint64_t rem = (uint64_t) n - tile_base;
+        const uint32_t tile_valid = rem < (uint64_t) TILE ? (uint32_t) rem : (uint32_t) TILE;
+        if (STAMPS) tprev = __builtin_amdgcn_s_memtime();
+
+        // ---- load (PREFETCH: already issued while the previous tile was being written out)
+        if (!PREFETCH) load_tile(tile);
         if (STAMPS)
         {
             stamp(0); // issue
@@ -489,6 +508,9 @@ __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_ker
                 }
             __syncthreads();
             if (r == 0) stamp(5); // stage + barrier
+            // keys and values now live in LDS: their registers are free, so the next tile's loads are issued here
+            // (ahead of this tile's stores in the memory queue) and complete under the write-out and the next rank phase
+            if (PREFETCH && r == ROUNDS - 1 && tile + 1 < last) load_tile(tile + 1);
 
             if (CARRY && r == 0)
             {
@@ -542,6 +564,138 @@ __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_ker
     {
 #pragma unroll
         for (int i = 0; i < 8; i++) atomicAdd(&stamps[i], acc[i]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Whole sort in ONE workgroup for inputs that fit one tile (n <= THREADS * KPT): every pass ranks, scans and
+// re-stages the tile in LDS; only the first load and the last store touch memory.  Replaces 3 launches per pass (the
+// reference needs 32 dispatches for N = 1024, README: 0.66 ms) with a single launch.
+// ---------------------------------------------------------------------------------------------------------
+template<typename KeyT, int BITS, int THREADS, int KPT>
+struct SingleBlockSmem
+{
+    static constexpr int RADIX = 1 << BITS;
+    static constexpr int WAVES = THREADS / kWave;
+    static constexpr int TILE = THREADS * KPT;
+    PairArray<KeyT, TILE> stage;
+    uint32_t wcnt[WAVES][RADIX];
+    uint32_t scan_tmp[WAVES];
+};
+
+template<typename KeyT, int BITS, int THREADS, int KPT>
+__global__ __launch_bounds__(THREADS) void radix_sort_single_block_kernel(KeyT* __restrict__ keys,
+                                                                          uint32_t* __restrict__ vals, uint32_t n,
+                                                                          uint32_t total_bits)
+{
+    using Smem = SingleBlockSmem<KeyT, BITS, THREADS, KPT>;
+    constexpr int RADIX = Smem::RADIX;
+    constexpr int WAVES = Smem::WAVES;
+    constexpr int WAVE_TILE = kWave * KPT;
+    constexpr int WQ = WAVES / 4;
+    constexpr int SCAN_THREADS = RADIX * WQ;
+    constexpr int SCAN_WAVES = (SCAN_THREADS + kWave - 1) / kWave;
+    static_assert(WAVES % 4 == 0 && SCAN_THREADS <= THREADS, "offset scan geometry");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    Smem& s = *reinterpret_cast<Smem*>(smem_raw);
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t wave_off = wave * WAVE_TILE + lane;
+
+    KeyT key[KPT];
+    uint32_t val[KPT];
+#pragma unroll
+    for (int i = 0; i < KPT; i++)
+    {
+        const uint32_t p = wave_off + i * kWave;
+        const bool ok = p < n;
+        key[i] = ok ? keys[p] : (KeyT) ~(KeyT) 0; // pads carry the highest digit in every pass: they stay at the end
+        val[i] = ok ? vals[p] : 0u;
+    }
+
+    uint32_t* my_cnt = s.wcnt[wave];
+    for (uint32_t shift = 0; shift < total_bits; shift += BITS)
+    {
+        const uint32_t bits = total_bits - shift < (uint32_t) BITS ? total_bits - shift : (uint32_t) BITS;
+        const uint32_t MASK = (1u << bits) - 1;
+        for (int i = tid; i < WAVES * RADIX; i += THREADS) (&s.wcnt[0][0])[i] = 0;
+        __syncthreads();
+
+        uint32_t rank[KPT];
+#pragma unroll
+        for (int i = 0; i < KPT; i++)
+        {
+            const uint32_t d = digit_of<KeyT>(key[i], shift, MASK);
+            uint32_t* const cnt = my_cnt + d;
+            const uint32_t prev = *cnt;
+            uint32_t plo = ~0u, phi = ~0u;
+#pragma unroll
+            for (int bit = 0; bit < BITS; bit++)
+            {
+                const int32_t sel = __builtin_amdgcn_sbfe((int32_t) d, bit, 1);
+                const uint64_t m = __ballot(sel < 0);
+                plo = __builtin_amdgcn_bitop3_b32(plo, (uint32_t) m, (uint32_t) sel, 0x90);
+                phi = __builtin_amdgcn_bitop3_b32(phi, (uint32_t) (m >> 32), (uint32_t) sel, 0x90);
+            }
+            const uint32_t lower = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
+            const uint32_t total = (uint32_t) __popc(plo) + (uint32_t) __popc(phi);
+            rank[i] = prev + lower;
+            *cnt = prev + total;
+        }
+        __syncthreads();
+
+        {
+            const uint32_t sd = tid / WQ, sw = (tid % WQ) * 4;
+            uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+            if (tid < SCAN_THREADS)
+            {
+                c0 = s.wcnt[sw + 0][sd];
+                c1 = s.wcnt[sw + 1][sd];
+                c2 = s.wcnt[sw + 2][sd];
+                c3 = s.wcnt[sw + 3][sd];
+            }
+            uint32_t excl = 0;
+            if (wave < SCAN_WAVES)
+            {
+                uint32_t wtotal;
+                excl = wave_exclusive_sum(c0 + c1 + c2 + c3, lane, wtotal);
+                if (SCAN_WAVES > 1 && lane == 0) s.scan_tmp[wave] = wtotal;
+            }
+            if (SCAN_WAVES > 1)
+            {
+                __syncthreads();
+#pragma unroll
+                for (int w = 0; w < SCAN_WAVES - 1; w++)
+                    if ((uint32_t) w < wave) excl += s.scan_tmp[w];
+            }
+            if (tid < SCAN_THREADS)
+            {
+                s.wcnt[sw + 0][sd] = excl;
+                s.wcnt[sw + 1][sd] = excl + c0;
+                s.wcnt[sw + 2][sd] = excl + c0 + c1;
+                s.wcnt[sw + 3][sd] = excl + c0 + c1 + c2;
+            }
+        }
+        __syncthreads();
+
+#pragma unroll
+        for (int i = 0; i < KPT; i++)
+            s.stage.put(my_cnt[digit_of<KeyT>(key[i], shift, MASK)] + rank[i], key[i], val[i]);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < KPT; i++) s.stage.get(wave_off + i * kWave, key[i], val[i]);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int i = 0; i < KPT; i++)
+    {
+        const uint32_t p = wave_off + i * kWave;
+        if (p < n)
+        {
+            keys[p] = key[i];
+            vals[p] = val[i];
+        }
     }
 }
 

@@ -149,6 +149,29 @@ def test_num_steps(G, bits, steps):
     assert (gk == ref["result_keys"]).all() and (gv == ref["result_vals"]).all()
 
 
+@pytest.mark.parametrize("n", [2, 777, 1024, 1025, 4096, 4097, 12288])
+@pytest.mark.parametrize("steps", [0, 1, 3, 5, 8])
+def test_single_workgroup_path(G, n, steps, monkeypatch):
+    """n <= 12288 pairs (8192 for 64-bit keys) are sorted by one workgroup in one launch; the multi-kernel path
+    (GLU_HIP_SORT_NO_SINGLE_BLOCK=1) must give the same pairs."""
+    rng = np.random.default_rng(n * 10 + steps)
+    keys = rng.integers(0, 2**32, n, dtype=np.uint32)
+    keys[::5] = keys[0]
+    vals = np.arange(n, dtype=np.uint32)
+    ref = O.radix_sort_reference(keys, vals, num_steps=steps)
+    gk, gv = gpu_sort(G, keys, vals, num_steps=steps)
+    assert (gk == ref["result_keys"]).all() and (gv == ref["result_vals"]).all()
+    monkeypatch.setenv("GLU_HIP_SORT_NO_SINGLE_BLOCK", "1")
+    gk2, gv2 = gpu_sort(G, keys, vals, num_steps=steps)
+    assert (gk2 == gk).all() and (gv2 == gv).all()
+    k64 = rng.integers(0, 2**64, min(n, 8192), dtype=np.uint64)
+    v64 = np.arange(k64.size, dtype=np.uint32)
+    monkeypatch.delenv("GLU_HIP_SORT_NO_SINGLE_BLOCK")
+    gk, gv = gpu_sort(G, k64, v64, num_steps=2 * steps, key_bytes=8)
+    ek, ev = O.stable_sort_pairs(k64, v64, key_bits=64 if steps in (0, 8) else 8 * steps)
+    assert (gk == ek).all() and (gv == ev).all()
+
+
 def test_prepare_then_no_growth_and_reuse(G):
     sorter = G.RadixSort()
     sorter.prepare_internal_buffers(1 << 20)
