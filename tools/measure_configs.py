@@ -1,0 +1,54 @@
+"""Times the BASELINE.json configurations that fit one GPU (device time via the library timer, best of 5 on
+restored inputs).  python tools/measure_configs.py"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "gl-radix-sort_amd"))
+import numpy as np
+import glu_hip as G
+
+print(G.device_info())
+rng = np.random.default_rng(0x5EED)
+
+
+def time_sort(keys, vals, bits, key_bytes=4, reps=5):
+    n = keys.size
+    s = G.RadixSort(digit_bits=bits)
+    s.prepare_internal_buffers(n, key_bytes=key_bytes)
+    k0, v0 = G.ShaderStorageBuffer(keys), G.ShaderStorageBuffer(vals)
+    k, v = G.ShaderStorageBuffer(size=keys.nbytes), G.ShaderStorageBuffer(size=vals.nbytes)
+    best = 1e18
+    for _ in range(reps):
+        G.check(G.lib().glu_buffer_copy(k0.handle(), k.handle(), keys.nbytes, 0, 0))
+        G.check(G.lib().glu_buffer_copy(v0.handle(), v.handle(), vals.nbytes, 0, 0))
+        best = min(best, G.measure_elapsed_time(lambda: s(k, v, n, 0, key_bytes=key_bytes)))
+    return best * 1e-9
+
+
+rows = []
+for name, log2n, kind, key_bytes in (("C2 2^20 u32+u32 uniform", 20, "uniform", 4), ("C3 2^28 u32+u32 uniform", 28, "uniform", 4),
+                                     ("   2^28 u32+u32 all-zero keys (README input)", 28, "zero", 4),
+                                     ("C5 2^28 u64+u32 uniform", 28, "uniform", 8)):
+    n = 1 << log2n
+    if key_bytes == 4:
+        keys = rng.integers(0, 2**32, n, dtype=np.uint32) if kind == "uniform" else np.zeros(n, dtype=np.uint32)
+    else:
+        keys = rng.integers(0, 2**64, n, dtype=np.uint64)
+    vals = np.arange(n, dtype=np.uint32)
+    for bits in (8, 4):
+        t = time_sort(keys, vals, bits, key_bytes)
+        passes = (8 * key_bytes) // bits
+        bpp = passes * (3 * key_bytes + 8)
+        print("%-46s digits %d-bit: %8.3f ms  %9.1f Mkeys/s  %6.0f GB/s at %d B/pair (%.1f %% of 8 TB/s)" % (
+            name, bits, t * 1e3, n / t / 1e6, n * bpp / t / 1e9, bpp, n * bpp / t / 8e12 * 100), flush=True)
+
+n = 1 << 28
+d = rng.integers(0, 2**32, n, dtype=np.uint32)
+b = G.ShaderStorageBuffer(d)
+sc = G.BlellochScan(G.DataType_Uint)
+sc(b, n)
+t = min(G.measure_elapsed_time(lambda: sc(b, n)) for _ in range(5)) * 1e-9
+print("BlellochScan 2^28 u32: %.3f ms  %.0f GB/s at 8 B/elem (%.1f %%)" % (t * 1e3, n * 8 / t / 1e9, n * 8 / t / 8e12 * 100))
+rd = G.Reduce(G.DataType_Uint, G.ReduceOperator_Sum)
+rd(b, n)
+t = min(G.measure_elapsed_time(lambda: rd(b, n)) for _ in range(5)) * 1e-9
+print("Reduce 2^28 u32 sum:   %.3f ms  %.0f GB/s at 4 B/elem (%.1f %%)" % (t * 1e3, n * 4 / t / 1e9, n * 4 / t / 8e12 * 100))
