@@ -219,7 +219,10 @@ struct PairArray<uint64_t, COUNT>
     }
 };
 
-constexpr int kBlockElems = 16; // 64-byte write block of 4-byte elements: the granule the carry keeps whole
+#ifndef GLU_CARRY_ELEMS
+#define GLU_CARRY_ELEMS 16 // tuning builds may override (tools/scatter_bench.hip)
+#endif
+constexpr int kBlockElems = GLU_CARRY_ELEMS; // 16 x 4 B = the 64-byte write block the carry keeps whole
 
 template<typename KeyT, int BITS, int THREADS, int KPT, bool CARRY, int ROUNDS = 1>
 struct ScatterSmem
