@@ -156,4 +156,47 @@ TEST_CASE("RadixSort-reuse-and-prepare")
     }
 }
 
+TEST_CASE("RadixSort-u64-keys")
+{
+    // 64-bit keys + 32-bit values (BASELINE config 5; not in the reference): same stable contract
+    std::mt19937_64 gen(0xC0FFEE);
+    for (size_t n : {2, 5000, 70001, 3 * (1 << 20) + 17})
+    {
+        std::vector<uint64_t> keys(n);
+        for (auto& k : keys) k = gen() >> (gen() % 3 == 0 ? 40 : 0); // mix of wide and narrow keys, duplicates in the narrow ones
+        std::vector<GLuint> vals(n);
+        std::iota(vals.begin(), vals.end(), 0u);
+        std::vector<GLuint> order(vals);
+        std::stable_sort(order.begin(), order.end(), [&](GLuint a, GLuint b) { return keys[a] < keys[b]; });
+
+        ShaderStorageBuffer key_buffer(keys), val_buffer(vals);
+        RadixSort radix_sort;
+        radix_sort.prepare_internal_buffers_u64(n);
+        radix_sort.sort_u64(key_buffer.handle(), val_buffer.handle(), n);
+        std::vector<uint64_t> out_keys = key_buffer.get_data<uint64_t>();
+        std::vector<GLuint> out_vals = val_buffer.get_data<GLuint>();
+        bool same = true;
+        for (size_t i = 0; i < n; i++) same = same && out_vals[i] == order[i] && out_keys[i] == keys[order[i]];
+        CHECK(same);
+    }
+}
+
+TEST_CASE("RadixSort-raw-pointer-overload")
+{
+    // native callers: raw device pointers (here taken from ShaderStorageBuffer) on the library queue
+    std::mt19937 gen(31);
+    const size_t n = 200003;
+    std::vector<GLuint> keys(n), vals(n);
+    for (auto& k : keys) k = gen();
+    std::iota(vals.begin(), vals.end(), 0u);
+    ShaderStorageBuffer kb(keys), vb(vals);
+    RadixSort radix_sort;
+    radix_sort(static_cast<uint32_t*>(kb.device_ptr()), static_cast<uint32_t*>(vb.device_ptr()), n, 0, nullptr);
+    std::vector<GLuint> sk = kb.get_data<GLuint>(), sv = vb.get_data<GLuint>();
+    check_sorted(sk);
+    bool paired = true;
+    for (size_t i = 0; i < n; i++) paired = paired && keys[sv[i]] == sk[i];
+    CHECK(paired);
+}
+
 int main(int argc, char** argv) { return mini_test::run(argc, argv); }

@@ -172,6 +172,45 @@ def test_single_workgroup_path(G, n, steps, monkeypatch):
     assert (gk == ek).all() and (gv == ev).all()
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_randomized_stress(G, seed):
+    """Random sizes around tile / workgroup-range boundaries, random key shapes, both digit widths, random num_steps:
+    every result must equal the stable sort by the masked key (= what the reference computes)."""
+    rng = np.random.default_rng(1000 + seed)
+    sorters = {4: G.RadixSort(digit_bits=4), 8: G.RadixSort(digit_bits=8)}
+    for _ in range(12):
+        base = int(rng.choice([1, 64, 4096, 12288, 12288 * 256, 4096 * 768, 1 << 20, 3 * (1 << 20)]))
+        n = max(2, base * int(rng.integers(1, 3)) + int(rng.integers(-70, 70)))
+        n = min(n, 7 * (1 << 20))
+        shape = rng.integers(0, 6)
+        if shape == 0:
+            keys = rng.integers(0, 2**32, n, dtype=np.uint32)
+        elif shape == 1:  # few distinct values anywhere in the 32 bits
+            pool = rng.integers(0, 2**32, int(rng.integers(1, 40)), dtype=np.uint32)
+            keys = pool[rng.integers(0, pool.size, n)]
+        elif shape == 2:  # one byte varies
+            keys = (rng.integers(0, 256, n, dtype=np.uint32) << np.uint32(8 * int(rng.integers(0, 4)))) | np.uint32(0x01020304)
+        elif shape == 3:  # sorted runs of random length
+            keys = np.sort(rng.integers(0, 2**32, n, dtype=np.uint32))
+            cut = int(rng.integers(1, n))
+            keys = np.concatenate([keys[cut:], keys[:cut]])
+        elif shape == 4:  # long constant stretches between random ones
+            keys = rng.integers(0, 2**32, n, dtype=np.uint32)
+            for _ in range(int(rng.integers(1, 6))):
+                a = int(rng.integers(0, n)); b = min(n, a + int(rng.integers(1, 200000)))
+                keys[a:b] = keys[a]
+        else:  # digits skewed towards the extremes
+            keys = np.where(rng.integers(0, 10, n) < 8, 0xFFFFFFFF, rng.integers(0, 2**32, n)).astype(np.uint32)
+        vals = rng.integers(0, 2**32, n, dtype=np.uint32) if rng.integers(0, 2) else np.arange(n, dtype=np.uint32)
+        steps = int(rng.choice([0, 0, 0, 1, 2, 3, 5, 7, 8]))
+        bits = int(rng.choice([4, 8]))
+        kb, vb = G.ShaderStorageBuffer(keys), G.ShaderStorageBuffer(vals)
+        sorters[bits](kb, vb, n, steps)
+        ek, ev = O.stable_sort_pairs(keys, vals, key_bits=32 if steps in (0, 8) else 4 * steps)
+        gk, gv = kb.get_data(np.uint32), vb.get_data(np.uint32)
+        assert (gk == ek).all() and (gv == ev).all(), (n, int(shape), steps, bits)
+
+
 def test_prepare_then_no_growth_and_reuse(G):
     sorter = G.RadixSort()
     sorter.prepare_internal_buffers(1 << 20)

@@ -180,3 +180,21 @@ def test_stable_sort_u64():
     k, v = O.stable_sort_pairs(keys, vals)
     idx = np.argsort(keys, kind="stable")
     assert (k == keys[idx]).all() and (v == idx.astype(np.uint32)).all()
+
+
+def test_radix_literal_vs_stable_sort_randomized():
+    """Many random (size, key range, num_steps): the literal restatement of the shaders equals the stable sort by the
+    masked key -- the property every GPU parity test relies on for sizes where the literal form is too slow."""
+    rng = np.random.default_rng(2024)
+    for _ in range(150):
+        n = int(rng.integers(0, 6000))
+        hi = int(rng.choice([2, 10, 300, 70000, 2**32]))
+        keys = rng.integers(0, hi, n, dtype=np.uint64).astype(np.uint32)
+        if rng.integers(0, 2):
+            keys = keys << np.uint32(rng.integers(0, 24))
+        vals = rng.integers(0, 2**32, n, dtype=np.uint32)
+        steps = int(rng.integers(0, 10))
+        res = O.radix_sort_reference(keys, vals, num_steps=steps)
+        eff = 8 if steps == 0 or steps > 8 else steps
+        ek, ev = O.stable_sort_pairs(keys, vals, key_bits=4 * eff) if n > 1 else (keys, vals)
+        assert (res["result_keys"] == ek).all() and (res["result_vals"] == ev).all(), (n, hi, steps)
