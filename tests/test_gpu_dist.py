@@ -37,3 +37,69 @@ def test_single_rank_nccl_distributed_sort(built):
             assert (kt.cpu().numpy().view(np.uint32) == keys).all()  # input untouched
     finally:
         dist.destroy_process_group()
+
+
+def _gpu_worker(rank, world, port, n_local, q):
+    """One of `world` processes sharing GPU 0: real device ops (HipLocalOps), gloo as the transport (RCCL refuses two
+    ranks on one GPU) -- exercises uneven splits, the plan and the receive ordering with the real kernels."""
+    import os
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (os.path.join(root, "gl-radix-sort_amd"), os.path.join(root, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from glu_hip import dist as D
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(50 + rank)
+        n = n_local + 1000 * rank
+        keys = rng.integers(0, 2**32, n, dtype=np.uint32)
+        keys[::9] = np.uint32(0x80000000 | rank)  # duplicates within and across ranks
+        if rank == 1:
+            keys[: n // 2] |= np.uint32(0xF0000000)  # skew: rank 1 is heavy in the top buckets
+        base = sum(n_local + 1000 * r for r in range(rank))
+        vals = np.arange(base, base + n, dtype=np.uint32)
+        sorter = D.DistributedRadixSort()
+        kt = torch.from_numpy(keys.view(np.int32).copy()).cuda()
+        vt = torch.from_numpy(vals.view(np.int32).copy()).cuda()
+        rk, rv, cnt = sorter.sort(kt, vt)
+        torch.cuda.synchronize()
+        q.put((rank, keys, vals, rk[:cnt].cpu().numpy().view(np.uint32).copy(), rv[:cnt].cpu().numpy().view(np.uint32).copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_multi_process_one_gpu_gloo_transport(built, world):
+    import socket
+
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gpu_worker, args=(r, world, port, 1 << 20, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    all_keys = np.concatenate([r[1] for r in results])
+    all_vals = np.concatenate([r[2] for r in results])
+    ek, ev = O.stable_sort_pairs(all_keys, all_vals)
+    gk = np.concatenate([r[3] for r in results])
+    gv = np.concatenate([r[4] for r in results])
+    assert gk.size == ek.size
+    assert (gk == ek).all() and (gv == ev).all()
