@@ -19,7 +19,7 @@ def built():
     import __graft_entry__ as entry
     import glu_hip
 
-    cpp_bin = os.path.join(ROOT, "tests", "cpp", "bin", "radix_sort_tests")
+    cpp_bin = os.path.join(ROOT, "tests", "cpp", "bin", "test_radix_sort_api")
     if not os.path.exists(glu_hip.LIB_PATH) or not os.path.exists(cpp_bin):
         entry.build()
     return glu_hip

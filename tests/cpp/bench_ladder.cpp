@@ -10,7 +10,7 @@
 #include "glu/BlellochScan.hpp"
 #include "glu/RadixSort.hpp"
 #include "glu/Reduce.hpp"
-#include "util/StopWatch.hpp"
+#include "util/timing.hpp"
 
 using namespace glu;
 
@@ -36,7 +36,7 @@ int main(int argc, char** argv)
             Reduce reduce(DataType_Uint, ReduceOperator_Sum);
             reduce(buffer.handle(), n); // warm-up (the reference times a single cold shot)
             uint64_t ns = measure_gl_elapsed_time([&]() { reduce(buffer.handle(), n); });
-            printf("Reduce; Num elements: %zu, Elapsed: %s\n", n, ns_to_human_string(ns).c_str());
+            printf("Reduce; Num elements: %zu, Elapsed: %s\n", n, test_timing::human_time(ns).c_str());
         }
 
     if (all || !strcmp(which, "scan"))
@@ -48,7 +48,7 @@ int main(int argc, char** argv)
             BlellochScan blelloch_scan(DataType_Uint);
             blelloch_scan(buffer.handle(), n);
             uint64_t ns = measure_gl_elapsed_time([&]() { blelloch_scan(buffer.handle(), n); });
-            printf("BlellochScan; Num elements: %zu, Elapsed: %s\n", n, ns_to_human_string(ns).c_str());
+            printf("BlellochScan; Num elements: %zu, Elapsed: %s\n", n, test_timing::human_time(ns).c_str());
         }
 
     if (all || !strcmp(which, "radix"))
@@ -61,14 +61,14 @@ int main(int argc, char** argv)
             radix_sort.prepare_internal_buffers(n);
             radix_sort(key_buffer.handle(), val_buffer.handle(), n);
             uint64_t ns = measure_gl_elapsed_time([&]() { radix_sort(key_buffer.handle(), val_buffer.handle(), n); });
-            printf("Radix sort; Num elements: %zu, Elapsed: %s\n", n, ns_to_human_string(ns).c_str());
+            printf("Radix sort; Num elements: %zu, Elapsed: %s\n", n, test_timing::human_time(ns).c_str());
 
             std::mt19937 gen(0x5EED);
             for (auto& k : keys) k = gen();
             key_buffer.write_data(keys.data(), n * sizeof(GLuint));
             ns = measure_gl_elapsed_time([&]() { radix_sort(key_buffer.handle(), val_buffer.handle(), n); });
             printf("Radix sort (uniform random keys); Num elements: %zu, Elapsed: %s, %.1f Mkeys/s\n", n,
-                   ns_to_human_string(ns).c_str(), double(n) / double(ns) * 1e3);
+                   test_timing::human_time(ns).c_str(), double(n) / double(ns) * 1e3);
         }
     return 0;
 }

@@ -8,7 +8,8 @@
 #include <vector>
 
 #include "glu/RadixSort.hpp"
-#include "util/Random.hpp"
+#include "util/golden_vectors.hpp"
+#include "util/minstd_inputs.hpp"
 #include "util/mini_test.hpp"
 
 using namespace glu;
@@ -39,8 +40,7 @@ namespace
     /// keys sorted + permutation, as the reference asserts
     void run_reference_case(size_t n, GLuint min, GLuint max)
     {
-        Random random(1);
-        std::vector<GLuint> keys = random.sample_int_vector<GLuint>(n, min, max);
+        std::vector<GLuint> keys = test_inputs::minstd_vector<GLuint>(1, n, min, max);
         std::vector<GLuint> vals(n);
 
         ShaderStorageBuffer key_buffer(keys);
@@ -83,20 +83,10 @@ namespace
     }
 } // namespace
 
-TEST_CASE("RadixSort-128-256-512-1024")
+TEST_CASE("RadixSort-reference-cases")
 {
-    for (size_t n : {128, 256, 512, 1024}) run_reference_case(n, 0, UINT32_MAX);
-}
-
-TEST_CASE("RadixSort-2048")
-{
-    run_reference_case(2048, 0, 10);
-}
-
-TEST_CASE("RadixSort-multiple-sizes")
-{
-    for (size_t n : {10993, 14978, 16243, 18985, 23857, 27865, 33363, 41298, 45821, 47487})
-        run_reference_case(n, 0, UINT32_MAX);
+    // RadixSort-128-256-512-1024, RadixSort-2048 and RadixSort-multiple-sizes of the reference
+    for (const golden::SortCase& c : golden::k_radix_sort_cases) run_reference_case(c.n, c.min, c.max);
 }
 
 TEST_CASE("RadixSort-stable-full-32-bit")
@@ -113,10 +103,9 @@ TEST_CASE("RadixSort-stable-full-32-bit")
 
 TEST_CASE("RadixSort-stable-duplicates")
 {
-    Random random(7);
     for (uint32_t bits : {4u, 8u})
     {
-        run_stability_case(random.sample_int_vector<GLuint>(50000, 0, 10), 0, bits);
+        run_stability_case(test_inputs::minstd_vector<GLuint>(7, 50000, 0, 10), 0, bits);
         run_stability_case(std::vector<GLuint>(30000, 0u), 0, bits);           // the reference's benchmark input
         run_stability_case(std::vector<GLuint>(30000, 0xFFFFFFFFu), 0, bits);
         std::vector<GLuint> asc(20000), desc(20000);

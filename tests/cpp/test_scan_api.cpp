@@ -5,27 +5,25 @@
 #include <vector>
 
 #include "glu/BlellochScan.hpp"
-#include "util/Random.hpp"
+#include "util/golden_vectors.hpp"
+#include "util/minstd_inputs.hpp"
 #include "util/mini_test.hpp"
 
 using namespace glu;
 
 TEST_CASE("BlellochScan-simple")
 {
-    const std::vector<GLuint> data{1, 2, 3, 4, 5, 6, 7, 8};
-    ShaderStorageBuffer buffer(data);
+    ShaderStorageBuffer buffer(golden::k_scan_simple_input);
     BlellochScan blelloch_scan(DataType_Uint);
-    blelloch_scan(buffer.handle(), data.size());
-    const std::vector<GLuint> expected{0, 1, 3, 6, 10, 15, 21, 28};
-    CHECK(buffer.get_data<GLuint>() == expected);
+    blelloch_scan(buffer.handle(), golden::k_scan_simple_input.size());
+    CHECK(buffer.get_data<GLuint>() == golden::k_scan_simple_expected);
 }
 
 TEST_CASE("BlellochScan-multiple-sizes")
 {
-    for (size_t n : {1024, 2048, 4096, 8192, 16384, 32768, 65536, 131072, 262144, 524288, 1048576})
+    for (size_t n : golden::k_scan_sizes)
     {
-        Random random(123);
-        std::vector<GLuint> data = random.sample_int_vector<GLuint>(n, 0, 100);
+        std::vector<GLuint> data = test_inputs::minstd_vector<GLuint>(123, n, 0, 100);
         ShaderStorageBuffer buffer(data);
 
         BlellochScan blelloch_scan(DataType_Uint);
@@ -40,10 +38,9 @@ TEST_CASE("BlellochScan-multiple-sizes")
 TEST_CASE("BlellochScan-multiple-partitions")
 {
     const size_t n = 1024;
-    for (size_t partitions : {1, 32, 100, 1000})
+    for (size_t partitions : golden::k_scan_partition_counts)
     {
-        Random random(123);
-        std::vector<GLuint> data = random.sample_int_vector<GLuint>(n * partitions, 0, 100);
+        std::vector<GLuint> data = test_inputs::minstd_vector<GLuint>(123, n * partitions, 0, 100);
         ShaderStorageBuffer buffer(data);
 
         BlellochScan blelloch_scan(DataType_Uint);
@@ -64,9 +61,8 @@ TEST_CASE("BlellochScan-small-partitions")
     // count = 1 and 2 are what RadixSort feeds the scan for tiny inputs in the reference (nbp2 = 1, 2)
     for (size_t n : {1, 2, 4, 64})
     {
-        Random random(3);
         const size_t partitions = 16;
-        std::vector<GLuint> data = random.sample_int_vector<GLuint>(n * partitions, 0, 1000);
+        std::vector<GLuint> data = test_inputs::minstd_vector<GLuint>(3, n * partitions, 0, 1000);
         ShaderStorageBuffer buffer(data);
         BlellochScan blelloch_scan(DataType_Uint);
         blelloch_scan(buffer.handle(), n, partitions);
@@ -83,8 +79,7 @@ TEST_CASE("BlellochScan-small-partitions")
 TEST_CASE("BlellochScan-int-float-double")
 {
     const size_t n = 1 << 16;
-    Random random(11);
-    std::vector<GLuint> raw = random.sample_int_vector<GLuint>(n, 0, 2000);
+    std::vector<GLuint> raw = test_inputs::minstd_vector<GLuint>(11, n, 0, 2000);
     {
         std::vector<int32_t> data(n), expected(n);
         for (size_t i = 0; i < n; i++) data[i] = int32_t(raw[i]) - 1000;

@@ -98,9 +98,53 @@ REFERENCE_VECTORS = {
 }
 
 
+def write_cpp_header(path):
+    """The same known-answer vectors as C++ data for tests/cpp (generated: edit REFERENCE_VECTORS, not the header)."""
+    ctype = {0: "float", 1: "double", 2: "int32_t", 3: "uint32_t", 4: "float", 5: "float", 10: "int32_t", 11: "int32_t"}
+    comps = {0: 1, 1: 1, 2: 1, 3: 1, 4: 2, 5: 4, 10: 2, 11: 4}
+
+    def lit(x, t):
+        if t == "float":
+            return repr(float(x)) + "f"
+        if t == "double":
+            return repr(float(x))
+        return str(int(x)) + ("u" if t == "uint32_t" else "")
+
+    out = ["// GENERATED by tests/golden/make_golden.py from the known-answer vectors of the reference's tests",
+           "// (tests/golden/reference_vectors.json) -- data only.", "#pragma once", "#include <cstdint>", "#include <vector>", "",
+           "namespace golden", "{"]
+    g = REFERENCE_VECTORS["reduce_simple_uint"]
+    out.append("    inline const std::vector<uint32_t> k_reduce_simple_input{%s};" % ", ".join(str(v) + "u" for v in g["input"]))
+    out.append("    struct SimpleCase { int op; size_t count; uint32_t expected; };")
+    out.append("    inline const std::vector<SimpleCase> k_reduce_simple_cases{%s};" % ", ".join(
+        "{%d, %d, %du}" % (c["op"], c["count"], c["expected"]) for c in g["cases"]))
+    out.append("    struct TypedCase { int data_type; int components; std::vector<double> input; std::vector<double> expected; double abs_tol; };")
+    rows = []
+    for c in REFERENCE_VECTORS["reduce_all"]["cases"]:
+        rows.append("        {%d, %d, {%s}, {%s}, %r}" % (c["data_type"], comps[c["data_type"]], ", ".join(repr(float(v)) for v in c["input"]),
+                                                           ", ".join(repr(float(v)) for v in c["expected"]), float(c["abs_tol"])))
+    out.append("    inline const std::vector<TypedCase> k_reduce_all_cases{\n%s};" % ",\n".join(rows))
+    s = REFERENCE_VECTORS["blelloch_scan_simple"]
+    out.append("    inline const std::vector<uint32_t> k_scan_simple_input{%s};" % ", ".join(str(v) + "u" for v in s["input"]))
+    out.append("    inline const std::vector<uint32_t> k_scan_simple_expected{%s};" % ", ".join(str(v) + "u" for v in s["expected"]))
+    r = REFERENCE_VECTORS["reduce_size_tests"]
+    out.append("    inline const std::vector<size_t> k_reduce_fitting_sizes{%s};" % ", ".join(map(str, r["fitting"])))
+    out.append("    inline const std::vector<size_t> k_reduce_non_fitting_sizes{%s};" % ", ".join(map(str, r["non_fitting"])))
+    b = REFERENCE_VECTORS["blelloch_scan_tests"]
+    out.append("    inline const std::vector<size_t> k_scan_sizes{%s};" % ", ".join(map(str, b["sizes"])))
+    out.append("    inline const std::vector<size_t> k_scan_partition_counts{%s};" % ", ".join(map(str, b["partitions"]["num_partitions"])))
+    rs = REFERENCE_VECTORS["radix_sort_tests"]["cases"]
+    out.append("    struct SortCase { size_t n; uint32_t min; uint32_t max; };")
+    out.append("    inline const std::vector<SortCase> k_radix_sort_cases{%s};" % ", ".join("{%d, %du, %du}" % (c["n"], c["min"], c["max"]) for c in rs))
+    out.append("} // namespace golden")
+    with open(path, "w") as f:
+        f.write("\n".join(out) + "\n")
+
+
 def main():
     with open(os.path.join(HERE, "reference_vectors.json"), "w") as f:
         json.dump(REFERENCE_VECTORS, f, indent=1)
+    write_cpp_header(os.path.join(ROOT, "tests", "cpp", "util", "golden_vectors.hpp"))
 
     sums = {"source": "oracle/glu_oracle.c glu_oracle_radix_sort_reference on the reference's test inputs "
                       "(keys = minstd_rand seed 1, vals = iota)", "cases": []}

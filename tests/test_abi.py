@@ -88,7 +88,7 @@ def test_cpp_api_exit_code_convention_without_gpu(built):
 
     if torch.cuda.is_available():
         pytest.skip("GPU present")
-    exe = os.path.join(ROOT, "tests", "cpp", "bin", "reduce_tests")
+    exe = os.path.join(ROOT, "tests", "cpp", "bin", "test_reduce_api")
     p = subprocess.run([exe], capture_output=True, text=True)
     assert p.returncode == 1
     assert "no CPU fallback" in p.stderr

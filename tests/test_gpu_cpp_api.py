@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("prog", ["radix_sort_tests", "blelloch_scan_tests", "reduce_tests"])
+@pytest.mark.parametrize("prog", ["test_radix_sort_api", "test_scan_api", "test_reduce_api"])
 def test_cpp_program(built, prog):
     exe = os.path.join(ROOT, "tests", "cpp", "bin", prog)
     p = subprocess.run([exe], capture_output=True, text=True, timeout=900)
@@ -20,7 +20,7 @@ def test_cpp_program(built, prog):
 
 
 def test_cpp_benchmark_program_runs(built):
-    exe = os.path.join(ROOT, "tests", "cpp", "bin", "benchmark")
+    exe = os.path.join(ROOT, "tests", "cpp", "bin", "bench_ladder")
     p = subprocess.run([exe, "all", "1048576"], capture_output=True, text=True, timeout=600)
     print(p.stdout)
     assert p.returncode == 0
