@@ -145,6 +145,11 @@ def load_traffic(workload_key):
 
 def main():
     args = parse_args()
+    # stdout must carry exactly ONE line (the JSON): RCCL prints a version banner to the C-level stdout at exit, so
+    # keep a private copy of the real stdout for the JSON and point fd 1 (and Python's sys.stdout) at stderr.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -358,7 +363,8 @@ def main():
         line.update(result)
         if world == 1 and not args.force_dist and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_sample_log2)
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
 
     if dist is not None:
         dist.barrier()
