@@ -394,11 +394,11 @@ struct glu_radix_sort_s
 
 namespace
 {
-glu_status sort_prepare(glu_radix_sort_s* s, size_t count, size_t key_size)
+glu_status sort_prepare(glu_radix_sort_s* s, size_t count, size_t key_size, bool with_vals = true)
 {
     if (count <= 1) return GLU_OK;
     GLU_TRY(s->keys.reserve(count * key_size));
-    GLU_TRY(s->vals.reserve(count * sizeof(uint32_t)));
+    if (with_vals) GLU_TRY(s->vals.reserve(count * sizeof(uint32_t)));
     uint64_t cap = (uint64_t) g_dev.num_cus * kMaxBlocksPerCu;
     GLU_TRY(s->table.reserve((kMaxRadix * cap + kMaxRadix) * sizeof(uint32_t)));
     return GLU_OK;
@@ -497,15 +497,16 @@ glu_status sort_single_block(KeyT* keys, uint32_t* vals, size_t count, uint32_t 
         return launch_single_block<KeyT, 1024, 8>(keys, vals, count, total_bits, stream);
 }
 
+// vals == nullptr: keys-only sort (no value traffic, no value scratch)
 template<typename KeyT>
 glu_status sort_run(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t count, size_t num_steps, hipStream_t stream)
 {
     constexpr size_t kMaxSteps = sizeof(KeyT) * 2; // 4-bit steps: 8 for 32-bit keys (RadixSort.hpp:289,332)
     if (count <= 1) return GLU_OK;                  // RadixSort.hpp:278-279
     if (count > 0xFFFF0000ull) return fail(GLU_ERROR_INVALID_ARGUMENT, "count %zu does not fit 32-bit indexing", count);
-    if (((uintptr_t) keys % sizeof(KeyT)) != 0 || ((uintptr_t) vals % sizeof(uint32_t)) != 0)
+    if (((uintptr_t) keys % sizeof(KeyT)) != 0 || (vals && ((uintptr_t) vals % sizeof(uint32_t)) != 0))
         return fail(GLU_ERROR_INVALID_ARGUMENT, "key/value arrays must be aligned to their element size");
-    GLU_TRY(sort_prepare(s, count, sizeof(KeyT))); // RadixSort.hpp:281 (no-op when prepared)
+    GLU_TRY(sort_prepare(s, count, sizeof(KeyT), vals != nullptr)); // RadixSort.hpp:281 (no-op when prepared)
 
     const size_t steps = (num_steps == 0 || num_steps > kMaxSteps) ? kMaxSteps : num_steps;
     uint32_t total_bits = (uint32_t) steps * 4;
@@ -520,7 +521,7 @@ glu_status sort_run(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t coun
     }
 
     KeyT* kbuf[2] = {keys, (KeyT*) s->keys.ptr};
-    uint32_t* vbuf[2] = {vals, (uint32_t*) s->vals.ptr};
+    uint32_t* vbuf[2] = {vals, vals ? (uint32_t*) s->vals.ptr : nullptr};
     int cur = 0;
     uint32_t shift = 0;
     while (shift < total_bits)
@@ -536,7 +537,7 @@ glu_status sort_run(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t coun
         // odd number of passes: the reference would leave the result in its private scratch (documented
         // deviation in glu_hip.h) -- bring it home
         HIP_TRY(hipMemcpyAsync(keys, kbuf[1], count * sizeof(KeyT), hipMemcpyDeviceToDevice, stream));
-        HIP_TRY(hipMemcpyAsync(vals, vbuf[1], count * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
+        if (vals) HIP_TRY(hipMemcpyAsync(vals, vbuf[1], count * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
     }
     return GLU_OK;
 }
@@ -629,6 +630,30 @@ glu_status glu_radix_sort_run_u64(glu_radix_sort sort, glu_buffer key_buffer, gl
     if (count > 1 && (k.size / sizeof(uint64_t) < count || v.size / sizeof(uint32_t) < count))
         return fail(GLU_ERROR_INVALID_ARGUMENT, "count %zu exceeds the key/value buffer size", count);
     return sort_run<uint64_t>(sort, (uint64_t*) k.ptr, (uint32_t*) v.ptr, count, num_steps, g_dev.queue);
+}
+
+glu_status glu_radix_sort_run_keys_ptr(glu_radix_sort sort, uint32_t* keys, size_t count, size_t num_steps, void* stream)
+{
+    if (!sort) return fail(GLU_ERROR_INVALID_ARGUMENT, "sort is NULL");
+    if (!keys) return fail(GLU_ERROR_INVALID_ARGUMENT, "Invalid key buffer");
+    return sort_run<uint32_t>(sort, keys, nullptr, count, num_steps, pick_stream(stream));
+}
+
+glu_status glu_radix_sort_run_keys_u64_ptr(glu_radix_sort sort, uint64_t* keys, size_t count, size_t num_steps, void* stream)
+{
+    if (!sort) return fail(GLU_ERROR_INVALID_ARGUMENT, "sort is NULL");
+    if (!keys) return fail(GLU_ERROR_INVALID_ARGUMENT, "Invalid key buffer");
+    return sort_run<uint64_t>(sort, keys, nullptr, count, num_steps, pick_stream(stream));
+}
+
+glu_status glu_radix_sort_run_keys(glu_radix_sort sort, glu_buffer key_buffer, size_t count, size_t num_steps)
+{
+    if (!sort) return fail(GLU_ERROR_INVALID_ARGUMENT, "sort is NULL");
+    Buffer k;
+    GLU_TRY(lookup(key_buffer, k, "key buffer"));
+    if (count > 1 && k.size / sizeof(uint32_t) < count)
+        return fail(GLU_ERROR_INVALID_ARGUMENT, "count %zu exceeds the key buffer size", count);
+    return sort_run<uint32_t>(sort, (uint32_t*) k.ptr, nullptr, count, num_steps, g_dev.queue);
 }
 
 glu_status glu_radix_sort_partition_ptr(glu_radix_sort sort, const uint32_t* src_keys, const uint32_t* src_vals,

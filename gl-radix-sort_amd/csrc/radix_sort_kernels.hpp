@@ -289,6 +289,7 @@ __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_ker
 
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t nb = gridDim.x, b = blockIdx.x;
+    const bool has_vals = src_vals != nullptr; // keys-only sorts pass no value arrays (kernel-uniform branch)
 
     // ---- prologue: this workgroup's global base for every digit:
     //      exclusive scan of the digit totals (RadixSort.hpp:148-152) + this block's scanned table entry (:176)
@@ -344,7 +345,7 @@ __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_ker
                 uint32_t v;
                 s.carry.get(e, k, v);
                 dst_keys[g] = k;
-                dst_vals[g] = v;
+                if (has_vals) dst_vals[g] = v;
             }
         }
     };
@@ -360,7 +361,7 @@ __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_ker
 #pragma unroll
             for (int i = 0; i < KPT; i++) key[i] = src_keys[base + wave_off + i * kWave];
 #pragma unroll
-            for (int i = 0; i < KPT; i++) val[i] = src_vals[base + wave_off + i * kWave];
+            for (int i = 0; i < KPT; i++) val[i] = has_vals ? src_vals[base + wave_off + i * kWave] : 0u;
         }
         else
         {
@@ -370,7 +371,7 @@ __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_ker
                 const uint32_t p = wave_off + i * kWave;
                 const bool ok = p < (uint32_t) left;
                 key[i] = ok ? src_keys[base + p] : (KeyT) ~(KeyT) 0; // pad: last digit, ranks after all real keys
-                val[i] = ok ? src_vals[base + p] : 0u;
+                val[i] = (ok && has_vals) ? src_vals[base + p] : 0u;
             }
         }
     };
@@ -541,7 +542,7 @@ __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_ker
                     }
                     if (ABLATE == 1) g = (uint32_t) tile_base + p;
                     dst_keys[g] = k;
-                    dst_vals[g] = v;
+                    if (has_vals) dst_vals[g] = v;
                 }
             }
             if (r + 1 < ROUNDS) __syncthreads(); // the next round overwrites the staging area
@@ -613,7 +614,7 @@ __global__ __launch_bounds__(THREADS) void radix_sort_single_block_kernel(KeyT* 
         const uint32_t p = wave_off + i * kWave;
         const bool ok = p < n;
         key[i] = ok ? keys[p] : (KeyT) ~(KeyT) 0; // pads carry the highest digit in every pass: they stay at the end
-        val[i] = ok ? vals[p] : 0u;
+        val[i] = (ok && vals) ? vals[p] : 0u;
     }
 
     uint32_t* my_cnt = s.wcnt[wave];
@@ -697,7 +698,7 @@ __global__ __launch_bounds__(THREADS) void radix_sort_single_block_kernel(KeyT* 
         if (p < n)
         {
             keys[p] = key[i];
-            vals[p] = val[i];
+            if (vals) vals[p] = val[i];
         }
     }
 }

@@ -44,6 +44,14 @@ namespace glu
             GLU_CHECK_STATUS(glu_radix_sort_run_ptr(m_impl, device_keys, device_vals, count, num_steps, stream));
         }
 
+        /// Keys only (not in the reference, which needs a dummy value buffer): sorts `count` uint32 keys in place.
+        void sort_keys(GLuint key_buffer, size_t count, size_t num_steps = 0)
+        {
+            GLU_CHECK_ARGUMENT(key_buffer, "Invalid key buffer");
+            if (count <= 1) return;
+            GLU_CHECK_STATUS(glu_radix_sort_run_keys(m_impl, key_buffer, count, num_steps));
+        }
+
         /// 64-bit keys with 32-bit values (not in the reference); num_steps counts 4-bit digits, 0 = all 64 bits.
         void sort_u64(GLuint key_buffer, GLuint val_buffer, size_t count, size_t num_steps = 0)
         {

@@ -54,6 +54,9 @@ SYMBOLS = [
     ("glu_radix_sort_run_ptr", _int, [_vp, _vp, _vp, _sz, _sz, _vp]),
     ("glu_radix_sort_run_u64", _int, [_vp, _u32, _u32, _sz, _sz]),
     ("glu_radix_sort_run_u64_ptr", _int, [_vp, _vp, _vp, _sz, _sz, _vp]),
+    ("glu_radix_sort_run_keys", _int, [_vp, _u32, _sz, _sz]),
+    ("glu_radix_sort_run_keys_ptr", _int, [_vp, _vp, _sz, _sz, _vp]),
+    ("glu_radix_sort_run_keys_u64_ptr", _int, [_vp, _vp, _sz, _sz, _vp]),
     ("glu_radix_sort_partition_ptr", _int, [_vp, _vp, _vp, _vp, _vp, _sz, _u32, _u32, _vp, _vp]),
     ("glu_radix_sort_set_digit_bits", _int, [_vp, _u32]),
     ("glu_radix_sort_get_digit_bits", _int, [_vp, _P(_u32)]),
@@ -243,6 +246,15 @@ class RadixSort:
         vb = val_buffer.handle() if isinstance(val_buffer, ShaderStorageBuffer) else val_buffer
         fn = lib().glu_radix_sort_run if key_bytes == 4 else lib().glu_radix_sort_run_u64
         check(fn(self._h, kb, vb, count, num_steps))
+
+    def sort_keys(self, key_buffer, count, num_steps=0):
+        """Keys-only sort of a uint32 buffer (no value buffer at all)."""
+        kb = key_buffer.handle() if isinstance(key_buffer, ShaderStorageBuffer) else key_buffer
+        check(lib().glu_radix_sort_run_keys(self._h, kb, count, num_steps))
+
+    def sort_keys_ptr(self, keys_ptr, count, num_steps=0, stream=None, key_bytes=4):
+        fn = lib().glu_radix_sort_run_keys_ptr if key_bytes == 4 else lib().glu_radix_sort_run_keys_u64_ptr
+        check(fn(self._h, _vp(keys_ptr), count, num_steps, _vp(stream)))
 
     def run_ptr(self, keys_ptr, vals_ptr, count, num_steps=0, stream=None, key_bytes=4):
         fn = lib().glu_radix_sort_run_ptr if key_bytes == 4 else lib().glu_radix_sort_run_u64_ptr

@@ -149,6 +149,13 @@ GLU_API glu_status glu_radix_sort_run_u64(glu_radix_sort sort, glu_buffer key_bu
                                           size_t count, size_t num_steps);
 GLU_API glu_status glu_radix_sort_run_u64_ptr(glu_radix_sort sort, uint64_t* keys, uint32_t* vals, size_t count,
                                               size_t num_steps, void* stream);
+/* Keys-only sorts (not in the reference, whose value buffer is mandatory -- README.md:88-89 tells users to allocate a
+ * dummy one): same ordering of the keys, no value traffic (12 instead of 20 bytes per key and pass). */
+GLU_API glu_status glu_radix_sort_run_keys(glu_radix_sort sort, glu_buffer key_buffer, size_t count, size_t num_steps);
+GLU_API glu_status glu_radix_sort_run_keys_ptr(glu_radix_sort sort, uint32_t* keys, size_t count, size_t num_steps,
+                                               void* stream);
+GLU_API glu_status glu_radix_sort_run_keys_u64_ptr(glu_radix_sort sort, uint64_t* keys, size_t count, size_t num_steps,
+                                                   void* stream);
 /* One stable counting pass on the digit (key >> shift) & ((1 << bits) - 1), 1 <= bits <= 8, from src to dst
  * (distinct buffers).  This is the partition step of the multi-GPU sort (top-8-bit buckets).  If
  * digit_histogram != NULL it receives the 1 << bits digit totals (device memory, uint32). */

@@ -170,6 +170,22 @@ TEST_CASE("RadixSort-u64-keys")
     }
 }
 
+TEST_CASE("RadixSort-keys-only")
+{
+    // the reference's README snippet sorts a single buffer; its header needs a dummy value buffer -- here both work
+    for (size_t n : {100, 20000, 4 * (1 << 20) + 1})
+    {
+        std::vector<GLuint> keys = test_inputs::minstd_vector<GLuint>(5, n, 0, UINT32_MAX);
+        for (size_t i = 0; i < n; i += 3) keys[i] ^= 0x80000000u;
+        ShaderStorageBuffer key_buffer(keys);
+        RadixSort radix_sort;
+        radix_sort.sort_keys(key_buffer.handle(), n);
+        std::vector<GLuint> expected(keys);
+        std::sort(expected.begin(), expected.end());
+        CHECK(key_buffer.get_data<GLuint>() == expected);
+    }
+}
+
 TEST_CASE("RadixSort-raw-pointer-overload")
 {
     // native callers: raw device pointers (here taken from ShaderStorageBuffer) on the library queue

@@ -257,6 +257,26 @@ def test_u64_keys(G, bits, n):
     assert (gk == ek).all() and (gv == ev).all()
 
 
+@pytest.mark.parametrize("bits", DIGIT_BITS)
+@pytest.mark.parametrize("n", [2, 1000, 12289, 1 << 20, 5 * (1 << 20) + 3])
+def test_keys_only_sort(G, bits, n):
+    """Keys-only entry points (the reference needs a dummy value buffer, README.md:88-89): the keys must come out exactly
+    as the key half of the pair sort, for every num_steps."""
+    rng = np.random.default_rng(n + bits)
+    keys = rng.integers(0, 2**32, n, dtype=np.uint32)
+    for steps in (0, 3, 6):
+        sorter = G.RadixSort(digit_bits=bits)
+        kb = G.ShaderStorageBuffer(keys)
+        sorter.sort_keys(kb, n, steps)
+        ek, _ = O.stable_sort_pairs(keys, np.zeros(n, dtype=np.uint32), key_bits=32 if steps == 0 else 4 * steps)
+        assert (kb.get_data(np.uint32) == ek).all()
+    k64 = rng.integers(0, 2**64, n, dtype=np.uint64)
+    kb = G.ShaderStorageBuffer(k64)
+    sorter = G.RadixSort(digit_bits=bits)
+    sorter.sort_keys_ptr(kb.device_ptr(), n, 0, None, key_bytes=8)
+    assert (kb.get_data(np.uint64) == np.sort(k64)).all()
+
+
 def test_raw_pointer_entry_on_torch_memory(G):
     import torch
 
