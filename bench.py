@@ -39,6 +39,8 @@ def parse_args():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample-log2", type=int, default=26)
     p.add_argument("--no-verify", action="store_true")
+    p.add_argument("--no-kernel-events", action="store_true",
+                   help="do not record per-kernel HIP events in the timed region (roofline fields become null)")
     p.add_argument("--no-alt", action="store_true", help="skip the extra 4-bit-digit (reference pass structure) measurement")
     p.add_argument("--force-dist", action="store_true",
                    help="run the multi-GPU code path (partition + all-to-all + local sort) even with one rank")
@@ -216,7 +218,7 @@ def main():
         for i in range(W):
             step(i)
         barrier()
-        sorter.set_profiling(True)
+        sorter.set_profiling(not args.no_kernel_events)
         t0 = time.perf_counter()
         for i in range(W, W + K):
             step(i)

@@ -243,16 +243,8 @@ int main(int argc, char** argv)
         run_variant<4, 1024, 16, true>(c, 1, shift);
         return 0;
     }
-#if GLU_CARRY_ELEMS == 16
     run_variant<8, 1024, 12, true>(c, 1, shift);
     run_variant<4, 1024, 12, false>(c, 1, shift);
-#elif GLU_CARRY_ELEMS == 8
-    run_variant<8, 512, 12, true>(c, 2, shift);
-    run_variant<8, 512, 8, true>(c, 2, shift);
     run_variant<8, 1024, 12, true>(c, 1, shift);
-    run_variant<8, 1024, 14, true>(c, 1, shift);
-#elif GLU_CARRY_ELEMS == 32
-    run_variant<8, 1024, 8, true>(c, 1, shift);
-#endif
     return 0;
 }
