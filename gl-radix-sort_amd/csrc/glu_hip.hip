@@ -406,7 +406,8 @@ glu_status sort_prepare(glu_radix_sort_s* s, size_t count, size_t key_size, bool
 
 template<typename KeyT, int BITS, bool LARGE>
 glu_status launch_pass(glu_radix_sort_s* s, const KeyT* src_k, const uint32_t* src_v, KeyT* dst_k, uint32_t* dst_v,
-                       size_t count, uint32_t shift, uint32_t bits, uint32_t* histogram_out, hipStream_t stream)
+                       size_t count, uint32_t shift, uint32_t bits, uint32_t* histogram_out, hipStream_t stream,
+                       uint32_t xform = 0)
 {
     using G = GeometryFor<KeyT, BITS, LARGE>;
     constexpr int RADIX = 1 << BITS;
@@ -432,7 +433,7 @@ glu_status launch_pass(glu_radix_sort_s* s, const KeyT* src_k, const uint32_t* s
     // when there is one workgroup per CU
     constexpr int COUNT_THREADS = LARGE ? 1024 : G::THREADS;
     hipLaunchKernelGGL((radix_count_kernel<KeyT, BITS, COUNT_THREADS, G::TILE>), dim3(nb), dim3(COUNT_THREADS), 0, stream,
-                       src_k, table, (uint32_t) count, shift, mask, tiles);
+                       src_k, table, (uint32_t) count, shift, mask, tiles, xform);
     s->mark(stream);
     hipLaunchKernelGGL((radix_row_scan_kernel<256>), dim3(RADIX), dim3(256), 0, stream, table, totals, nb);
     s->mark(stream);
@@ -441,7 +442,7 @@ glu_status launch_pass(glu_radix_sort_s* s, const KeyT* src_k, const uint32_t* s
                                stream));
     hipLaunchKernelGGL(scatter, dim3(nb), dim3(G::THREADS), sizeof(Smem), stream, src_k, src_v, dst_k, dst_v,
                        (const uint32_t*) table, (const uint32_t*) totals, (uint32_t) count, shift, mask, tiles,
-                       (unsigned long long*) nullptr);
+                       (unsigned long long*) nullptr, xform);
     s->mark(stream);
     HIP_TRY(hipGetLastError());
     return GLU_OK;
@@ -449,26 +450,29 @@ glu_status launch_pass(glu_radix_sort_s* s, const KeyT* src_k, const uint32_t* s
 
 template<typename KeyT, int BITS>
 glu_status launch_pass_sized(glu_radix_sort_s* s, const KeyT* src_k, const uint32_t* src_v, KeyT* dst_k, uint32_t* dst_v,
-                             size_t count, uint32_t shift, uint32_t bits, uint32_t* histogram_out, hipStream_t stream)
+                             size_t count, uint32_t shift, uint32_t bits, uint32_t* histogram_out, hipStream_t stream,
+                             uint32_t xform = 0)
 {
     // large geometry once every CU gets at least one large tile
     const bool large = count >= (size_t) g_dev.num_cus * GeometryFor<KeyT, BITS, true>::TILE && !s->force_small;
-    if (large) return launch_pass<KeyT, BITS, true>(s, src_k, src_v, dst_k, dst_v, count, shift, bits, histogram_out, stream);
-    return launch_pass<KeyT, BITS, false>(s, src_k, src_v, dst_k, dst_v, count, shift, bits, histogram_out, stream);
+    if (large) return launch_pass<KeyT, BITS, true>(s, src_k, src_v, dst_k, dst_v, count, shift, bits, histogram_out, stream, xform);
+    return launch_pass<KeyT, BITS, false>(s, src_k, src_v, dst_k, dst_v, count, shift, bits, histogram_out, stream, xform);
 }
 
 template<typename KeyT>
 glu_status dispatch_pass(glu_radix_sort_s* s, const KeyT* src_k, const uint32_t* src_v, KeyT* dst_k, uint32_t* dst_v,
-                         size_t count, uint32_t shift, uint32_t bits, uint32_t* histogram_out, hipStream_t stream)
+                         size_t count, uint32_t shift, uint32_t bits, uint32_t* histogram_out, hipStream_t stream,
+                         uint32_t xform = 0)
 {
-    if (bits <= 4) return launch_pass_sized<KeyT, 4>(s, src_k, src_v, dst_k, dst_v, count, shift, bits, histogram_out, stream);
-    return launch_pass_sized<KeyT, 8>(s, src_k, src_v, dst_k, dst_v, count, shift, bits, histogram_out, stream);
+    if (bits <= 4) return launch_pass_sized<KeyT, 4>(s, src_k, src_v, dst_k, dst_v, count, shift, bits, histogram_out, stream, xform);
+    return launch_pass_sized<KeyT, 8>(s, src_k, src_v, dst_k, dst_v, count, shift, bits, histogram_out, stream, xform);
 }
 
 // n <= one tile: the whole sort in a single workgroup / single launch (always 8-bit digits: the result does not
 // depend on the digit width)
 template<typename KeyT, int THREADS, int KPT>
-glu_status launch_single_block(KeyT* keys, uint32_t* vals, size_t count, uint32_t total_bits, hipStream_t stream)
+glu_status launch_single_block(KeyT* keys, uint32_t* vals, size_t count, uint32_t total_bits, hipStream_t stream,
+                               uint32_t xform)
 {
     using Smem = SingleBlockSmem<KeyT, 8, THREADS, KPT>;
     auto kern = radix_sort_single_block_kernel<KeyT, 8, THREADS, KPT>;
@@ -478,7 +482,7 @@ glu_status launch_single_block(KeyT* keys, uint32_t* vals, size_t count, uint32_
         HIP_TRY(hipFuncSetAttribute((const void*) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sizeof(Smem)));
         lds_opt_in = true;
     }
-    hipLaunchKernelGGL(kern, dim3(1), dim3(THREADS), sizeof(Smem), stream, keys, vals, (uint32_t) count, total_bits);
+    hipLaunchKernelGGL(kern, dim3(1), dim3(THREADS), sizeof(Smem), stream, keys, vals, (uint32_t) count, total_bits, xform);
     HIP_TRY(hipGetLastError());
     return GLU_OK;
 }
@@ -487,19 +491,21 @@ template<typename KeyT>
 constexpr size_t single_block_limit() { return sizeof(KeyT) == 4 ? 1024 * 12 : 1024 * 8; }
 
 template<typename KeyT>
-glu_status sort_single_block(KeyT* keys, uint32_t* vals, size_t count, uint32_t total_bits, hipStream_t stream)
+glu_status sort_single_block(KeyT* keys, uint32_t* vals, size_t count, uint32_t total_bits, hipStream_t stream,
+                             uint32_t xform)
 {
-    if (count <= 1024) return launch_single_block<KeyT, 256, 4>(keys, vals, count, total_bits, stream);
-    if (count <= 4096) return launch_single_block<KeyT, 256, 16>(keys, vals, count, total_bits, stream);
+    if (count <= 1024) return launch_single_block<KeyT, 256, 4>(keys, vals, count, total_bits, stream, xform);
+    if (count <= 4096) return launch_single_block<KeyT, 256, 16>(keys, vals, count, total_bits, stream, xform);
     if constexpr (sizeof(KeyT) == 4)
-        return launch_single_block<KeyT, 1024, 12>(keys, vals, count, total_bits, stream);
+        return launch_single_block<KeyT, 1024, 12>(keys, vals, count, total_bits, stream, xform);
     else
-        return launch_single_block<KeyT, 1024, 8>(keys, vals, count, total_bits, stream);
+        return launch_single_block<KeyT, 1024, 8>(keys, vals, count, total_bits, stream, xform);
 }
 
 // vals == nullptr: keys-only sort (no value traffic, no value scratch)
 template<typename KeyT>
-glu_status sort_run(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t count, size_t num_steps, hipStream_t stream)
+glu_status sort_run(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t count, size_t num_steps, hipStream_t stream,
+                    uint32_t key_xf = KEY_XF_NONE)
 {
     constexpr size_t kMaxSteps = sizeof(KeyT) * 2; // 4-bit steps: 8 for 32-bit keys (RadixSort.hpp:289,332)
     if (count <= 1) return GLU_OK;                  // RadixSort.hpp:278-279
@@ -515,7 +521,7 @@ glu_status sort_run(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t coun
         s->mark(stream); // profiling: booked as one "scatter" launch (count / scan intervals are empty)
         s->mark(stream);
         s->mark(stream);
-        GLU_TRY(sort_single_block<KeyT>(keys, vals, count, total_bits, stream));
+        GLU_TRY(sort_single_block<KeyT>(keys, vals, count, total_bits, stream, key_xf | (key_xf << 2)));
         s->mark(stream);
         return GLU_OK;
     }
@@ -527,8 +533,10 @@ glu_status sort_run(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t coun
     while (shift < total_bits)
     {
         uint32_t bits = std::min<uint32_t>(s->digit_bits, total_bits - shift);
+        // typed keys: encode on the first pass's loads, decode on the last pass's stores
+        const uint32_t xform = (shift == 0 ? key_xf : 0u) | (shift + bits >= total_bits ? key_xf << 2 : 0u);
         GLU_TRY(dispatch_pass<KeyT>(s, kbuf[cur], vbuf[cur], kbuf[cur ^ 1], vbuf[cur ^ 1], count, shift, bits, nullptr,
-                                    stream));
+                                    stream, xform));
         cur ^= 1;
         shift += bits;
     }
@@ -644,6 +652,24 @@ glu_status glu_radix_sort_run_keys_u64_ptr(glu_radix_sort sort, uint64_t* keys, 
     if (!sort) return fail(GLU_ERROR_INVALID_ARGUMENT, "sort is NULL");
     if (!keys) return fail(GLU_ERROR_INVALID_ARGUMENT, "Invalid key buffer");
     return sort_run<uint64_t>(sort, keys, nullptr, count, num_steps, pick_stream(stream));
+}
+
+glu_status glu_radix_sort_run_typed_ptr(glu_radix_sort sort, void* keys, uint32_t* vals, size_t count, glu_key_type key_type,
+                                        void* stream)
+{
+    if (!sort) return fail(GLU_ERROR_INVALID_ARGUMENT, "sort is NULL");
+    if (!keys) return fail(GLU_ERROR_INVALID_ARGUMENT, "Invalid key buffer");
+    hipStream_t st = pick_stream(stream);
+    switch (key_type)
+    {
+    case GLU_KEY_UINT32: return sort_run<uint32_t>(sort, (uint32_t*) keys, vals, count, 0, st, KEY_XF_NONE);
+    case GLU_KEY_INT32: return sort_run<uint32_t>(sort, (uint32_t*) keys, vals, count, 0, st, KEY_XF_SIGNED);
+    case GLU_KEY_FLOAT32: return sort_run<uint32_t>(sort, (uint32_t*) keys, vals, count, 0, st, KEY_XF_FLOAT);
+    case GLU_KEY_UINT64: return sort_run<uint64_t>(sort, (uint64_t*) keys, vals, count, 0, st, KEY_XF_NONE);
+    case GLU_KEY_INT64: return sort_run<uint64_t>(sort, (uint64_t*) keys, vals, count, 0, st, KEY_XF_SIGNED);
+    case GLU_KEY_FLOAT64: return sort_run<uint64_t>(sort, (uint64_t*) keys, vals, count, 0, st, KEY_XF_FLOAT);
+    default: return fail(GLU_ERROR_INVALID_ARGUMENT, "Invalid key type: %d", (int) key_type);
+    }
 }
 
 glu_status glu_radix_sort_run_keys(glu_radix_sort sort, glu_buffer key_buffer, size_t count, size_t num_steps)

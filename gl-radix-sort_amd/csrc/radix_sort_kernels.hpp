@@ -28,6 +28,34 @@ __device__ __forceinline__ uint32_t digit_of(KeyT key, uint32_t shift, uint32_t 
     return (uint32_t) (key >> shift) & mask;
 }
 
+// Key encodings.  The kernels sort unsigned bit patterns; signed-integer and IEEE-float keys are mapped to unsigned
+// patterns with the same order on the first pass's loads and mapped back on the last pass's stores (kernel-uniform
+// switches, nothing extra touches memory).  xform = input transform | output transform << 2.
+enum KeyTransform : uint32_t
+{
+    KEY_XF_NONE = 0,
+    KEY_XF_SIGNED = 1, // flip the sign bit
+    KEY_XF_FLOAT = 2   // negative: flip every bit, non-negative: flip the sign bit (total order, -0 < +0, NaNs at the ends)
+};
+
+// Branch-free form (a uniform `if` per key would split the unrolled load / store loops into basic blocks and cost
+// the scatter kernel 50 %): code(k) = k ^ ((sign_fill(k or ~k) & all) | sign), with (all, sign) = (0, 0) for no
+// transform, (0, SIGN) for signed integers, (~0, SIGN) for floats.
+template<typename KeyT>
+struct KeyCodec
+{
+    using S = typename std::make_signed<KeyT>::type;
+    static constexpr int TOP = sizeof(KeyT) * 8 - 1;
+    KeyT all, sign;
+    __device__ __forceinline__ explicit KeyCodec(uint32_t xf) :
+        all(xf == KEY_XF_FLOAT ? (KeyT) ~(KeyT) 0 : (KeyT) 0),
+        sign(xf == KEY_XF_NONE ? (KeyT) 0 : (KeyT) 1 << TOP)
+    {
+    }
+    __device__ __forceinline__ KeyT encode(KeyT k) const { return k ^ (((KeyT) ((S) k >> TOP) & all) | sign); }
+    __device__ __forceinline__ KeyT decode(KeyT k) const { return k ^ (((KeyT) ((S) ~k >> TOP) & all) | sign); }
+};
+
 // Contiguous tile range [first, last) owned by workgroup `b` of `nb`, tiles_total >= nb.
 __device__ __forceinline__ void block_tile_range(uint32_t b, uint32_t nb, uint32_t tiles_total, uint32_t& first,
                                                  uint32_t& last)
@@ -57,7 +85,8 @@ __device__ __forceinline__ uint32_t wave_exclusive_sum(uint32_t v, uint32_t lane
 template<typename KeyT, int BITS, int THREADS, int TILE>
 __global__ __launch_bounds__(THREADS) void radix_count_kernel(const KeyT* __restrict__ keys,
                                                               uint32_t* __restrict__ table, uint32_t n,
-                                                              uint32_t shift, uint32_t mask, uint32_t tiles_total)
+                                                              uint32_t shift, uint32_t mask, uint32_t tiles_total,
+                                                              uint32_t xform = 0)
 {
     constexpr int RADIX = 1 << BITS;
     constexpr int WAVES = THREADS / kWave;
@@ -98,15 +127,16 @@ __global__ __launch_bounds__(THREADS) void radix_count_kernel(const KeyT* __rest
     const bool vec_ok = (reinterpret_cast<uintptr_t>(keys) & 15u) == 0;
     const uint64_t nvec = vec_ok ? (end - begin) / VEC : 0;
     const VecT* vkeys = reinterpret_cast<const VecT*>(keys + begin);
+    const KeyCodec<KeyT> codec_in(xform & 3u);
+    auto dig = [&](KeyT k) { return digit_of<KeyT>(codec_in.encode(k), shift, MASK); };
     auto tally_vec = [&](const VecT& a) {
         if constexpr (sizeof(KeyT) == 4)
         {
-            tally(digit_of<uint32_t>(a.x, shift, MASK)); tally(digit_of<uint32_t>(a.y, shift, MASK));
-            tally(digit_of<uint32_t>(a.z, shift, MASK)); tally(digit_of<uint32_t>(a.w, shift, MASK));
+            tally(dig(a.x)); tally(dig(a.y)); tally(dig(a.z)); tally(dig(a.w));
         }
         else
         {
-            tally(digit_of<uint64_t>(a.x, shift, MASK)); tally(digit_of<uint64_t>(a.y, shift, MASK));
+            tally(dig(a.x)); tally(dig(a.y));
         }
     };
     uint64_t vbase = 0;
@@ -129,9 +159,9 @@ __global__ __launch_bounds__(THREADS) void radix_count_kernel(const KeyT* __rest
 #pragma unroll
         for (int j = 0; j < 8; j++) k[j] = keys[i + (uint64_t) j * THREADS];
 #pragma unroll
-        for (int j = 0; j < 8; j++) atomicAdd(&my_hist[digit_of<KeyT>(k[j], shift, MASK)], 1u);
+        for (int j = 0; j < 8; j++) atomicAdd(&my_hist[dig(k[j])], 1u);
     }
-    for (; i < end; i += THREADS) atomicAdd(&my_hist[digit_of<KeyT>(keys[i], shift, MASK)], 1u);
+    for (; i < end; i += THREADS) atomicAdd(&my_hist[dig(keys[i])], 1u);
     __syncthreads();
 
     for (int d = tid; d < RADIX; d += THREADS)
@@ -268,7 +298,8 @@ template<typename KeyT, int BITS, int THREADS, int KPT, bool CARRY = true, int A
 __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_kernel(
     const KeyT* __restrict__ src_keys, const uint32_t* __restrict__ src_vals, KeyT* __restrict__ dst_keys,
     uint32_t* __restrict__ dst_vals, const uint32_t* __restrict__ table, const uint32_t* __restrict__ totals,
-    uint32_t n, uint32_t shift, uint32_t mask, uint32_t tiles_total, unsigned long long* stamps = nullptr)
+    uint32_t n, uint32_t shift, uint32_t mask, uint32_t tiles_total, unsigned long long* stamps = nullptr,
+    uint32_t xform = 0)
 {
     using Smem = ScatterSmem<KeyT, BITS, THREADS, KPT, CARRY, ROUNDS>;
     constexpr int STAGE = Smem::STAGE;
@@ -290,6 +321,7 @@ __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_ker
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t nb = gridDim.x, b = blockIdx.x;
     const bool has_vals = src_vals != nullptr; // keys-only sorts pass no value arrays (kernel-uniform branch)
+    const KeyCodec<KeyT> codec_in(xform & 3u), codec_out((xform >> 2) & 3u); // key encode on load / decode on store
 
     // ---- prologue: this workgroup's global base for every digit:
     //      exclusive scan of the digit totals (RadixSort.hpp:148-152) + this block's scanned table entry (:176)
@@ -331,21 +363,30 @@ __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_ker
     // writes the carried elements [flush_lo, flush_hi) of every digit: thread (digit, slot) pairs, 16 consecutive
     // lanes per digit
     auto flush_carry = [&]() {
+        // batched: all LDS reads of the FJ (digit, slot) pairs of this thread are issued before any dependent work
+        constexpr int FJ = (RADIX * (int) BLK + THREADS - 1) / THREADS;
+        uint32_t lo[FJ], hi[FJ];
+        KeyT fk[FJ];
+        uint32_t fv[FJ];
 #pragma unroll
-        for (int j = 0; j < (RADIX * (int) BLK + THREADS - 1) / THREADS; j++)
+        for (int j = 0; j < FJ; j++)
+        {
+            uint32_t e = j * THREADS + tid;
+            if (RADIX * BLK % THREADS != 0 && e >= RADIX * BLK) e = RADIX * BLK - 1; // clamp (result unused)
+            lo[j] = s.flush_lo[e / BLK];
+            hi[j] = s.flush_hi[e / BLK];
+            s.carry.get(e, fk[j], fv[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < FJ; j++)
         {
             const uint32_t e = j * THREADS + tid;
-            const uint32_t d = e / BLK, slot = e % BLK;
-            if (RADIX * BLK % THREADS != 0 && e >= RADIX * BLK) break;
-            const uint32_t lo = s.flush_lo[d], hi = s.flush_hi[d];
-            const uint32_t g = (lo & ~(BLK - 1)) + slot;
-            if (g >= lo && g < hi)
+            const uint32_t g = (lo[j] & ~(BLK - 1)) + (e % BLK);
+            const bool live = g >= lo[j] && g < hi[j] && (RADIX * BLK % THREADS == 0 || e < RADIX * BLK);
+            if (live)
             {
-                KeyT k;
-                uint32_t v;
-                s.carry.get(e, k, v);
-                dst_keys[g] = k;
-                if (has_vals) dst_vals[g] = v;
+                dst_keys[g] = codec_out.decode(fk[j]);
+                if (has_vals) dst_vals[g] = fv[j];
             }
         }
     };
@@ -359,7 +400,7 @@ __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_ker
         if (left >= (uint64_t) TILE)
         {
 #pragma unroll
-            for (int i = 0; i < KPT; i++) key[i] = src_keys[base + wave_off + i * kWave];
+            for (int i = 0; i < KPT; i++) key[i] = codec_in.encode(src_keys[base + wave_off + i * kWave]);
 #pragma unroll
             for (int i = 0; i < KPT; i++) val[i] = has_vals ? src_vals[base + wave_off + i * kWave] : 0u;
         }
@@ -370,7 +411,7 @@ __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_ker
             {
                 const uint32_t p = wave_off + i * kWave;
                 const bool ok = p < (uint32_t) left;
-                key[i] = ok ? src_keys[base + p] : (KeyT) ~(KeyT) 0; // pad: last digit, ranks after all real keys
+                key[i] = ok ? codec_in.encode(src_keys[base + p]) : (KeyT) ~(KeyT) 0; // pad: last digit, after all real keys
                 val[i] = (ok && has_vals) ? src_vals[base + p] : 0u;
             }
         }
@@ -522,28 +563,36 @@ __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_ker
                 __syncthreads();
             }
 
-            // ---- write out: consecutive threads -> consecutive ranked positions -> (per digit) consecutive addresses
+            // ---- write out: consecutive threads -> consecutive ranked positions -> (per digit) consecutive addresses.
+            //      Three batched sweeps (staged pairs, per-digit lookups, stores) so that the LDS latencies overlap
+            //      instead of being paid once per item behind a branch.
+            constexpr int WI = KPT / ROUNDS;
+            KeyT wk[WI];
+            uint32_t wv[WI], wg[WI], wlim[WI];
 #pragma unroll
-            for (int i = 0; i < KPT / ROUNDS; i++)
+            for (int i = 0; i < WI; i++) s.stage.get(i * THREADS + tid, wk[i], wv[i]);
+#pragma unroll
+            for (int i = 0; i < WI; i++)
             {
-                const uint32_t q = i * THREADS + tid;       // position inside the staging area
-                const uint32_t p = r * STAGE + q;           // ranked position inside the tile
-                if (p < tile_valid)
+                const uint32_t wd = digit_of<KeyT>(wk[i], shift, MASK);
+                wg[i] = r * STAGE + i * THREADS + tid + s.gdelta[wd];
+                wlim[i] = CARRY ? s.wend[wd] : 0xFFFFFFFFu;
+            }
+#pragma unroll
+            for (int i = 0; i < WI; i++)
+            {
+                const uint32_t p = r * STAGE + i * THREADS + tid; // ranked position inside the tile
+                const bool valid = p < tile_valid;
+                const bool to_carry = CARRY && wg[i] >= wlim[i];
+                uint32_t g = wg[i];
+                if (ABLATE == 1) g = (uint32_t) tile_base + p;
+                if (valid && !to_carry)
                 {
-                    KeyT k;
-                    uint32_t v;
-                    s.stage.get(q, k, v);
-                    const uint32_t wd = digit_of<KeyT>(k, shift, MASK);
-                    uint32_t g = p + s.gdelta[wd];
-                    if (CARRY && g >= s.wend[wd])
-                    {
-                        s.carry.put(wd * BLK + (g & (BLK - 1)), k, v);
-                        continue;
-                    }
-                    if (ABLATE == 1) g = (uint32_t) tile_base + p;
-                    dst_keys[g] = k;
-                    if (has_vals) dst_vals[g] = v;
+                    dst_keys[g] = codec_out.decode(wk[i]);
+                    if (has_vals) dst_vals[g] = wv[i];
                 }
+                if (CARRY && valid && to_carry)
+                    s.carry.put(digit_of<KeyT>(wk[i], shift, MASK) * BLK + (wg[i] & (BLK - 1)), wk[i], wv[i]);
             }
             if (r + 1 < ROUNDS) __syncthreads(); // the next round overwrites the staging area
         }
@@ -590,7 +639,7 @@ struct SingleBlockSmem
 template<typename KeyT, int BITS, int THREADS, int KPT>
 __global__ __launch_bounds__(THREADS) void radix_sort_single_block_kernel(KeyT* __restrict__ keys,
                                                                           uint32_t* __restrict__ vals, uint32_t n,
-                                                                          uint32_t total_bits)
+                                                                          uint32_t total_bits, uint32_t xform = 0)
 {
     using Smem = SingleBlockSmem<KeyT, BITS, THREADS, KPT>;
     constexpr int RADIX = Smem::RADIX;
@@ -606,6 +655,7 @@ __global__ __launch_bounds__(THREADS) void radix_sort_single_block_kernel(KeyT* 
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t wave_off = wave * WAVE_TILE + lane;
 
+    const KeyCodec<KeyT> codec_in(xform & 3u), codec_out((xform >> 2) & 3u);
     KeyT key[KPT];
     uint32_t val[KPT];
 #pragma unroll
@@ -613,7 +663,7 @@ __global__ __launch_bounds__(THREADS) void radix_sort_single_block_kernel(KeyT* 
     {
         const uint32_t p = wave_off + i * kWave;
         const bool ok = p < n;
-        key[i] = ok ? keys[p] : (KeyT) ~(KeyT) 0; // pads carry the highest digit in every pass: they stay at the end
+        key[i] = ok ? codec_in.encode(keys[p]) : (KeyT) ~(KeyT) 0; // pads: highest digit in every pass
         val[i] = (ok && vals) ? vals[p] : 0u;
     }
 
@@ -697,7 +747,7 @@ __global__ __launch_bounds__(THREADS) void radix_sort_single_block_kernel(KeyT* 
         const uint32_t p = wave_off + i * kWave;
         if (p < n)
         {
-            keys[p] = key[i];
+            keys[p] = codec_out.decode(key[i]);
             if (vals) vals[p] = val[i];
         }
     }

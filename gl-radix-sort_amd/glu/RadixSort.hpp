@@ -3,6 +3,7 @@
 #define GLU_RADIXSORT_HPP
 
 #include <cstdint>
+#include <type_traits>
 
 #include "BlellochScan.hpp"
 #include "hip_utils.hpp"
@@ -52,6 +53,14 @@ namespace glu
             GLU_CHECK_STATUS(glu_radix_sort_run_keys(m_impl, key_buffer, count, num_steps));
         }
 
+        /// Typed keys on raw device pointers (not in the reference): KeyT in {uint32_t, int32_t, float, uint64_t,
+        /// int64_t, double}; natural order (floats as a total order), stable; device_vals may be nullptr.
+        template<typename KeyT>
+        void sort_typed(KeyT* device_keys, uint32_t* device_vals, size_t count, void* stream = nullptr)
+        {
+            GLU_CHECK_STATUS(glu_radix_sort_run_typed_ptr(m_impl, device_keys, device_vals, count, key_type_of<KeyT>(), stream));
+        }
+
         /// 64-bit keys with 32-bit values (not in the reference); num_steps counts 4-bit digits, 0 = all 64 bits.
         void sort_u64(GLuint key_buffer, GLuint val_buffer, size_t count, size_t num_steps = 0)
         {
@@ -72,6 +81,20 @@ namespace glu
         }
 
     private:
+        template<typename KeyT>
+        static constexpr glu_key_type key_type_of()
+        {
+            static_assert(std::is_same_v<KeyT, uint32_t> || std::is_same_v<KeyT, int32_t> || std::is_same_v<KeyT, float> ||
+                              std::is_same_v<KeyT, uint64_t> || std::is_same_v<KeyT, int64_t> || std::is_same_v<KeyT, double>,
+                          "unsupported key type");
+            if constexpr (std::is_same_v<KeyT, uint32_t>) return GLU_KEY_UINT32;
+            else if constexpr (std::is_same_v<KeyT, int32_t>) return GLU_KEY_INT32;
+            else if constexpr (std::is_same_v<KeyT, float>) return GLU_KEY_FLOAT32;
+            else if constexpr (std::is_same_v<KeyT, uint64_t>) return GLU_KEY_UINT64;
+            else if constexpr (std::is_same_v<KeyT, int64_t>) return GLU_KEY_INT64;
+            else return GLU_KEY_FLOAT64;
+        }
+
         glu_radix_sort m_impl = nullptr;
     };
 } // namespace glu

@@ -57,6 +57,7 @@ SYMBOLS = [
     ("glu_radix_sort_run_keys", _int, [_vp, _u32, _sz, _sz]),
     ("glu_radix_sort_run_keys_ptr", _int, [_vp, _vp, _sz, _sz, _vp]),
     ("glu_radix_sort_run_keys_u64_ptr", _int, [_vp, _vp, _sz, _sz, _vp]),
+    ("glu_radix_sort_run_typed_ptr", _int, [_vp, _vp, _vp, _sz, _int, _vp]),
     ("glu_radix_sort_partition_ptr", _int, [_vp, _vp, _vp, _vp, _vp, _sz, _u32, _u32, _vp, _vp]),
     ("glu_radix_sort_set_digit_bits", _int, [_vp, _u32]),
     ("glu_radix_sort_get_digit_bits", _int, [_vp, _P(_u32)]),
@@ -255,6 +256,13 @@ class RadixSort:
     def sort_keys_ptr(self, keys_ptr, count, num_steps=0, stream=None, key_bytes=4):
         fn = lib().glu_radix_sort_run_keys_ptr if key_bytes == 4 else lib().glu_radix_sort_run_keys_u64_ptr
         check(fn(self._h, _vp(keys_ptr), count, num_steps, _vp(stream)))
+
+    KEY_TYPES = {"uint32": 0, "int32": 1, "float32": 2, "uint64": 3, "int64": 4, "float64": 5}
+
+    def sort_typed_ptr(self, keys_ptr, vals_ptr, count, key_type, stream=None):
+        """key_type: a numpy dtype name in KEY_TYPES; vals_ptr may be None (keys only)."""
+        check(lib().glu_radix_sort_run_typed_ptr(self._h, _vp(keys_ptr), _vp(vals_ptr), count, self.KEY_TYPES[key_type],
+                                                 _vp(stream)))
 
     def run_ptr(self, keys_ptr, vals_ptr, count, num_steps=0, stream=None, key_bytes=4):
         fn = lib().glu_radix_sort_run_ptr if key_bytes == 4 else lib().glu_radix_sort_run_u64_ptr

@@ -156,6 +156,20 @@ GLU_API glu_status glu_radix_sort_run_keys_ptr(glu_radix_sort sort, uint32_t* ke
                                                void* stream);
 GLU_API glu_status glu_radix_sort_run_keys_u64_ptr(glu_radix_sort sort, uint64_t* keys, size_t count, size_t num_steps,
                                                    void* stream);
+/* Typed keys (not in the reference: uint32 only).  Signed integers and IEEE floats are sorted in their natural order
+ * (floats as a total order: -0 < +0, NaNs beyond the infinities of their sign) by encoding the key on the first pass's
+ * loads and decoding on the last pass's stores -- no extra pass over memory.  vals may be NULL (keys only). */
+typedef enum glu_key_type
+{
+    GLU_KEY_UINT32 = 0,
+    GLU_KEY_INT32,
+    GLU_KEY_FLOAT32,
+    GLU_KEY_UINT64,
+    GLU_KEY_INT64,
+    GLU_KEY_FLOAT64
+} glu_key_type;
+GLU_API glu_status glu_radix_sort_run_typed_ptr(glu_radix_sort sort, void* keys, uint32_t* vals, size_t count,
+                                                glu_key_type key_type, void* stream);
 /* One stable counting pass on the digit (key >> shift) & ((1 << bits) - 1), 1 <= bits <= 8, from src to dst
  * (distinct buffers).  This is the partition step of the multi-GPU sort (top-8-bit buckets).  If
  * digit_histogram != NULL it receives the 1 << bits digit totals (device memory, uint32). */

@@ -186,6 +186,34 @@ TEST_CASE("RadixSort-keys-only")
     }
 }
 
+TEST_CASE("RadixSort-typed-keys")
+{
+    std::mt19937 gen(77);
+    const size_t n = 100001;
+    std::vector<float> keys(n);
+    for (auto& k : keys) k = float(int(gen() % 20001) - 10000) * 0.25f;
+    std::vector<GLuint> vals(n);
+    std::iota(vals.begin(), vals.end(), 0u);
+    std::vector<GLuint> order(vals);
+    std::stable_sort(order.begin(), order.end(), [&](GLuint a, GLuint b) { return keys[a] < keys[b]; });
+    ShaderStorageBuffer kb(keys), vb(vals);
+    RadixSort radix_sort;
+    radix_sort.sort_typed(static_cast<float*>(kb.device_ptr()), static_cast<uint32_t*>(vb.device_ptr()), n);
+    std::vector<float> out_keys = kb.get_data<float>();
+    std::vector<GLuint> out_vals = vb.get_data<GLuint>();
+    bool same = true;
+    for (size_t i = 0; i < n; i++) same = same && out_vals[i] == order[i] && out_keys[i] == keys[order[i]];
+    CHECK(same);
+
+    std::vector<int64_t> ikeys(n);
+    for (auto& k : ikeys) k = int64_t(gen()) * int64_t(gen() % 2 ? -1 : 1) * 65537;
+    std::vector<int64_t> expected(ikeys);
+    std::sort(expected.begin(), expected.end());
+    ShaderStorageBuffer ib(ikeys);
+    radix_sort.sort_typed(static_cast<int64_t*>(ib.device_ptr()), static_cast<uint32_t*>(nullptr), n);
+    CHECK(ib.get_data<int64_t>() == expected);
+}
+
 TEST_CASE("RadixSort-raw-pointer-overload")
 {
     // native callers: raw device pointers (here taken from ShaderStorageBuffer) on the library queue

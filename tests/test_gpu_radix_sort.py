@@ -277,6 +277,53 @@ def test_keys_only_sort(G, bits, n):
     assert (kb.get_data(np.uint64) == np.sort(k64)).all()
 
 
+@pytest.mark.parametrize("bits", DIGIT_BITS)
+@pytest.mark.parametrize("dtype", ["int32", "float32", "int64", "float64", "uint32", "uint64"])
+@pytest.mark.parametrize("n", [3, 5000, 300001, 4 * (1 << 20) + 9])
+def test_typed_keys(G, bits, dtype, n):
+    """Signed and floating-point keys (not in the reference): natural order, stable, values travel with their keys;
+    floats as a total order (-0 < +0, -inf first, +inf last)."""
+    rng = np.random.default_rng(n)
+    dt = np.dtype(dtype)
+    if dt.kind == "f":
+        keys = (rng.standard_normal(n) * 1e3).astype(dt)
+        keys[rng.integers(0, n, max(1, n // 50))] = 0.0
+        keys[rng.integers(0, n, max(1, n // 50))] = -0.0
+        keys[rng.integers(0, n, 2)] = np.inf
+        keys[rng.integers(0, n, 2)] = -np.inf
+        keys[rng.integers(0, n, max(1, n // 20))] = dt.type(1.5)  # duplicates
+    elif dt.kind == "i":
+        info = np.iinfo(dt)
+        keys = rng.integers(info.min, info.max, n, dtype=dt, endpoint=True)
+        keys[::7] = -3
+    else:
+        keys = rng.integers(0, np.iinfo(dt).max, n, dtype=dt, endpoint=True)
+    vals = np.arange(n, dtype=np.uint32)
+    sorter = G.RadixSort(digit_bits=bits)
+    kb, vb = G.ShaderStorageBuffer(keys), G.ShaderStorageBuffer(vals)
+    sorter.sort_typed_ptr(kb.device_ptr(), vb.device_ptr(), n, dtype)
+    gk, gv = kb.get_data(dt), vb.get_data(np.uint32)
+    # expected: stable sort by the order-preserving unsigned image of the key
+    u = keys.view(np.uint32 if dt.itemsize == 4 else np.uint64)
+    sign = u.dtype.type(1) << u.dtype.type(dt.itemsize * 8 - 1)
+    if dt.kind == "i":
+        image = u ^ sign
+    elif dt.kind == "f":
+        image = np.where(u & sign, ~u, u ^ sign)
+    else:
+        image = u
+    order = np.argsort(image, kind="stable")
+    assert (gk.view(u.dtype) == u[order]).all() and (gv == vals[order]).all()
+    if dt.kind == "f":
+        finite = gk[np.isfinite(gk)]
+        assert (np.diff(finite) >= 0).all()
+    else:
+        assert (np.diff(gk.astype(object) if dt.itemsize == 8 and dt.kind == "u" else gk.astype(np.float64)) >= 0).all()
+    kb2 = G.ShaderStorageBuffer(keys)
+    sorter.sort_typed_ptr(kb2.device_ptr(), None, n, dtype)  # keys only
+    assert (kb2.get_data(dt).view(u.dtype) == u[order]).all()
+
+
 def test_raw_pointer_entry_on_torch_memory(G):
     import torch
 

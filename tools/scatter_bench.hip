@@ -167,14 +167,14 @@ void run_variant(Ctx& c, int blocks_per_cu, uint32_t shift, uint32_t mask_overri
     });
     float t_scatter = time_min(c, 5, [&] {
         hipLaunchKernelGGL(scatter, dim3(nb), dim3(THREADS), sizeof(Smem), 0, c.keys, c.vals, c.keys2, c.vals2, c.table,
-                           totals, (uint32_t) c.n, shift, mask, tiles, (unsigned long long*) nullptr);
+                           totals, (uint32_t) c.n, shift, mask, tiles, (unsigned long long*) nullptr, 0u);
     });
     CK(hipGetLastError());
     unsigned long long* st;
     CK(hipMalloc(&st, 64));
     CK(hipMemset(st, 0, 64));
     hipLaunchKernelGGL(scatter_st, dim3(nb), dim3(THREADS), sizeof(Smem), 0, c.keys, c.vals, c.keys2, c.vals2, c.table,
-                       totals, (uint32_t) c.n, shift, mask, tiles, st);
+                       totals, (uint32_t) c.n, shift, mask, tiles, st, 0u);
     unsigned long long hst[8];
     CK(hipMemcpy(hst, st, 64, hipMemcpyDeviceToHost));
     CK(hipFree(st));
