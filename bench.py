@@ -42,6 +42,8 @@ def parse_args():
     p.add_argument("--no-kernel-events", action="store_true",
                    help="do not record per-kernel HIP events in the timed region (roofline fields become null)")
     p.add_argument("--no-alt", action="store_true", help="skip the extra 4-bit-digit (reference pass structure) measurement")
+    p.add_argument("--pipeline-depth", type=int, default=2,
+                   help="N>1: consecutive sorts in flight (own stream + buffers each); 1 = strictly one after the other")
     p.add_argument("--force-dist", action="store_true",
                    help="run the multi-GPU code path (partition + all-to-all + local sort) even with one rank")
     return p.parse_args()
@@ -296,17 +298,22 @@ def main():
     else:
         from glu_hip import dist as D
 
-        ops = D.HipLocalOps(digit_bits=args.digit_bits)
-        dsort = D.DistributedRadixSort(local_ops=ops)
+        # consecutive sorts are independent batches: with pipeline depth 2 each runs on its own stream / buffers, so the
+        # all-to-all of step i+1 (RCCL) can proceed under the local sort of step i; every step is still a complete sort
+        depth = max(1, args.pipeline_depth)
+        dsort = D.DistributedRadixSort(local_ops_factory=lambda: D.HipLocalOps(digit_bits=args.digit_bits), slots=depth)
         keys0, vals0 = make_input(torch, n, args.keys, rank, device, index_base=rank * n)
         for i in range(W):
-            dsort.sort(keys0, vals0)
+            dsort.sort_async(keys0, vals0)
         barrier()
         t0 = time.perf_counter()
+        handle = None
         for i in range(K):
-            rk, rv, cnt = dsort.sort(keys0, vals0)
+            handle = dsort.sort_async(keys0, vals0)
         barrier()
         elapsed = time.perf_counter() - t0
+        rk, rv, cnt = handle.synchronize()
+        result["pipeline_depth"] = depth
         units = n * world * K
         verified = None
         if not args.no_verify:
@@ -337,7 +344,7 @@ def main():
         result["shard_pairs_rank0"] = int(cnt)
         workload = ("2^%d uint32 key+val pairs per GPU (%d GPUs, 2^%.2f total), uniform-random keys; top-8-bit bucket "
                     "partition + one RCCL all-to-all over xGMI + local sort") % (log2n, world, log2n + __import__("math").log2(world))
-        parallelism = "bucket-sharded x%d (1 all-to-all)" % world
+        parallelism = "bucket-sharded x%d (1 all-to-all), %d sorts in flight" % (world, depth)
 
     # max over ranks
     if dist is not None:

@@ -96,26 +96,54 @@ class HipLocalOps:
         self.sorter.run_ptr(keys.data_ptr(), vals.data_ptr(), count, 0, self._stream())
 
 
+class SortHandle:
+    """Result of DistributedRadixSort.sort_async: this rank's shard (views into the slot's receive buffers, valid until
+    the slot is used again, i.e. for `slots` further sort_async calls).  wait() makes the caller's current stream wait
+    for the sort; synchronize() blocks the host."""
+
+    def __init__(self, owner, slot, keys, vals, count, event):
+        self._owner, self.slot, self.keys, self.vals, self.count, self._event = owner, slot, keys, vals, count, event
+
+    def wait(self):
+        if self._event is not None:
+            self._owner.torch.cuda.current_stream(self.keys.device).wait_event(self._event)
+        return self.keys, self.vals, self.count
+
+    def synchronize(self):
+        if self._event is not None:
+            self._event.synchronize()
+        return self.keys, self.vals, self.count
+
+
 class DistributedRadixSort:
     """sort(keys, vals) -> (sorted_keys, sorted_vals, count): this rank's shard of the globally sorted array
-    (shard sizes vary with the data).  keys / vals: 1-D int32 torch tensors holding uint32 bit patterns."""
+    (shard sizes vary with the data).  keys / vals: 1-D int32 torch tensors holding uint32 bit patterns.
 
-    def __init__(self, group=None, local_ops=None, capacity_factor=1.25):
+    slots > 1 lets consecutive sorts overlap: sort_async() runs each sort on its own stream with its own buffers and
+    device-op object, so the all-to-all of sort i+1 (RCCL, few CUs) can run under the local sort of sort i.  The order
+    of collectives is the call order on every rank, so ranks must issue the same sequence of sorts."""
+
+    def __init__(self, group=None, local_ops=None, capacity_factor=1.25, slots=1, local_ops_factory=None):
         import torch
         import torch.distributed as dist
 
         self.torch, self.dist, self.group = torch, dist, group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
-        self.ops = local_ops if local_ops is not None else HipLocalOps()
+        if local_ops_factory is None:
+            local_ops_factory = (lambda: local_ops) if local_ops is not None else HipLocalOps
         self.capacity_factor = capacity_factor
-        self._bufs = None
+        self._slots = [{"ops": local_ops_factory(), "bufs": None, "stream": None} for _ in range(max(1, slots))]
+        self._next_slot = 0
         self.last_plan = None
-        self._stream = None
 
-    def _buffers(self, n_local, device, need_recv=0):
+    @property
+    def ops(self):
+        return self._slots[0]["ops"]
+
+    def _buffers(self, slot, n_local, device, need_recv=0):
         cap = max(int(n_local * self.capacity_factor) + 4096, need_recv)
-        b = self._bufs
+        b = slot["bufs"]
         if b is None or b["n_local"] < n_local or b["cap"] < cap or b["device"] != device:
             t = self.torch
             b = {
@@ -127,9 +155,9 @@ class DistributedRadixSort:
                 "hist": t.zeros(NUM_BUCKETS, dtype=t.int32, device=device),
                 "all_hist": t.zeros(self.world * NUM_BUCKETS, dtype=t.int32, device=device),
             }
-            self._bufs = b
-            if hasattr(self.ops, "prepare"):
-                self.ops.prepare(cap)
+            slot["bufs"] = b
+            if hasattr(slot["ops"], "prepare"):
+                slot["ops"].prepare(cap)
         return b
 
     def _all_to_all(self, out, inp, recv_counts, send_counts):
@@ -154,28 +182,37 @@ class DistributedRadixSort:
             dist.all_to_all_single(out, inp, [int(c) for c in recv_counts], [int(c) for c in send_counts],
                                    group=self.group)
 
-    def sort(self, keys, vals):
-        """Runs on a private torch stream (ordered after the caller's current stream on entry, and the caller's
-        stream waits for it on exit), so the raw-pointer kernels, the RCCL calls and torch ops share one queue."""
+    def sort_async(self, keys, vals):
+        """Enqueues one distributed sort on the next slot's private stream (ordered after the caller's current stream)
+        and returns a SortHandle.  The host blocks only for the bucket-histogram exchange."""
+        slot = self._slots[self._next_slot]
+        index = self._next_slot
+        self._next_slot = (self._next_slot + 1) % len(self._slots)
         if not keys.is_cuda:
-            return self._sort(keys, vals)
+            k, v, c = self._sort(slot, keys, vals)
+            return SortHandle(self, index, k, v, c, None)
         t = self.torch
-        if self._stream is None:
-            self._stream = t.cuda.Stream(device=keys.device)
-        caller = t.cuda.current_stream(keys.device)
-        self._stream.wait_stream(caller)
-        with t.cuda.stream(self._stream):
-            out = self._sort(keys, vals)
-        caller.wait_stream(self._stream)
-        return out
+        if slot["stream"] is None:
+            slot["stream"] = t.cuda.Stream(device=keys.device)
+        slot["stream"].wait_stream(t.cuda.current_stream(keys.device))
+        with t.cuda.stream(slot["stream"]):
+            k, v, c = self._sort(slot, keys, vals)
+            event = t.cuda.Event()
+            event.record(slot["stream"])
+        return SortHandle(self, index, k, v, c, event)
 
-    def _sort(self, keys, vals):
+    def sort(self, keys, vals):
+        """One sort, complete (stream-wise) when it returns: the caller's current stream waits for it."""
+        return self.sort_async(keys, vals).wait()
+
+    def _sort(self, slot, keys, vals):
         t, dist = self.torch, self.dist
+        ops = slot["ops"]
         n_local = keys.numel()
-        b = self._buffers(n_local, keys.device)
+        b = self._buffers(slot, n_local, keys.device)
 
         # 1. local stable partition by top-8-bit bucket + histogram
-        self.ops.partition(keys, vals, b["part_k"], b["part_v"], b["hist"])
+        ops.partition(keys, vals, b["part_k"], b["part_v"], b["hist"])
 
         # 2. everyone learns every rank's histogram (R x 256 int32: latency-bound, tiny)
         dist.all_gather_into_tensor(b["all_hist"], b["hist"], group=self.group)
@@ -186,7 +223,7 @@ class DistributedRadixSort:
         send_counts, recv_counts = split_counts(all_hist, owner, self.rank)
         n_recv = int(recv_counts.sum())
         if n_recv > b["cap"]:
-            b = self._grow_recv(b, n_recv)
+            b = self._grow_recv(slot, b, n_recv)
         self.last_plan = {"owner": owner, "send": send_counts, "recv": recv_counts}
 
         # 4. one exchange for keys, one for values; receive segments ordered by source rank
@@ -196,15 +233,15 @@ class DistributedRadixSort:
         self._all_to_all(recv_v, b["part_v"][:n_local], recv_counts, send_counts)
 
         # 5. local stable sort of the received pairs
-        self.ops.sort(recv_k, recv_v, n_recv)
+        ops.sort(recv_k, recv_v, n_recv)
         return recv_k, recv_v, n_recv
 
-    def _grow_recv(self, b, n_recv):
+    def _grow_recv(self, slot, b, n_recv):
         t = self.torch
         cap = int(n_recv * 1.1) + 4096
         b["recv_k"] = t.empty(cap, dtype=t.int32, device=b["device"])
         b["recv_v"] = t.empty(cap, dtype=t.int32, device=b["device"])
         b["cap"] = cap
-        if hasattr(self.ops, "prepare"):
-            self.ops.prepare(cap)
+        if hasattr(slot["ops"], "prepare"):
+            slot["ops"].prepare(cap)
         return b

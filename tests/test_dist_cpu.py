@@ -150,3 +150,47 @@ def test_two_process_gloo_sort_matches_oracle(kind):
     gk = np.concatenate([r[1] for r in results])
     gv = np.concatenate([r[2] for r in results])
     assert (gk == ek).all() and (gv == ev).all()
+
+
+def _pipelined_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sorter = D.DistributedRadixSort(local_ops_factory=OracleLocalOps, slots=2)
+        out = []
+        for step in range(5):  # alternates between the two slots; results are copied out before a slot is reused
+            keys = make_keys(["uniform", "dups", "hot"][step % 3], 9000 + 100 * step + 7 * rank, 31 * step + rank)
+            vals = np.arange(keys.size, dtype=np.uint32) + np.uint32(1000000 * rank)
+            h = sorter.sort_async(torch.from_numpy(keys.view(np.int32).copy()), torch.from_numpy(vals.view(np.int32).copy()))
+            rk, rv, cnt = h.wait()
+            out.append((keys, vals, rk.numpy().view(np.uint32)[:cnt].copy(), rv.numpy().view(np.uint32)[:cnt].copy()))
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_slot_pipelined_sorts_over_gloo():
+    import torch.multiprocessing as mp
+
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipelined_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for step in range(5):
+        all_keys = np.concatenate([results[r][step][0] for r in range(world)])
+        all_vals = np.concatenate([results[r][step][1] for r in range(world)])
+        ek, ev = O.stable_sort_pairs(all_keys, all_vals)
+        gk = np.concatenate([results[r][step][2] for r in range(world)])
+        gv = np.concatenate([results[r][step][3] for r in range(world)])
+        assert (gk == ek).all() and (gv == ev).all(), step

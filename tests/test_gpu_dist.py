@@ -67,11 +67,14 @@ def _gpu_worker(rank, world, port, n_local, q):
             keys[: n // 2] |= np.uint32(0xF0000000)  # skew: rank 1 is heavy in the top buckets
         base = sum(n_local + 1000 * r for r in range(rank))
         vals = np.arange(base, base + n, dtype=np.uint32)
-        sorter = D.DistributedRadixSort()
+        sorter = D.DistributedRadixSort(slots=2)  # two slots: consecutive sorts run on alternating streams / buffers
         kt = torch.from_numpy(keys.view(np.int32).copy()).cuda()
         vt = torch.from_numpy(vals.view(np.int32).copy()).cuda()
-        rk, rv, cnt = sorter.sort(kt, vt)
+        handles = [sorter.sort_async(kt, vt) for _ in range(3)]  # same input three times, overlapping in flight
         torch.cuda.synchronize()
+        first = handles[1].synchronize()
+        rk, rv, cnt = handles[2].synchronize()
+        assert cnt == first[2] and bool((rk[:cnt] == first[0][:cnt]).all()) and bool((rv[:cnt] == first[1][:cnt]).all())
         q.put((rank, keys, vals, rk[:cnt].cpu().numpy().view(np.uint32).copy(), rv[:cnt].cpu().numpy().view(np.uint32).copy()))
     finally:
         dist.destroy_process_group()
