@@ -160,7 +160,7 @@ void run_variant(Ctx& c, int blocks_per_cu, uint32_t shift, uint32_t mask_overri
 
     float t_count = time_min(c, 5, [&] {
         hipLaunchKernelGGL((radix_count_kernel<uint32_t, BITS, THREADS, TILE>), dim3(nb), dim3(THREADS), 0, 0, c.keys, c.table,
-                           (uint32_t) c.n, shift, mask, tiles);
+                           (uint32_t) c.n, shift, mask, tiles, 0u);
     });
     float t_scan = time_min(c, 1, [&] {
         hipLaunchKernelGGL((radix_row_scan_kernel<256>), dim3(RADIX), dim3(256), 0, 0, c.table, totals, nb);
@@ -243,8 +243,20 @@ int main(int argc, char** argv)
         run_variant<4, 1024, 16, true>(c, 1, shift);
         return 0;
     }
-    run_variant<8, 1024, 12, true>(c, 1, shift);
-    run_variant<4, 1024, 12, false>(c, 1, shift);
+    {   // count kernel alone: threads per workgroup at one workgroup per CU
+        const uint32_t tiles = (uint32_t) ((c.n + 12288 - 1) / 12288), nb = std::min<uint32_t>(tiles, (uint32_t) c.cus);
+        auto cnt = [&](auto kern, int threads, const char* name) {
+            float t = time_min(c, 7, [&] { hipLaunchKernelGGL(kern, dim3(nb), dim3(threads), 0, 0, c.keys, c.table, (uint32_t) c.n, shift, 255u, tiles, 0u); });
+            printf("count %s: %.3f ms (%.0f GB/s)\n", name, t, c.n * 4.0 / t / 1e6);
+        };
+        cnt(radix_count_kernel<uint32_t, 8, 256, 12288>, 256, "8-bit  256 thr");
+        cnt(radix_count_kernel<uint32_t, 8, 512, 12288>, 512, "8-bit  512 thr");
+        cnt(radix_count_kernel<uint32_t, 8, 1024, 12288>, 1024, "8-bit 1024 thr");
+        cnt(radix_count_kernel<uint32_t, 4, 256, 12288>, 256, "4-bit  256 thr");
+        cnt(radix_count_kernel<uint32_t, 4, 512, 12288>, 512, "4-bit  512 thr");
+        cnt(radix_count_kernel<uint32_t, 4, 1024, 12288>, 1024, "4-bit 1024 thr");
+        cnt(radix_count_kernel<uint32_t, 8, 512, 12288>, 512, "8-bit  512 thr");
+    }
     run_variant<8, 1024, 12, true>(c, 1, shift);
     return 0;
 }
