@@ -807,6 +807,7 @@ struct glu_scan_s
     Scratch ticket;
     uint32_t epoch = 0;
     bool chained = true; // GLU_HIP_SCAN_CHAINED=0 falls back to reduce-then-scan
+    size_t chain_min_chunks = kChainMinChunks; // GLU_HIP_SCAN_CHAINED=2: chained from 2 chunks up (tests)
 };
 
 struct glu_reduce_s
@@ -841,7 +842,7 @@ template<typename S, int N>
 glu_status scan_chained(glu_scan_s* scan, Elem<S, N>* data, size_t count, size_t partitions, hipStream_t stream)
 {
     using T = Elem<S, N>;
-    using C = ScanCfg<T, kChainGroups>;
+    using C = ScanCfg<T, kChainGroups, kChainThreads>;
     const size_t chunks = (count + C::CHUNK - 1) / C::CHUNK;
     const size_t words = chunks * partitions;
     if (scan->chain.size < words * sizeof(unsigned long long))
@@ -916,8 +917,10 @@ struct ScanRunner
         using T = Elem<S, N>;
         if constexpr (sizeof(T) == 4)
         {
-            const size_t chunks = (count + ScanCfg<T, kChainGroups>::CHUNK - 1) / ScanCfg<T, kChainGroups>::CHUNK;
-            if (scan->chained && chunks > 1 && chunks * partitions <= 0x7FFFFFFFull)
+            const size_t chunks = (count + ScanCfg<T, kChainGroups, kChainThreads>::CHUNK - 1) / ScanCfg<T, kChainGroups, kChainThreads>::CHUNK;
+            // Below about one chunk per CU the ticket chain is latency-bound and the three-launch reduce-then-scan
+            // wins (measured crossover between 2^22 and 2^24 elements, tools/scan_probe.py).
+            if (scan->chained && chunks > 1 && chunks * partitions >= scan->chain_min_chunks && chunks * partitions <= 0x7FFFFFFFull)
             {
                 if (size_only)
                 {
@@ -1001,7 +1004,11 @@ glu_status glu_scan_create(glu_data_type data_type, glu_scan* out)
         return fail(GLU_ERROR_INVALID_ARGUMENT, "Invalid data type: %d", (int) data_type);
     glu_scan_s* s = new glu_scan_s();
     s->type = data_type;
-    if (const char* e = getenv("GLU_HIP_SCAN_CHAINED")) s->chained = atoi(e) != 0;
+    if (const char* e = getenv("GLU_HIP_SCAN_CHAINED"))
+    {
+        s->chained = atoi(e) != 0;
+        if (atoi(e) == 2) s->chain_min_chunks = 2;
+    }
     *out = s;
     return GLU_OK;
 }

@@ -107,13 +107,13 @@ __device__ __forceinline__ T shfl_t(const T& v, int src)
 // ---- scan -------------------------------------------------------------------------------------------------
 // A chunk = THREADS * GROUPS * VEC elements.  Inside a wave the layout is "group-major, then lane, then the VEC
 // elements of a 16-byte vector", so every load/store instruction of a wave is one contiguous 1 KiB.
-// GROUPS_ = 4: 4096 4-byte elements per chunk (reduce-then-scan path); the chained path uses 16 (16384 elements, 64 KiB
-// per workgroup) so that the single ticket counter sees ~16 K atomics for 2^28 elements instead of 65 K (one global
-// counter sustains only ~90 returning atomics per microsecond on MI355X).
-template<typename T, int GROUPS_ = 4>
+// GROUPS_ = 4, THREADS_ = 256: 4096 4-byte elements per chunk (reduce-then-scan path); the chained path uses 1024
+// threads x 8 groups (32768 elements, 128 KiB per workgroup) so that the single ticket counter sees 8 K atomics for 2^28
+// elements instead of 65 K (one global counter sustains only ~90 returning atomics per microsecond on MI355X).
+template<typename T, int GROUPS_ = 4, int THREADS_ = 256>
 struct ScanCfg
 {
-    static constexpr int THREADS = 256;
+    static constexpr int THREADS = THREADS_;
     static constexpr int WAVES = THREADS / kW;
     static constexpr int VEC = sizeof(T) >= 16 ? 1 : 16 / (int) sizeof(T);
     static constexpr int GROUPS = GROUPS_;
@@ -134,7 +134,7 @@ __device__ __forceinline__ void scan_load(const Elem<S, N>* base, uint32_t valid
                                           Elem<S, N> (&x)[GROUPS][ScanCfg<Elem<S, N>>::VEC])
 {
     using T = Elem<S, N>;
-    using C = ScanCfg<T, GROUPS>;
+    using C = ScanCfg<T, GROUPS>; // only WAVE_ELEMS / VEC are used here: independent of the thread count
 #pragma unroll
     for (int g = 0; g < C::GROUPS; g++)
     {
@@ -198,7 +198,9 @@ __device__ __forceinline__ uint64_t chain_pack(uint32_t epoch, uint64_t flag, ui
 {
     return ((uint64_t) epoch << 34) | (flag << 32) | value;
 }
-constexpr int kChainGroups = 16;              // 16-byte load groups per thread in the chained kernel
+constexpr int kChainThreads = 1024;
+constexpr int kChainMinChunks = 256;
+constexpr int kChainGroups = 8;               // 16-byte load groups per thread in the chained kernel
 constexpr uint32_t kChainSpinLimit = 1u << 24; // polls before the kernel gives up loudly (trap) instead of hanging
 
 // In-place exclusive scan of every chunk.
@@ -207,13 +209,13 @@ constexpr uint32_t kChainSpinLimit = 1u << 24; // polls before the kernel gives 
 //   workgroup waits for is already running), each publishes its total, looks back over its predecessors' words for
 //   the carry-in, then publishes its inclusive prefix.  8 B/element of HBM traffic instead of 12.
 template<typename S, int N, bool ALIGNED, bool CHAINED = false>
-__global__ __launch_bounds__(256) void scan_chunks_kernel(Elem<S, N>* __restrict__ data,
+__global__ __launch_bounds__(CHAINED ? kChainThreads : 256) void scan_chunks_kernel(Elem<S, N>* __restrict__ data,
                                                           const Elem<S, N>* __restrict__ carry, uint64_t count,
                                                           uint32_t chunks, unsigned long long* __restrict__ chain = nullptr,
                                                           uint32_t* __restrict__ ticket = nullptr, uint32_t epoch = 0)
 {
     using T = Elem<S, N>;
-    using C = ScanCfg<T, CHAINED ? kChainGroups : 4>;
+    using C = ScanCfg<T, CHAINED ? kChainGroups : 4, CHAINED ? kChainThreads : 256>;
     static_assert(!CHAINED || sizeof(T) == 4, "chained scan packs the value into 32 bits");
     __shared__ T wsum[C::WAVES];
     __shared__ uint32_t s_ticket;

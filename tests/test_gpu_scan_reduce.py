@@ -62,15 +62,16 @@ def test_scan_non_power_of_two_through_raw_pointer_entry(G, count):
     assert (b.get_data(np.uint32) == O.exclusive_scan_u32(d, count, parts)).all()
 
 
-@pytest.mark.parametrize("chained", ["1", "0"])
+@pytest.mark.parametrize("chained", ["2", "1", "0"])
 def test_scan_chained_and_reduce_then_scan_paths_agree(G, monkeypatch, chained):
-    """4-byte types use the single-pass chained scan (decoupled look-back) by default; GLU_HIP_SCAN_CHAINED=0 selects the
-    3-launch reduce-then-scan path that the wider types always use.  Both must equal the oracle."""
+    """4-byte types use the single-pass chained scan (decoupled look-back) from 256 chunks of 32768 elements up
+    (GLU_HIP_SCAN_CHAINED=2: from 2 chunks up, so the small cases here exercise it too); GLU_HIP_SCAN_CHAINED=0 selects
+    the 3-launch reduce-then-scan path that the wider types and the smaller counts always use.  All equal the oracle."""
     monkeypatch.setenv("GLU_HIP_SCAN_CHAINED", chained)
     rng = np.random.default_rng(int(chained))
     for dt, npdt in ((G.DataType_Uint, np.uint32), (G.DataType_Int, np.int32), (G.DataType_Float, np.float32)):
         scan = G.BlellochScan(dt)
-        for count, parts in ((1 << 13, 5), (1 << 20, 3), (1 << 25 if npdt != np.float32 else 1 << 22, 1), (16384 * 65 + 7, 2)):
+        for count, parts in ((1 << 13, 5), (1 << 20, 3), (1 << 25 if npdt != np.float32 else 1 << 22, 1), (32768 * 65 + 7, 2), (32768 * 2 + 1, 7)):
             raw = rng.integers(0, 4, count * parts)
             d = (raw * (0.5 if npdt == np.float32 else 1)).astype(npdt)  # float partial sums stay exact
             b = G.ShaderStorageBuffer(d)
