@@ -407,3 +407,54 @@ def test_full_size_2_28_u64(G):
     vals = np.arange(n, dtype=np.uint32)
     gk, gv = gpu_sort(G, keys, vals, key_bytes=8)
     _check_sorted_properties(keys, gk, gv)
+
+
+def _device_sorted_properties(torch, orig, gk, gv, chunk=1 << 28):
+    """The properties of _check_sorted_properties evaluated on the device in chunks (arrays too large for the host):
+    int32 tensors holding uint32 bit patterns; unsigned order = signed order after flipping bit 31."""
+    n = gk.numel()
+    flip = -(1 << 31)
+    seen = torch.zeros(n, dtype=torch.bool, device=gk.device)
+    for lo in range(0, n, chunk):
+        hi = min(n, lo + chunk)
+        k = gk[lo:hi] ^ flip
+        nxt = gk[lo + 1:min(n, hi + 1)] ^ flip
+        assert bool((nxt >= k[:nxt.numel()]).all()), "keys not ascending in [%d, %d)" % (lo, hi)
+        idx = gv[lo:hi].to(torch.int64) & 0xFFFFFFFF
+        assert bool((orig[idx] == gk[lo:hi]).all()), "gk[i] != keys[gv[i]] in [%d, %d)" % (lo, hi)
+        seen[idx] = True
+        v = gv[lo:hi] ^ flip
+        vn = gv[lo + 1:min(n, hi + 1)] ^ flip
+        eq = nxt == k[:nxt.numel()]
+        assert bool(((vn > v[:vn.numel()]) | ~eq).all()), "not stable in [%d, %d)" % (lo, hi)
+        del k, nxt, idx, v, vn, eq
+    assert bool(seen.all()), "vals are not a permutation"
+
+
+@pytest.mark.parametrize("n,bits", [(0xFFFF0000, 8), ((1 << 31) + 12345, 4)])
+def test_maximum_count_on_device(G, n, bits):
+    """The largest count the ABI accepts (2^32 - 65536: 16 GiB of keys, 16 GiB of values, as much scratch) and one just
+    past 2^31 (sign / 32-bit byte-offset overflows), checked by the size-independent properties on the device."""
+    import torch
+
+    free, _ = torch.cuda.mem_get_info()
+    if free < 150 * (1 << 30):
+        pytest.skip("needs 150 GiB of free HBM")
+    gen = torch.Generator(device="cuda").manual_seed(n & 0xFFFF)
+    keys = torch.empty(n, dtype=torch.int32, device="cuda")
+    step = 1 << 28
+    for lo in range(0, n, step):  # full-range 32-bit patterns; duplicates guaranteed (n ~ 2^32 draws)
+        m = min(step, n - lo)
+        keys[lo:lo + m] = torch.randint(-(1 << 31), 1 << 31, (m,), generator=gen, device="cuda", dtype=torch.int64).to(torch.int32)
+    vals = torch.arange(n, dtype=torch.int64, device="cuda").to(torch.int32)  # iota as uint32 bit patterns
+    orig = keys.clone()
+    sorter = G.RadixSort(digit_bits=bits)
+    sorter.prepare_internal_buffers(n)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        sorter.run_ptr(keys.data_ptr(), vals.data_ptr(), n, 0, side.cuda_stream)
+    side.synchronize()
+    _device_sorted_properties(torch, orig, keys, vals)
+    del sorter, keys, vals, orig
+    torch.cuda.empty_cache()
