@@ -226,3 +226,72 @@ def test_buffer_object_semantics(G):
     assert 0 < ns < 10**9
     empty = G.ShaderStorageBuffer()
     assert empty.handle() == 0 and empty.size() == 0
+
+
+@pytest.mark.parametrize("count,parts", [(1 << 32, 1), (1 << 31, 3), ((1 << 32) + 12345, 1)])
+def test_scan_beyond_32_bit_counts_on_device(G, count, parts):
+    """Element indices past 2^32 (16 - 24 GiB of uint32): checked on the device against torch.cumsum in int64, chunk by
+    chunk with the carried total, modulo 2^32 as the operator wraps."""
+    import torch
+
+    free, _ = torch.cuda.mem_get_info()
+    if free < 120 * (1 << 30):
+        pytest.skip("needs 120 GiB of free HBM")
+    n = count * parts
+    gen = torch.Generator(device="cuda").manual_seed(parts)
+    data = torch.empty(n, dtype=torch.int32, device="cuda")
+    step = 1 << 28
+    for lo in range(0, n, step):
+        m = min(step, n - lo)
+        data[lo:lo + m] = torch.randint(0, 1 << 20, (m,), generator=gen, device="cuda", dtype=torch.int32)
+    orig = data.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        G.BlellochScan(G.DataType_Uint).run_ptr(data.data_ptr(), count, parts, side.cuda_stream)
+    side.synchronize()
+    for p in range(parts):
+        carry = 0
+        for lo in range(0, count, step):
+            m = min(step, count - lo)
+            x = orig[p * count + lo:p * count + lo + m].to(torch.int64)
+            inc = torch.cumsum(x, 0)
+            exp = (inc - x + carry) & 0xFFFFFFFF
+            got = data[p * count + lo:p * count + lo + m].to(torch.int64) & 0xFFFFFFFF
+            assert bool((got == exp).all()), (p, lo)
+            carry += int(inc[-1])
+            del x, inc, exp, got
+    del data, orig
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("count", [(1 << 33) + 7])
+def test_reduce_beyond_32_bit_counts_on_device(G, count):
+    import torch
+
+    free, _ = torch.cuda.mem_get_info()
+    if free < 80 * (1 << 30):
+        pytest.skip("needs 80 GiB of free HBM")
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    data = torch.empty(count, dtype=torch.int32, device="cuda")
+    step = 1 << 28
+    for lo in range(0, count, step):
+        m = min(step, count - lo)
+        data[lo:lo + m] = torch.randint(-(1 << 20), 1 << 20, (m,), generator=gen, device="cuda", dtype=torch.int32)
+    data[count - 1] = (1 << 20) + 5  # the maximum sits in the last element, past index 2^33
+    total = sum(int(data[lo:min(count, lo + step)].sum(dtype=torch.int64)) for lo in range(0, count, step))
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    for op, expect in ((G.ReduceOperator_Max, (1 << 20) + 5), (G.ReduceOperator_Sum, None)):
+        work = data.clone()
+        side.wait_stream(torch.cuda.current_stream())  # the clone runs on torch's current stream
+        with torch.cuda.stream(side):
+            G.Reduce(G.DataType_Int, op).run_ptr(work.data_ptr(), count, side.cuda_stream)
+        side.synchronize()
+        got = int(work[0].item())
+        if expect is None:
+            expect = ((total + (1 << 31)) % (1 << 32)) - (1 << 31)  # int32 wrap
+        assert got == expect, (op, got, expect)
+        del work
+    del data
+    torch.cuda.empty_cache()
