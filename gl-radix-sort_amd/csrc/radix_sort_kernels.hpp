@@ -65,17 +65,31 @@ __device__ __forceinline__ void block_tile_range(uint32_t b, uint32_t nb, uint32
     last = first + q + (b < r ? 1u : 0u);
 }
 
+// Wave64 exclusive prefix sum with DPP moves (VALU only; the __shfl_up form goes through the LDS crossbar with
+// ds_bpermute, 6 dependent LDS round trips).  update_dpp(0, x, ...) yields 0 in lanes without a source lane / in rows
+// outside row_mask, so no lane predicate is needed.
 __device__ __forceinline__ uint32_t wave_exclusive_sum(uint32_t v, uint32_t lane, uint32_t& total)
 {
-    uint32_t incl = v;
-#pragma unroll
-    for (int off = 1; off < kWave; off <<= 1)
-    {
-        uint32_t t = __shfl_up(incl, off, kWave);
-        if (lane >= (uint32_t) off) incl += t;
-    }
-    total = __shfl(incl, kWave - 1, kWave);
-    return incl - v;
+    (void) lane;
+    int incl = (int) v;
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, false); // row_shr:1
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, false); // row_shr:2
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, false); // row_shr:4
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, false); // row_shr:8   -> scanned inside rows of 16
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xa, 0xf, false); // row_bcast:15 into rows 1 and 3
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xc, 0xf, false); // row_bcast:31 into rows 2 and 3
+    total = (uint32_t) __builtin_amdgcn_readlane(incl, kWave - 1);
+    return (uint32_t) incl - v;
+}
+
+// Sum of the first `wave` entries of an LDS array of per-wave totals (count <= 64), without a branch per entry: lane l
+// reads entry l, the wave scans them, and the (wave-uniform) result is read from lane `wave`.
+__device__ __forceinline__ uint32_t sum_of_preceding_waves(const uint32_t* totals, int count, uint32_t wave, uint32_t lane)
+{
+    const uint32_t v = lane < (uint32_t) count ? totals[lane] : 0u;
+    uint32_t all;
+    const uint32_t excl = wave_exclusive_sum(v, lane, all);
+    return (uint32_t) __builtin_amdgcn_readlane((int) excl, (int) __builtin_amdgcn_readfirstlane((int) wave));
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -294,7 +308,7 @@ struct ScatterSmem
 // ~145 dwords per lane (it also hoists lane-constant shuffle addresses out of the tile loop) and the kernel runs 4x
 // slower; it needs the values to be loaded per round instead of being held in registers.
 template<typename KeyT, int BITS, int THREADS, int KPT, bool CARRY = true, int ABLATE = 0, bool STAMPS = false,
-         int MIN_WAVES_PER_SIMD = 1, int ROUNDS = 1, bool PREFETCH = false>
+         int MIN_WAVES_PER_SIMD = 1, int ROUNDS = 1, int PREFETCH = 0, bool DMA = false>
 __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_kernel(
     const KeyT* __restrict__ src_keys, const uint32_t* __restrict__ src_vals, KeyT* __restrict__ dst_keys,
     uint32_t* __restrict__ dst_vals, const uint32_t* __restrict__ table, const uint32_t* __restrict__ totals,
@@ -321,6 +335,7 @@ __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_ker
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t nb = gridDim.x, b = blockIdx.x;
     const bool has_vals = src_vals != nullptr; // keys-only sorts pass no value arrays (kernel-uniform branch)
+    const bool dma_ok = ((reinterpret_cast<uintptr_t>(src_keys) | reinterpret_cast<uintptr_t>(src_vals)) & 15u) == 0;
     const KeyCodec<KeyT> codec_in(xform & 3u), codec_out((xform >> 2) & 3u); // key encode on load / decode on store
 
     // ---- prologue: this workgroup's global base for every digit:
@@ -344,6 +359,12 @@ __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_ker
 
     uint32_t first, last;
     block_tile_range(b, nb, tiles_total, first, last);
+    if (ABLATE == 3)
+    {
+        // experiment: spread the workgroups' phases over one tile time so that the chip is not in lockstep
+        for (uint32_t k = 0; k < (b * 7u) % 16u; k++) __builtin_amdgcn_s_sleep(30);
+        __syncthreads();
+    }
 
     // wave-striped layout: item i of lane l of wave w is element w*WAVE_TILE + i*64 + l of the tile, so that
     // "item-major, then lane" order inside a wave is memory order -> ranks are stable
@@ -394,15 +415,59 @@ __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_ker
     // loads one tile into registers (wave-striped); positions past the end of the array read as pads
     KeyT key[KPT];
     uint32_t val[KPT];
-    auto load_tile = [&](uint32_t t) {
+    auto load_tile = [&](uint32_t t, int what = 3) { // what: 1 = keys, 2 = values, 3 = both
         const uint64_t base = (uint64_t) t * TILE;
         const uint64_t left = (uint64_t) n - base;
-        if (left >= (uint64_t) TILE)
+        if (DMA && what == 3 && dma_ok && left >= (uint64_t) TILE)
         {
+            // Full tile of 16-byte aligned arrays: every wave copies ITS 64 * KPT keys and values into the (idle) staging
+            // area with 1 KiB LDS-DMA pieces (global_load_lds_dwordx4: no VGPRs, 4x fewer vector-memory instructions
+            // than dword loads, which are issue-bound here), then reads them back wave-striped.  The raw image is
+            // wave-private, so no workgroup barrier is needed between the copy and the reads.
+            unsigned char* raw = reinterpret_cast<unsigned char*>(&s.stage);
+            const KeyT* rawk = reinterpret_cast<const KeyT*>(raw) + wave * WAVE_TILE;
+            const uint32_t* rawv = reinterpret_cast<const uint32_t*>(raw + (size_t) TILE * sizeof(KeyT)) + wave * WAVE_TILE;
+            const unsigned char* gk = reinterpret_cast<const unsigned char*>(src_keys + base + wave * WAVE_TILE);
+            const unsigned char* gv = reinterpret_cast<const unsigned char*>(src_vals + base + wave * WAVE_TILE);
+            constexpr int KEY_PIECES = KPT * (int) sizeof(KeyT) / 16, VAL_PIECES = KPT * 4 / 16;
+            static_assert(!DMA || (KPT * sizeof(KeyT)) % 16 == 0 && (KPT * 4) % 16 == 0, "whole 1 KiB pieces per wave");
 #pragma unroll
-            for (int i = 0; i < KPT; i++) key[i] = codec_in.encode(src_keys[base + wave_off + i * kWave]);
+            for (int j = 0; j < KEY_PIECES; j++)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*) (gk + j * 1024 + lane * 16),
+                    (__attribute__((address_space(3))) void*) (reinterpret_cast<const unsigned char*>(rawk) + j * 1024), 16, 0, 0);
+            if (has_vals)
+            {
 #pragma unroll
-            for (int i = 0; i < KPT; i++) val[i] = has_vals ? src_vals[base + wave_off + i * kWave] : 0u;
+                for (int j = 0; j < VAL_PIECES; j++)
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void*) (gv + j * 1024 + lane * 16),
+                        (__attribute__((address_space(3))) void*) (reinterpret_cast<const unsigned char*>(rawv) + j * 1024), 16, 0, 0);
+            }
+            if (STAMPS) stamp(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < KPT; i++) key[i] = codec_in.encode(rawk[i * kWave + lane]);
+#pragma unroll
+            for (int i = 0; i < KPT; i++) val[i] = has_vals ? rawv[i * kWave + lane] : 0u;
+            if (STAMPS)
+            {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                stamp(1);
+            }
+        }
+        else if (left >= (uint64_t) TILE)
+        {
+            if (what & 1)
+            {
+#pragma unroll
+                for (int i = 0; i < KPT; i++) key[i] = codec_in.encode(src_keys[base + wave_off + i * kWave]);
+            }
+            if (what & 2)
+            {
+#pragma unroll
+                for (int i = 0; i < KPT; i++) val[i] = has_vals ? src_vals[base + wave_off + i * kWave] : 0u;
+            }
         }
         else
         {
@@ -411,12 +476,15 @@ __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_ker
             {
                 const uint32_t p = wave_off + i * kWave;
                 const bool ok = p < (uint32_t) left;
-                key[i] = ok ? codec_in.encode(src_keys[base + p]) : (KeyT) ~(KeyT) 0; // pad: last digit, after all real keys
-                val[i] = (ok && has_vals) ? src_vals[base + p] : 0u;
+                // pad: last digit, after all real keys
+                if (what & 1) key[i] = ok ? codec_in.encode(src_keys[base + p]) : (KeyT) ~(KeyT) 0;
+                if (what & 2) val[i] = (ok && has_vals) ? src_vals[base + p] : 0u;
             }
         }
     };
-    if (PREFETCH && first < last) load_tile(first);
+    // PREFETCH 1: keys and values of tile t+1 are loaded during the write-out of tile t; 2: keys only, the values at the
+    // top of their own tile (they are not needed before the staging step, two phases later)
+    if (PREFETCH && first < last) load_tile(first, PREFETCH == 2 ? 1 : 3);
 
     for (uint32_t tile = first; tile < last; tile++)
     {
@@ -427,6 +495,7 @@ __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_ker
 
         // ---- load (PREFETCH: already issued while the previous tile was being written out)
         if (!PREFETCH) load_tile(tile);
+        if (PREFETCH == 2) load_tile(tile, 2);
         if (STAMPS)
         {
             stamp(0); // issue
@@ -434,12 +503,24 @@ __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_ker
             stamp(1); // load latency (diagnostic builds wait here; production waits at first use)
         }
 
+        // PREFETCH 3: the next tile's loads are issued one pair per rank iteration (into their own registers), so that
+        // they neither wait for a full vector-memory queue nor sit between this tile's stores
+        const bool sprinkle = PREFETCH == 3 && tile + 1 < last && (uint64_t) n - (tile_base + TILE) >= (uint64_t) TILE;
+        KeyT nk[PREFETCH == 3 ? KPT : 1];
+        uint32_t nv[PREFETCH == 3 ? KPT : 1];
+
         // ---- rank inside the wave
         uint32_t rank[KPT];
         uint32_t* my_cnt = s.wcnt[wave];
 #pragma unroll
         for (int i = 0; i < KPT; i++)
         {
+            if (PREFETCH == 3 && sprinkle)
+            {
+                const uint64_t nbase = tile_base + TILE + wave_off;
+                nk[i] = src_keys[nbase + i * kWave];
+                nv[i] = has_vals ? src_vals[nbase + i * kWave] : 0u;
+            }
             const uint32_t d = digit_of<KeyT>(key[i], shift, MASK);
             uint32_t* const cnt = my_cnt + d;
             const uint32_t prev = *cnt; // issued first: its LDS latency hides under the ballots below
@@ -457,6 +538,7 @@ __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_ker
             const uint32_t lower = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
             const uint32_t total = (uint32_t) __popc(plo) + (uint32_t) __popc(phi);
             rank[i] = prev + lower;
+            asm volatile("" : "+v"(rank[i])); // keep the rank (1 register), not the two peer masks, live across the phases
             // every peer stores the same new count to the same address (no exec-mask juggling for a leader lane)
             *cnt = prev + total;
         }
@@ -486,9 +568,7 @@ __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_ker
             if (SCAN_WAVES > 1)
             {
                 __syncthreads();
-#pragma unroll
-                for (int w = 0; w < SCAN_WAVES - 1; w++)
-                    if ((uint32_t) w < wave) excl += s.scan_tmp[w];
+                excl += sum_of_preceding_waves(s.scan_tmp, SCAN_WAVES, wave, lane);
             }
             if (tid < SCAN_THREADS)
             {
@@ -553,10 +633,6 @@ __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_ker
                 }
             __syncthreads();
             if (r == 0) stamp(5); // stage + barrier
-            // keys and values now live in LDS: their registers are free, so the next tile's loads are issued here
-            // (ahead of this tile's stores in the memory queue) and complete under the write-out and the next rank phase
-            if (PREFETCH && r == ROUNDS - 1 && tile + 1 < last) load_tile(tile + 1);
-
             if (CARRY && r == 0)
             {
                 flush_carry(); // old carry out before the write-out below refills the slots
@@ -564,35 +640,72 @@ __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_ker
             }
 
             // ---- write out: consecutive threads -> consecutive ranked positions -> (per digit) consecutive addresses.
-            //      Three batched sweeps (staged pairs, per-digit lookups, stores) so that the LDS latencies overlap
-            //      instead of being paid once per item behind a branch.
+            //      Batched sweeps (staged pairs, per-digit lookups, stores) so that the LDS latencies overlap instead of
+            //      being paid once per item behind a branch.
+            //      PREFETCH: keys and values now live in LDS, their registers are free: the loads of the next tile are
+            //      issued here, a few in front of every batch of stores, so that the CU's read and write paths are
+            //      both busy (all loads first would hold the stores back: vector-memory instructions issue in order).
             constexpr int WI = KPT / ROUNDS;
-            KeyT wk[WI];
-            uint32_t wv[WI], wg[WI], wlim[WI];
+            constexpr int WB = PREFETCH ? (WI % 4 == 0 ? 4 : WI) : WI; // items per batch
+            const bool next_full = (PREFETCH == 1 || PREFETCH == 2) && tile + 1 < last && (uint64_t) n - (tile_base + TILE) >= (uint64_t) TILE;
 #pragma unroll
-            for (int i = 0; i < WI; i++) s.stage.get(i * THREADS + tid, wk[i], wv[i]);
-#pragma unroll
-            for (int i = 0; i < WI; i++)
+            for (int b0 = 0; b0 < WI; b0 += WB)
             {
-                const uint32_t wd = digit_of<KeyT>(wk[i], shift, MASK);
-                wg[i] = r * STAGE + i * THREADS + tid + s.gdelta[wd];
-                wlim[i] = CARRY ? s.wend[wd] : 0xFFFFFFFFu;
-            }
-#pragma unroll
-            for (int i = 0; i < WI; i++)
-            {
-                const uint32_t p = r * STAGE + i * THREADS + tid; // ranked position inside the tile
-                const bool valid = p < tile_valid;
-                const bool to_carry = CARRY && wg[i] >= wlim[i];
-                uint32_t g = wg[i];
-                if (ABLATE == 1) g = (uint32_t) tile_base + p;
-                if (valid && !to_carry)
+                if ((PREFETCH == 1 || PREFETCH == 2) && r == ROUNDS - 1 && next_full)
                 {
-                    dst_keys[g] = codec_out.decode(wk[i]);
-                    if (has_vals) dst_vals[g] = wv[i];
+                    const uint64_t nbase = tile_base + TILE + wave_off;
+#pragma unroll
+                    for (int i = b0; i < b0 + WB; i++) key[i] = codec_in.encode(src_keys[nbase + i * kWave]);
+                    if (PREFETCH == 1)
+                    {
+#pragma unroll
+                        for (int i = b0; i < b0 + WB; i++) val[i] = has_vals ? src_vals[nbase + i * kWave] : 0u;
+                    }
                 }
-                if (CARRY && valid && to_carry)
-                    s.carry.put(digit_of<KeyT>(wk[i], shift, MASK) * BLK + (wg[i] & (BLK - 1)), wk[i], wv[i]);
+                KeyT wk[WB];
+                uint32_t wv[WB], wg[WB], wlim[WB];
+#pragma unroll
+                for (int i = 0; i < WB; i++) s.stage.get((b0 + i) * THREADS + tid, wk[i], wv[i]);
+#pragma unroll
+                for (int i = 0; i < WB; i++)
+                {
+                    const uint32_t wd = digit_of<KeyT>(wk[i], shift, MASK);
+                    wg[i] = r * STAGE + (b0 + i) * THREADS + tid + s.gdelta[wd];
+                    wlim[i] = CARRY ? s.wend[wd] : 0xFFFFFFFFu;
+                }
+#pragma unroll
+                for (int i = 0; i < WB; i++)
+                {
+                    const uint32_t p = r * STAGE + (b0 + i) * THREADS + tid; // ranked position inside the tile
+                    const bool valid = p < tile_valid;
+                    const bool to_carry = CARRY && wg[i] >= wlim[i];
+                    uint32_t g = wg[i];
+                    if (ABLATE == 1) g = (uint32_t) tile_base + p;
+                    if (valid && !to_carry)
+                    {
+                        dst_keys[g] = codec_out.decode(wk[i]);
+                        if (has_vals) dst_vals[g] = wv[i];
+                    }
+                    if (CARRY && valid && to_carry)
+                        s.carry.put(digit_of<KeyT>(wk[i], shift, MASK) * BLK + (wg[i] & (BLK - 1)), wk[i], wv[i]);
+                }
+            }
+            // a partial next tile (the last of the array) takes the guarded loads
+            if ((PREFETCH == 1 || PREFETCH == 2) && r == ROUNDS - 1 && tile + 1 < last && !next_full)
+                load_tile(tile + 1, PREFETCH == 2 ? 1 : 3);
+            if (PREFETCH == 3 && r == ROUNDS - 1 && tile + 1 < last)
+            {
+                if (sprinkle)
+                {
+#pragma unroll
+                    for (int i = 0; i < KPT; i++)
+                    {
+                        key[i] = codec_in.encode(nk[i]);
+                        val[i] = nv[i];
+                    }
+                }
+                else
+                    load_tile(tile + 1);
             }
             if (r + 1 < ROUNDS) __syncthreads(); // the next round overwrites the staging area
         }
@@ -694,6 +807,7 @@ __global__ __launch_bounds__(THREADS) void radix_sort_single_block_kernel(KeyT* 
             const uint32_t lower = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
             const uint32_t total = (uint32_t) __popc(plo) + (uint32_t) __popc(phi);
             rank[i] = prev + lower;
+            asm volatile("" : "+v"(rank[i])); // keep the rank (1 register), not the two peer masks, live across the phases
             *cnt = prev + total;
         }
         __syncthreads();
@@ -718,9 +832,7 @@ __global__ __launch_bounds__(THREADS) void radix_sort_single_block_kernel(KeyT* 
             if (SCAN_WAVES > 1)
             {
                 __syncthreads();
-#pragma unroll
-                for (int w = 0; w < SCAN_WAVES - 1; w++)
-                    if ((uint32_t) w < wave) excl += s.scan_tmp[w];
+                excl += sum_of_preceding_waves(s.scan_tmp, SCAN_WAVES, wave, lane);
             }
             if (tid < SCAN_THREADS)
             {
