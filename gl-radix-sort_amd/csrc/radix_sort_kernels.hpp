@@ -22,10 +22,21 @@ namespace glu_hip
 {
 constexpr int kWave = 64;
 
+// Digit of a key: bits [shift, shift + popcount(mask)).  `mask` is always a run of low one-bits (a narrower last digit
+// reuses the wider kernel), so this is one v_bfe_u32 instead of a shift and an and; for 64-bit keys the word holding the
+// digit is picked first (digits of 4 / 8 bits at multiples of their width never straddle the two words).
 template<typename KeyT>
 __device__ __forceinline__ uint32_t digit_of(KeyT key, uint32_t shift, uint32_t mask)
 {
-    return (uint32_t) (key >> shift) & mask;
+    const uint32_t width = (uint32_t) __popc(mask);
+    if constexpr (sizeof(KeyT) == 4)
+        return __builtin_amdgcn_ubfe((uint32_t) key, shift, width);
+    else
+    {
+        if ((shift & 31u) + width > 32u) return (uint32_t) (key >> shift) & mask; // kernel-uniform, not taken by the sort
+        const uint32_t word = shift >= 32u ? (uint32_t) (key >> 32) : (uint32_t) key;
+        return __builtin_amdgcn_ubfe(word, shift & 31u, width);
+    }
 }
 
 // Key encodings.  The kernels sort unsigned bit patterns; signed-integer and IEEE-float keys are mapped to unsigned
@@ -280,10 +291,9 @@ struct ScatterSmem
     PairArray<KeyT, CARRY ? RADIX * kBlockElems : 1> carry;      // per digit: elements of a not yet complete 64-B block
     uint32_t wcnt[WAVES][RADIX]; // wave-private running digit counters -> first ranked position of (wave, digit)
     uint32_t tstart[RADIX];      // first ranked position of each digit in the tile
-    uint32_t gdelta[RADIX];      // global index = ranked position + gdelta[digit]
-    uint32_t wend[RADIX];        // CARRY: elements with global index >= wend[digit] go to the carry, not to memory
-    uint32_t flush_lo[RADIX];    // CARRY: carried elements [flush_lo, flush_hi) of the digit are written this tile
-    uint32_t flush_hi[RADIX];
+    uint2 dest[RADIX];           // .x: global index = ranked position + dest[digit].x;  .y (CARRY): elements with a
+                                 // global index >= dest[digit].y go to the carry, not to memory (one ds_read_b64 for both)
+    uint2 flush[RADIX];          // CARRY: carried elements [.x, .y) of the digit are written this tile
     uint32_t scan_tmp[WAVES];
 };
 
@@ -394,8 +404,9 @@ __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_ker
         {
             uint32_t e = j * THREADS + tid;
             if (RADIX * BLK % THREADS != 0 && e >= RADIX * BLK) e = RADIX * BLK - 1; // clamp (result unused)
-            lo[j] = s.flush_lo[e / BLK];
-            hi[j] = s.flush_hi[e / BLK];
+            const uint2 f = s.flush[e / BLK];
+            lo[j] = f.x;
+            hi[j] = f.y;
             s.carry.get(e, fk[j], fv[j]);
         }
 #pragma unroll
@@ -530,7 +541,8 @@ __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_ker
 #pragma unroll
             for (int bit = 0; bit < BITS; bit++)
             {
-                const int32_t sel = __builtin_amdgcn_sbfe((int32_t) d, bit, 1);
+                int32_t sel; // asm: keeps bit 0 from being rewritten as -(d & 1) and a compare chain (6 instructions)
+                asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(sel) : "v"(d), "n"(bit));
                 const uint64_t m = __ballot(sel < 0);
                 plo = __builtin_amdgcn_bitop3_b32(plo, (uint32_t) m, (uint32_t) sel, 0x90);
                 phi = __builtin_amdgcn_bitop3_b32(phi, (uint32_t) (m >> 32), (uint32_t) sel, 0x90);
@@ -590,7 +602,9 @@ __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_ker
             uint32_t len = te - ts;
             // pads (last, partial tile only) were ranked at the end of the highest used digit: not real elements
             if (tid == MASK) len -= (uint32_t) TILE - tile_valid;
-            s.gdelta[tid] = digit_base - ts;
+            uint2 dst;
+            dst.x = digit_base - ts;
+            dst.y = 0xFFFFFFFFu;
             if (CARRY)
             {
                 const uint32_t end = digit_base + len;
@@ -599,19 +613,18 @@ __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_ker
                 {
                     // the run reaches past a 64-byte boundary: the carried elements are completed -> write them,
                     // write the run up to its last boundary, carry its tail
-                    s.flush_lo[tid] = carry_start;
-                    s.flush_hi[tid] = digit_base;
-                    s.wend[tid] = aligned_end;
+                    s.flush[tid] = make_uint2(carry_start, digit_base);
+                    dst.y = aligned_end;
                     carry_start = aligned_end;
                 }
                 else
                 {
                     // still inside the same 64-byte block: everything joins the carry
-                    s.flush_lo[tid] = 0;
-                    s.flush_hi[tid] = 0;
-                    s.wend[tid] = digit_base;
+                    s.flush[tid] = make_uint2(0u, 0u);
+                    dst.y = digit_base;
                 }
             }
+            s.dest[tid] = dst;
             digit_base += len;
         }
         // ---- ranked position of every item (rank[] becomes the position inside the tile)
@@ -670,8 +683,9 @@ __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_ker
                 for (int i = 0; i < WB; i++)
                 {
                     const uint32_t wd = digit_of<KeyT>(wk[i], shift, MASK);
-                    wg[i] = r * STAGE + (b0 + i) * THREADS + tid + s.gdelta[wd];
-                    wlim[i] = CARRY ? s.wend[wd] : 0xFFFFFFFFu;
+                    const uint2 dst = s.dest[wd];
+                    wg[i] = r * STAGE + (b0 + i) * THREADS + tid + dst.x;
+                    wlim[i] = dst.y;
                 }
 #pragma unroll
                 for (int i = 0; i < WB; i++)
@@ -720,8 +734,7 @@ __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_ker
         // what is still carried at the end of this workgroup's range: the (partial) last block of every digit
         if (tid < RADIX)
         {
-            s.flush_lo[tid] = carry_start;
-            s.flush_hi[tid] = digit_base;
+            s.flush[tid] = make_uint2(carry_start, digit_base);
         }
         __syncthreads();
         flush_carry();
@@ -799,7 +812,8 @@ __global__ __launch_bounds__(THREADS) void radix_sort_single_block_kernel(KeyT* 
 #pragma unroll
             for (int bit = 0; bit < BITS; bit++)
             {
-                const int32_t sel = __builtin_amdgcn_sbfe((int32_t) d, bit, 1);
+                int32_t sel; // asm: keeps bit 0 from being rewritten as -(d & 1) and a compare chain (6 instructions)
+                asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(sel) : "v"(d), "n"(bit));
                 const uint64_t m = __ballot(sel < 0);
                 plo = __builtin_amdgcn_bitop3_b32(plo, (uint32_t) m, (uint32_t) sel, 0x90);
                 phi = __builtin_amdgcn_bitop3_b32(phi, (uint32_t) (m >> 32), (uint32_t) sel, 0x90);
