@@ -318,7 +318,7 @@ struct ScatterSmem
 // ~145 dwords per lane (it also hoists lane-constant shuffle addresses out of the tile loop) and the kernel runs 4x
 // slower; it needs the values to be loaded per round instead of being held in registers.
 template<typename KeyT, int BITS, int THREADS, int KPT, bool CARRY = true, int ABLATE = 0, bool STAMPS = false,
-         int MIN_WAVES_PER_SIMD = 1, int ROUNDS = 1, int PREFETCH = 0, bool DMA = false>
+         int MIN_WAVES_PER_SIMD = 1, int ROUNDS = 1, int PREFETCH = 0, bool DMA = false, int RANK_MODE = 0>
 __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_kernel(
     const KeyT* __restrict__ src_keys, const uint32_t* __restrict__ src_vals, KeyT* __restrict__ dst_keys,
     uint32_t* __restrict__ dst_vals, const uint32_t* __restrict__ table, const uint32_t* __restrict__ totals,
@@ -534,6 +534,13 @@ __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_ker
             }
             const uint32_t d = digit_of<KeyT>(key[i], shift, MASK);
             uint32_t* const cnt = my_cnt + d;
+            if (RANK_MODE == 1)
+            {
+                // EXPERIMENT: one returning LDS atomic per item.  Stable only if the LDS serves the lanes of one
+                // instruction that hit the same address in increasing lane order (not an architectural promise).
+                rank[i] = atomicAdd(cnt, 1u);
+                continue;
+            }
             const uint32_t prev = *cnt; // issued first: its LDS latency hides under the ballots below
             // peers = lanes whose digit equals mine.  Per digit bit: sel = 0 / ~0 (v_bfe_i32), m = ballot(bit set),
             // peers &= ~(m ^ sel) -- one v_bitop3_b32 per 32-bit half (truth table 0x90: a & ~(b ^ c)).

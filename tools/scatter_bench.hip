@@ -142,7 +142,7 @@ float time_min(Ctx& c, int reps, F&& f)
     return best;
 }
 
-template<int BITS, int THREADS, int KPT, bool CARRY = true, int ABLATE = 0, int ROUNDS = 1, int PREFETCH = 0, bool DMA = false>
+template<int BITS, int THREADS, int KPT, bool CARRY = true, int ABLATE = 0, int ROUNDS = 1, int PREFETCH = 0, bool DMA = false, int RANK_MODE = 0>
 void run_variant(Ctx& c, int blocks_per_cu, uint32_t shift, uint32_t mask_override = 0)
 {
     constexpr int RADIX = 1 << BITS;
@@ -153,8 +153,8 @@ void run_variant(Ctx& c, int blocks_per_cu, uint32_t shift, uint32_t mask_overri
     uint32_t* totals = c.table + (size_t) RADIX * nb;
     const uint32_t mask = mask_override ? mask_override : RADIX - 1;
     if (mask_override) printf("mask %u: ", mask);
-    auto scatter = radix_scatter_kernel<uint32_t, BITS, THREADS, KPT, CARRY, ABLATE, false, 1, ROUNDS, PREFETCH, DMA>;
-    auto scatter_st = radix_scatter_kernel<uint32_t, BITS, THREADS, KPT, CARRY, ABLATE, true, 1, ROUNDS, PREFETCH, DMA>;
+    auto scatter = radix_scatter_kernel<uint32_t, BITS, THREADS, KPT, CARRY, ABLATE, false, 1, ROUNDS, PREFETCH, DMA, RANK_MODE>;
+    auto scatter_st = radix_scatter_kernel<uint32_t, BITS, THREADS, KPT, CARRY, ABLATE, true, 1, ROUNDS, PREFETCH, DMA, RANK_MODE>;
     CK(hipFuncSetAttribute((const void*) scatter_st, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sizeof(Smem)));
     CK(hipFuncSetAttribute((const void*) scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sizeof(Smem)));
 
@@ -187,6 +187,7 @@ void run_variant(Ctx& c, int blocks_per_cu, uint32_t shift, uint32_t mask_overri
     if (ROUNDS > 1) printf("rounds %d ", ROUNDS);
     if (PREFETCH) printf("prefetch%d ", PREFETCH);
     if (DMA) printf("dma ");
+    if (RANK_MODE) printf("rank%d ", RANK_MODE);
     printf("bits %d threads %4d kpt %2d tile %5d lds %6zu blk/cu %d nb %5u | count %.3f ms (%.0f GB/s) scan %.3f | scatter %.3f ms "
            "(%.0f GB/s) | pass %.3f ms %s\n",
            BITS, THREADS, KPT, TILE, sizeof(Smem), blocks_per_cu, nb, t_count, c.n * 4.0 / t_count / 1e6, t_scan, t_scatter,
@@ -265,6 +266,15 @@ int main(int argc, char** argv)
         cnt(radix_count_kernel<uint32_t, 8, 512, 12288>, 512, "8-bit  512 thr");
     }
     run_variant<8, 1024, 12, true>(c, 1, shift);
+    if (getenv("SB_RANK"))
+    {
+        run_variant<8, 1024, 12, true, 0, 1, 0, false, 1>(c, 1, shift);
+        run_variant<8, 1024, 12, true, 0, 1, 3, false, 1>(c, 1, shift);
+        run_variant<8, 1024, 12, true, 0, 1, 0, true, 1>(c, 1, shift);
+        run_variant<4, 1024, 12, false, 0, 1, 3, false, 1>(c, 1, shift);
+        run_variant<4, 1024, 12, false, 0, 1, 0, false, 1>(c, 1, shift);
+        run_variant<4, 1024, 12, false>(c, 1, shift);
+    }
     if (getenv("SB_DMA"))
     {
         run_variant<8, 1024, 12, true, 0, 1, 0, true>(c, 1, shift);
