@@ -404,7 +404,9 @@ glu_status sort_prepare(glu_radix_sort_s* s, size_t count, size_t key_size, bool
     return GLU_OK;
 }
 
-template<typename KeyT, int BITS, bool LARGE>
+// XF: this pass encodes keys on load and / or decodes them on store (first / last pass of a typed sort); every other
+// pass runs the instantiation without the codec arithmetic.
+template<typename KeyT, int BITS, bool LARGE, bool XF>
 glu_status launch_pass(glu_radix_sort_s* s, const KeyT* src_k, const uint32_t* src_v, KeyT* dst_k, uint32_t* dst_v,
                        size_t count, uint32_t shift, uint32_t bits, uint32_t* histogram_out, hipStream_t stream,
                        uint32_t xform = 0)
@@ -420,7 +422,7 @@ glu_status launch_pass(glu_radix_sort_s* s, const KeyT* src_k, const uint32_t* s
     uint32_t* totals = table + (size_t) RADIX * nb;
 
     using Smem = ScatterSmem<KeyT, BITS, G::THREADS, G::KPT, G::CARRY>;
-    auto scatter = radix_scatter_kernel<KeyT, BITS, G::THREADS, G::KPT, G::CARRY, 0, false, G::BLOCKS_PER_CU * G::THREADS / 256>;
+    auto scatter = radix_scatter_kernel<KeyT, BITS, G::THREADS, G::KPT, G::CARRY, 0, false, G::BLOCKS_PER_CU * G::THREADS / 256, 1, 0, false, 0, XF>;
     static bool lds_opt_in = false; // per instantiation: allow > 64 KiB of dynamic LDS
     if (!lds_opt_in)
     {
@@ -432,7 +434,7 @@ glu_status launch_pass(glu_radix_sort_s* s, const KeyT* src_k, const uint32_t* s
     // the count kernel only shares TILE and the grid with the scatter kernel; 1024 threads keep enough loads in flight
     // when there is one workgroup per CU
     constexpr int COUNT_THREADS = LARGE ? 1024 : G::THREADS;
-    hipLaunchKernelGGL((radix_count_kernel<KeyT, BITS, COUNT_THREADS, G::TILE>), dim3(nb), dim3(COUNT_THREADS), 0, stream,
+    hipLaunchKernelGGL((radix_count_kernel<KeyT, BITS, COUNT_THREADS, G::TILE, XF>), dim3(nb), dim3(COUNT_THREADS), 0, stream,
                        src_k, table, (uint32_t) count, shift, mask, tiles, xform);
     s->mark(stream);
     hipLaunchKernelGGL((radix_row_scan_kernel<256>), dim3(RADIX), dim3(256), 0, stream, table, totals, nb);
@@ -455,8 +457,13 @@ glu_status launch_pass_sized(glu_radix_sort_s* s, const KeyT* src_k, const uint3
 {
     // large geometry once every CU gets at least one large tile
     const bool large = count >= (size_t) g_dev.num_cus * GeometryFor<KeyT, BITS, true>::TILE && !s->force_small;
-    if (large) return launch_pass<KeyT, BITS, true>(s, src_k, src_v, dst_k, dst_v, count, shift, bits, histogram_out, stream, xform);
-    return launch_pass<KeyT, BITS, false>(s, src_k, src_v, dst_k, dst_v, count, shift, bits, histogram_out, stream, xform);
+    if (xform)
+    {
+        if (large) return launch_pass<KeyT, BITS, true, true>(s, src_k, src_v, dst_k, dst_v, count, shift, bits, histogram_out, stream, xform);
+        return launch_pass<KeyT, BITS, false, true>(s, src_k, src_v, dst_k, dst_v, count, shift, bits, histogram_out, stream, xform);
+    }
+    if (large) return launch_pass<KeyT, BITS, true, false>(s, src_k, src_v, dst_k, dst_v, count, shift, bits, histogram_out, stream, 0);
+    return launch_pass<KeyT, BITS, false, false>(s, src_k, src_v, dst_k, dst_v, count, shift, bits, histogram_out, stream, 0);
 }
 
 template<typename KeyT>
@@ -470,12 +477,12 @@ glu_status dispatch_pass(glu_radix_sort_s* s, const KeyT* src_k, const uint32_t*
 
 // n <= one tile: the whole sort in a single workgroup / single launch (always 8-bit digits: the result does not
 // depend on the digit width)
-template<typename KeyT, int THREADS, int KPT>
-glu_status launch_single_block(KeyT* keys, uint32_t* vals, size_t count, uint32_t total_bits, hipStream_t stream,
-                               uint32_t xform)
+template<typename KeyT, int THREADS, int KPT, bool XF>
+glu_status launch_single_block_xf(KeyT* keys, uint32_t* vals, size_t count, uint32_t total_bits, hipStream_t stream,
+                                  uint32_t xform)
 {
     using Smem = SingleBlockSmem<KeyT, 8, THREADS, KPT>;
-    auto kern = radix_sort_single_block_kernel<KeyT, 8, THREADS, KPT>;
+    auto kern = radix_sort_single_block_kernel<KeyT, 8, THREADS, KPT, XF>;
     static bool lds_opt_in = false;
     if (!lds_opt_in)
     {
@@ -485,6 +492,14 @@ glu_status launch_single_block(KeyT* keys, uint32_t* vals, size_t count, uint32_
     hipLaunchKernelGGL(kern, dim3(1), dim3(THREADS), sizeof(Smem), stream, keys, vals, (uint32_t) count, total_bits, xform);
     HIP_TRY(hipGetLastError());
     return GLU_OK;
+}
+
+template<typename KeyT, int THREADS, int KPT>
+glu_status launch_single_block(KeyT* keys, uint32_t* vals, size_t count, uint32_t total_bits, hipStream_t stream,
+                               uint32_t xform)
+{
+    if (xform) return launch_single_block_xf<KeyT, THREADS, KPT, true>(keys, vals, count, total_bits, stream, xform);
+    return launch_single_block_xf<KeyT, THREADS, KPT, false>(keys, vals, count, total_bits, stream, 0);
 }
 
 template<typename KeyT>

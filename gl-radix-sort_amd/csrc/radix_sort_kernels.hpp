@@ -33,8 +33,9 @@ __device__ __forceinline__ uint32_t digit_of(KeyT key, uint32_t shift, uint32_t 
         return __builtin_amdgcn_ubfe((uint32_t) key, shift, width);
     else
     {
-        if ((shift & 31u) + width > 32u) return (uint32_t) (key >> shift) & mask; // kernel-uniform, not taken by the sort
-        const uint32_t word = shift >= 32u ? (uint32_t) (key >> 32) : (uint32_t) key;
+        // branch-free word pick (a uniform branch here would split the unrolled per-item loops into basic blocks)
+        const uint32_t hi_sel = shift >= 32u ? 0xFFFFFFFFu : 0u;
+        const uint32_t word = ((uint32_t) key & ~hi_sel) | ((uint32_t) (key >> 32) & hi_sel);
         return __builtin_amdgcn_ubfe(word, shift & 31u, width);
     }
 }
@@ -52,7 +53,7 @@ enum KeyTransform : uint32_t
 // Branch-free form (a uniform `if` per key would split the unrolled load / store loops into basic blocks and cost
 // the scatter kernel 50 %): code(k) = k ^ ((sign_fill(k or ~k) & all) | sign), with (all, sign) = (0, 0) for no
 // transform, (0, SIGN) for signed integers, (~0, SIGN) for floats.
-template<typename KeyT>
+template<typename KeyT, bool XF = true>
 struct KeyCodec
 {
     using S = typename std::make_signed<KeyT>::type;
@@ -65,6 +66,16 @@ struct KeyCodec
     }
     __device__ __forceinline__ KeyT encode(KeyT k) const { return k ^ (((KeyT) ((S) k >> TOP) & all) | sign); }
     __device__ __forceinline__ KeyT decode(KeyT k) const { return k ^ (((KeyT) ((S) ~k >> TOP) & all) | sign); }
+};
+// XF = false: the kernels instantiated for plain unsigned keys and for the middle passes of typed sorts carry no codec
+// arithmetic at all (3 VALU instructions per 32-bit key on each side, twice that for 64-bit keys, in kernels whose
+// per-tile time is set by VALU issue as much as by memory).
+template<typename KeyT>
+struct KeyCodec<KeyT, false>
+{
+    __device__ __forceinline__ explicit KeyCodec(uint32_t) {}
+    __device__ __forceinline__ KeyT encode(KeyT k) const { return k; }
+    __device__ __forceinline__ KeyT decode(KeyT k) const { return k; }
 };
 
 // Contiguous tile range [first, last) owned by workgroup `b` of `nb`, tiles_total >= nb.
@@ -107,7 +118,7 @@ __device__ __forceinline__ uint32_t sum_of_preceding_waves(const uint32_t* total
 // K1: per-workgroup digit histogram.  table[d * num_blocks + b] = #keys of block b's range with digit d.
 // Reads 1 key per pair (sizeof(KeyT) bytes), writes RADIX counters per workgroup.
 // ---------------------------------------------------------------------------------------------------------
-template<typename KeyT, int BITS, int THREADS, int TILE>
+template<typename KeyT, int BITS, int THREADS, int TILE, bool XF = false>
 __global__ __launch_bounds__(THREADS) void radix_count_kernel(const KeyT* __restrict__ keys,
                                                               uint32_t* __restrict__ table, uint32_t n,
                                                               uint32_t shift, uint32_t mask, uint32_t tiles_total,
@@ -152,7 +163,7 @@ __global__ __launch_bounds__(THREADS) void radix_count_kernel(const KeyT* __rest
     const bool vec_ok = (reinterpret_cast<uintptr_t>(keys) & 15u) == 0;
     const uint64_t nvec = vec_ok ? (end - begin) / VEC : 0;
     const VecT* vkeys = reinterpret_cast<const VecT*>(keys + begin);
-    const KeyCodec<KeyT> codec_in(xform & 3u);
+    const KeyCodec<KeyT, XF> codec_in(xform & 3u);
     auto dig = [&](KeyT k) { return digit_of<KeyT>(codec_in.encode(k), shift, MASK); };
     auto tally_vec = [&](const VecT& a) {
         if constexpr (sizeof(KeyT) == 4)
@@ -318,7 +329,7 @@ struct ScatterSmem
 // ~145 dwords per lane (it also hoists lane-constant shuffle addresses out of the tile loop) and the kernel runs 4x
 // slower; it needs the values to be loaded per round instead of being held in registers.
 template<typename KeyT, int BITS, int THREADS, int KPT, bool CARRY = true, int ABLATE = 0, bool STAMPS = false,
-         int MIN_WAVES_PER_SIMD = 1, int ROUNDS = 1, int PREFETCH = 0, bool DMA = false, int RANK_MODE = 0>
+         int MIN_WAVES_PER_SIMD = 1, int ROUNDS = 1, int PREFETCH = 0, bool DMA = false, int RANK_MODE = 0, bool XF = false>
 __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_kernel(
     const KeyT* __restrict__ src_keys, const uint32_t* __restrict__ src_vals, KeyT* __restrict__ dst_keys,
     uint32_t* __restrict__ dst_vals, const uint32_t* __restrict__ table, const uint32_t* __restrict__ totals,
@@ -346,7 +357,7 @@ __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_ker
     const uint32_t nb = gridDim.x, b = blockIdx.x;
     const bool has_vals = src_vals != nullptr; // keys-only sorts pass no value arrays (kernel-uniform branch)
     const bool dma_ok = ((reinterpret_cast<uintptr_t>(src_keys) | reinterpret_cast<uintptr_t>(src_vals)) & 15u) == 0;
-    const KeyCodec<KeyT> codec_in(xform & 3u), codec_out((xform >> 2) & 3u); // key encode on load / decode on store
+    const KeyCodec<KeyT, XF> codec_in(xform & 3u), codec_out((xform >> 2) & 3u); // key encode on load / decode on store
 
     // ---- prologue: this workgroup's global base for every digit:
     //      exclusive scan of the digit totals (RadixSort.hpp:148-152) + this block's scanned table entry (:176)
@@ -666,7 +677,12 @@ __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_ker
             //      issued here, a few in front of every batch of stores, so that the CU's read and write paths are
             //      both busy (all loads first would hold the stores back: vector-memory instructions issue in order).
             constexpr int WI = KPT / ROUNDS;
-            constexpr int WB = PREFETCH ? (WI % 4 == 0 ? 4 : WI) : WI; // items per batch
+#ifndef GLU_WRITE_BATCH
+#define GLU_WRITE_BATCH 4 // items per write-out batch (tuning builds override; 0 = the whole round)
+#endif
+            // 4 items per batch: enough LDS reads in flight to cover their latency; the whole round in one batch costs
+            // 5 registers per item and was 2 % (32-bit keys, 12 items) to 17 % (64-bit keys, 16 items) slower
+            constexpr int WB = (GLU_WRITE_BATCH > 0 && WI % GLU_WRITE_BATCH == 0) ? GLU_WRITE_BATCH : WI;
             const bool next_full = (PREFETCH == 1 || PREFETCH == 2) && tile + 1 < last && (uint64_t) n - (tile_base + TILE) >= (uint64_t) TILE;
 #pragma unroll
             for (int b0 = 0; b0 < WI; b0 += WB)
@@ -769,7 +785,7 @@ struct SingleBlockSmem
     uint32_t scan_tmp[WAVES];
 };
 
-template<typename KeyT, int BITS, int THREADS, int KPT>
+template<typename KeyT, int BITS, int THREADS, int KPT, bool XF = false>
 __global__ __launch_bounds__(THREADS) void radix_sort_single_block_kernel(KeyT* __restrict__ keys,
                                                                           uint32_t* __restrict__ vals, uint32_t n,
                                                                           uint32_t total_bits, uint32_t xform = 0)
@@ -788,7 +804,7 @@ __global__ __launch_bounds__(THREADS) void radix_sort_single_block_kernel(KeyT* 
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t wave_off = wave * WAVE_TILE + lane;
 
-    const KeyCodec<KeyT> codec_in(xform & 3u), codec_out((xform >> 2) & 3u);
+    const KeyCodec<KeyT, XF> codec_in(xform & 3u), codec_out((xform >> 2) & 3u);
     KeyT key[KPT];
     uint32_t val[KPT];
 #pragma unroll

@@ -170,6 +170,20 @@ void run_variant(Ctx& c, int blocks_per_cu, uint32_t shift, uint32_t mask_overri
                            totals, (uint32_t) c.n, shift, mask, tiles, (unsigned long long*) nullptr, 0u);
     });
     CK(hipGetLastError());
+    if (getenv("SB_TRACE"))
+    { // time series of one variant inside one process: clock-state drift shows up here, buffer placement cannot
+        printf("    trace:");
+        const int groups = atoi(getenv("SB_TRACE")) > 1 ? atoi(getenv("SB_TRACE")) : 60;
+        for (int r = 0; r < groups; r++)
+        {
+            float t = time_min(c, groups > 60 ? 50 : 1, [&] { // long traces: best of 50 launches per point
+                hipLaunchKernelGGL(scatter, dim3(nb), dim3(THREADS), sizeof(Smem), 0, c.keys, c.vals, c.keys2, c.vals2, c.table,
+                                   totals, (uint32_t) c.n, shift, mask, tiles, (unsigned long long*) nullptr, 0u);
+            });
+            printf(" %.3f", t);
+        }
+        printf("\n");
+    }
     unsigned long long* st;
     CK(hipMalloc(&st, 64));
     CK(hipMemset(st, 0, 64));
@@ -212,10 +226,34 @@ int main(int argc, char** argv)
     CK(hipGetDeviceProperties(&p, 0));
     c.cus = p.multiProcessorCount;
     printf("%s %s CUs %d, N = 2^%d %s\n", p.name, p.gcnArchName, c.cus, log2n, zero ? "(zero keys)" : "");
-    CK(hipMalloc(&c.keys, c.n * 4));
-    CK(hipMalloc(&c.vals, c.n * 4));
-    CK(hipMalloc(&c.keys2, c.n * 4));
-    CK(hipMalloc(&c.vals2, c.n * 4));
+    if (getenv("SB_PLACE"))
+    {
+        // placement experiment: the four arrays cut from ONE allocation at chosen relative offsets (bytes, from the
+        // environment: SB_PLACE="d1,d2,d3" added to the natural 1x, 2x, 3x array-size offsets)
+        size_t d1 = 0, d2 = 0, d3 = 0;
+        sscanf(getenv("SB_PLACE"), "%zu,%zu,%zu", &d1, &d2, &d3);
+        char* pool;
+        CK(hipMalloc(&pool, c.n * 16 + d1 + d2 + d3 + (64u << 20)));
+        c.keys = (uint32_t*) pool;
+        c.vals = (uint32_t*) (pool + c.n * 4 + d1);
+        c.keys2 = (uint32_t*) (pool + c.n * 8 + d1 + d2);
+        c.vals2 = (uint32_t*) (pool + c.n * 12 + d1 + d2 + d3);
+    }
+    else
+    {
+        // SB_GAP="g1,g2,g3" (MiB): dummy allocations between the four arrays (shifts their relative physical placement)
+        size_t g1 = 0, g2 = 0, g3 = 0;
+        if (getenv("SB_GAP")) sscanf(getenv("SB_GAP"), "%zu,%zu,%zu", &g1, &g2, &g3);
+        void* dummy;
+        CK(hipMalloc(&c.keys, c.n * 4));
+        if (g1) CK(hipMalloc(&dummy, g1 << 20));
+        CK(hipMalloc(&c.vals, c.n * 4));
+        if (g2) CK(hipMalloc(&dummy, g2 << 20));
+        CK(hipMalloc(&c.keys2, c.n * 4));
+        if (g3) CK(hipMalloc(&dummy, g3 << 20));
+        CK(hipMalloc(&c.vals2, c.n * 4));
+    }
+    printf("arrays at %p %p %p %p\n", (void*) c.keys, (void*) c.vals, (void*) c.keys2, (void*) c.vals2);
     CK(hipMalloc(&c.table, (256 * 8192 + 256) * 4));
     CK(hipMalloc(&c.bad, 8));
     for (int i = 0; i < 4; i++) CK(hipEventCreate(&c.ev[i]));
@@ -244,6 +282,155 @@ int main(int argc, char** argv)
             cw(copy_width_kernel<16, 16>, "ld16 st16", g, 1024);
         }
     const uint32_t shift = 8; // any digit of uniform keys
+    if (getenv("SB_COPYSWEEP"))
+    {
+        // one pool, one process: a 4-stream copy (2 in, 2 out, all at the same element offset) as a function of the byte
+        // distances between the four arrays
+        char* pool;
+        const size_t G1 = (size_t) 1 << 30;
+        CK(hipMalloc(&pool, 14 * G1));
+        auto run = [&](size_t ob, size_t oc, size_t od, const char* what) {
+            const uint32_t* a = (const uint32_t*) pool;
+            const uint32_t* b = (const uint32_t*) (pool + ob);
+            uint32_t* cc = (uint32_t*) (pool + oc);
+            uint32_t* dd = (uint32_t*) (pool + od);
+            float t = time_min(c, 7, [&] { hipLaunchKernelGGL((copy_width_kernel<4, 4>), dim3(256), dim3(1024), 0, 0, a, b, cc, dd, c.n); });
+            printf("copy b@%.4f c@%.4f d@%.4f GiB %s: %.3f ms (%.0f GB/s)\n", ob / (double) G1, oc / (double) G1, od / (double) G1, what, t,
+                   c.n * 16.0 / t / 1e6);
+        };
+        const size_t M1 = 1 << 20;
+        printf("-- pairs (a,b) and (c,d) at distance D, a-c 4 GiB apart\n");
+        for (size_t k = 0; k <= 32; k++) run(G1 + k * 64 * M1, 4 * G1, 5 * G1 + k * 64 * M1, "D = 1 GiB + k*64 MiB");
+        printf("-- D = 1.5 GiB, c moved by y\n");
+        for (size_t k = 0; k <= 16; k++) run(G1 + 512 * M1, 4 * G1 + k * 64 * M1, 5 * G1 + 512 * M1 + k * 64 * M1, "c,d + k*64 MiB");
+        printf("-- fine sweep around D = 1.5 GiB\n");
+        for (long k = -8; k <= 8; k++) run(G1 + 512 * M1 + k * 8 * (long) M1, 4 * G1, 5 * G1 + 512 * M1 + k * 8 * (long) M1, "D = 1.5 GiB + k*8 MiB");
+        return 0;
+    }
+    if (getenv("SB_SCATSWEEP"))
+    {
+        // one pool, one process: the production scatter as a function of (vals - keys) for the source and destination pair
+        char* pool;
+        const size_t G1 = (size_t) 1 << 30, M1 = 1 << 20;
+        CK(hipMalloc(&pool, 16 * G1));
+        uint32_t *k0 = c.keys, *v0 = c.vals;
+        printf("rows: source vals - keys = 1 GiB + ds; columns: destination vals - keys = 1 GiB + dd; ds, dd = 0, 128, ... 1024 MiB\n");
+        for (size_t is = 0; is <= 8; is++)
+        {
+            uint32_t* sk = (uint32_t*) pool;
+            uint32_t* sv = (uint32_t*) (pool + G1 + is * 128 * M1);
+            CK(hipMemcpy(sk, k0, c.n * 4, hipMemcpyDeviceToDevice));
+            CK(hipMemcpy(sv, v0, c.n * 4, hipMemcpyDeviceToDevice));
+            printf("ds %4zu:", is * 128);
+            for (size_t id = 0; id <= 8; id++)
+            {
+                uint32_t* dk = (uint32_t*) (pool + 6 * G1);
+                uint32_t* dv = (uint32_t*) (pool + 7 * G1 + id * 128 * M1);
+                using Smem = ScatterSmem<uint32_t, 8, 1024, 12, true, 1>;
+                const uint32_t tiles = (uint32_t) ((c.n + 12288 - 1) / 12288), nb = 256;
+                uint32_t* totals = c.table + (size_t) 256 * nb;
+                auto scatter = radix_scatter_kernel<uint32_t, 8, 1024, 12, true, 0, false, 1>;
+                CK(hipFuncSetAttribute((const void*) scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sizeof(Smem)));
+                hipLaunchKernelGGL((radix_count_kernel<uint32_t, 8, 1024, 12288>), dim3(nb), dim3(1024), 0, 0, sk, c.table, (uint32_t) c.n, shift, 255u, tiles, 0u);
+                hipLaunchKernelGGL((radix_row_scan_kernel<256>), dim3(256), dim3(256), 0, 0, c.table, totals, nb);
+                float t = time_min(c, 7, [&] {
+                    hipLaunchKernelGGL(scatter, dim3(nb), dim3(1024), sizeof(Smem), 0, sk, sv, dk, dv, c.table, totals, (uint32_t) c.n, shift, 255u, tiles,
+                                       (unsigned long long*) nullptr, 0u);
+                });
+                printf(" %.3f", t);
+            }
+            printf("\n");
+        }
+        return 0;
+    }
+    if (getenv("SB_SCATRAND"))
+    {
+        // random placements of the four arrays inside one pool (offsets in units of 64 MiB), production scatter + copy
+        char* pool;
+        const size_t G1 = (size_t) 1 << 30, U = 64u << 20;
+        CK(hipMalloc(&pool, 24 * G1));
+        uint32_t *k0 = c.keys, *v0 = c.vals;
+        using Smem = ScatterSmem<uint32_t, 8, 1024, 12, true, 1>;
+        const uint32_t tiles = (uint32_t) ((c.n + 12288 - 1) / 12288), nb = 256;
+        uint32_t* totals = c.table + (size_t) 256 * nb;
+        auto scatter = radix_scatter_kernel<uint32_t, 8, 1024, 12, true, 0, false, 1>;
+        CK(hipFuncSetAttribute((const void*) scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sizeof(Smem)));
+        uint64_t rng = 12345 + (getenv("SB_SEED") ? atoi(getenv("SB_SEED")) : 0);
+        auto next = [&]() { rng = rng * 6364136223846793005ull + 1442695040888963407ull; return (uint32_t) (rng >> 33); };
+        for (int it = 0; it < 48; it++)
+        {
+            // four disjoint 1 GiB (16-unit) slots inside 24 GiB (384 units): slot bases 0, 96, 192, 288 units + random 0..79
+            size_t o[4];
+            for (int j = 0; j < 4; j++) o[j] = (size_t) (96 * j + next() % 80);
+            if (it == 0) { o[0] = 0; o[1] = 96; o[2] = 192; o[3] = 288; } // all congruent mod 1 GiB... (96 units = 6 GiB)
+            uint32_t* sk = (uint32_t*) (pool + o[0] * U);
+            uint32_t* sv = (uint32_t*) (pool + o[1] * U);
+            uint32_t* dk = (uint32_t*) (pool + o[2] * U);
+            uint32_t* dv = (uint32_t*) (pool + o[3] * U);
+            CK(hipMemcpy(sk, k0, c.n * 4, hipMemcpyDeviceToDevice));
+            CK(hipMemcpy(sv, v0, c.n * 4, hipMemcpyDeviceToDevice));
+            hipLaunchKernelGGL((radix_count_kernel<uint32_t, 8, 1024, 12288>), dim3(nb), dim3(1024), 0, 0, sk, c.table, (uint32_t) c.n, shift, 255u, tiles, 0u);
+            hipLaunchKernelGGL((radix_row_scan_kernel<256>), dim3(256), dim3(256), 0, 0, c.table, totals, nb);
+            float t = time_min(c, 7, [&] {
+                hipLaunchKernelGGL(scatter, dim3(nb), dim3(1024), sizeof(Smem), 0, sk, sv, dk, dv, c.table, totals, (uint32_t) c.n, shift, 255u, tiles,
+                                   (unsigned long long*) nullptr, 0u);
+            });
+            float tc = time_min(c, 5, [&] { hipLaunchKernelGGL((copy_width_kernel<4, 4>), dim3(256), dim3(1024), 0, 0, sk, sv, dk, dv, c.n); });
+            printf("units mod16: sk %2zu sv %2zu dk %2zu dv %2zu | sv-sk %2zu dv-dk %2zu dk-sk %2zu dv-sv %2zu | scatter %.3f copy %.3f\n", o[0] % 16, o[1] % 16, o[2] % 16,
+                   o[3] % 16, (o[1] - o[0]) % 16, (o[3] - o[2]) % 16, (o[2] - o[0]) % 16, (o[3] - o[1]) % 16, t, tc);
+        }
+        return 0;
+    }
+    if (getenv("SB_DSTS"))
+    {
+        // does the time depend on WHICH allocation the scatter writes to / reads from?  (same process, same kernel)
+        const int K = 5;
+        uint32_t *dk[K], *dv[K], *sk[K], *sv[K];
+        for (int i = 0; i < K; i++)
+        {
+            CK(hipMalloc(&dk[i], c.n * 4));
+            CK(hipMalloc(&dv[i], c.n * 4));
+            CK(hipMalloc(&sk[i], c.n * 4));
+            CK(hipMalloc(&sv[i], c.n * 4));
+            CK(hipMemcpy(sk[i], c.keys, c.n * 4, hipMemcpyDeviceToDevice));
+            CK(hipMemcpy(sv[i], c.vals, c.n * 4, hipMemcpyDeviceToDevice));
+        }
+        uint32_t *k0 = c.keys, *v0 = c.vals, *k2 = c.keys2, *v2 = c.vals2;
+        for (int i = 0; i < K; i++)
+        {
+            c.keys = k0; c.vals = v0; c.keys2 = dk[i]; c.vals2 = dv[i];
+            printf("dst pair %d (%p %p): ", i, (void*) dk[i], (void*) dv[i]);
+            run_variant<8, 1024, 12, true>(c, 1, shift);
+        }
+        for (int i = 0; i < K; i++)
+        {
+            c.keys = sk[i]; c.vals = sv[i]; c.keys2 = k2; c.vals2 = v2;
+            printf("src pair %d (%p %p): ", i, (void*) sk[i], (void*) sv[i]);
+            run_variant<8, 1024, 12, true>(c, 1, shift);
+        }
+        for (int i = 0; i < K; i++)
+        {
+            c.keys = k0; c.vals = v0; c.keys2 = dk[i]; c.vals2 = dv[(i + 1) % K];
+            printf("dst keys %d vals %d: ", i, (i + 1) % K);
+            run_variant<8, 1024, 12, true>(c, 1, shift);
+        }
+        // alternate two fixed configurations: a drift in time shows in both, a placement effect in one
+        for (int rep = 0; rep < 6; rep++)
+        {
+            c.keys = k0; c.vals = v0; c.keys2 = dk[1]; c.vals2 = dv[1];
+            printf("alt A (dst keys 1 vals 1): ");
+            run_variant<8, 1024, 12, true>(c, 1, shift);
+            c.keys2 = dk[1]; c.vals2 = dv[2];
+            printf("alt B (dst keys 1 vals 2): ");
+            run_variant<8, 1024, 12, true>(c, 1, shift);
+        }
+        return 0;
+    }
+    if (getenv("SB_QUICK"))
+    {
+        run_variant<8, 1024, 12, true>(c, 1, shift);
+        return 0;
+    }
     if (argc > 3)
     { // short list for counter collection (rocprofv3 --pmc)
         run_variant<8, 1024, 12, true>(c, 1, shift);
