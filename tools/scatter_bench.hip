@@ -426,6 +426,13 @@ int main(int argc, char** argv)
         }
         return 0;
     }
+    if (getenv("SB_TWO"))
+    { // two 512-thread workgroups per CU (needs -DGLU_CARRY_ELEMS=8 to fit 2 x 79 KB of LDS)
+        run_variant<8, 512, 12, true>(c, 2, shift);
+        run_variant<8, 512, 12, true>(c, 1, shift);
+        run_variant<8, 1024, 12, true>(c, 1, shift);
+        return 0;
+    }
     if (getenv("SB_QUICK"))
     {
         run_variant<8, 1024, 12, true>(c, 1, shift);
