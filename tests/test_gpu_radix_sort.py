@@ -458,3 +458,62 @@ def test_maximum_count_on_device(G, n, bits):
     _device_sorted_properties(torch, orig, keys, vals)
     del sorter, keys, vals, orig
     torch.cuda.empty_cache()
+
+
+def test_sort_is_graph_capturable_and_replayable(G):
+    """run_ptr only enqueues kernels (and, for odd pass counts, one device copy) on the caller's stream once the scratch is
+    prepared: it can be captured into a HIP graph and replayed on new data in the same buffers."""
+    import torch
+
+    n = 300001
+    sorter = G.RadixSort()
+    sorter.prepare_internal_buffers(n)
+    kt = torch.empty(n, dtype=torch.int32, device="cuda")
+    vt = torch.empty(n, dtype=torch.int32, device="cuda")
+    side = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    rng = np.random.default_rng(77)
+    with torch.cuda.stream(side):
+        keys = rng.integers(0, 2**32, n, dtype=np.uint32)
+        kt.copy_(torch.from_numpy(keys.view(np.int32)))
+        vt.copy_(torch.arange(n, dtype=torch.int32))
+        sorter.run_ptr(kt.data_ptr(), vt.data_ptr(), n, 0, side.cuda_stream)  # warm-up outside the capture
+        side.synchronize()
+        with torch.cuda.graph(graph, stream=side):
+            sorter.run_ptr(kt.data_ptr(), vt.data_ptr(), n, 0, torch.cuda.current_stream().cuda_stream)
+        for rep in range(3):
+            keys = rng.integers(0, 2**32 if rep else 50, n, dtype=np.uint32)
+            vals = np.arange(n, dtype=np.uint32)
+            kt.copy_(torch.from_numpy(keys.view(np.int32)))
+            vt.copy_(torch.from_numpy(vals.view(np.int32)))
+            graph.replay()
+            side.synchronize()
+            ek, ev = O.stable_sort_pairs(keys, vals)
+            assert (kt.cpu().numpy().view(np.uint32) == ek).all() and (vt.cpu().numpy().view(np.uint32) == ev).all()
+
+
+def test_two_sorters_on_two_streams_concurrently(G):
+    """Distinct RadixSort instances on distinct streams are independent (the reference's objects are bound to one GL
+    context; here each owns its scratch): interleaved launches must not disturb each other."""
+    import torch
+
+    sizes = (1 << 22, (1 << 21) + 12345)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    sorters = [G.RadixSort(), G.RadixSort(digit_bits=4)]
+    rng = np.random.default_rng(5)
+    host = [(rng.integers(0, 2**32, n, dtype=np.uint32), np.arange(n, dtype=np.uint32)) for n in sizes]
+    dev = [(torch.from_numpy(k.view(np.int32)).cuda(), torch.from_numpy(v.view(np.int32)).cuda()) for k, v in host]
+    pristine = [(k.clone(), v.clone()) for k, v in dev]
+    for s, n in zip(sorters, sizes):
+        s.prepare_internal_buffers(n)
+    torch.cuda.synchronize()
+    for rep in range(4):
+        for i in (0, 1):
+            with torch.cuda.stream(streams[i]):
+                dev[i][0].copy_(pristine[i][0])
+                dev[i][1].copy_(pristine[i][1])
+                sorters[i].run_ptr(dev[i][0].data_ptr(), dev[i][1].data_ptr(), sizes[i], 0, streams[i].cuda_stream)
+    torch.cuda.synchronize()
+    for i in (0, 1):
+        ek, ev = O.stable_sort_pairs(*host[i])
+        assert (dev[i][0].cpu().numpy().view(np.uint32) == ek).all() and (dev[i][1].cpu().numpy().view(np.uint32) == ev).all()
