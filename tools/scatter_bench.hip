@@ -426,6 +426,44 @@ int main(int argc, char** argv)
         }
         return 0;
     }
+    if (getenv("SB_COUNTAFTER"))
+    { // the count kernel alone vs right behind a scatter (as inside a sort): where do its extra 0.06 ms come from?
+        using Smem = ScatterSmem<uint32_t, 8, 1024, 12, true, 1>;
+        const uint32_t tiles = (uint32_t) ((c.n + 12288 - 1) / 12288), nb = 256;
+        uint32_t* totals = c.table + (size_t) 256 * nb;
+        auto scatter = radix_scatter_kernel<uint32_t, 8, 1024, 12, true, 0, false, 1>;
+        CK(hipFuncSetAttribute((const void*) scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sizeof(Smem)));
+        auto count = [&](const uint32_t* k) {
+            hipLaunchKernelGGL((radix_count_kernel<uint32_t, 8, 1024, 12288>), dim3(nb), dim3(1024), 0, 0, k, c.table, (uint32_t) c.n, shift, 255u, tiles, 0u);
+        };
+        count(c.keys);
+        hipLaunchKernelGGL((radix_row_scan_kernel<256>), dim3(256), dim3(256), 0, 0, c.table, totals, nb);
+        CK(hipDeviceSynchronize());
+        uint32_t* table2;
+        CK(hipMalloc(&table2, (256 * 8192 + 256) * 4));
+        auto timed_count = [&](const uint32_t* k, bool after_scatter, const char* what) {
+            float best = 1e9f;
+            for (int r = 0; r < 7; r++)
+            {
+                if (after_scatter)
+                    hipLaunchKernelGGL(scatter, dim3(nb), dim3(1024), sizeof(Smem), 0, c.keys, c.vals, c.keys2, c.vals2, c.table, totals, (uint32_t) c.n, shift,
+                                       255u, tiles, (unsigned long long*) nullptr, 0u);
+                CK(hipEventRecord(c.ev[0]));
+                hipLaunchKernelGGL((radix_count_kernel<uint32_t, 8, 1024, 12288>), dim3(nb), dim3(1024), 0, 0, k, table2, (uint32_t) c.n, shift + 8, 255u, tiles, 0u);
+                CK(hipEventRecord(c.ev[1]));
+                CK(hipEventSynchronize(c.ev[1]));
+                float ms;
+                CK(hipEventElapsedTime(&ms, c.ev[0], c.ev[1]));
+                best = std::min(best, ms);
+            }
+            printf("count %-46s %.3f ms (%.0f GB/s)\n", what, best, c.n * 4.0 / best / 1e6);
+        };
+        timed_count(c.keys, false, "of the source keys, alone");
+        timed_count(c.keys2, false, "of the scattered keys, alone");
+        timed_count(c.keys2, true, "of the scattered keys, right after the scatter");
+        timed_count(c.keys, true, "of the source keys, right after the scatter");
+        return 0;
+    }
     if (getenv("SB_TWO"))
     { // two 512-thread workgroups per CU (needs -DGLU_CARRY_ELEMS=8 to fit 2 x 79 KB of LDS)
         run_variant<8, 512, 12, true>(c, 2, shift);
