@@ -464,6 +464,16 @@ int main(int argc, char** argv)
         timed_count(c.keys, true, "of the source keys, right after the scatter");
         return 0;
     }
+    if (getenv("SB_ROUNDS"))
+    { // tiles of 2 x the staging area (keys, values, ranks stay in registers across the two staging rounds)
+        run_variant<8, 1024, 12, true>(c, 1, shift);
+        run_variant<8, 1024, 24, true, 0, 2>(c, 1, shift);
+        run_variant<8, 1024, 16, true, 0, 2>(c, 1, shift);
+        run_variant<8, 1024, 20, true, 0, 2>(c, 1, shift);
+        run_variant<4, 1024, 24, false, 0, 2>(c, 1, shift);
+        run_variant<4, 1024, 12, false>(c, 1, shift);
+        return 0;
+    }
     if (getenv("SB_TWO"))
     { // two 512-thread workgroups per CU (needs -DGLU_CARRY_ELEMS=8 to fit 2 x 79 KB of LDS)
         run_variant<8, 512, 12, true>(c, 2, shift);
