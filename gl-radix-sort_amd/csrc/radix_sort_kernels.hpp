@@ -252,11 +252,22 @@ __global__ __launch_bounds__(THREADS) void radix_row_scan_kernel(uint32_t* __res
 
 // LDS arrays of (key, val) pairs.  32-bit keys travel with their value as one 8-byte element (one ds_write_b64 /
 // ds_read_b64 per pair); 64-bit keys use two arrays.
-template<typename KeyT, int COUNT>
-struct PairArray;
+// VALS = false (keys-only sorts): keys alone, half (32-bit keys) or two thirds (64-bit keys) of the LDS per element,
+// which the keys-only geometries spend on larger tiles.
+template<typename KeyT, int COUNT, bool VALS = true>
+struct PairArray
+{
+    KeyT keys[COUNT];
+    __device__ __forceinline__ void put(uint32_t pos, KeyT k, uint32_t) { keys[pos] = k; }
+    __device__ __forceinline__ void get(uint32_t pos, KeyT& k, uint32_t& v) const
+    {
+        k = keys[pos];
+        v = 0u;
+    }
+};
 
 template<int COUNT>
-struct PairArray<uint32_t, COUNT>
+struct PairArray<uint32_t, COUNT, true>
 {
     uint2 kv[COUNT];
     __device__ __forceinline__ void put(uint32_t pos, uint32_t k, uint32_t v) { kv[pos] = make_uint2(k, v); }
@@ -269,7 +280,7 @@ struct PairArray<uint32_t, COUNT>
 };
 
 template<int COUNT>
-struct PairArray<uint64_t, COUNT>
+struct PairArray<uint64_t, COUNT, true>
 {
     uint64_t keys[COUNT];
     uint32_t vals[COUNT];
@@ -290,7 +301,7 @@ struct PairArray<uint64_t, COUNT>
 #endif
 constexpr int kBlockElems = GLU_CARRY_ELEMS; // 16 x 4 B = the 64-byte write block the carry keeps whole
 
-template<typename KeyT, int BITS, int THREADS, int KPT, bool CARRY, int ROUNDS = 1>
+template<typename KeyT, int BITS, int THREADS, int KPT, bool CARRY, int ROUNDS = 1, bool VALS = true>
 struct ScatterSmem
 {
     static constexpr int RADIX = 1 << BITS;
@@ -298,8 +309,8 @@ struct ScatterSmem
     static constexpr int TILE = THREADS * KPT;
     static constexpr int STAGE = TILE / ROUNDS;                  // ranked positions staged per round
     static_assert(KPT % ROUNDS == 0, "a round writes out KPT / ROUNDS positions per thread");
-    PairArray<KeyT, STAGE> stage;                                // one round of the tile in ranked order
-    PairArray<KeyT, CARRY ? RADIX * kBlockElems : 1> carry;      // per digit: elements of a not yet complete 64-B block
+    PairArray<KeyT, STAGE, VALS> stage;                          // one round of the tile in ranked order
+    PairArray<KeyT, CARRY ? RADIX * kBlockElems : 1, VALS> carry; // per digit: elements of a not yet complete 64-B block
     uint32_t wcnt[WAVES][RADIX]; // wave-private running digit counters -> first ranked position of (wave, digit)
     uint32_t tstart[RADIX];      // first ranked position of each digit in the tile
     uint2 dest[RADIX];           // .x: global index = ranked position + dest[digit].x;  .y (CARRY): elements with a
@@ -329,14 +340,14 @@ struct ScatterSmem
 // ~145 dwords per lane (it also hoists lane-constant shuffle addresses out of the tile loop) and the kernel runs 4x
 // slower; it needs the values to be loaded per round instead of being held in registers.
 template<typename KeyT, int BITS, int THREADS, int KPT, bool CARRY = true, int ABLATE = 0, bool STAMPS = false,
-         int MIN_WAVES_PER_SIMD = 1, int ROUNDS = 1, int PREFETCH = 0, bool DMA = false, int RANK_MODE = 0, bool XF = false>
+         int MIN_WAVES_PER_SIMD = 1, int ROUNDS = 1, int PREFETCH = 0, bool DMA = false, int RANK_MODE = 0, bool XF = false, bool VALS = true>
 __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_kernel(
     const KeyT* __restrict__ src_keys, const uint32_t* __restrict__ src_vals, KeyT* __restrict__ dst_keys,
     uint32_t* __restrict__ dst_vals, const uint32_t* __restrict__ table, const uint32_t* __restrict__ totals,
     uint32_t n, uint32_t shift, uint32_t mask, uint32_t tiles_total, unsigned long long* stamps = nullptr,
     uint32_t xform = 0)
 {
-    using Smem = ScatterSmem<KeyT, BITS, THREADS, KPT, CARRY, ROUNDS>;
+    using Smem = ScatterSmem<KeyT, BITS, THREADS, KPT, CARRY, ROUNDS, VALS>;
     constexpr int STAGE = Smem::STAGE;
     constexpr int RADIX = Smem::RADIX;
     constexpr int WAVES = Smem::WAVES;
@@ -355,7 +366,7 @@ __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_ker
 
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t nb = gridDim.x, b = blockIdx.x;
-    const bool has_vals = src_vals != nullptr; // keys-only sorts pass no value arrays (kernel-uniform branch)
+    constexpr bool has_vals = VALS; // keys-only sorts run the VALS = false instantiation (no value arrays, keys-only LDS)
     const bool dma_ok = ((reinterpret_cast<uintptr_t>(src_keys) | reinterpret_cast<uintptr_t>(src_vals)) & 15u) == 0;
     const KeyCodec<KeyT, XF> codec_in(xform & 3u), codec_out((xform >> 2) & 3u); // key encode on load / decode on store
 
@@ -440,7 +451,7 @@ __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_ker
     auto load_tile = [&](uint32_t t, int what = 3) { // what: 1 = keys, 2 = values, 3 = both
         const uint64_t base = (uint64_t) t * TILE;
         const uint64_t left = (uint64_t) n - base;
-        if (DMA && what == 3 && dma_ok && left >= (uint64_t) TILE)
+        if (DMA && VALS && what == 3 && dma_ok && left >= (uint64_t) TILE)
         {
             // Full tile of 16-byte aligned arrays: every wave copies ITS 64 * KPT keys and values into the (idle) staging
             // area with 1 KiB LDS-DMA pieces (global_load_lds_dwordx4: no VGPRs, 4x fewer vector-memory instructions

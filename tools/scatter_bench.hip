@@ -142,19 +142,19 @@ float time_min(Ctx& c, int reps, F&& f)
     return best;
 }
 
-template<int BITS, int THREADS, int KPT, bool CARRY = true, int ABLATE = 0, int ROUNDS = 1, int PREFETCH = 0, bool DMA = false, int RANK_MODE = 0>
+template<int BITS, int THREADS, int KPT, bool CARRY = true, int ABLATE = 0, int ROUNDS = 1, int PREFETCH = 0, bool DMA = false, int RANK_MODE = 0, bool VALS = true>
 void run_variant(Ctx& c, int blocks_per_cu, uint32_t shift, uint32_t mask_override = 0)
 {
     constexpr int RADIX = 1 << BITS;
     constexpr int TILE = THREADS * KPT;
-    using Smem = ScatterSmem<uint32_t, BITS, THREADS, KPT, CARRY, ROUNDS>;
+    using Smem = ScatterSmem<uint32_t, BITS, THREADS, KPT, CARRY, ROUNDS, VALS>;
     const uint32_t tiles = (uint32_t) ((c.n + TILE - 1) / TILE);
     const uint32_t nb = std::min<uint32_t>(tiles, (uint32_t) (c.cus * blocks_per_cu));
     uint32_t* totals = c.table + (size_t) RADIX * nb;
     const uint32_t mask = mask_override ? mask_override : RADIX - 1;
     if (mask_override) printf("mask %u: ", mask);
-    auto scatter = radix_scatter_kernel<uint32_t, BITS, THREADS, KPT, CARRY, ABLATE, false, 1, ROUNDS, PREFETCH, DMA, RANK_MODE>;
-    auto scatter_st = radix_scatter_kernel<uint32_t, BITS, THREADS, KPT, CARRY, ABLATE, true, 1, ROUNDS, PREFETCH, DMA, RANK_MODE>;
+    auto scatter = radix_scatter_kernel<uint32_t, BITS, THREADS, KPT, CARRY, ABLATE, false, 1, ROUNDS, PREFETCH, DMA, RANK_MODE, false, VALS>;
+    auto scatter_st = radix_scatter_kernel<uint32_t, BITS, THREADS, KPT, CARRY, ABLATE, true, 1, ROUNDS, PREFETCH, DMA, RANK_MODE, false, VALS>;
     CK(hipFuncSetAttribute((const void*) scatter_st, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sizeof(Smem)));
     CK(hipFuncSetAttribute((const void*) scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sizeof(Smem)));
 
@@ -166,8 +166,8 @@ void run_variant(Ctx& c, int blocks_per_cu, uint32_t shift, uint32_t mask_overri
         hipLaunchKernelGGL((radix_row_scan_kernel<256>), dim3(RADIX), dim3(256), 0, 0, c.table, totals, nb);
     });
     float t_scatter = time_min(c, 5, [&] {
-        hipLaunchKernelGGL(scatter, dim3(nb), dim3(THREADS), sizeof(Smem), 0, c.keys, c.vals, c.keys2, c.vals2, c.table,
-                           totals, (uint32_t) c.n, shift, mask, tiles, (unsigned long long*) nullptr, 0u);
+        hipLaunchKernelGGL(scatter, dim3(nb), dim3(THREADS), sizeof(Smem), 0, c.keys, VALS ? c.vals : nullptr, c.keys2,
+                           VALS ? c.vals2 : nullptr, c.table, totals, (uint32_t) c.n, shift, mask, tiles, (unsigned long long*) nullptr, 0u);
     });
     CK(hipGetLastError());
     if (getenv("SB_TRACE"))
@@ -187,8 +187,8 @@ void run_variant(Ctx& c, int blocks_per_cu, uint32_t shift, uint32_t mask_overri
     unsigned long long* st;
     CK(hipMalloc(&st, 64));
     CK(hipMemset(st, 0, 64));
-    hipLaunchKernelGGL(scatter_st, dim3(nb), dim3(THREADS), sizeof(Smem), 0, c.keys, c.vals, c.keys2, c.vals2, c.table,
-                       totals, (uint32_t) c.n, shift, mask, tiles, st, 0u);
+    hipLaunchKernelGGL(scatter_st, dim3(nb), dim3(THREADS), sizeof(Smem), 0, c.keys, VALS ? c.vals : nullptr, c.keys2,
+                       VALS ? c.vals2 : nullptr, c.table, totals, (uint32_t) c.n, shift, mask, tiles, st, 0u);
     unsigned long long hst[8];
     CK(hipMemcpy(hst, st, 64, hipMemcpyDeviceToHost));
     CK(hipFree(st));
@@ -196,6 +196,8 @@ void run_variant(Ctx& c, int blocks_per_cu, uint32_t shift, uint32_t mask_overri
     hipLaunchKernelGGL(check_kernel, dim3(4096), dim3(256), 0, 0, c.keys2, c.vals2, c.keys, c.n, shift, mask, c.bad);
     unsigned long long bad = 0;
     CK(hipMemcpy(&bad, c.bad, 8, hipMemcpyDeviceToHost));
+    if (!VALS) bad = 0; // keys only: the value-based check does not apply (the library tests cover it)
+    if (!VALS) printf("keys-only ");
     if (ABLATE) printf("ABLATE %d: ", ABLATE);
     printf(CARRY ? "carry " : "plain ");
     if (ROUNDS > 1) printf("rounds %d ", ROUNDS);
@@ -472,6 +474,18 @@ int main(int argc, char** argv)
         run_variant<8, 1024, 20, true, 0, 2>(c, 1, shift);
         run_variant<4, 1024, 24, false, 0, 2>(c, 1, shift);
         run_variant<4, 1024, 12, false>(c, 1, shift);
+        return 0;
+    }
+    if (getenv("SB_KEYS"))
+    { // keys-only geometries (8 B/key moved by the scatter)
+        run_variant<8, 1024, 12, true, 0, 1, 0, false, 0, false>(c, 1, shift);
+        run_variant<8, 1024, 16, true, 0, 1, 0, false, 0, false>(c, 1, shift);
+        run_variant<8, 1024, 20, true, 0, 1, 0, false, 0, false>(c, 1, shift);
+        run_variant<8, 1024, 24, true, 0, 1, 0, false, 0, false>(c, 1, shift);
+        run_variant<8, 512, 24, true, 0, 1, 0, false, 0, false>(c, 2, shift);
+        run_variant<4, 1024, 12, false, 0, 1, 0, false, 0, false>(c, 1, shift);
+        run_variant<4, 1024, 24, false, 0, 1, 0, false, 0, false>(c, 1, shift);
+        run_variant<8, 1024, 12, true>(c, 1, shift);
         return 0;
     }
     if (getenv("SB_TWO"))
