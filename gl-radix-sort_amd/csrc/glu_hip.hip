@@ -490,8 +490,8 @@ glu_status dispatch_pass(glu_radix_sort_s* s, const KeyT* src_k, const uint32_t*
 // n <= one tile: the whole sort in a single workgroup / single launch (always 8-bit digits: the result does not
 // depend on the digit width)
 template<typename KeyT, int THREADS, int KPT, bool XF>
-glu_status launch_single_block_xf(KeyT* keys, uint32_t* vals, size_t count, uint32_t total_bits, hipStream_t stream,
-                                  uint32_t xform)
+glu_status launch_single_block_xf(KeyT* keys, uint32_t* vals, size_t count, uint32_t first_bit, uint32_t end_bit,
+                                  hipStream_t stream, uint32_t xform)
 {
     using Smem = SingleBlockSmem<KeyT, 8, THREADS, KPT>;
     auto kern = radix_sort_single_block_kernel<KeyT, 8, THREADS, KPT, XF>;
@@ -501,54 +501,51 @@ glu_status launch_single_block_xf(KeyT* keys, uint32_t* vals, size_t count, uint
         HIP_TRY(hipFuncSetAttribute((const void*) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sizeof(Smem)));
         lds_opt_in = true;
     }
-    hipLaunchKernelGGL(kern, dim3(1), dim3(THREADS), sizeof(Smem), stream, keys, vals, (uint32_t) count, total_bits, xform);
+    hipLaunchKernelGGL(kern, dim3(1), dim3(THREADS), sizeof(Smem), stream, keys, vals, (uint32_t) count, first_bit, end_bit, xform);
     HIP_TRY(hipGetLastError());
     return GLU_OK;
 }
 
 template<typename KeyT, int THREADS, int KPT>
-glu_status launch_single_block(KeyT* keys, uint32_t* vals, size_t count, uint32_t total_bits, hipStream_t stream,
-                               uint32_t xform)
+glu_status launch_single_block(KeyT* keys, uint32_t* vals, size_t count, uint32_t first_bit, uint32_t end_bit,
+                               hipStream_t stream, uint32_t xform)
 {
-    if (xform) return launch_single_block_xf<KeyT, THREADS, KPT, true>(keys, vals, count, total_bits, stream, xform);
-    return launch_single_block_xf<KeyT, THREADS, KPT, false>(keys, vals, count, total_bits, stream, 0);
+    if (xform) return launch_single_block_xf<KeyT, THREADS, KPT, true>(keys, vals, count, first_bit, end_bit, stream, xform);
+    return launch_single_block_xf<KeyT, THREADS, KPT, false>(keys, vals, count, first_bit, end_bit, stream, 0);
 }
 
 template<typename KeyT>
 constexpr size_t single_block_limit() { return sizeof(KeyT) == 4 ? 1024 * 12 : 1024 * 8; }
 
 template<typename KeyT>
-glu_status sort_single_block(KeyT* keys, uint32_t* vals, size_t count, uint32_t total_bits, hipStream_t stream,
-                             uint32_t xform)
+glu_status sort_single_block(KeyT* keys, uint32_t* vals, size_t count, uint32_t first_bit, uint32_t end_bit,
+                             hipStream_t stream, uint32_t xform)
 {
-    if (count <= 1024) return launch_single_block<KeyT, 256, 4>(keys, vals, count, total_bits, stream, xform);
-    if (count <= 4096) return launch_single_block<KeyT, 256, 16>(keys, vals, count, total_bits, stream, xform);
+    if (count <= 1024) return launch_single_block<KeyT, 256, 4>(keys, vals, count, first_bit, end_bit, stream, xform);
+    if (count <= 4096) return launch_single_block<KeyT, 256, 16>(keys, vals, count, first_bit, end_bit, stream, xform);
     if constexpr (sizeof(KeyT) == 4)
-        return launch_single_block<KeyT, 1024, 12>(keys, vals, count, total_bits, stream, xform);
+        return launch_single_block<KeyT, 1024, 12>(keys, vals, count, first_bit, end_bit, stream, xform);
     else
-        return launch_single_block<KeyT, 1024, 8>(keys, vals, count, total_bits, stream, xform);
+        return launch_single_block<KeyT, 1024, 8>(keys, vals, count, first_bit, end_bit, stream, xform);
 }
 
 // vals == nullptr: keys-only sort (no value traffic, no value scratch)
 template<typename KeyT>
-glu_status sort_run(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t count, size_t num_steps, hipStream_t stream,
-                    uint32_t key_xf = KEY_XF_NONE)
+glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t count, uint32_t first_bit, uint32_t end_bit,
+                     hipStream_t stream, uint32_t key_xf = KEY_XF_NONE)
 {
-    constexpr size_t kMaxSteps = sizeof(KeyT) * 2; // 4-bit steps: 8 for 32-bit keys (RadixSort.hpp:289,332)
-    if (count <= 1) return GLU_OK;                  // RadixSort.hpp:278-279
+    if (count <= 1 || first_bit >= end_bit) return GLU_OK; // RadixSort.hpp:278-279
     if (count > 0xFFFF0000ull) return fail(GLU_ERROR_INVALID_ARGUMENT, "count %zu does not fit 32-bit indexing", count);
     if (((uintptr_t) keys % sizeof(KeyT)) != 0 || (vals && ((uintptr_t) vals % sizeof(uint32_t)) != 0))
         return fail(GLU_ERROR_INVALID_ARGUMENT, "key/value arrays must be aligned to their element size");
     GLU_TRY(sort_prepare(s, count, sizeof(KeyT), vals != nullptr)); // RadixSort.hpp:281 (no-op when prepared)
 
-    const size_t steps = (num_steps == 0 || num_steps > kMaxSteps) ? kMaxSteps : num_steps;
-    uint32_t total_bits = (uint32_t) steps * 4;
     if (count <= single_block_limit<KeyT>() && !s->no_single_block)
     {
         s->mark(stream); // profiling: booked as one "scatter" launch (count / scan intervals are empty)
         s->mark(stream);
         s->mark(stream);
-        GLU_TRY(sort_single_block<KeyT>(keys, vals, count, total_bits, stream, key_xf | (key_xf << 2)));
+        GLU_TRY(sort_single_block<KeyT>(keys, vals, count, first_bit, end_bit, stream, key_xf | (key_xf << 2)));
         s->mark(stream);
         return GLU_OK;
     }
@@ -556,12 +553,13 @@ glu_status sort_run(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t coun
     KeyT* kbuf[2] = {keys, (KeyT*) s->keys.ptr};
     uint32_t* vbuf[2] = {vals, vals ? (uint32_t*) s->vals.ptr : nullptr};
     int cur = 0;
-    uint32_t shift = 0;
-    while (shift < total_bits)
+    uint32_t shift = first_bit;
+    while (shift < end_bit)
     {
-        uint32_t bits = std::min<uint32_t>(s->digit_bits, total_bits - shift);
+        uint32_t bits = std::min<uint32_t>(s->digit_bits, end_bit - shift);
+        if (sizeof(KeyT) == 8 && shift < 32 && shift + bits > 32) bits = 32 - shift; // a digit stays inside one key word
         // typed keys: encode on the first pass's loads, decode on the last pass's stores
-        const uint32_t xform = (shift == 0 ? key_xf : 0u) | (shift + bits >= total_bits ? key_xf << 2 : 0u);
+        const uint32_t xform = (shift == first_bit ? key_xf : 0u) | (shift + bits >= end_bit ? key_xf << 2 : 0u);
         GLU_TRY(dispatch_pass<KeyT>(s, kbuf[cur], vbuf[cur], kbuf[cur ^ 1], vbuf[cur ^ 1], count, shift, bits, nullptr,
                                     stream, xform));
         cur ^= 1;
@@ -575,6 +573,17 @@ glu_status sort_run(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t coun
         if (vals) HIP_TRY(hipMemcpyAsync(vals, vbuf[1], count * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
     }
     return GLU_OK;
+}
+
+// the reference's interface: num_steps 4-bit steps from bit 0 (0 or more than the key holds = the whole key,
+// RadixSort.hpp:289,332)
+template<typename KeyT>
+glu_status sort_run(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t count, size_t num_steps, hipStream_t stream,
+                    uint32_t key_xf = KEY_XF_NONE)
+{
+    constexpr size_t kMaxSteps = sizeof(KeyT) * 2; // 4-bit steps: 8 for 32-bit keys
+    const size_t steps = (num_steps == 0 || num_steps > kMaxSteps) ? kMaxSteps : num_steps;
+    return sort_bits<KeyT>(s, keys, vals, count, 0u, (uint32_t) steps * 4, stream, key_xf);
 }
 } // namespace
 
@@ -697,6 +706,19 @@ glu_status glu_radix_sort_run_typed_ptr(glu_radix_sort sort, void* keys, uint32_
     case GLU_KEY_FLOAT64: return sort_run<uint64_t>(sort, (uint64_t*) keys, vals, count, 0, st, KEY_XF_FLOAT);
     default: return fail(GLU_ERROR_INVALID_ARGUMENT, "Invalid key type: %d", (int) key_type);
     }
+}
+
+glu_status glu_radix_sort_run_bit_range_ptr(glu_radix_sort sort, void* keys, uint32_t* vals, size_t count, uint32_t key_bits,
+                                            uint32_t begin_bit, uint32_t end_bit, void* stream)
+{
+    if (!sort) return fail(GLU_ERROR_INVALID_ARGUMENT, "sort is NULL");
+    if (!keys) return fail(GLU_ERROR_INVALID_ARGUMENT, "Invalid key buffer");
+    if (key_bits != 32 && key_bits != 64) return fail(GLU_ERROR_INVALID_ARGUMENT, "key_bits must be 32 or 64 (got %u)", key_bits);
+    if (begin_bit > end_bit || end_bit > key_bits)
+        return fail(GLU_ERROR_INVALID_ARGUMENT, "bad bit range [%u, %u) for %u-bit keys", begin_bit, end_bit, key_bits);
+    hipStream_t st = pick_stream(stream);
+    if (key_bits == 32) return sort_bits<uint32_t>(sort, (uint32_t*) keys, vals, count, begin_bit, end_bit, st);
+    return sort_bits<uint64_t>(sort, (uint64_t*) keys, vals, count, begin_bit, end_bit, st);
 }
 
 glu_status glu_radix_sort_run_keys(glu_radix_sort sort, glu_buffer key_buffer, size_t count, size_t num_steps)

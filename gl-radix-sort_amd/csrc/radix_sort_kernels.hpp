@@ -799,7 +799,8 @@ struct SingleBlockSmem
 template<typename KeyT, int BITS, int THREADS, int KPT, bool XF = false>
 __global__ __launch_bounds__(THREADS) void radix_sort_single_block_kernel(KeyT* __restrict__ keys,
                                                                           uint32_t* __restrict__ vals, uint32_t n,
-                                                                          uint32_t total_bits, uint32_t xform = 0)
+                                                                          uint32_t first_bit, uint32_t end_bit,
+                                                                          uint32_t xform = 0)
 {
     using Smem = SingleBlockSmem<KeyT, BITS, THREADS, KPT>;
     constexpr int RADIX = Smem::RADIX;
@@ -828,9 +829,13 @@ __global__ __launch_bounds__(THREADS) void radix_sort_single_block_kernel(KeyT* 
     }
 
     uint32_t* my_cnt = s.wcnt[wave];
-    for (uint32_t shift = 0; shift < total_bits; shift += BITS)
+    // stable passes over the key bits [first_bit, end_bit), BITS at a time (a digit never straddles the two words of a
+    // 64-bit key: digit_of picks one word)
+    uint32_t bits = 0;
+    for (uint32_t shift = first_bit; shift < end_bit; shift += bits)
     {
-        const uint32_t bits = total_bits - shift < (uint32_t) BITS ? total_bits - shift : (uint32_t) BITS;
+        bits = end_bit - shift < (uint32_t) BITS ? end_bit - shift : (uint32_t) BITS;
+        if (sizeof(KeyT) == 8 && shift < 32u && shift + bits > 32u) bits = 32u - shift;
         const uint32_t MASK = (1u << bits) - 1;
         for (int i = tid; i < WAVES * RADIX; i += THREADS) (&s.wcnt[0][0])[i] = 0;
         __syncthreads();

@@ -61,6 +61,17 @@ namespace glu
             GLU_CHECK_STATUS(glu_radix_sort_run_typed_ptr(m_impl, device_keys, device_vals, count, key_type_of<KeyT>(), stream));
         }
 
+        /// Stable sort by the key bits [begin_bit, end_bit) only (not in the reference): KeyT in {uint32_t, uint64_t},
+        /// device_vals may be nullptr.
+        template<typename KeyT>
+        void sort_bit_range(KeyT* device_keys, uint32_t* device_vals, size_t count, uint32_t begin_bit, uint32_t end_bit,
+                            void* stream = nullptr)
+        {
+            static_assert(std::is_same<KeyT, uint32_t>::value || std::is_same<KeyT, uint64_t>::value, "unsigned keys");
+            GLU_CHECK_STATUS(glu_radix_sort_run_bit_range_ptr(m_impl, device_keys, device_vals, count, sizeof(KeyT) * 8,
+                                                              begin_bit, end_bit, stream));
+        }
+
         /// 64-bit keys with 32-bit values (not in the reference); num_steps counts 4-bit digits, 0 = all 64 bits.
         void sort_u64(GLuint key_buffer, GLuint val_buffer, size_t count, size_t num_steps = 0)
         {

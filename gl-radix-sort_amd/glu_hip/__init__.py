@@ -58,6 +58,7 @@ SYMBOLS = [
     ("glu_radix_sort_run_keys_ptr", _int, [_vp, _vp, _sz, _sz, _vp]),
     ("glu_radix_sort_run_keys_u64_ptr", _int, [_vp, _vp, _sz, _sz, _vp]),
     ("glu_radix_sort_run_typed_ptr", _int, [_vp, _vp, _vp, _sz, _int, _vp]),
+    ("glu_radix_sort_run_bit_range_ptr", _int, [_vp, _vp, _vp, _sz, _u32, _u32, _u32, _vp]),
     ("glu_radix_sort_partition_ptr", _int, [_vp, _vp, _vp, _vp, _vp, _sz, _u32, _u32, _vp, _vp]),
     ("glu_radix_sort_set_digit_bits", _int, [_vp, _u32]),
     ("glu_radix_sort_get_digit_bits", _int, [_vp, _P(_u32)]),
@@ -263,6 +264,11 @@ class RadixSort:
         """key_type: a numpy dtype name in KEY_TYPES; vals_ptr may be None (keys only)."""
         check(lib().glu_radix_sort_run_typed_ptr(self._h, _vp(keys_ptr), _vp(vals_ptr), count, self.KEY_TYPES[key_type],
                                                  _vp(stream)))
+
+    def sort_bit_range_ptr(self, keys_ptr, vals_ptr, count, begin_bit, end_bit, stream=None, key_bytes=4):
+        """Stable sort by the key bits [begin_bit, end_bit) only; vals_ptr may be None (keys only)."""
+        check(lib().glu_radix_sort_run_bit_range_ptr(self._h, _vp(keys_ptr), _vp(vals_ptr), count, key_bytes * 8, begin_bit,
+                                                     end_bit, _vp(stream)))
 
     def run_ptr(self, keys_ptr, vals_ptr, count, num_steps=0, stream=None, key_bytes=4):
         fn = lib().glu_radix_sort_run_ptr if key_bytes == 4 else lib().glu_radix_sort_run_u64_ptr

@@ -170,6 +170,12 @@ typedef enum glu_key_type
 } glu_key_type;
 GLU_API glu_status glu_radix_sort_run_typed_ptr(glu_radix_sort sort, void* keys, uint32_t* vals, size_t count,
                                                 glu_key_type key_type, void* stream);
+/* Stable sort by the key bits [begin_bit, end_bit) only (not in the reference, whose num_steps always starts at bit 0,
+ * RadixSort.hpp:303,331-332): keys that are known to fit 24 bits sort in 3 passes instead of 4, a sort by the high bits
+ * alone leaves the low-bit order untouched.  key_bits is 32 or 64 (unsigned keys), vals may be NULL (keys only), the
+ * result is in the caller's arrays for every pass count; begin_bit == end_bit is a no-op. */
+GLU_API glu_status glu_radix_sort_run_bit_range_ptr(glu_radix_sort sort, void* keys, uint32_t* vals, size_t count,
+                                                    uint32_t key_bits, uint32_t begin_bit, uint32_t end_bit, void* stream);
 /* One stable counting pass on the digit (key >> shift) & ((1 << bits) - 1), 1 <= bits <= 8, from src to dst
  * (distinct buffers).  This is the partition step of the multi-GPU sort (top-8-bit buckets).  If
  * digit_histogram != NULL it receives the 1 << bits digit totals (device memory, uint32). */

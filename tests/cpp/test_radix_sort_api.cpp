@@ -214,6 +214,31 @@ TEST_CASE("RadixSort-typed-keys")
     CHECK(ib.get_data<int64_t>() == expected);
 }
 
+TEST_CASE("RadixSort-bit-range")
+{
+    // keys that fit 24 bits sort in three 8-bit passes; a sort by the middle bits is stable in everything else
+    std::mt19937 gen(5);
+    const size_t n = 150001;
+    std::vector<GLuint> keys(n), vals(n);
+    for (auto& k : keys) k = gen();
+    std::iota(vals.begin(), vals.end(), 0u);
+    for (auto range : {std::pair<uint32_t, uint32_t>{0, 24}, {8, 20}, {24, 32}})
+    {
+        const uint32_t width = range.second - range.first;
+        auto field = [&](GLuint k) { return (k >> range.first) & ((width == 32 ? 0u : (1u << width)) - 1u); };
+        std::vector<GLuint> order(vals);
+        std::stable_sort(order.begin(), order.end(), [&](GLuint a, GLuint b) { return field(keys[a]) < field(keys[b]); });
+        ShaderStorageBuffer kb(keys), vb(vals);
+        RadixSort radix_sort;
+        radix_sort.sort_bit_range(static_cast<uint32_t*>(kb.device_ptr()), static_cast<uint32_t*>(vb.device_ptr()), n, range.first,
+                                  range.second);
+        std::vector<GLuint> out_keys = kb.get_data<GLuint>(), out_vals = vb.get_data<GLuint>();
+        bool same = true;
+        for (size_t i = 0; i < n; i++) same = same && out_vals[i] == order[i] && out_keys[i] == keys[order[i]];
+        CHECK(same);
+    }
+}
+
 TEST_CASE("RadixSort-raw-pointer-overload")
 {
     // native callers: raw device pointers (here taken from ShaderStorageBuffer) on the library queue

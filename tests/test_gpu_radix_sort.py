@@ -517,3 +517,33 @@ def test_two_sorters_on_two_streams_concurrently(G):
     for i in (0, 1):
         ek, ev = O.stable_sort_pairs(*host[i])
         assert (dev[i][0].cpu().numpy().view(np.uint32) == ek).all() and (dev[i][1].cpu().numpy().view(np.uint32) == ev).all()
+
+
+@pytest.mark.parametrize("bits", DIGIT_BITS)
+@pytest.mark.parametrize("key_bytes,begin,end", [(4, 0, 32), (4, 0, 24), (4, 8, 20), (4, 24, 32), (4, 5, 6), (4, 13, 13),
+                                                  (8, 0, 64), (8, 28, 36), (8, 30, 51), (8, 40, 64), (8, 0, 20)])
+@pytest.mark.parametrize("n", [777, 20001, 600011])
+def test_bit_range_sort(G, bits, key_bytes, begin, end, n):
+    """glu_radix_sort_run_bit_range_ptr: stable sort by the key bits [begin, end) only, pairs and keys-only; ranges that
+    cross the two words of a 64-bit key and ranges narrower than a digit included."""
+    rng = np.random.default_rng(n + begin * 64 + end)
+    dt = np.uint32 if key_bytes == 4 else np.uint64
+    keys = rng.integers(0, 2 ** (8 * key_bytes), n, dtype=dt)
+    vals = np.arange(n, dtype=np.uint32)
+    field = (keys >> dt(begin)) & dt((1 << (end - begin)) - 1) if end > begin else np.zeros(n, dtype=dt)
+    order = np.argsort(field, kind="stable")
+    sorter = G.RadixSort(digit_bits=bits)
+    kb, vb = G.ShaderStorageBuffer(keys), G.ShaderStorageBuffer(vals)
+    sorter.sort_bit_range_ptr(kb.device_ptr(), vb.device_ptr(), n, begin, end, None, key_bytes)
+    assert (kb.get_data(dt) == keys[order]).all() and (vb.get_data(np.uint32) == vals[order]).all()
+    kb2 = G.ShaderStorageBuffer(keys)
+    sorter.sort_bit_range_ptr(kb2.device_ptr(), None, n, begin, end, None, key_bytes)
+    assert (kb2.get_data(dt) == keys[order]).all()
+
+
+def test_bit_range_argument_checks(G):
+    sorter = G.RadixSort()
+    kb = G.ShaderStorageBuffer(np.arange(64, dtype=np.uint32))
+    for begin, end, kbytes in ((9, 8, 4), (0, 33, 4), (0, 65, 8)):
+        with pytest.raises(G.GluError):
+            sorter.sort_bit_range_ptr(kb.device_ptr(), None, 64, begin, end, None, kbytes)
