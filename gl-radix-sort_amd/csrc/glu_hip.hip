@@ -428,7 +428,7 @@ glu_status launch_pass(glu_radix_sort_s* s, const KeyT* src_k, const uint32_t* s
     uint32_t* totals = table + (size_t) RADIX * nb;
 
     using Smem = ScatterSmem<KeyT, BITS, G::THREADS, G::KPT, G::CARRY, 1, VALS>;
-    auto scatter = radix_scatter_kernel<KeyT, BITS, G::THREADS, G::KPT, G::CARRY, 0, false, G::BLOCKS_PER_CU * G::THREADS / 256, 1, 0, false, 0, XF, VALS>;
+    auto scatter = radix_scatter_kernel<KeyT, BITS, G::THREADS, G::KPT, G::CARRY, 0, false, G::BLOCKS_PER_CU * G::THREADS / 256, 1, false, false, XF, VALS>;
     static bool lds_opt_in = false; // per instantiation: allow > 64 KiB of dynamic LDS
     if (!lds_opt_in)
     {

@@ -340,7 +340,7 @@ struct ScatterSmem
 // ~145 dwords per lane (it also hoists lane-constant shuffle addresses out of the tile loop) and the kernel runs 4x
 // slower; it needs the values to be loaded per round instead of being held in registers.
 template<typename KeyT, int BITS, int THREADS, int KPT, bool CARRY = true, int ABLATE = 0, bool STAMPS = false,
-         int MIN_WAVES_PER_SIMD = 1, int ROUNDS = 1, int PREFETCH = 0, bool DMA = false, int RANK_MODE = 0, bool XF = false, bool VALS = true>
+         int MIN_WAVES_PER_SIMD = 1, int ROUNDS = 1, bool PREFETCH = false, bool DMA = false, bool XF = false, bool VALS = true>
 __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_kernel(
     const KeyT* __restrict__ src_keys, const uint32_t* __restrict__ src_vals, KeyT* __restrict__ dst_keys,
     uint32_t* __restrict__ dst_vals, const uint32_t* __restrict__ table, const uint32_t* __restrict__ totals,
@@ -448,10 +448,10 @@ __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_ker
     // loads one tile into registers (wave-striped); positions past the end of the array read as pads
     KeyT key[KPT];
     uint32_t val[KPT];
-    auto load_tile = [&](uint32_t t, int what = 3) { // what: 1 = keys, 2 = values, 3 = both
+    auto load_tile = [&](uint32_t t) {
         const uint64_t base = (uint64_t) t * TILE;
         const uint64_t left = (uint64_t) n - base;
-        if (DMA && VALS && what == 3 && dma_ok && left >= (uint64_t) TILE)
+        if (DMA && VALS && dma_ok && left >= (uint64_t) TILE)
         {
             // Full tile of 16-byte aligned arrays: every wave copies ITS 64 * KPT keys and values into the (idle) staging
             // area with 1 KiB LDS-DMA pieces (global_load_lds_dwordx4: no VGPRs, 4x fewer vector-memory instructions
@@ -491,16 +491,10 @@ __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_ker
         }
         else if (left >= (uint64_t) TILE)
         {
-            if (what & 1)
-            {
 #pragma unroll
-                for (int i = 0; i < KPT; i++) key[i] = codec_in.encode(src_keys[base + wave_off + i * kWave]);
-            }
-            if (what & 2)
-            {
+            for (int i = 0; i < KPT; i++) key[i] = codec_in.encode(src_keys[base + wave_off + i * kWave]);
 #pragma unroll
-                for (int i = 0; i < KPT; i++) val[i] = has_vals ? src_vals[base + wave_off + i * kWave] : 0u;
-            }
+            for (int i = 0; i < KPT; i++) val[i] = has_vals ? src_vals[base + wave_off + i * kWave] : 0u;
         }
         else
         {
@@ -510,14 +504,13 @@ __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_ker
                 const uint32_t p = wave_off + i * kWave;
                 const bool ok = p < (uint32_t) left;
                 // pad: last digit, after all real keys
-                if (what & 1) key[i] = ok ? codec_in.encode(src_keys[base + p]) : (KeyT) ~(KeyT) 0;
-                if (what & 2) val[i] = (ok && has_vals) ? src_vals[base + p] : 0u;
+                key[i] = ok ? codec_in.encode(src_keys[base + p]) : (KeyT) ~(KeyT) 0;
+                val[i] = (ok && has_vals) ? src_vals[base + p] : 0u;
             }
         }
     };
-    // PREFETCH 1: keys and values of tile t+1 are loaded during the write-out of tile t; 2: keys only, the values at the
-    // top of their own tile (they are not needed before the staging step, two phases later)
-    if (PREFETCH && first < last) load_tile(first, PREFETCH == 2 ? 1 : 3);
+    // PREFETCH (experimental, off): the first tile is loaded here, every later one while its predecessor is ranked
+    if (PREFETCH && first < last) load_tile(first);
 
     for (uint32_t tile = first; tile < last; tile++)
     {
@@ -526,9 +519,8 @@ __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_ker
         const uint32_t tile_valid = rem < (uint64_t) TILE ? (uint32_t) rem : (uint32_t) TILE;
         if (STAMPS) tprev = __builtin_amdgcn_s_memtime();
 
-        // ---- load (PREFETCH: already issued while the previous tile was being written out)
+        // ---- load (PREFETCH: already issued while the previous tile was being ranked)
         if (!PREFETCH) load_tile(tile);
-        if (PREFETCH == 2) load_tile(tile, 2);
         if (STAMPS)
         {
             stamp(0); // issue
@@ -536,11 +528,11 @@ __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_ker
             stamp(1); // load latency (diagnostic builds wait here; production waits at first use)
         }
 
-        // PREFETCH 3: the next tile's loads are issued one pair per rank iteration (into their own registers), so that
+        // PREFETCH: the next tile's loads are issued one pair per rank iteration (into their own registers), so that
         // they neither wait for a full vector-memory queue nor sit between this tile's stores
-        const bool sprinkle = PREFETCH == 3 && tile + 1 < last && (uint64_t) n - (tile_base + TILE) >= (uint64_t) TILE;
-        KeyT nk[PREFETCH == 3 ? KPT : 1];
-        uint32_t nv[PREFETCH == 3 ? KPT : 1];
+        const bool sprinkle = PREFETCH && tile + 1 < last && (uint64_t) n - (tile_base + TILE) >= (uint64_t) TILE;
+        KeyT nk[PREFETCH ? KPT : 1];
+        uint32_t nv[PREFETCH ? KPT : 1];
 
         // ---- rank inside the wave
         uint32_t rank[KPT];
@@ -548,7 +540,7 @@ __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_ker
 #pragma unroll
         for (int i = 0; i < KPT; i++)
         {
-            if (PREFETCH == 3 && sprinkle)
+            if (PREFETCH && sprinkle)
             {
                 const uint64_t nbase = tile_base + TILE + wave_off;
                 nk[i] = src_keys[nbase + i * kWave];
@@ -556,13 +548,6 @@ __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_ker
             }
             const uint32_t d = digit_of<KeyT>(key[i], shift, MASK);
             uint32_t* const cnt = my_cnt + d;
-            if (RANK_MODE == 1)
-            {
-                // EXPERIMENT: one returning LDS atomic per item.  Stable only if the LDS serves the lanes of one
-                // instruction that hit the same address in increasing lane order (not an architectural promise).
-                rank[i] = atomicAdd(cnt, 1u);
-                continue;
-            }
             const uint32_t prev = *cnt; // issued first: its LDS latency hides under the ballots below
             // peers = lanes whose digit equals mine.  Per digit bit: sel = 0 / ~0 (v_bfe_i32), m = ballot(bit set),
             // peers &= ~(m ^ sel) -- one v_bitop3_b32 per 32-bit half (truth table 0x90: a & ~(b ^ c)).
@@ -684,9 +669,6 @@ __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_ker
             // ---- write out: consecutive threads -> consecutive ranked positions -> (per digit) consecutive addresses.
             //      Batched sweeps (staged pairs, per-digit lookups, stores) so that the LDS latencies overlap instead of
             //      being paid once per item behind a branch.
-            //      PREFETCH: keys and values now live in LDS, their registers are free: the loads of the next tile are
-            //      issued here, a few in front of every batch of stores, so that the CU's read and write paths are
-            //      both busy (all loads first would hold the stores back: vector-memory instructions issue in order).
             constexpr int WI = KPT / ROUNDS;
 #ifndef GLU_WRITE_BATCH
 #define GLU_WRITE_BATCH 4 // items per write-out batch (tuning builds override; 0 = the whole round)
@@ -694,21 +676,9 @@ __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_ker
             // 4 items per batch: enough LDS reads in flight to cover their latency; the whole round in one batch costs
             // 5 registers per item and was 2 % (32-bit keys, 12 items) to 17 % (64-bit keys, 16 items) slower
             constexpr int WB = (GLU_WRITE_BATCH > 0 && WI % GLU_WRITE_BATCH == 0) ? GLU_WRITE_BATCH : WI;
-            const bool next_full = (PREFETCH == 1 || PREFETCH == 2) && tile + 1 < last && (uint64_t) n - (tile_base + TILE) >= (uint64_t) TILE;
 #pragma unroll
             for (int b0 = 0; b0 < WI; b0 += WB)
             {
-                if ((PREFETCH == 1 || PREFETCH == 2) && r == ROUNDS - 1 && next_full)
-                {
-                    const uint64_t nbase = tile_base + TILE + wave_off;
-#pragma unroll
-                    for (int i = b0; i < b0 + WB; i++) key[i] = codec_in.encode(src_keys[nbase + i * kWave]);
-                    if (PREFETCH == 1)
-                    {
-#pragma unroll
-                        for (int i = b0; i < b0 + WB; i++) val[i] = has_vals ? src_vals[nbase + i * kWave] : 0u;
-                    }
-                }
                 KeyT wk[WB];
                 uint32_t wv[WB], wg[WB], wlim[WB];
 #pragma unroll
@@ -739,9 +709,7 @@ __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_ker
                 }
             }
             // a partial next tile (the last of the array) takes the guarded loads
-            if ((PREFETCH == 1 || PREFETCH == 2) && r == ROUNDS - 1 && tile + 1 < last && !next_full)
-                load_tile(tile + 1, PREFETCH == 2 ? 1 : 3);
-            if (PREFETCH == 3 && r == ROUNDS - 1 && tile + 1 < last)
+            if (PREFETCH && r == ROUNDS - 1 && tile + 1 < last)
             {
                 if (sprinkle)
                 {

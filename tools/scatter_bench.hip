@@ -142,7 +142,7 @@ float time_min(Ctx& c, int reps, F&& f)
     return best;
 }
 
-template<int BITS, int THREADS, int KPT, bool CARRY = true, int ABLATE = 0, int ROUNDS = 1, int PREFETCH = 0, bool DMA = false, int RANK_MODE = 0, bool VALS = true>
+template<int BITS, int THREADS, int KPT, bool CARRY = true, int ABLATE = 0, int ROUNDS = 1, bool PREFETCH = false, bool DMA = false, bool VALS = true>
 void run_variant(Ctx& c, int blocks_per_cu, uint32_t shift, uint32_t mask_override = 0)
 {
     constexpr int RADIX = 1 << BITS;
@@ -153,8 +153,8 @@ void run_variant(Ctx& c, int blocks_per_cu, uint32_t shift, uint32_t mask_overri
     uint32_t* totals = c.table + (size_t) RADIX * nb;
     const uint32_t mask = mask_override ? mask_override : RADIX - 1;
     if (mask_override) printf("mask %u: ", mask);
-    auto scatter = radix_scatter_kernel<uint32_t, BITS, THREADS, KPT, CARRY, ABLATE, false, 1, ROUNDS, PREFETCH, DMA, RANK_MODE, false, VALS>;
-    auto scatter_st = radix_scatter_kernel<uint32_t, BITS, THREADS, KPT, CARRY, ABLATE, true, 1, ROUNDS, PREFETCH, DMA, RANK_MODE, false, VALS>;
+    auto scatter = radix_scatter_kernel<uint32_t, BITS, THREADS, KPT, CARRY, ABLATE, false, 1, ROUNDS, PREFETCH, DMA, false, VALS>;
+    auto scatter_st = radix_scatter_kernel<uint32_t, BITS, THREADS, KPT, CARRY, ABLATE, true, 1, ROUNDS, PREFETCH, DMA, false, VALS>;
     CK(hipFuncSetAttribute((const void*) scatter_st, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sizeof(Smem)));
     CK(hipFuncSetAttribute((const void*) scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sizeof(Smem)));
 
@@ -201,9 +201,8 @@ void run_variant(Ctx& c, int blocks_per_cu, uint32_t shift, uint32_t mask_overri
     if (ABLATE) printf("ABLATE %d: ", ABLATE);
     printf(CARRY ? "carry " : "plain ");
     if (ROUNDS > 1) printf("rounds %d ", ROUNDS);
-    if (PREFETCH) printf("prefetch%d ", PREFETCH);
+    if (PREFETCH) printf("prefetch ");
     if (DMA) printf("dma ");
-    if (RANK_MODE) printf("rank%d ", RANK_MODE);
     printf("bits %d threads %4d kpt %2d tile %5d lds %6zu blk/cu %d nb %5u | count %.3f ms (%.0f GB/s) scan %.3f | scatter %.3f ms "
            "(%.0f GB/s) | pass %.3f ms %s\n",
            BITS, THREADS, KPT, TILE, sizeof(Smem), blocks_per_cu, nb, t_count, c.n * 4.0 / t_count / 1e6, t_scan, t_scatter,
@@ -478,13 +477,13 @@ int main(int argc, char** argv)
     }
     if (getenv("SB_KEYS"))
     { // keys-only geometries (8 B/key moved by the scatter)
-        run_variant<8, 1024, 12, true, 0, 1, 0, false, 0, false>(c, 1, shift);
-        run_variant<8, 1024, 16, true, 0, 1, 0, false, 0, false>(c, 1, shift);
-        run_variant<8, 1024, 20, true, 0, 1, 0, false, 0, false>(c, 1, shift);
-        run_variant<8, 1024, 24, true, 0, 1, 0, false, 0, false>(c, 1, shift);
-        run_variant<8, 512, 24, true, 0, 1, 0, false, 0, false>(c, 2, shift);
-        run_variant<4, 1024, 12, false, 0, 1, 0, false, 0, false>(c, 1, shift);
-        run_variant<4, 1024, 24, false, 0, 1, 0, false, 0, false>(c, 1, shift);
+        run_variant<8, 1024, 12, true, 0, 1, false, false, false>(c, 1, shift);
+        run_variant<8, 1024, 16, true, 0, 1, false, false, false>(c, 1, shift);
+        run_variant<8, 1024, 20, true, 0, 1, false, false, false>(c, 1, shift);
+        run_variant<8, 1024, 24, true, 0, 1, false, false, false>(c, 1, shift);
+        run_variant<8, 512, 24, true, 0, 1, false, false, false>(c, 2, shift);
+        run_variant<4, 1024, 12, false, 0, 1, false, false, false>(c, 1, shift);
+        run_variant<4, 1024, 24, false, 0, 1, false, false, false>(c, 1, shift);
         run_variant<8, 1024, 12, true>(c, 1, shift);
         return 0;
     }
@@ -522,33 +521,24 @@ int main(int argc, char** argv)
         cnt(radix_count_kernel<uint32_t, 8, 512, 12288>, 512, "8-bit  512 thr");
     }
     run_variant<8, 1024, 12, true>(c, 1, shift);
-    if (getenv("SB_RANK"))
-    {
-        run_variant<8, 1024, 12, true, 0, 1, 0, false, 1>(c, 1, shift);
-        run_variant<8, 1024, 12, true, 0, 1, 3, false, 1>(c, 1, shift);
-        run_variant<8, 1024, 12, true, 0, 1, 0, true, 1>(c, 1, shift);
-        run_variant<4, 1024, 12, false, 0, 1, 3, false, 1>(c, 1, shift);
-        run_variant<4, 1024, 12, false, 0, 1, 0, false, 1>(c, 1, shift);
-        run_variant<4, 1024, 12, false>(c, 1, shift);
-    }
     if (getenv("SB_DMA"))
     {
-        run_variant<8, 1024, 12, true, 0, 1, 0, true>(c, 1, shift);
-        run_variant<8, 1024, 12, true, 3, 1, 0, false>(c, 1, shift);
-        run_variant<8, 1024, 12, true, 3, 1, 0, true>(c, 1, shift);
-        run_variant<4, 1024, 12, false, 0, 1, 0, true>(c, 1, shift);
+        run_variant<8, 1024, 12, true, 0, 1, false, true>(c, 1, shift);
+        run_variant<8, 1024, 12, true, 3, 1, false, false>(c, 1, shift);
+        run_variant<8, 1024, 12, true, 3, 1, false, true>(c, 1, shift);
+        run_variant<4, 1024, 12, false, 0, 1, false, true>(c, 1, shift);
         run_variant<4, 1024, 12, false>(c, 1, shift);
-        run_variant<8, 256, 16, true, 0, 1, 0, true>(c, 3, shift);
+        run_variant<8, 256, 16, true, 0, 1, false, true>(c, 3, shift);
         run_variant<8, 256, 16, true>(c, 3, shift);
     }
     if (getenv("SB_PREFETCH"))
     {
-        run_variant<8, 1024, 12, true, 0, 1, 3>(c, 1, shift);
+        run_variant<8, 1024, 12, true, 0, 1, true>(c, 1, shift);
         run_variant<8, 1024, 8, true>(c, 1, shift);
-        run_variant<8, 1024, 8, true, 0, 1, 3>(c, 1, shift);
+        run_variant<8, 1024, 8, true, 0, 1, true>(c, 1, shift);
         run_variant<8, 512, 24, true>(c, 1, shift);
-        run_variant<8, 512, 24, true, 0, 1, 3>(c, 1, shift);
-        run_variant<4, 1024, 12, false, 0, 1, 3>(c, 1, shift);
+        run_variant<8, 512, 24, true, 0, 1, true>(c, 1, shift);
+        run_variant<4, 1024, 12, false, 0, 1, true>(c, 1, shift);
     }
     return 0;
 }
