@@ -547,3 +547,30 @@ def test_bit_range_argument_checks(G):
     for begin, end, kbytes in ((9, 8, 4), (0, 33, 4), (0, 65, 8)):
         with pytest.raises(G.GluError):
             sorter.sort_bit_range_ptr(kb.device_ptr(), None, 64, begin, end, None, kbytes)
+
+
+@pytest.mark.parametrize("mode,threshold", [("pairs", 256 * 12288), ("keys", 256 * 20480), ("u64", 256 * 8192)])
+@pytest.mark.parametrize("delta", [-1, 0, 1, 12287])
+def test_geometry_switch_points(G, mode, threshold, delta):
+    """Sizes right at the small -> large geometry switch of each kernel family (256 CUs x one large tile; the large tile is
+    12288 pairs, 20480 keys for keys-only sorts, 8192 pairs for 64-bit keys): last tile partial / exactly full / one over."""
+    n = threshold + delta
+    rng = np.random.default_rng(n)
+    if mode == "u64":
+        keys = rng.integers(0, 2**64, n, dtype=np.uint64)
+    else:
+        keys = rng.integers(0, 2**32, n, dtype=np.uint32)
+    keys[rng.integers(0, n, n // 50)] = keys[0]  # some duplicates
+    if mode == "keys":
+        kb = G.ShaderStorageBuffer(keys)
+        G.RadixSort().sort_keys(kb, n)
+        assert (kb.get_data(np.uint32) == np.sort(keys, kind="stable")).all()
+        return
+    vals = np.arange(n, dtype=np.uint32)
+    gk, gv = gpu_sort(G, keys, vals, key_bytes=8 if mode == "u64" else 4)
+    ek, ev = O.stable_sort_pairs(keys, vals) if mode == "pairs" else (None, None)
+    if mode == "pairs":
+        assert (gk == ek).all() and (gv == ev).all()
+    else:
+        order = np.argsort(keys, kind="stable")
+        assert (gk == keys[order]).all() and (gv == vals[order]).all()
