@@ -100,6 +100,35 @@ __global__ __launch_bounds__(1024) void copy_width_kernel(const uint32_t* __rest
     }
 }
 
+// 4-stream copy in which a workgroup never touches a[x] and b[x] (or c[x] and d[x]) close together in time: per chunk it
+// first moves a -> c, then b -> d
+template<int CH>
+__global__ __launch_bounds__(1024) void copy_split_kernel(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b,
+                                                          uint32_t* __restrict__ c, uint32_t* __restrict__ d, size_t n)
+{
+    for (size_t base = (size_t) blockIdx.x * CH; base < n; base += (size_t) gridDim.x * CH)
+    {
+        for (int i = threadIdx.x; i < CH; i += 16 * 1024)
+        {
+            uint32_t r[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) r[j] = (i + j * 1024 < CH) ? a[base + i + j * 1024] : 0;
+#pragma unroll
+            for (int j = 0; j < 16; j++)
+                if (i + j * 1024 < CH) c[base + i + j * 1024] = r[j];
+        }
+        for (int i = threadIdx.x; i < CH; i += 16 * 1024)
+        {
+            uint32_t r[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) r[j] = (i + j * 1024 < CH) ? b[base + i + j * 1024] : 0;
+#pragma unroll
+            for (int j = 0; j < 16; j++)
+                if (i + j * 1024 < CH) d[base + i + j * 1024] = r[j];
+        }
+    }
+}
+
 __global__ void check_kernel(const uint32_t* keys, const uint32_t* vals, const uint32_t* src_keys, size_t n,
                              uint32_t shift, uint32_t mask, unsigned long long* bad)
 {
@@ -300,6 +329,23 @@ int main(int argc, char** argv)
                    c.n * 16.0 / t / 1e6);
         };
         const size_t M1 = 1 << 20;
+        auto run_split = [&](auto kern, size_t ob, size_t oc, size_t od, const char* what) {
+            const uint32_t* a = (const uint32_t*) pool;
+            const uint32_t* b = (const uint32_t*) (pool + ob);
+            uint32_t* cc = (uint32_t*) (pool + oc);
+            uint32_t* dd = (uint32_t*) (pool + od);
+            float t = time_min(c, 7, [&] { hipLaunchKernelGGL(kern, dim3(256), dim3(1024), 0, 0, a, b, cc, dd, c.n); });
+            printf("split copy b@%.4f c@%.4f d@%.4f GiB %s: %.3f ms (%.0f GB/s)\n", ob / (double) G1, oc / (double) G1, od / (double) G1, what, t,
+                   c.n * 16.0 / t / 1e6);
+        };
+        printf("-- interleaved copy vs copies split in time, at the worst (1 GiB) and the best (1.5 GiB) distance\n");
+        for (size_t D : {G1, G1 + 512 * M1})
+        {
+            run(D, 4 * G1, 4 * G1 + D, "interleaved");
+            run_split(copy_split_kernel<16384>, D, 4 * G1, 4 * G1 + D, "split, 16 Ki elements per stream and turn");
+            run_split(copy_split_kernel<65536>, D, 4 * G1, 4 * G1 + D, "split, 64 Ki");
+            run_split(copy_split_kernel<262144>, D, 4 * G1, 4 * G1 + D, "split, 256 Ki");
+        }
         printf("-- pairs (a,b) and (c,d) at distance D, a-c 4 GiB apart\n");
         for (size_t k = 0; k <= 32; k++) run(G1 + k * 64 * M1, 4 * G1, 5 * G1 + k * 64 * M1, "D = 1 GiB + k*64 MiB");
         printf("-- D = 1.5 GiB, c moved by y\n");
