@@ -301,11 +301,16 @@ def main():
         # consecutive sorts are independent batches: with pipeline depth 2 each runs on its own stream / buffers, so the
         # all-to-all of step i+1 (RCCL) can proceed under the local sort of step i; every step is still a complete sort
         depth = max(1, args.pipeline_depth)
-        dsort = D.DistributedRadixSort(local_ops_factory=lambda: D.HipLocalOps(digit_bits=args.digit_bits), slots=depth)
+        dsort = D.DistributedRadixSort(local_ops_factory=lambda: D.HipLocalOps(digit_bits=args.digit_bits), slots=depth,
+                                       profile=not args.no_kernel_events)
         keys0, vals0 = make_input(torch, n, args.keys, rank, device, index_base=rank * n)
         for i in range(W):
             dsort.sort_async(keys0, vals0)
         barrier()
+        dsort.phase_times()  # drop the warm-up stamps
+        sorters = [slot["ops"].sorter for slot in dsort._slots]
+        for srt in sorters:
+            srt.set_profiling(not args.no_kernel_events)
         t0 = time.perf_counter()
         handle = None
         for i in range(K):
@@ -314,6 +319,26 @@ def main():
         elapsed = time.perf_counter() - t0
         rk, rv, cnt = handle.synchronize()
         result["pipeline_depth"] = depth
+        # rank 0's view: the scatter kernel (1 partition launch over n pairs + 4 sort launches over its shard per sort)
+        # and the device time of every phase of a sort (they overlap between the sorts in flight)
+        profs = [srt.read_profile() for srt in sorters]
+        for srt in sorters:
+            srt.set_profiling(False)
+        launches = sum(int(pf["passes"]) for pf in profs)
+        scatter_ms = sum(pf["scatter_ms"] for pf in profs) / max(launches, 1)
+        per_sort = max(launches // max(K, 1), 1)
+        alg_bytes = 2 * (KEY_BYTES + VAL_BYTES) * (n + (per_sort - 1) * int(cnt)) // per_sort
+        if launches and scatter_ms > 0:
+            achieved = alg_bytes / (scatter_ms * 1e-3) / 1e9
+            result["roofline"] = {
+                "bound": "hbm", "kernel": "radix_scatter_kernel<u32,%d> (rank 0)" % sorters[0].digit_bits,
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                "traffic": None, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(scatter_ms, 4),
+                "launches_timed": launches,
+                "count_kernel_avg_ms": round(sum(pf["count_ms"] for pf in profs) / launches, 4),
+            }
+        phases = dsort.phase_times()
+        result["phases_ms_rank0"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in phases.items()}
         units = n * world * K
         verified = None
         if not args.no_verify:

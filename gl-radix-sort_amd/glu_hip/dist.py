@@ -123,7 +123,7 @@ class DistributedRadixSort:
     device-op object, so the all-to-all of sort i+1 (RCCL, few CUs) can run under the local sort of sort i.  The order
     of collectives is the call order on every rank, so ranks must issue the same sequence of sorts."""
 
-    def __init__(self, group=None, local_ops=None, capacity_factor=1.25, slots=1, local_ops_factory=None):
+    def __init__(self, group=None, local_ops=None, capacity_factor=1.25, slots=1, local_ops_factory=None, profile=False):
         import torch
         import torch.distributed as dist
 
@@ -136,6 +136,10 @@ class DistributedRadixSort:
         self._slots = [{"ops": local_ops_factory(), "bufs": None, "stream": None} for _ in range(max(1, slots))]
         self._next_slot = 0
         self.last_plan = None
+        # profile=True: device-time stamps around the phases of every sort (events on the slot's stream), summed by
+        # phase_times(); they are what tells a slow exchange from a slow local sort in a multi-GPU run
+        self.profile = profile
+        self._stamps = []
 
     @property
     def ops(self):
@@ -205,14 +209,37 @@ class DistributedRadixSort:
         """One sort, complete (stream-wise) when it returns: the caller's current stream waits for it."""
         return self.sort_async(keys, vals).wait()
 
+    def _stamp(self, marks, device):
+        if self.profile and device.type == "cuda":
+            e = self.torch.cuda.Event(enable_timing=True)
+            e.record(self.torch.cuda.current_stream(device))
+            marks.append(e)
+
+    def phase_times(self, reset=True):
+        """Average device milliseconds per sort of each phase (profile=True; call after synchronising)."""
+        names = ("partition", "histogram_exchange_and_plan", "all_to_all", "local_sort")
+        sums, count = [0.0] * len(names), 0
+        for marks in self._stamps:
+            if len(marks) != len(names) + 1:
+                continue
+            for i in range(len(names)):
+                sums[i] += marks[i].elapsed_time(marks[i + 1])
+            count += 1
+        if reset:
+            self._stamps = []
+        return {"sorts": count, **{n: (sums[i] / count if count else 0.0) for i, n in enumerate(names)}}
+
     def _sort(self, slot, keys, vals):
         t, dist = self.torch, self.dist
         ops = slot["ops"]
         n_local = keys.numel()
         b = self._buffers(slot, n_local, keys.device)
+        marks = []
+        self._stamp(marks, keys.device)
 
         # 1. local stable partition by top-8-bit bucket + histogram
         ops.partition(keys, vals, b["part_k"], b["part_v"], b["hist"])
+        self._stamp(marks, keys.device)
 
         # 2. everyone learns every rank's histogram (R x 256 int32: latency-bound, tiny)
         dist.all_gather_into_tensor(b["all_hist"], b["hist"], group=self.group)
@@ -225,15 +252,20 @@ class DistributedRadixSort:
         if n_recv > b["cap"]:
             b = self._grow_recv(slot, b, n_recv)
         self.last_plan = {"owner": owner, "send": send_counts, "recv": recv_counts}
+        self._stamp(marks, keys.device)
 
         # 4. one exchange for keys, one for values; receive segments ordered by source rank
         recv_k = b["recv_k"][:n_recv]
         recv_v = b["recv_v"][:n_recv]
         self._all_to_all(recv_k, b["part_k"][:n_local], recv_counts, send_counts)
         self._all_to_all(recv_v, b["part_v"][:n_local], recv_counts, send_counts)
+        self._stamp(marks, keys.device)
 
         # 5. local stable sort of the received pairs
         ops.sort(recv_k, recv_v, n_recv)
+        self._stamp(marks, keys.device)
+        if marks:
+            self._stamps.append(marks)
         return recv_k, recv_v, n_recv
 
     def _grow_recv(self, slot, b, n_recv):
