@@ -149,10 +149,10 @@ def test_num_steps(G, bits, steps):
     assert (gk == ref["result_keys"]).all() and (gv == ref["result_vals"]).all()
 
 
-@pytest.mark.parametrize("n", [2, 777, 1024, 1025, 4096, 4097, 12288])
+@pytest.mark.parametrize("n", [2, 777, 1024, 1025, 4096, 4097, 12288, 12289, 16383, 16384, 16385])
 @pytest.mark.parametrize("steps", [0, 1, 3, 5, 8])
 def test_single_workgroup_path(G, n, steps, monkeypatch):
-    """n <= 12288 pairs (8192 for 64-bit keys) are sorted by one workgroup in one launch; the multi-kernel path
+    """n <= 16384 pairs (8192 for 64-bit keys) are sorted by one workgroup in one launch; the multi-kernel path
     (GLU_HIP_SORT_NO_SINGLE_BLOCK=1) must give the same pairs."""
     rng = np.random.default_rng(n * 10 + steps)
     keys = rng.integers(0, 2**32, n, dtype=np.uint32)
@@ -179,7 +179,7 @@ def test_randomized_stress(G, seed):
     rng = np.random.default_rng(1000 + seed)
     sorters = {4: G.RadixSort(digit_bits=4), 8: G.RadixSort(digit_bits=8)}
     for _ in range(12):
-        base = int(rng.choice([1, 64, 4096, 12288, 12288 * 256, 4096 * 768, 1 << 20, 3 * (1 << 20)]))
+        base = int(rng.choice([1, 64, 4096, 12288, 16384, 12288 * 256, 4096 * 768, 1 << 20, 3 * (1 << 20)]))
         n = max(2, base * int(rng.integers(1, 3)) + int(rng.integers(-70, 70)))
         n = min(n, 7 * (1 << 20))
         shape = rng.integers(0, 6)
