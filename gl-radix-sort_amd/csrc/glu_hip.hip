@@ -377,6 +377,7 @@ struct glu_radix_sort_s
     uint32_t max_blocks = 0;   // GLU_HIP_SORT_BLOCKS: cap on the number of workgroups (tuning)
     bool force_small = false;  // GLU_HIP_SORT_SMALL=1: always use the small-tile geometry (tests / tuning)
     bool no_single_block = false; // GLU_HIP_SORT_NO_SINGLE_BLOCK=1: never take the one-workgroup path (tests / tuning)
+    bool no_fused_scan = false;   // GLU_HIP_SORT_NO_FUSED_SCAN=1: always launch the row-scan kernel (tests / tuning)
     // optional per-kernel timing: 4 events per pass (before count, after count, after scan, after scatter)
     bool profiling = false;
     std::vector<hipEvent_t> events;
@@ -429,10 +430,14 @@ glu_status launch_pass(glu_radix_sort_s* s, const KeyT* src_k, const uint32_t* s
 
     using Smem = ScatterSmem<KeyT, BITS, G::THREADS, G::KPT, G::CARRY, 1, VALS>;
     auto scatter = radix_scatter_kernel<KeyT, BITS, G::THREADS, G::KPT, G::CARRY, 0, false, G::BLOCKS_PER_CU * G::THREADS / 256, 1, false, false, XF, VALS>;
+    // launch-bound sizes (small geometry, few workgroups): the scatter sums the counts itself, no row-scan launch
+    auto scatter_fused = radix_scatter_kernel<KeyT, BITS, G::THREADS, G::KPT, G::CARRY, 0, false, G::BLOCKS_PER_CU * G::THREADS / 256, 1, false, false, XF, VALS, !LARGE>;
+    const bool fused = !LARGE && nb <= kFusedScanMaxBlocks && !histogram_out && !s->no_fused_scan;
     static bool lds_opt_in = false; // per instantiation: allow > 64 KiB of dynamic LDS
     if (!lds_opt_in)
     {
         HIP_TRY(hipFuncSetAttribute((const void*) scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sizeof(Smem)));
+        HIP_TRY(hipFuncSetAttribute((const void*) scatter_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sizeof(Smem)));
         lds_opt_in = true;
     }
 
@@ -443,13 +448,13 @@ glu_status launch_pass(glu_radix_sort_s* s, const KeyT* src_k, const uint32_t* s
     hipLaunchKernelGGL((radix_count_kernel<KeyT, BITS, COUNT_THREADS, G::TILE, XF>), dim3(nb), dim3(COUNT_THREADS), 0, stream,
                        src_k, table, (uint32_t) count, shift, mask, tiles, xform);
     s->mark(stream);
-    hipLaunchKernelGGL((radix_row_scan_kernel<256>), dim3(RADIX), dim3(256), 0, stream, table, totals, nb);
+    if (!fused) hipLaunchKernelGGL((radix_row_scan_kernel<256>), dim3(RADIX), dim3(256), 0, stream, table, totals, nb);
     s->mark(stream);
     if (histogram_out)
         HIP_TRY(hipMemcpyAsync(histogram_out, totals, ((size_t) 1 << bits) * sizeof(uint32_t), hipMemcpyDeviceToDevice,
                                stream));
-    hipLaunchKernelGGL(scatter, dim3(nb), dim3(G::THREADS), sizeof(Smem), stream, src_k, src_v, dst_k, dst_v,
-                       (const uint32_t*) table, (const uint32_t*) totals, (uint32_t) count, shift, mask, tiles,
+    hipLaunchKernelGGL(fused ? scatter_fused : scatter, dim3(nb), dim3(G::THREADS), sizeof(Smem), stream, src_k, src_v, dst_k,
+                       dst_v, (const uint32_t*) table, (const uint32_t*) totals, (uint32_t) count, shift, mask, tiles,
                        (unsigned long long*) nullptr, xform);
     s->mark(stream);
     HIP_TRY(hipGetLastError());
@@ -613,6 +618,7 @@ glu_status glu_radix_sort_create(glu_radix_sort* out)
     }
     if (const char* e = getenv("GLU_HIP_SORT_SMALL")) s->force_small = atoi(e) != 0;
     if (const char* e = getenv("GLU_HIP_SORT_NO_SINGLE_BLOCK")) s->no_single_block = atoi(e) != 0;
+    if (const char* e = getenv("GLU_HIP_SORT_NO_FUSED_SCAN")) s->no_fused_scan = atoi(e) != 0;
     *out = s;
     return GLU_OK;
 }

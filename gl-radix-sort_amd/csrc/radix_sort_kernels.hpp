@@ -246,6 +246,8 @@ __global__ __launch_bounds__(THREADS) void radix_row_scan_kernel(uint32_t* __res
     if (tid == 0) totals[blockIdx.x] = carry;
 }
 
+constexpr uint32_t kFusedScanMaxBlocks = 32; // FUSED_SCAN scatter: every workgroup reads RADIX x nb counts itself
+
 // ---------------------------------------------------------------------------------------------------------
 // K4: stable scatter of (key, val) by one digit.
 // ---------------------------------------------------------------------------------------------------------
@@ -340,7 +342,7 @@ struct ScatterSmem
 // ~145 dwords per lane (it also hoists lane-constant shuffle addresses out of the tile loop) and the kernel runs 4x
 // slower; it needs the values to be loaded per round instead of being held in registers.
 template<typename KeyT, int BITS, int THREADS, int KPT, bool CARRY = true, int ABLATE = 0, bool STAMPS = false,
-         int MIN_WAVES_PER_SIMD = 1, int ROUNDS = 1, bool PREFETCH = false, bool DMA = false, bool XF = false, bool VALS = true>
+         int MIN_WAVES_PER_SIMD = 1, int ROUNDS = 1, bool PREFETCH = false, bool DMA = false, bool XF = false, bool VALS = true, bool FUSED_SCAN = false>
 __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_kernel(
     const KeyT* __restrict__ src_keys, const uint32_t* __restrict__ src_vals, KeyT* __restrict__ dst_keys,
     uint32_t* __restrict__ dst_vals, const uint32_t* __restrict__ table, const uint32_t* __restrict__ totals,
@@ -372,9 +374,28 @@ __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_ker
 
     // ---- prologue: this workgroup's global base for every digit:
     //      exclusive scan of the digit totals (RadixSort.hpp:148-152) + this block's scanned table entry (:176)
+    //      FUSED_SCAN (few workgroups: launch-bound sizes): `table` holds the raw counts of the count kernel and every
+    //      workgroup sums its own row prefixes and the row totals, which saves the row-scan launch of the pass.
     uint32_t digit_base = 0; // valid in threads tid < RADIX: global index of the digit's next element
     {
-        uint32_t t = tid < RADIX ? totals[tid] : 0;
+        uint32_t t = 0, before = 0;
+        if (FUSED_SCAN)
+        {
+            if (tid < RADIX)
+            {
+                // nb <= kFusedScanMaxBlocks, uniform trip count, independent loads of one contiguous row per thread
+                // (measured against 16 guarded loads in flight and against a block-major table: this plain loop wins)
+                const uint32_t* row = table + (size_t) tid * nb;
+                for (uint32_t j = 0; j < nb; j++)
+                {
+                    const uint32_t c = row[j];
+                    t += c;
+                    before += j < b ? c : 0u;
+                }
+            }
+        }
+        else
+            t = tid < RADIX ? totals[tid] : 0;
         uint32_t wtotal;
         uint32_t excl = wave_exclusive_sum(t, lane, wtotal);
         if (lane == 0) s.scan_tmp[wave] = wtotal;
@@ -383,7 +404,7 @@ __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_ker
 #pragma unroll
         for (int w = 0; w < WAVES; w++)
             if ((uint32_t) w < wave) woff += s.scan_tmp[w];
-        if (tid < RADIX) digit_base = woff + excl + table[(size_t) tid * nb + b];
+        if (tid < RADIX) digit_base = woff + excl + (FUSED_SCAN ? before : table[(size_t) tid * nb + b]);
     }
     uint32_t carry_start = digit_base; // CARRY: elements [carry_start, digit_base) of the digit are held in s.carry
     for (int i = tid; i < WAVES * RADIX; i += THREADS) (&s.wcnt[0][0])[i] = 0;

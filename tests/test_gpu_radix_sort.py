@@ -574,3 +574,27 @@ def test_geometry_switch_points(G, mode, threshold, delta):
     else:
         order = np.argsort(keys, kind="stable")
         assert (gk == keys[order]).all() and (gv == vals[order]).all()
+
+
+@pytest.mark.parametrize("bits", DIGIT_BITS)
+@pytest.mark.parametrize("n", [16385, 20000, 4096 * 5 + 1, 65536, 4096 * 32, 4096 * 32 + 1, 2048 * 32, 2048 * 33])
+def test_fused_row_scan_path(G, bits, n, monkeypatch):
+    """Up to 32 workgroups the scatter kernel sums the count table itself (no row-scan launch); the three-launch path
+    (GLU_HIP_SORT_NO_FUSED_SCAN=1) must give the same result, for pairs, keys only and 64-bit keys."""
+    rng = np.random.default_rng(n + bits)
+    keys = rng.integers(0, 2**32, n, dtype=np.uint32)
+    keys[::7] = keys[3]
+    vals = np.arange(n, dtype=np.uint32)
+    k64 = rng.integers(0, 2**64, n, dtype=np.uint64)
+    ek, ev = O.stable_sort_pairs(keys, vals)
+    o64 = np.argsort(k64, kind="stable")
+    for env in (None, "1"):
+        if env:
+            monkeypatch.setenv("GLU_HIP_SORT_NO_FUSED_SCAN", env)
+        gk, gv = gpu_sort(G, keys, vals, bits=bits)
+        assert (gk == ek).all() and (gv == ev).all()
+        kb = G.ShaderStorageBuffer(keys)
+        G.RadixSort(digit_bits=bits).sort_keys(kb, n)
+        assert (kb.get_data(np.uint32) == ek).all()
+        gk, gv = gpu_sort(G, k64, vals, bits=bits, key_bytes=8)
+        assert (gk == k64[o64]).all() and (gv == vals[o64]).all()
