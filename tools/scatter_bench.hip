@@ -271,6 +271,22 @@ int main(int argc, char** argv)
     }
     else
     {
+        // SB_OFFS="o0,o1,o2,o3" (MiB): every array gets its own allocation of size + 1 GiB and starts o_i MiB into it
+        // (if the driver hands out 1 GiB-aligned physical blocks, these offsets ARE the arrays' phases modulo 1 GiB)
+        if (getenv("SB_OFFS"))
+        {
+            size_t o[4] = {0, 0, 0, 0};
+            sscanf(getenv("SB_OFFS"), "%zu,%zu,%zu,%zu", &o[0], &o[1], &o[2], &o[3]);
+            uint32_t** arr[4] = {&c.keys, &c.vals, &c.keys2, &c.vals2};
+            for (int i = 0; i < 4; i++)
+            {
+                char* base;
+                CK(hipMalloc(&base, c.n * 4 + ((size_t) 1 << 30)));
+                *arr[i] = (uint32_t*) (base + (o[i] << 20));
+            }
+        }
+        else
+        {
         // SB_GAP="g1,g2,g3" (MiB): dummy allocations between the four arrays (shifts their relative physical placement)
         size_t g1 = 0, g2 = 0, g3 = 0;
         if (getenv("SB_GAP")) sscanf(getenv("SB_GAP"), "%zu,%zu,%zu", &g1, &g2, &g3);
@@ -282,6 +298,7 @@ int main(int argc, char** argv)
         CK(hipMalloc(&c.keys2, c.n * 4));
         if (g3) CK(hipMalloc(&dummy, g3 << 20));
         CK(hipMalloc(&c.vals2, c.n * 4));
+        }
     }
     printf("arrays at %p %p %p %p\n", (void*) c.keys, (void*) c.vals, (void*) c.keys2, (void*) c.vals2);
     CK(hipMalloc(&c.table, (256 * 8192 + 256) * 4));
