@@ -221,11 +221,20 @@ def main():
             step(i)
         barrier()
         sorter.set_profiling(not args.no_kernel_events)
+        step_events = []
         t0 = time.perf_counter()
         for i in range(W, W + K):
-            step(i)
+            if not args.no_kernel_events:  # per-step device time (every step sorts a differently placed copy)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(work_stream)
+                step(i)
+                e1.record(work_stream)
+                step_events.append((e0, e1))
+            else:
+                step(i)
         barrier()
         elapsed = time.perf_counter() - t0
+        step_ms = sorted(a.elapsed_time(b) for a, b in step_events)
         prof = sorter.read_profile()
         sorter.set_profiling(False)
         bits = sorter.digit_bits
@@ -266,6 +275,10 @@ def main():
             "verified": verified,
             "restore_copies_in_timed_region": restore_in_region,
         })
+        if step_ms:
+            # the spread is the physical placement of each copy's arrays in HBM, not noise
+            result["step_device_ms"] = {"min": round(step_ms[0], 4), "median": round(step_ms[len(step_ms) // 2], 4),
+                                        "max": round(step_ms[-1], 4)}
         # the same sort with the reference's pass structure (8 x 4-bit digits, 160 B/pair), a few untimed-region
         # steps on restored inputs: reported next to the headline, not part of `value`
         if bits != 4 and not args.no_alt:
