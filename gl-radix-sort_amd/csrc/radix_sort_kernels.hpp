@@ -331,16 +331,16 @@ struct ScatterSmem
 // in LDS and is written, together with the head of the digit's next run, when its block is complete -- the only
 // partial blocks left are at the two ends of a workgroup's range.
 //
-// ABLATE (tuning builds only, results are wrong for != 0): 1 = write every tile back linearly (prices the
-// scattered stores).  STAMPS (diagnostic builds): wave 0 of every workgroup adds the s_memtime cycles of each
-// phase to stamps[0..7].
-//
-// ROUNDS > 1: the tile is ROUNDS times larger than the LDS staging area.  Keys, values and ranked positions stay in
-// registers; round r stages and writes out the ranked positions [r * STAGE, (r + 1) * STAGE).  A digit's run per tile
-// (TILE / RADIX elements) gets ROUNDS times longer for the same LDS, which is what the 64-byte-granular scattered
-// writes of wide digits need.  EXPERIMENTAL, not used by the library: with 1024 threads x 24 keys hipcc 7.2 spills
-// ~145 dwords per lane (it also hoists lane-constant shuffle addresses out of the tile loop) and the kernel runs 4x
-// slower; it needs the values to be loaded per round instead of being held in registers.
+// Template parameters beyond the geometry (the library instantiates the defaults except XF / VALS / FUSED_SCAN):
+//   XF          the pass encodes keys on load / decodes them on store (first / last pass of a signed or float sort);
+//   VALS        false: keys-only sort, no value arrays, LDS arrays of keys alone;
+//   FUSED_SCAN  the prologue sums the raw count table itself (<= kFusedScanMaxBlocks workgroups, no row-scan launch);
+//   ABLATE      tuning builds: 1 = write every tile back linearly (prices the scattered stores; wrong results),
+//               3 = stagger the workgroups' start;  STAMPS: wave 0 adds the s_memtime cycles of each phase to stamps[0..7];
+//   ROUNDS > 1  tile = ROUNDS x the staging area (keys, values, ranks stay in registers across the staging rounds);
+//   PREFETCH    the next tile's loads are issued one pair per rank iteration;  DMA: tile loads as LDS-DMA into the idle
+//               staging area.  ROUNDS / PREFETCH / DMA are measured alternatives kept for tools/scatter_bench.hip
+//               (level with or slower than the defaults), not used by the library.
 template<typename KeyT, int BITS, int THREADS, int KPT, bool CARRY = true, int ABLATE = 0, bool STAMPS = false,
          int MIN_WAVES_PER_SIMD = 1, int ROUNDS = 1, bool PREFETCH = false, bool DMA = false, bool XF = false, bool VALS = true, bool FUSED_SCAN = false>
 __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_kernel(
