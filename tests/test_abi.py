@@ -92,3 +92,17 @@ def test_cpp_api_exit_code_convention_without_gpu(built):
     p = subprocess.run([exe], capture_output=True, text=True)
     assert p.returncode == 1
     assert "no CPU fallback" in p.stderr
+
+
+def test_standalone_dist_headers_are_current_and_compile(tmp_path):
+    """dist/{RadixSort,BlellochScan,Reduce}.hpp (the reference ships the same three, built by its generate.py) are what
+    tools/make_dist.py produces from the current headers, and one translation unit can include all three."""
+    import subprocess, sys, filecmp
+
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_dist.py"), str(tmp_path)])
+    for name in ("RadixSort.hpp", "BlellochScan.hpp", "Reduce.hpp"):
+        assert filecmp.cmp(os.path.join(ROOT, "dist", name), str(tmp_path / name), shallow=False), name + " is stale"
+    tu = tmp_path / "tu.cpp"
+    tu.write_text('#include "RadixSort.hpp"\n#include "BlellochScan.hpp"\n#include "Reduce.hpp"\n'
+                  "int main() { return glu::is_power_of_2(8) ? 0 : 1; }\n")
+    subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-I", os.path.join(ROOT, "dist"), str(tu)])
