@@ -373,11 +373,13 @@ struct glu_radix_sort_s
     Scratch keys;   // one key scratch array (ping-pong partner of the caller's buffer)
     Scratch vals;
     Scratch table;  // [RADIX][num_blocks] digit counts -> scanned offsets, + RADIX digit totals
+    Scratch plan;   // PassPlan of large sorts (which arrays hold the data before each pass, which passes are identities)
     uint32_t digit_bits = 8;
     uint32_t max_blocks = 0;   // GLU_HIP_SORT_BLOCKS: cap on the number of workgroups (tuning)
     bool force_small = false;  // GLU_HIP_SORT_SMALL=1: always use the small-tile geometry (tests / tuning)
     bool no_single_block = false; // GLU_HIP_SORT_NO_SINGLE_BLOCK=1: never take the one-workgroup path (tests / tuning)
     bool no_fused_scan = false;   // GLU_HIP_SORT_NO_FUSED_SCAN=1: always launch the row-scan kernel (tests / tuning)
+    bool no_plan = false;         // GLU_HIP_SORT_NO_PLAN=1: never skip constant-digit passes (tests / tuning)
     // optional per-kernel timing: 4 events per pass (before count, after count, after scan, after scatter)
     bool profiling = false;
     std::vector<hipEvent_t> events;
@@ -408,15 +410,27 @@ glu_status sort_prepare(glu_radix_sort_s* s, size_t count, size_t key_size, bool
     if (with_vals) GLU_TRY(s->vals.reserve(count * sizeof(uint32_t)));
     uint64_t cap = (uint64_t) g_dev.num_cus * kMaxBlocksPerCu;
     GLU_TRY(s->table.reserve((kMaxRadix * cap + kMaxRadix) * sizeof(uint32_t)));
+    GLU_TRY(s->plan.reserve(sizeof(PassPlan)));
     return GLU_OK;
 }
+
+// Planned sorts (count >= kPlanMinCount): the kernels pick source / destination from the device-side PassPlan and skip
+// the scatter of passes whose digit is constant over the input (radix_sort_kernels.hpp).  `may_skip` is false for the
+// passes that must run whatever the data looks like (key encode / decode passes of typed sorts).
+constexpr size_t kPlanMinCount = (size_t) 1 << 22;
+struct PlanArgs
+{
+    PassPlan* plan = nullptr;
+    uint32_t pass = 0;
+    bool may_skip = false;
+};
 
 // XF: this pass encodes keys on load and / or decodes them on store (first / last pass of a typed sort); every other
 // pass runs the instantiation without the codec arithmetic.
 template<typename KeyT, int BITS, bool LARGE, bool XF, bool VALS>
 glu_status launch_pass(glu_radix_sort_s* s, const KeyT* src_k, const uint32_t* src_v, KeyT* dst_k, uint32_t* dst_v,
                        size_t count, uint32_t shift, uint32_t bits, uint32_t* histogram_out, hipStream_t stream,
-                       uint32_t xform = 0)
+                       uint32_t xform = 0, PlanArgs pa = PlanArgs())
 {
     using G = GeometryFor<KeyT, BITS, LARGE, VALS>;
     constexpr int RADIX = 1 << BITS;
@@ -432,7 +446,7 @@ glu_status launch_pass(glu_radix_sort_s* s, const KeyT* src_k, const uint32_t* s
     auto scatter = radix_scatter_kernel<KeyT, BITS, G::THREADS, G::KPT, G::CARRY, 0, false, G::BLOCKS_PER_CU * G::THREADS / 256, 1, false, false, XF, VALS>;
     // launch-bound sizes (small geometry, few workgroups): the scatter sums the counts itself, no row-scan launch
     auto scatter_fused = radix_scatter_kernel<KeyT, BITS, G::THREADS, G::KPT, G::CARRY, 0, false, G::BLOCKS_PER_CU * G::THREADS / 256, 1, false, false, XF, VALS, !LARGE>;
-    const bool fused = !LARGE && nb <= kFusedScanMaxBlocks && !histogram_out && !s->no_fused_scan;
+    const bool fused = !LARGE && nb <= kFusedScanMaxBlocks && !histogram_out && !s->no_fused_scan && !pa.plan;
     static bool lds_opt_in = false; // per instantiation: allow > 64 KiB of dynamic LDS
     if (!lds_opt_in)
     {
@@ -446,16 +460,18 @@ glu_status launch_pass(glu_radix_sort_s* s, const KeyT* src_k, const uint32_t* s
     // when there is one workgroup per CU
     constexpr int COUNT_THREADS = LARGE ? 1024 : G::THREADS;
     hipLaunchKernelGGL((radix_count_kernel<KeyT, BITS, COUNT_THREADS, G::TILE, XF>), dim3(nb), dim3(COUNT_THREADS), 0, stream,
-                       src_k, table, (uint32_t) count, shift, mask, tiles, xform);
+                       src_k, table, (uint32_t) count, shift, mask, tiles, xform, (const KeyT*) dst_k, pa.plan, pa.pass);
     s->mark(stream);
-    if (!fused) hipLaunchKernelGGL((radix_row_scan_kernel<256>), dim3(RADIX), dim3(256), 0, stream, table, totals, nb);
+    if (!fused)
+        hipLaunchKernelGGL((radix_row_scan_kernel<256>), dim3(RADIX), dim3(256), 0, stream, table, totals, nb, (uint32_t) count,
+                           pa.may_skip ? pa.plan : (PassPlan*) nullptr, pa.pass);
     s->mark(stream);
     if (histogram_out)
         HIP_TRY(hipMemcpyAsync(histogram_out, totals, ((size_t) 1 << bits) * sizeof(uint32_t), hipMemcpyDeviceToDevice,
                                stream));
     hipLaunchKernelGGL(fused ? scatter_fused : scatter, dim3(nb), dim3(G::THREADS), sizeof(Smem), stream, src_k, src_v, dst_k,
                        dst_v, (const uint32_t*) table, (const uint32_t*) totals, (uint32_t) count, shift, mask, tiles,
-                       (unsigned long long*) nullptr, xform);
+                       (unsigned long long*) nullptr, xform, pa.plan, pa.pass);
     s->mark(stream);
     HIP_TRY(hipGetLastError());
     return GLU_OK;
@@ -464,7 +480,7 @@ glu_status launch_pass(glu_radix_sort_s* s, const KeyT* src_k, const uint32_t* s
 template<typename KeyT, int BITS>
 glu_status launch_pass_sized(glu_radix_sort_s* s, const KeyT* src_k, const uint32_t* src_v, KeyT* dst_k, uint32_t* dst_v,
                              size_t count, uint32_t shift, uint32_t bits, uint32_t* histogram_out, hipStream_t stream,
-                             uint32_t xform = 0)
+                             uint32_t xform = 0, PlanArgs pa = PlanArgs())
 {
     // large geometry once every CU gets at least one large tile; keys-only sorts (no value arrays) run the VALS = false
     // instantiations
@@ -472,7 +488,7 @@ glu_status launch_pass_sized(glu_radix_sort_s* s, const KeyT* src_k, const uint3
     const size_t large_tile = vals ? GeometryFor<KeyT, BITS, true, true>::TILE : GeometryFor<KeyT, BITS, true, false>::TILE;
     const bool large = count >= (size_t) g_dev.num_cus * large_tile && !s->force_small;
 #define GLU_LAUNCH(LARGE_, XF_, VALS_) \
-    launch_pass<KeyT, BITS, LARGE_, XF_, VALS_>(s, src_k, src_v, dst_k, dst_v, count, shift, bits, histogram_out, stream, XF_ ? xform : 0u)
+    launch_pass<KeyT, BITS, LARGE_, XF_, VALS_>(s, src_k, src_v, dst_k, dst_v, count, shift, bits, histogram_out, stream, XF_ ? xform : 0u, pa)
     if (vals)
     {
         if (xform) return large ? GLU_LAUNCH(true, true, true) : GLU_LAUNCH(false, true, true);
@@ -486,10 +502,10 @@ glu_status launch_pass_sized(glu_radix_sort_s* s, const KeyT* src_k, const uint3
 template<typename KeyT>
 glu_status dispatch_pass(glu_radix_sort_s* s, const KeyT* src_k, const uint32_t* src_v, KeyT* dst_k, uint32_t* dst_v,
                          size_t count, uint32_t shift, uint32_t bits, uint32_t* histogram_out, hipStream_t stream,
-                         uint32_t xform = 0)
+                         uint32_t xform = 0, PlanArgs pa = PlanArgs())
 {
-    if (bits <= 4) return launch_pass_sized<KeyT, 4>(s, src_k, src_v, dst_k, dst_v, count, shift, bits, histogram_out, stream, xform);
-    return launch_pass_sized<KeyT, 8>(s, src_k, src_v, dst_k, dst_v, count, shift, bits, histogram_out, stream, xform);
+    if (bits <= 4) return launch_pass_sized<KeyT, 4>(s, src_k, src_v, dst_k, dst_v, count, shift, bits, histogram_out, stream, xform, pa);
+    return launch_pass_sized<KeyT, 8>(s, src_k, src_v, dst_k, dst_v, count, shift, bits, histogram_out, stream, xform, pa);
 }
 
 // n <= one tile: the whole sort in a single workgroup / single launch (always 8-bit digits: the result does not
@@ -566,16 +582,44 @@ glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t cou
     uint32_t* vbuf[2] = {vals, vals ? (uint32_t*) s->vals.ptr : nullptr};
     int cur = 0;
     uint32_t shift = first_bit;
+    // large sorts: device-side pass plan (constant-digit passes are skipped, the arrays' roles follow on the device)
+    const bool planned = count >= kPlanMinCount && !s->no_plan;
+    uint32_t pass = 0;
     while (shift < end_bit)
     {
         uint32_t bits = std::min<uint32_t>(s->digit_bits, end_bit - shift);
         if (sizeof(KeyT) == 8 && shift < 32 && shift + bits > 32) bits = 32 - shift; // a digit stays inside one key word
         // typed keys: encode on the first pass's loads, decode on the last pass's stores
         const uint32_t xform = (shift == first_bit ? key_xf : 0u) | (shift + bits >= end_bit ? key_xf << 2 : 0u);
-        GLU_TRY(dispatch_pass<KeyT>(s, kbuf[cur], vbuf[cur], kbuf[cur ^ 1], vbuf[cur ^ 1], count, shift, bits, nullptr,
-                                    stream, xform));
-        cur ^= 1;
+        if (planned)
+        {
+            PlanArgs pa;
+            pa.plan = (PassPlan*) s->plan.ptr;
+            pa.pass = pass;
+            pa.may_skip = xform == 0; // encode / decode passes run whatever the data looks like
+            GLU_TRY(dispatch_pass<KeyT>(s, kbuf[0], vbuf[0], kbuf[1], vbuf[1], count, shift, bits, nullptr, stream, xform, pa));
+        }
+        else
+        {
+            GLU_TRY(dispatch_pass<KeyT>(s, kbuf[cur], vbuf[cur], kbuf[cur ^ 1], vbuf[cur ^ 1], count, shift, bits, nullptr,
+                                        stream, xform));
+            cur ^= 1;
+        }
+        pass++;
         shift += bits;
+    }
+    if (planned)
+    {
+        // the data is home unless an odd number of passes ran: decided and, if need be, copied on the device
+        const dim3 grid((uint32_t) std::min<size_t>((count + 255) / 256, (size_t) g_dev.num_cus * 16));
+        if (vals)
+            hipLaunchKernelGGL((radix_finalize_kernel<KeyT, true>), grid, dim3(256), 0, stream, kbuf[0], vbuf[0], (const KeyT*) kbuf[1],
+                               (const uint32_t*) vbuf[1], (uint32_t) count, (const PassPlan*) s->plan.ptr, pass);
+        else
+            hipLaunchKernelGGL((radix_finalize_kernel<KeyT, false>), grid, dim3(256), 0, stream, kbuf[0], (uint32_t*) nullptr,
+                               (const KeyT*) kbuf[1], (const uint32_t*) nullptr, (uint32_t) count, (const PassPlan*) s->plan.ptr, pass);
+        HIP_TRY(hipGetLastError());
+        return GLU_OK;
     }
     if (cur == 1)
     {
@@ -619,6 +663,7 @@ glu_status glu_radix_sort_create(glu_radix_sort* out)
     if (const char* e = getenv("GLU_HIP_SORT_SMALL")) s->force_small = atoi(e) != 0;
     if (const char* e = getenv("GLU_HIP_SORT_NO_SINGLE_BLOCK")) s->no_single_block = atoi(e) != 0;
     if (const char* e = getenv("GLU_HIP_SORT_NO_FUSED_SCAN")) s->no_fused_scan = atoi(e) != 0;
+    if (const char* e = getenv("GLU_HIP_SORT_NO_PLAN")) s->no_plan = atoi(e) != 0;
     *out = s;
     return GLU_OK;
 }
@@ -630,6 +675,7 @@ glu_status glu_radix_sort_destroy(glu_radix_sort sort)
     sort->keys.release();
     sort->vals.release();
     sort->table.release();
+    sort->plan.release();
     for (hipEvent_t e : sort->events) (void) hipEventDestroy(e);
     delete sort;
     return GLU_OK;

@@ -115,14 +115,30 @@ __device__ __forceinline__ uint32_t sum_of_preceding_waves(const uint32_t* total
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Pass plan (device memory, one per sort object; only the sort of >= kPlanMinCount elements uses it).  A counting pass
+// whose digit has the same value in every key is an identity permutation; its scatter is skipped.  Which pair of arrays
+// holds the data before pass p then depends on the data, so it is tracked on the device:
+//   flip[p]  1 = the data is in the scratch arrays ("B") before pass p, 0 = in the caller's ("A"); flip[0] = 0
+//   skip[p]  set by the row-scan kernel of pass p when one digit value holds all n keys, reset by its count kernel
+// The scatter kernel of pass p publishes flip[p + 1] = flip[p] ^ !skip[p]; the count kernel of pass p + 1 runs after it.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kPlanMaxPasses = 32;
+struct PassPlan
+{
+    uint32_t flip[kPlanMaxPasses + 1];
+    uint32_t skip[kPlanMaxPasses];
+};
+
+// ---------------------------------------------------------------------------------------------------------
 // K1: per-workgroup digit histogram.  table[d * num_blocks + b] = #keys of block b's range with digit d.
 // Reads 1 key per pair (sizeof(KeyT) bytes), writes RADIX counters per workgroup.
 // ---------------------------------------------------------------------------------------------------------
 template<typename KeyT, int BITS, int THREADS, int TILE, bool XF = false>
-__global__ __launch_bounds__(THREADS) void radix_count_kernel(const KeyT* __restrict__ keys,
+__global__ __launch_bounds__(THREADS) void radix_count_kernel(const KeyT* __restrict__ keys_a,
                                                               uint32_t* __restrict__ table, uint32_t n,
                                                               uint32_t shift, uint32_t mask, uint32_t tiles_total,
-                                                              uint32_t xform = 0)
+                                                              uint32_t xform = 0, const KeyT* keys_b = nullptr,
+                                                              PassPlan* plan = nullptr, uint32_t pass = 0)
 {
     constexpr int RADIX = 1 << BITS;
     constexpr int WAVES = THREADS / kWave;
@@ -130,6 +146,13 @@ __global__ __launch_bounds__(THREADS) void radix_count_kernel(const KeyT* __rest
     __shared__ uint32_t hist[WAVES][RADIX];
 
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // planned sorts: read whichever pair of arrays holds the data before this pass; arm the pass's skip flag
+    const KeyT* __restrict__ keys = keys_a;
+    if (plan)
+    {
+        if (pass > 0 && plan->flip[pass]) keys = keys_b;
+        if (blockIdx.x == 0 && tid == 0) plan->skip[pass] = 0;
+    }
     for (int i = tid; i < WAVES * RADIX; i += THREADS) (&hist[0][0])[i] = 0;
     __syncthreads();
 
@@ -216,7 +239,9 @@ __global__ __launch_bounds__(THREADS) void radix_count_kernel(const KeyT* __rest
 // ---------------------------------------------------------------------------------------------------------
 template<int THREADS>
 __global__ __launch_bounds__(THREADS) void radix_row_scan_kernel(uint32_t* __restrict__ table,
-                                                                 uint32_t* __restrict__ totals, uint32_t num_blocks)
+                                                                 uint32_t* __restrict__ totals, uint32_t num_blocks,
+                                                                 uint32_t n = 0, PassPlan* plan = nullptr,
+                                                                 uint32_t pass = 0)
 {
     constexpr int WAVES = THREADS / kWave;
     __shared__ uint32_t wave_sums[WAVES];
@@ -243,7 +268,11 @@ __global__ __launch_bounds__(THREADS) void radix_row_scan_kernel(uint32_t* __res
         carry += all;
         __syncthreads();
     }
-    if (tid == 0) totals[blockIdx.x] = carry;
+    if (tid == 0)
+    {
+        totals[blockIdx.x] = carry;
+        if (plan && carry == n) plan->skip[pass] = 1; // every key has this digit value: the pass permutes nothing
+    }
 }
 
 constexpr uint32_t kFusedScanMaxBlocks = 32; // FUSED_SCAN scatter: every workgroup reads RADIX x nb counts itself
@@ -344,11 +373,31 @@ struct ScatterSmem
 template<typename KeyT, int BITS, int THREADS, int KPT, bool CARRY = true, int ABLATE = 0, bool STAMPS = false,
          int MIN_WAVES_PER_SIMD = 1, int ROUNDS = 1, bool PREFETCH = false, bool DMA = false, bool XF = false, bool VALS = true, bool FUSED_SCAN = false>
 __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_kernel(
-    const KeyT* __restrict__ src_keys, const uint32_t* __restrict__ src_vals, KeyT* __restrict__ dst_keys,
-    uint32_t* __restrict__ dst_vals, const uint32_t* __restrict__ table, const uint32_t* __restrict__ totals,
+    const KeyT* __restrict__ keys_a, const uint32_t* __restrict__ vals_a, KeyT* __restrict__ keys_b,
+    uint32_t* __restrict__ vals_b, const uint32_t* __restrict__ table, const uint32_t* __restrict__ totals,
     uint32_t n, uint32_t shift, uint32_t mask, uint32_t tiles_total, unsigned long long* stamps = nullptr,
-    uint32_t xform = 0)
+    uint32_t xform = 0, PassPlan* plan = nullptr, uint32_t pass = 0)
 {
+    // Source and destination arrays: (a -> b) as passed, or (b -> a) when the plan says that the data sits in b.  The
+    // body only ever touches memory through the four local pointers below.
+    const KeyT* __restrict__ src_keys = keys_a;
+    const uint32_t* __restrict__ src_vals = vals_a;
+    KeyT* __restrict__ dst_keys = keys_b;
+    uint32_t* __restrict__ dst_vals = vals_b;
+    if (plan)
+    {
+        const uint32_t flip = pass > 0 ? plan->flip[pass] : 0u;
+        const uint32_t skip = plan->skip[pass];
+        if (blockIdx.x == 0 && threadIdx.x == 0) plan->flip[pass + 1] = flip ^ (skip ? 0u : 1u);
+        if (skip) return; // identity pass (kernel-uniform)
+        if (flip)
+        {
+            src_keys = keys_b;
+            src_vals = vals_b;
+            dst_keys = const_cast<KeyT*>(keys_a);
+            dst_vals = const_cast<uint32_t*>(vals_a);
+        }
+    }
     using Smem = ScatterSmem<KeyT, BITS, THREADS, KPT, CARRY, ROUNDS, VALS>;
     constexpr int STAGE = Smem::STAGE;
     constexpr int RADIX = Smem::RADIX;
@@ -484,7 +533,7 @@ __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_ker
             const unsigned char* gk = reinterpret_cast<const unsigned char*>(src_keys + base + wave * WAVE_TILE);
             const unsigned char* gv = reinterpret_cast<const unsigned char*>(src_vals + base + wave * WAVE_TILE);
             constexpr int KEY_PIECES = KPT * (int) sizeof(KeyT) / 16, VAL_PIECES = KPT * 4 / 16;
-            static_assert(!DMA || (KPT * sizeof(KeyT)) % 16 == 0 && (KPT * 4) % 16 == 0, "whole 1 KiB pieces per wave");
+            static_assert(!DMA || ((KPT * sizeof(KeyT)) % 16 == 0 && (KPT * 4) % 16 == 0), "whole 1 KiB pieces per wave");
 #pragma unroll
             for (int j = 0; j < KEY_PIECES; j++)
                 __builtin_amdgcn_global_load_lds(
@@ -766,6 +815,22 @@ __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_ker
     {
 #pragma unroll
         for (int i = 0; i < 8; i++) atomicAdd(&stamps[i], acc[i]);
+    }
+}
+
+// Planned sorts: if the data ended up in the scratch arrays (odd number of executed passes), bring it home.
+template<typename KeyT, bool VALS>
+__global__ __launch_bounds__(256) void radix_finalize_kernel(KeyT* __restrict__ keys_a, uint32_t* __restrict__ vals_a,
+                                                             const KeyT* __restrict__ keys_b,
+                                                             const uint32_t* __restrict__ vals_b, uint32_t n,
+                                                             const PassPlan* plan, uint32_t passes)
+{
+    if (!plan->flip[passes]) return;
+    const size_t stride = (size_t) gridDim.x * blockDim.x;
+    for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    {
+        keys_a[i] = keys_b[i];
+        if (VALS) vals_a[i] = vals_b[i];
     }
 }
 

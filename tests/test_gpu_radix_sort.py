@@ -598,3 +598,75 @@ def test_fused_row_scan_path(G, bits, n, monkeypatch):
         assert (kb.get_data(np.uint32) == ek).all()
         gk, gv = gpu_sort(G, k64, vals, bits=bits, key_bytes=8)
         assert (gk == k64[o64]).all() and (gv == vals[o64]).all()
+
+
+def _constant_byte_keys(rng, n, dtype, const_bytes):
+    """Random keys whose bytes listed in const_bytes hold one value for the whole array."""
+    bits = np.dtype(dtype).itemsize * 8
+    keys = rng.integers(0, 2**bits, n, dtype=dtype)
+    for b in const_bytes:
+        m = dtype(0xFF) << dtype(8 * b)
+        keys = (keys & ~m) | (dtype(int(rng.integers(0, 256))) << dtype(8 * b))
+    return keys
+
+
+@pytest.mark.parametrize("bits", DIGIT_BITS)
+@pytest.mark.parametrize("const_bytes", [(), (3,), (0,), (1, 2), (0, 1, 2, 3), (2, 3), (0, 3)])
+def test_planned_sort_skips_constant_digit_passes(G, bits, const_bytes, monkeypatch):
+    """From 2^22 elements up a pass whose digit is the same in every key is skipped on the device (its scatter returns at
+    once, the arrays' roles for the later passes follow a device-side plan, an odd number of executed passes is copied
+    home at the end).  Every combination of constant bytes must give the stable sort, with and without the plan."""
+    n = (1 << 22) + 4321
+    rng = np.random.default_rng(len(const_bytes) * 10 + sum(const_bytes) + bits)
+    keys = _constant_byte_keys(rng, n, np.uint32, const_bytes)
+    vals = np.arange(n, dtype=np.uint32)
+    order = np.argsort(keys, kind="stable")
+    for env in (None, "1"):
+        if env:
+            monkeypatch.setenv("GLU_HIP_SORT_NO_PLAN", env)
+        gk, gv = gpu_sort(G, keys, vals, bits=bits)
+        assert (gk == keys[order]).all() and (gv == vals[order]).all(), (const_bytes, env)
+        kb = G.ShaderStorageBuffer(keys)
+        G.RadixSort(digit_bits=bits).sort_keys(kb, n)
+        assert (kb.get_data(np.uint32) == keys[order]).all()
+
+
+@pytest.mark.parametrize("const_bytes", [(7, 6, 5), (4,), (0, 7), (1, 3, 5, 7)])
+def test_planned_sort_u64_and_typed(G, const_bytes):
+    n = (1 << 22) + 99
+    rng = np.random.default_rng(sum(const_bytes))
+    k64 = _constant_byte_keys(rng, n, np.uint64, const_bytes)
+    vals = np.arange(n, dtype=np.uint32)
+    gk, gv = gpu_sort(G, k64, vals, key_bytes=8)
+    o = np.argsort(k64, kind="stable")
+    assert (gk == k64[o]).all() and (gv == vals[o]).all()
+    # typed: floats in [1, 2) share sign and exponent (top 9 bits constant); the encode / decode passes still run
+    f = (1.0 + rng.random(n)).astype(np.float32)
+    kb, vb = G.ShaderStorageBuffer(f), G.ShaderStorageBuffer(vals)
+    G.RadixSort().sort_typed_ptr(kb.device_ptr(), vb.device_ptr(), n, "float32")
+    o = np.argsort(f, kind="stable")
+    assert (kb.get_data(np.float32) == f[o]).all() and (vb.get_data(np.uint32) == vals[o]).all()
+    i64 = (k64 >> np.uint64(40)).astype(np.int64) - (1 << 20)  # small signed range: five constant high bytes after encode? no: sign-extended
+    kb = G.ShaderStorageBuffer(i64)
+    G.RadixSort().sort_typed_ptr(kb.device_ptr(), None, n, "int64")
+    assert (kb.get_data(np.int64) == np.sort(i64)).all()
+
+
+def test_planned_sort_really_skips(G, monkeypatch):
+    """All-equal keys (the reference README's benchmark input): with the plan every scatter returns at once."""
+    n = 1 << 24
+    keys = np.full(n, 0x12345678, dtype=np.uint32)
+    vals = np.arange(n, dtype=np.uint32)
+    times = {}
+    for env in ("0", "1"):
+        monkeypatch.setenv("GLU_HIP_SORT_NO_PLAN", env)
+        s = G.RadixSort()
+        s.prepare_internal_buffers(n)
+        kb, vb = G.ShaderStorageBuffer(keys), G.ShaderStorageBuffer(vals)
+        s(kb, vb, n)  # warm-up
+        s.set_profiling(True)
+        s(kb, vb, n)
+        G.synchronize()
+        times[env] = s.read_profile()["scatter_ms"]
+        assert (vb.get_data(np.uint32) == vals).all() and (kb.get_data(np.uint32) == keys).all()
+    assert times["0"] < 0.25 * times["1"], times
