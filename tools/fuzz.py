@@ -77,7 +77,7 @@ while time.time() < t_end:
                 s(kb, vb, n, steps)
                 ok = (kb.get_data(np.uint32) == keys[order]).all() and (vb.get_data(np.uint32) == vals[order]).all()
         elif api == "u64":
-            n = draw_n(1 << 22)
+            n = draw_n(1 << 23)
             keys = draw_keys(n, 64)
             vals = np.arange(n, dtype=np.uint32)
             desc = (api, n, dbits)
@@ -87,7 +87,7 @@ while time.time() < t_end:
             order = np.argsort(keys, kind="stable")
             ok = (kb.get_data(np.uint64) == keys[order]).all() and (vb.get_data(np.uint32) == vals[order]).all()
         elif api == "typed":
-            n = draw_n(1 << 22)
+            n = draw_n(1 << 23)
             name = str(rng.choice(["int32", "float32", "int64", "float64"]))
             dt = np.dtype(name)
             raw = draw_keys(n, dt.itemsize * 8)
@@ -108,7 +108,7 @@ while time.time() < t_end:
             ok = (gk.view(u.dtype) == u[order]).all() and (gv == vals[order]).all()
         elif api == "bits":
             kbytes = int(rng.choice([4, 8]))
-            n = draw_n(1 << 22)
+            n = draw_n(1 << 23)
             keys = draw_keys(n, kbytes * 8)
             a, b = sorted(int(x) for x in rng.integers(0, kbytes * 8 + 1, 2))
             vals = np.arange(n, dtype=np.uint32)
