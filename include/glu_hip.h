@@ -138,7 +138,10 @@ GLU_API glu_status glu_radix_sort_prepare_u64(glu_radix_sort sort, size_t count)
  * Stable ascending sort of `count` (uint32 key, uint32 val) pairs by the low 4*num_steps key bits
  * (num_steps == 0 or > 8: all 32 bits).  count <= 1 returns immediately (:278).  count must be < 2^32.
  * Deliberate deviation: the result is always left in key_buffer / val_buffer; the
- * reference leaves it in its private scratch buffers when num_steps is odd. */
+ * reference leaves it in its private scratch buffers when num_steps is odd.
+ * Every sort entry point below behaves the same way: the call only enqueues work (no host synchronisation, no allocation
+ * once prepared: it can be captured into a HIP graph); up to 16384 pairs it is one kernel launch; from 2^22 elements up a
+ * counting pass whose digit is the same in every key is skipped on the device (same result, less work). */
 GLU_API glu_status glu_radix_sort_run(glu_radix_sort sort, glu_buffer key_buffer, glu_buffer val_buffer, size_t count,
                                       size_t num_steps);
 /* Raw-pointer form of the same call; `stream` is a hipStream_t or NULL. */
