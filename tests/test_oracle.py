@@ -198,3 +198,15 @@ def test_radix_literal_vs_stable_sort_randomized():
         eff = 8 if steps == 0 or steps > 8 else steps
         ek, ev = O.stable_sort_pairs(keys, vals, key_bits=4 * eff) if n > 1 else (keys, vals)
         assert (res["result_keys"] == ek).all() and (res["result_vals"] == ev).all(), (n, hi, steps)
+
+
+def test_oracle_under_address_and_ub_sanitizers():
+    """The C oracle (both restatements, scan, reduce, generator) on the reference tests' sizes under ASan + UBSan
+    (`make -C oracle sanitize`): no report, and the literal restatement, the LSD checker and plain loops agree.
+    Sanitizers run on the CPU build only: there is no GPU ASan on this pool."""
+    import os, subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run(["make", "-C", os.path.join(root, "oracle"), "sanitize"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "oracle selfcheck: 0 failure(s)" in out.stdout
