@@ -11,6 +11,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "device_utils.hpp"
+
 namespace glu_hip
 {
 constexpr int kW = 64;
@@ -141,7 +143,7 @@ __device__ __forceinline__ void scan_load(const Elem<S, N>* base, uint32_t valid
         const uint32_t e0 = wave * C::WAVE_ELEMS + (g * kW + lane) * C::VEC;
         if (ALIGNED && e0 + C::VEC <= valid)
         {
-            Pack<T, C::VEC> p = *reinterpret_cast<const Pack<T, C::VEC>*>(base + e0);
+            Pack<T, C::VEC> p = *reinterpret_cast<const Pack<T, C::VEC>*>(base + e0); // (non-temporal: slower, the chunk is rewritten in place)
 #pragma unroll
             for (int k = 0; k < C::VEC; k++) x[g][k] = p.v[k];
         }
@@ -433,7 +435,7 @@ __global__ __launch_bounds__(256) void reduce_kernel(const Elem<S, N>* __restric
     {
         P v[UNROLL];
 #pragma unroll
-        for (int u = 0; u < UNROLL; u++) v[u] = pin[i + u * stride];
+        for (int u = 0; u < UNROLL; u++) v[u] = load_streaming(&pin[i + u * stride]); // read once
 #pragma unroll
         for (int u = 0; u < UNROLL; u++)
 #pragma unroll
