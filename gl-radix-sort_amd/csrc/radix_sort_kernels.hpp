@@ -20,6 +20,10 @@
 
 #include "device_utils.hpp"
 
+#ifndef GLU_DMA_AUX
+#define GLU_DMA_AUX 0 // cache-policy bits of the experimental LDS-DMA tile loads (tuning builds)
+#endif
+
 namespace glu_hip
 {
 constexpr int kWave = 64;
@@ -543,14 +547,14 @@ __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_ker
             for (int j = 0; j < KEY_PIECES; j++)
                 __builtin_amdgcn_global_load_lds(
                     (const __attribute__((address_space(1))) void*) (gk + j * 1024 + lane * 16),
-                    (__attribute__((address_space(3))) void*) (reinterpret_cast<const unsigned char*>(rawk) + j * 1024), 16, 0, 0);
+                    (__attribute__((address_space(3))) void*) (reinterpret_cast<const unsigned char*>(rawk) + j * 1024), 16, 0, GLU_DMA_AUX);
             if (has_vals)
             {
 #pragma unroll
                 for (int j = 0; j < VAL_PIECES; j++)
                     __builtin_amdgcn_global_load_lds(
                         (const __attribute__((address_space(1))) void*) (gv + j * 1024 + lane * 16),
-                        (__attribute__((address_space(3))) void*) (reinterpret_cast<const unsigned char*>(rawv) + j * 1024), 16, 0, 0);
+                        (__attribute__((address_space(3))) void*) (reinterpret_cast<const unsigned char*>(rawv) + j * 1024), 16, 0, GLU_DMA_AUX);
             }
             if (STAMPS) stamp(0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
