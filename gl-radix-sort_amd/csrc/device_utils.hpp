@@ -29,4 +29,23 @@ __device__ __forceinline__ T load_streaming(const T* p)
     else
         return *p;
 }
+// Non-temporal store, 16 bytes at a time (objects whose size is a multiple of 16 bytes), plain store otherwise.
+template<typename T>
+__device__ __forceinline__ void store_streaming(T* p, const T& value)
+{
+    if constexpr (sizeof(T) % 16 == 0)
+    {
+        typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+        u32x4_t* dst = reinterpret_cast<u32x4_t*>(p);
+#pragma unroll
+        for (unsigned i = 0; i < sizeof(T) / 16; i++)
+        {
+            u32x4_t r;
+            __builtin_memcpy(&r, reinterpret_cast<const char*>(&value) + 16 * i, 16);
+            __builtin_nontemporal_store(r, dst + i);
+        }
+    }
+    else
+        *p = value;
+}
 } // namespace glu_hip

@@ -356,7 +356,7 @@ __global__ __launch_bounds__(CHAINED ? kChainThreads : 256) void scan_chunks_ker
         const uint32_t e0 = wave * C::WAVE_ELEMS + (g * kW + lane) * C::VEC;
         if (ALIGNED && e0 + C::VEC <= valid)
         {
-            *reinterpret_cast<Pack<T, C::VEC>*>(base + e0) = p;
+            *reinterpret_cast<Pack<T, C::VEC>*>(base + e0) = p; // (non-temporal stores: no gain at 2^28, slower at 2^26)
         }
         else
         {
