@@ -670,3 +670,35 @@ def test_planned_sort_really_skips(G, monkeypatch):
         times[env] = s.read_profile()["scatter_ms"]
         assert (vb.get_data(np.uint32) == vals).all() and (kb.get_data(np.uint32) == keys).all()
     assert times["0"] < 0.25 * times["1"], times
+
+
+def test_planned_sort_inside_a_captured_graph(G):
+    """The skip decisions live on the device, so one captured graph of a large sort replays correctly on inputs that skip
+    different passes (none / the top byte / all of them)."""
+    import torch
+
+    n = (1 << 22) + 77
+    sorter = G.RadixSort()
+    sorter.prepare_internal_buffers(n)
+    kt = torch.empty(n, dtype=torch.int32, device="cuda")
+    vt = torch.empty(n, dtype=torch.int32, device="cuda")
+    side = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    rng = np.random.default_rng(2024)
+    vals = np.arange(n, dtype=np.uint32)
+    inputs = [rng.integers(0, 2**32, n, dtype=np.uint32), rng.integers(0, 2**24, n, dtype=np.uint32),
+              np.full(n, 7, dtype=np.uint32), rng.integers(0, 2**32, n, dtype=np.uint32) & np.uint32(0xFF00FF00)]
+    with torch.cuda.stream(side):
+        kt.copy_(torch.from_numpy(inputs[0].view(np.int32)))
+        vt.copy_(torch.from_numpy(vals.view(np.int32)))
+        sorter.run_ptr(kt.data_ptr(), vt.data_ptr(), n, 0, side.cuda_stream)
+        side.synchronize()
+        with torch.cuda.graph(graph, stream=side):
+            sorter.run_ptr(kt.data_ptr(), vt.data_ptr(), n, 0, torch.cuda.current_stream().cuda_stream)
+        for keys in inputs:
+            kt.copy_(torch.from_numpy(keys.view(np.int32)))
+            vt.copy_(torch.from_numpy(vals.view(np.int32)))
+            graph.replay()
+            side.synchronize()
+            order = np.argsort(keys, kind="stable")
+            assert (kt.cpu().numpy().view(np.uint32) == keys[order]).all() and (vt.cpu().numpy().view(np.uint32) == vals[order]).all()
