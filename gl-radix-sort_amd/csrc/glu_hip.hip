@@ -343,7 +343,8 @@ constexpr int kMaxBlocksPerCu = 4;
 // Launch geometry of one counting pass.  "Large" = one 1024-thread workgroup per CU with the biggest tile LDS
 // allows (long per-digit runs, fewest partial 64-byte blocks); "small" = 256-thread workgroups, 4 per CU, for inputs
 // that cannot give every CU a large tile.  Measured on MI355X, 2^28 pairs (tools/scatter_bench.hip):
-//   8-bit digits: 1024 x 12 + carry 1.17 ms/pass vs 256 x 16 1.95 ms;  4-bit digits: 1024 x 16 0.90-0.95 ms vs 1.03 ms.
+//   8-bit digits: 1024 x 12 + carry 0.95-1.15 ms/pass vs 256 x 16 1.4-1.65 ms;  4-bit digits: 1024 x 12 + carry 0.87 ms vs
+//   0.93 ms without the carry (same process), 64-bit keys 1024 x 8 + carry 1.30 vs 1.37 ms.
 template<int THREADS_, int KPT_, int BLOCKS_PER_CU_, bool CARRY_>
 struct Geometry
 {
@@ -353,11 +354,11 @@ struct Geometry
 template<typename KeyT, int BITS, bool LARGE>
 struct PairGeometry;
 template<> struct PairGeometry<uint32_t, 8, true> : Geometry<1024, 12, 1, true> {};
-template<> struct PairGeometry<uint32_t, 4, true> : Geometry<1024, 12, 1, false> {};
+template<> struct PairGeometry<uint32_t, 4, true> : Geometry<1024, 12, 1, true> {};
 template<> struct PairGeometry<uint32_t, 8, false> : Geometry<256, 16, 3, false> {};
 template<> struct PairGeometry<uint32_t, 4, false> : Geometry<256, 16, 3, false> {};
 template<> struct PairGeometry<uint64_t, 8, true> : Geometry<512, 16, 1, true> {};
-template<> struct PairGeometry<uint64_t, 4, true> : Geometry<1024, 8, 1, false> {};
+template<> struct PairGeometry<uint64_t, 4, true> : Geometry<1024, 8, 1, true> {};
 template<> struct PairGeometry<uint64_t, 8, false> : Geometry<256, 8, 4, false> {};
 template<> struct PairGeometry<uint64_t, 4, false> : Geometry<256, 8, 4, false> {};
 // VALS = false (keys-only sorts): the LDS arrays hold keys alone, so the large 32-bit / 8-bit-digit geometry takes 20 keys

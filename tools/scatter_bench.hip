@@ -550,6 +550,16 @@ int main(int argc, char** argv)
         run_variant<8, 1024, 12, true>(c, 1, shift);
         return 0;
     }
+    if (getenv("SB_FOUR"))
+    { // 4-bit digits (the reference's pass structure): tile size and carry
+        run_variant<4, 1024, 12, false>(c, 1, shift);
+        run_variant<4, 1024, 12, true>(c, 1, shift);
+        run_variant<4, 1024, 16, false>(c, 1, shift);
+        run_variant<4, 1024, 16, true>(c, 1, shift);
+        run_variant<4, 512, 24, false>(c, 1, shift);
+        run_variant<4, 1024, 12, false>(c, 1, shift);
+        return 0;
+    }
     if (getenv("SB_TWO"))
     { // two 512-thread workgroups per CU (needs -DGLU_CARRY_ELEMS=8 to fit 2 x 79 KB of LDS)
         run_variant<8, 512, 12, true>(c, 2, shift);

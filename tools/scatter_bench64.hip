@@ -77,6 +77,8 @@ int main(int argc, char** argv)
     run<8, 1024, 10, false>(c, 1, shift);
     run<8, 512, 12, true>(c, 1, shift);
     run<4, 1024, 8, false>(c, 1, shift);
+    run<4, 1024, 8, true>(c, 1, shift);
+    run<4, 1024, 12, true>(c, 1, shift);
     run<4, 1024, 10, false>(c, 1, shift);
     run<4, 512, 16, false>(c, 1, shift);
     return 0;
