@@ -549,11 +549,11 @@ def test_bit_range_argument_checks(G):
             sorter.sort_bit_range_ptr(kb.device_ptr(), None, 64, begin, end, None, kbytes)
 
 
-@pytest.mark.parametrize("mode,threshold", [("pairs", 256 * 12288), ("keys", 256 * 20480), ("u64", 256 * 8192)])
+@pytest.mark.parametrize("mode,threshold", [("pairs", 256 * 12288 * 3 // 2), ("keys", 256 * 20480 * 3 // 2), ("u64", 256 * 8192 * 3 // 2)])
 @pytest.mark.parametrize("delta", [-1, 0, 1, 12287])
 def test_geometry_switch_points(G, mode, threshold, delta):
-    """Sizes right at the small -> large geometry switch of each kernel family (256 CUs x one large tile; the large tile is
-    12288 pairs, 20480 keys for keys-only sorts, 8192 pairs for 64-bit keys): last tile partial / exactly full / one over."""
+    """Sizes right at the small -> large geometry switch of each kernel family (3/2 large tiles per CU on 256 CUs; the
+    large tile is 12288 pairs, 20480 keys for keys-only sorts, 8192 pairs for 64-bit keys)."""
     n = threshold + delta
     rng = np.random.default_rng(n)
     if mode == "u64":
