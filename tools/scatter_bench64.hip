@@ -76,6 +76,9 @@ int main(int argc, char** argv)
     run<8, 512, 16, false>(c, 1, shift);
     run<8, 1024, 10, false>(c, 1, shift);
     run<8, 512, 12, true>(c, 1, shift);
+    run<8, 1024, 6, true>(c, 1, shift);
+    run<8, 768, 8, true>(c, 1, shift);
+    run<8, 768, 10, true>(c, 1, shift);
     run<4, 1024, 8, false>(c, 1, shift);
     run<4, 1024, 8, true>(c, 1, shift);
     run<4, 1024, 12, true>(c, 1, shift);
