@@ -550,6 +550,15 @@ int main(int argc, char** argv)
         run_variant<8, 1024, 12, true>(c, 1, shift);
         return 0;
     }
+    if (getenv("SB_SMALL"))
+    { // small geometry (sizes below the large-tile switch): carry or not, 2 or 3 workgroups per CU
+        run_variant<8, 256, 16, false>(c, 3, shift);
+        run_variant<8, 256, 16, true>(c, 2, shift);
+        run_variant<8, 256, 16, false>(c, 4, shift);
+        run_variant<8, 512, 8, false>(c, 2, shift);
+        run_variant<8, 256, 16, false>(c, 3, shift);
+        return 0;
+    }
     if (getenv("SB_FOUR"))
     { // 4-bit digits (the reference's pass structure): tile size and carry
         run_variant<4, 1024, 12, false>(c, 1, shift);
