@@ -24,8 +24,7 @@ while n < (1 << 27):
             vb = G.ShaderStorageBuffer(vals)
             best = min(best, G.measure_elapsed_time(lambda: s(kb, vb, m, 0, key_bytes=8 if mode == "u64" else 4)))
     us = best * 1e-3
-    flag = "  <-- slower than the previous (smaller) size" if prev is not None and us < prev * 0.97 and False else ""
     jump = "  <-- +%.0f %% for +25 %% elements" % ((us / prev - 1) * 100) if prev is not None and us > prev * 1.45 else ""
-    print("n %10d: %9.1f us  %7.2f ns/1000 elem%s%s" % (m, us, us * 1e6 / m / 1e3 * 1e-3 * 1e3, jump, flag), flush=True)
+    print("n %10d: %9.1f us  %9.1f Mkeys/s%s" % (m, us, m / us, jump), flush=True)
     prev = us
     n *= 1.25
