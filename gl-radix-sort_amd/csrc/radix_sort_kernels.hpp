@@ -341,6 +341,11 @@ struct PairArray<uint64_t, COUNT, true>
 #endif
 constexpr int kBlockElems = GLU_CARRY_ELEMS; // 16 x 4 B = the 64-byte write block the carry keeps whole
 
+// Row padding of the wave-private counter table: the offsets scan reads counters (wave 4q + k, digit) with q varying
+// fastest across lanes; with rows of RADIX words all q land in the same bank (4-way / 2-way conflicts for 16 / 8 waves).
+// Rows padded to RADIX + 16 / (WAVES / 4) words make those accesses conflict-free.
+constexpr int wcnt_row_pad(int waves) { return waves >= 16 ? 4 : waves >= 8 ? 8 : 0; }
+
 template<typename KeyT, int BITS, int THREADS, int KPT, bool CARRY, int ROUNDS = 1, bool VALS = true>
 struct ScatterSmem
 {
@@ -351,7 +356,8 @@ struct ScatterSmem
     static_assert(KPT % ROUNDS == 0, "a round writes out KPT / ROUNDS positions per thread");
     PairArray<KeyT, STAGE, VALS> stage;                          // one round of the tile in ranked order
     PairArray<KeyT, CARRY ? RADIX * kBlockElems : 1, VALS> carry; // per digit: elements of a not yet complete 64-B block
-    uint32_t wcnt[WAVES][RADIX]; // wave-private running digit counters -> first ranked position of (wave, digit)
+    static constexpr int WCNT_STRIDE = RADIX + wcnt_row_pad(WAVES);
+    uint32_t wcnt[WAVES][WCNT_STRIDE]; // wave-private running digit counters -> first ranked position of (wave, digit)
     uint32_t tstart[RADIX];      // first ranked position of each digit in the tile
     uint2 dest[RADIX];           // .x: global index = ranked position + dest[digit].x;  .y (CARRY): elements with a
                                  // global index >= dest[digit].y go to the carry, not to memory (one ds_read_b64 for both)
@@ -465,7 +471,7 @@ __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_ker
         if (tid < RADIX) digit_base = woff + excl + (FUSED_SCAN ? before : table[(size_t) tid * nb + b]);
     }
     uint32_t carry_start = digit_base; // CARRY: elements [carry_start, digit_base) of the digit are held in s.carry
-    for (int i = tid; i < WAVES * RADIX; i += THREADS) (&s.wcnt[0][0])[i] = 0;
+    for (int i = tid; i < WAVES * Smem::WCNT_STRIDE; i += THREADS) (&s.wcnt[0][0])[i] = 0;
     __syncthreads();
 
     uint32_t first, last;
@@ -804,7 +810,7 @@ __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_ker
             }
             if (r + 1 < ROUNDS) __syncthreads(); // the next round overwrites the staging area
         }
-        for (int i = tid; i < WAVES * RADIX; i += THREADS) (&s.wcnt[0][0])[i] = 0;
+        for (int i = tid; i < WAVES * Smem::WCNT_STRIDE; i += THREADS) (&s.wcnt[0][0])[i] = 0;
         stamp(6); // write-out issue
         __syncthreads();
         stamp(7); // final barrier
@@ -855,7 +861,8 @@ struct SingleBlockSmem
     static constexpr int WAVES = THREADS / kWave;
     static constexpr int TILE = THREADS * KPT;
     PairArray<KeyT, TILE> stage;
-    uint32_t wcnt[WAVES][RADIX];
+    static constexpr int WCNT_STRIDE = RADIX + wcnt_row_pad(WAVES);
+    uint32_t wcnt[WAVES][WCNT_STRIDE];
     uint32_t scan_tmp[WAVES];
 };
 
@@ -900,7 +907,7 @@ __global__ __launch_bounds__(THREADS) void radix_sort_single_block_kernel(KeyT* 
         bits = end_bit - shift < (uint32_t) BITS ? end_bit - shift : (uint32_t) BITS;
         if (sizeof(KeyT) == 8 && shift < 32u && shift + bits > 32u) bits = 32u - shift;
         const uint32_t MASK = (1u << bits) - 1;
-        for (int i = tid; i < WAVES * RADIX; i += THREADS) (&s.wcnt[0][0])[i] = 0;
+        for (int i = tid; i < WAVES * Smem::WCNT_STRIDE; i += THREADS) (&s.wcnt[0][0])[i] = 0;
         __syncthreads();
 
         uint32_t rank[KPT];
