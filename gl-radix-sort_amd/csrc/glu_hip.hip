@@ -14,6 +14,7 @@
 #define GLU_HIP_BUILD 1
 #include "glu_hip.h"
 #include "radix_sort_kernels.hpp"
+#include "radix_scatter_lines.hpp"
 #include "scan_reduce_kernels.hpp"
 
 using namespace glu_hip;
@@ -367,6 +368,15 @@ template<> struct PairGeometry<uint64_t, 4, false> : Geometry<256, 8, 4, false> 
 template<typename KeyT, int BITS, bool LARGE, bool VALS = true>
 struct GeometryFor : PairGeometry<KeyT, BITS, LARGE> {};
 template<> struct GeometryFor<uint32_t, 8, true, false> : Geometry<1024, 20, 1, true> {};
+
+// 128-byte-line scatter (radix_scatter_lines.hpp): 4-byte keys, large inputs, 16-byte aligned arrays.  The carry is
+// RADIX x 32 elements of LDS (64 KiB for 8-bit digits of pairs), so the tile is what is left of the 160 KiB: 9 pairs per
+// thread (1024 x 9 = 9216), 16 keys per thread for keys-only sorts.
+template<int BITS, bool VALS>
+struct LinesGeometry : Geometry<1024, 9, 1, true> {};
+template<> struct LinesGeometry<8, false> : Geometry<1024, 16, 1, true> {};
+template<> struct LinesGeometry<4, true> : Geometry<1024, 12, 1, true> {};
+template<> struct LinesGeometry<4, false> : Geometry<1024, 16, 1, true> {};
 }
 
 struct glu_radix_sort_s
@@ -381,6 +391,7 @@ struct glu_radix_sort_s
     bool no_single_block = false; // GLU_HIP_SORT_NO_SINGLE_BLOCK=1: never take the one-workgroup path (tests / tuning)
     bool no_fused_scan = false;   // GLU_HIP_SORT_NO_FUSED_SCAN=1: always launch the row-scan kernel (tests / tuning)
     bool no_plan = false;         // GLU_HIP_SORT_NO_PLAN=1: never skip constant-digit passes (tests / tuning)
+    bool no_lines = false;        // GLU_HIP_SORT_NO_LINES=1: never use the 128-byte-line scatter kernel (tests / tuning)
     size_t large_min = 0;         // GLU_HIP_SORT_LARGE_MIN=N: element count from which the large geometry is used (tuning)
     // optional per-kernel timing: 4 events per pass (before count, after count, after scan, after scatter)
     bool profiling = false;
@@ -449,13 +460,14 @@ glu_status launch_pass(glu_radix_sort_s* s, const KeyT* src_k, const uint32_t* s
     // launch-bound sizes (small geometry, few workgroups): the scatter sums the counts itself, no row-scan launch
     auto scatter_fused = radix_scatter_kernel<KeyT, BITS, G::THREADS, G::KPT, G::CARRY, 0, false, G::BLOCKS_PER_CU * G::THREADS / 256, 1, false, false, XF, VALS, !LARGE>;
     const bool fused = !LARGE && nb <= kFusedScanMaxBlocks && !histogram_out && !s->no_fused_scan && !pa.plan;
-    static bool lds_opt_in = false; // per instantiation: allow > 64 KiB of dynamic LDS
-    if (!lds_opt_in)
-    {
-        HIP_TRY(hipFuncSetAttribute((const void*) scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sizeof(Smem)));
-        HIP_TRY(hipFuncSetAttribute((const void*) scatter_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sizeof(Smem)));
-        lds_opt_in = true;
-    }
+    static std::once_flag lds_opt_in; // per instantiation: allow > 64 KiB of dynamic LDS (handles may live on several threads)
+    static hipError_t lds_opt_in_result = hipSuccess;
+    std::call_once(lds_opt_in, [&] {
+        lds_opt_in_result = hipFuncSetAttribute((const void*) scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sizeof(Smem));
+        if (lds_opt_in_result == hipSuccess)
+            lds_opt_in_result = hipFuncSetAttribute((const void*) scatter_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sizeof(Smem));
+    });
+    HIP_TRY(lds_opt_in_result);
 
     s->mark(stream);
     // the count kernel only shares TILE and the grid with the scatter kernel; 1024 threads keep enough loads in flight
@@ -479,6 +491,52 @@ glu_status launch_pass(glu_radix_sort_s* s, const KeyT* src_k, const uint32_t* s
     return GLU_OK;
 }
 
+// Large inputs of 4-byte keys in 16-byte aligned arrays: the same three launches with the 128-byte-line scatter kernel
+// (its own tile size, shared by the count kernel: both cut the input with block_tile_range).
+template<typename KeyT, int BITS, bool XF, bool VALS>
+glu_status launch_pass_lines(glu_radix_sort_s* s, const KeyT* src_k, const uint32_t* src_v, KeyT* dst_k, uint32_t* dst_v,
+                             size_t count, uint32_t shift, uint32_t bits, uint32_t* histogram_out, hipStream_t stream,
+                             uint32_t xform, PlanArgs pa)
+{
+    using G = LinesGeometry<BITS, VALS>;
+    constexpr int RADIX = 1 << BITS;
+    const uint32_t tiles = (uint32_t) ((count + G::TILE - 1) / G::TILE);
+    uint64_t cap = (uint64_t) g_dev.num_cus;
+    if (s->max_blocks) cap = std::min<uint64_t>(cap, s->max_blocks);
+    const uint32_t nb = (uint32_t) std::max<uint64_t>(1, std::min<uint64_t>(tiles, cap));
+    const uint32_t mask = (1u << bits) - 1;
+    uint32_t* table = (uint32_t*) s->table.ptr;
+    uint32_t* totals = table + (size_t) RADIX * nb;
+
+    using Smem = LineSmem<KeyT, BITS, G::THREADS, G::KPT, VALS>;
+    auto scatter = radix_scatter_lines_kernel<KeyT, BITS, G::THREADS, G::KPT, XF, VALS>;
+    static std::once_flag lds_opt_in; // per instantiation: allow > 64 KiB of dynamic LDS
+    static hipError_t lds_opt_in_result = hipSuccess;
+    std::call_once(lds_opt_in, [&] {
+        lds_opt_in_result = hipFuncSetAttribute((const void*) scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sizeof(Smem));
+    });
+    HIP_TRY(lds_opt_in_result);
+
+    s->mark(stream);
+    hipLaunchKernelGGL((radix_count_kernel<KeyT, BITS, 1024, G::TILE, XF>), dim3(nb), dim3(1024), 0, stream, src_k, table,
+                       (uint32_t) count, shift, mask, tiles, xform, (const KeyT*) dst_k, pa.plan, pa.pass);
+    HIP_TRY(hipGetLastError());
+    s->mark(stream);
+    hipLaunchKernelGGL((radix_row_scan_kernel<256>), dim3(RADIX), dim3(256), 0, stream, table, totals, nb, (uint32_t) count,
+                       pa.may_skip ? pa.plan : (PassPlan*) nullptr, pa.pass);
+    HIP_TRY(hipGetLastError());
+    s->mark(stream);
+    if (histogram_out)
+        HIP_TRY(hipMemcpyAsync(histogram_out, totals, ((size_t) 1 << bits) * sizeof(uint32_t), hipMemcpyDeviceToDevice,
+                               stream));
+    hipLaunchKernelGGL(scatter, dim3(nb), dim3(G::THREADS), sizeof(Smem), stream, src_k, src_v, dst_k, dst_v,
+                       (const uint32_t*) table, (const uint32_t*) totals, (uint32_t) count, shift, mask, tiles,
+                       (unsigned long long*) nullptr, xform, pa.plan, pa.pass);
+    s->mark(stream);
+    HIP_TRY(hipGetLastError());
+    return GLU_OK;
+}
+
 template<typename KeyT, int BITS>
 glu_status launch_pass_sized(glu_radix_sort_s* s, const KeyT* src_k, const uint32_t* src_v, KeyT* dst_k, uint32_t* dst_v,
                              size_t count, uint32_t shift, uint32_t bits, uint32_t* histogram_out, hipStream_t stream,
@@ -490,6 +548,23 @@ glu_status launch_pass_sized(glu_radix_sort_s* s, const KeyT* src_k, const uint3
     const bool vals = src_v != nullptr;
     const size_t large_tile = vals ? GeometryFor<KeyT, BITS, true, true>::TILE : GeometryFor<KeyT, BITS, true, false>::TILE;
     const bool large = count >= (s->large_min ? s->large_min : (size_t) g_dev.num_cus * large_tile * 3 / 2) && !s->force_small;
+    if constexpr (sizeof(KeyT) == 4)
+    {
+        // whole-line stores need 16-byte aligned destinations (hipMalloc gives 256); both pairs of arrays are checked
+        // because a planned sort swaps their roles on the device.  Same size rule as the large geometry, with its tile.
+        const size_t lines_tile = vals ? LinesGeometry<BITS, true>::TILE : LinesGeometry<BITS, false>::TILE;
+        const bool aligned = (((uintptr_t) src_k | (uintptr_t) src_v | (uintptr_t) dst_k | (uintptr_t) dst_v) & 15u) == 0;
+        const bool lines = aligned && !s->no_lines && !s->force_small &&
+                           count >= (s->large_min ? s->large_min : (size_t) g_dev.num_cus * lines_tile * 3 / 2);
+        if (lines)
+        {
+#define GLU_LAUNCH_LINES(XF_, VALS_) \
+    launch_pass_lines<KeyT, BITS, XF_, VALS_>(s, src_k, src_v, dst_k, dst_v, count, shift, bits, histogram_out, stream, XF_ ? xform : 0u, pa)
+            if (vals) return xform ? GLU_LAUNCH_LINES(true, true) : GLU_LAUNCH_LINES(false, true);
+            return xform ? GLU_LAUNCH_LINES(true, false) : GLU_LAUNCH_LINES(false, false);
+#undef GLU_LAUNCH_LINES
+        }
+    }
 #define GLU_LAUNCH(LARGE_, XF_, VALS_) \
     launch_pass<KeyT, BITS, LARGE_, XF_, VALS_>(s, src_k, src_v, dst_k, dst_v, count, shift, bits, histogram_out, stream, XF_ ? xform : 0u, pa)
     if (vals)
@@ -519,12 +594,12 @@ glu_status launch_single_block_xf(KeyT* keys, uint32_t* vals, size_t count, uint
 {
     using Smem = SingleBlockSmem<KeyT, 8, THREADS, KPT>;
     auto kern = radix_sort_single_block_kernel<KeyT, 8, THREADS, KPT, XF>;
-    static bool lds_opt_in = false;
-    if (!lds_opt_in)
-    {
-        HIP_TRY(hipFuncSetAttribute((const void*) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sizeof(Smem)));
-        lds_opt_in = true;
-    }
+    static std::once_flag lds_opt_in;
+    static hipError_t lds_opt_in_result = hipSuccess;
+    std::call_once(lds_opt_in, [&] {
+        lds_opt_in_result = hipFuncSetAttribute((const void*) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sizeof(Smem));
+    });
+    HIP_TRY(lds_opt_in_result);
     hipLaunchKernelGGL(kern, dim3(1), dim3(THREADS), sizeof(Smem), stream, keys, vals, (uint32_t) count, first_bit, end_bit, xform);
     HIP_TRY(hipGetLastError());
     return GLU_OK;
@@ -667,6 +742,7 @@ glu_status glu_radix_sort_create(glu_radix_sort* out)
     if (const char* e = getenv("GLU_HIP_SORT_NO_SINGLE_BLOCK")) s->no_single_block = atoi(e) != 0;
     if (const char* e = getenv("GLU_HIP_SORT_NO_FUSED_SCAN")) s->no_fused_scan = atoi(e) != 0;
     if (const char* e = getenv("GLU_HIP_SORT_NO_PLAN")) s->no_plan = atoi(e) != 0;
+    if (const char* e = getenv("GLU_HIP_SORT_NO_LINES")) s->no_lines = atoi(e) != 0;
     if (const char* e = getenv("GLU_HIP_SORT_LARGE_MIN")) s->large_min = (size_t) atoll(e);
     *out = s;
     return GLU_OK;

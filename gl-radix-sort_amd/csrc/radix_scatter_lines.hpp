@@ -1,0 +1,404 @@
+// radix_scatter_lines.hpp -- the large-input scatter pass of the LSD radix sort, written around whole 128-byte lines.
+//
+// Replaces k_radix_sort_reordering_shader (reference glu/RadixSort.hpp:60-183) for 4-byte keys on inputs large enough for
+// one persistent 1024-thread workgroup per CU (the other geometries keep radix_scatter_kernel of radix_sort_kernels.hpp).
+// Same contract: a stable counting pass on one digit, dst = digit base + block offset + local rank (RadixSort.hpp:174-177).
+//
+// Why a second kernel.  On MI355X what the memory system delivers for a streaming read + scattered write mix depends on
+// the write chunks alone (tools/pattern_bench.hip, 2^28 pairs, 256 destination regions per workgroup):
+//     64-B chunks 3.5-3.8 TB/s | 192-B chunks at 64-B alignment 3.8 TB/s | 128-B-aligned chunks of 128 B and up 5.0-5.1 TB/s
+// (5.1-5.4 TB/s is the plain copy).  radix_scatter_kernel writes 64-byte blocks (its carry granule) and sat exactly on the
+// 3.8 TB/s line.  Here every store to memory is a whole, aligned 128-byte line of one digit's output, written by 8 lanes
+// with one 16-byte store each:
+//   * per digit a carry of up to 31 elements (the part of the digit's output past its last 128-byte boundary) stays in
+//     LDS between tiles; a tile appends its run; the full lines of (carry ++ run) are written, the rest is the new carry;
+//   * the write-out walks LINES, not elements: a packed block scan gives every digit its first ranked position (low half)
+//     and its first line (high half) at once; a line -> digit table makes a quad of 4 elements = 1 lane-store;
+//   * the only partial lines are at the two ends of a workgroup's range of a digit (element-wise stores).
+// The next tile's keys are loaded while the current tile is ranked, its values at the top of the tile: both are in flight
+// under the rank / scan phases instead of in front of them.
+#pragma once
+
+#include "radix_sort_kernels.hpp"
+
+namespace glu_hip
+{
+constexpr int kLineElems = 32; // 4-byte elements per 128-byte line
+
+template<typename KeyT, int BITS, int THREADS, int KPT, bool VALS = true>
+struct LineSmem
+{
+    static_assert(sizeof(KeyT) == 4, "the line kernel handles 4-byte keys");
+    static constexpr int RADIX = 1 << BITS;
+    static constexpr int WAVES = THREADS / kWave;
+    static constexpr int TILE = THREADS * KPT;
+    static constexpr int CARRY = RADIX * kLineElems;
+    static constexpr int MAXLINES = (TILE + RADIX * (kLineElems - 1)) / kLineElems + 2;
+    static_assert(TILE < 65536 && MAXLINES < 65536, "ranked positions and line numbers share one 32-bit scan word");
+    PairArray<KeyT, TILE + CARRY, VALS> buf; // [0, TILE): the tile in ranked order;  [TILE + d * 32, +32): carry of digit d
+    static constexpr int WCNT_STRIDE = RADIX + wcnt_row_pad(WAVES);
+    uint32_t wcnt[WAVES][WCNT_STRIDE]; // wave-private running digit counters -> first ranked position of (wave, digit)
+    uint4 dinfo[RADIX];  // .x global index of the digit's first line this tile (= of its carried elements), .y ranked position
+                         // of combined element 0 (= first ranked position - carried count), .z first line | carried << 16,
+                         // .w first global index of the digit that this workgroup owns
+    uint2 tail[RADIX];   // new carry: slot s in [.y & 0xff, .y >> 8) <- ranked position .x + s
+    uint16_t ltab[(MAXLINES + 1) & ~1]; // digit of every line written this tile
+    uint32_t scan_tmp[WAVES];
+    uint32_t total_lines;
+};
+
+// ABLATE (tuning builds, wrong results): 4 = nothing is written out.
+template<typename KeyT, int BITS, int THREADS, int KPT, bool XF = false, bool VALS = true, int ABLATE = 0, bool STAMPS = false>
+__global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
+    const KeyT* __restrict__ keys_a, const uint32_t* __restrict__ vals_a, KeyT* __restrict__ keys_b,
+    uint32_t* __restrict__ vals_b, const uint32_t* __restrict__ table, const uint32_t* __restrict__ totals, uint32_t n,
+    uint32_t shift, uint32_t mask, uint32_t tiles_total, unsigned long long* stamps = nullptr, uint32_t xform = 0,
+    PassPlan* plan = nullptr, uint32_t pass = 0)
+{
+    const KeyT* __restrict__ src_keys = keys_a;
+    const uint32_t* __restrict__ src_vals = vals_a;
+    KeyT* __restrict__ dst_keys = keys_b;
+    uint32_t* __restrict__ dst_vals = vals_b;
+    if (plan)
+    {
+        const uint32_t flip = pass > 0 ? plan->flip[pass] : 0u;
+        const uint32_t skip = plan->skip[pass];
+        if (blockIdx.x == 0 && threadIdx.x == 0) plan->flip[pass + 1] = flip ^ (skip ? 0u : 1u);
+        if (skip) return; // identity pass (kernel-uniform)
+        if (flip)
+        {
+            src_keys = keys_b;
+            src_vals = vals_b;
+            dst_keys = const_cast<KeyT*>(keys_a);
+            dst_vals = const_cast<uint32_t*>(vals_a);
+        }
+    }
+    using Smem = LineSmem<KeyT, BITS, THREADS, KPT, VALS>;
+    constexpr int RADIX = Smem::RADIX;
+    constexpr int WAVES = Smem::WAVES;
+    constexpr int TILE = Smem::TILE;
+    constexpr int WAVE_TILE = kWave * KPT;
+    constexpr int WQ = WAVES / 4;            // scan threads per digit (4 waves' counters each)
+    constexpr int SCAN_THREADS = RADIX * WQ;
+    constexpr int SCAN_WAVES = (SCAN_THREADS + kWave - 1) / kWave;
+    constexpr uint32_t LINE = kLineElems;
+    static_assert(WQ == 4, "the digit bookkeeping below is written for 16 waves (quads of scan threads)");
+    static_assert(SCAN_THREADS <= THREADS, "one scan thread per (digit, 4 waves)");
+    const uint32_t MASK = mask; // <= RADIX - 1
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    Smem& s = *reinterpret_cast<Smem*>(smem_raw);
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t nb = gridDim.x, b = blockIdx.x;
+    const KeyCodec<KeyT, XF> codec_in(xform & 3u), codec_out((xform >> 2) & 3u);
+
+    // scan-thread coordinates: thread t < SCAN_THREADS owns digit t / 4, waves 4 * (t % 4) .. + 3; the q == 0 thread of a
+    // digit also owns the digit's running state (registers):
+    const uint32_t sd = tid / WQ, sq = tid % WQ, sw = sq * 4;
+    const bool scan_thread = tid < SCAN_THREADS;
+    const bool digit_owner = scan_thread && sq == 0;
+    uint32_t digit_base = 0;  // global index of the digit's next element
+    uint32_t carry_start = 0; // 32-aligned global index of the digit's first carried element; carried = digit_base - carry_start
+    uint32_t owned_from = 0;  // first global index of the digit inside this workgroup's range
+
+    // ---- prologue: exclusive scan of the digit totals (RadixSort.hpp:148-152) + this block's scanned table entry (:176)
+    {
+        const uint32_t t = digit_owner ? totals[sd] : 0u;
+        uint32_t wtotal;
+        uint32_t excl = wave_exclusive_sum(t, lane, wtotal);
+        if (lane == 0) s.scan_tmp[wave] = wtotal;
+        __syncthreads();
+        excl += sum_of_preceding_waves(s.scan_tmp, WAVES, wave, lane);
+        if (digit_owner)
+        {
+            digit_base = excl + table[(size_t) sd * nb + b];
+            owned_from = digit_base;
+            carry_start = digit_base & ~(LINE - 1); // the slots below digit_base are never written (another workgroup's)
+        }
+    }
+    for (int i = tid; i < WAVES * Smem::WCNT_STRIDE; i += THREADS) (&s.wcnt[0][0])[i] = 0;
+    __syncthreads();
+
+    uint32_t first, last;
+    block_tile_range(b, nb, tiles_total, first, last);
+    const uint32_t wave_off = wave * WAVE_TILE + lane; // wave-striped: item i of lane l of wave w = element w*64*KPT + i*64 + l
+
+    unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = 0;
+    auto stamp = [&](int slot) {
+        if (STAMPS)
+        {
+            unsigned long long t = __builtin_amdgcn_s_memtime();
+            acc[slot] += t - tprev;
+            tprev = t;
+        }
+    };
+
+    KeyT key[KPT], nkey[KPT];
+    uint32_t val[KPT];
+    // guarded loads of a partial tile: positions past the end of the array read as pads (highest digit, after all keys)
+    auto load_tile_guarded = [&](uint32_t t) {
+        const uint64_t base = (uint64_t) t * TILE;
+        const uint32_t left = (uint32_t) ((uint64_t) n - base);
+#pragma unroll
+        for (int i = 0; i < KPT; i++)
+        {
+            const uint32_t p = wave_off + i * kWave;
+            key[i] = p < left ? codec_in.encode(src_keys[base + p]) : (KeyT) ~(KeyT) 0;
+            if (VALS) val[i] = p < left ? src_vals[base + p] : 0u;
+        }
+    };
+    if (first < last)
+    {
+        if ((uint64_t) n - (uint64_t) first * TILE >= (uint64_t) TILE)
+        {
+            const uint64_t base = (uint64_t) first * TILE + wave_off;
+#pragma unroll
+            for (int i = 0; i < KPT; i++) key[i] = codec_in.encode(src_keys[base + i * kWave]);
+            if (VALS)
+            {
+#pragma unroll
+                for (int i = 0; i < KPT; i++) val[i] = src_vals[base + i * kWave];
+            }
+        }
+        else
+            load_tile_guarded(first);
+    }
+
+    for (uint32_t tile = first; tile < last; tile++)
+    {
+        const uint64_t tile_base = (uint64_t) tile * TILE;
+        const uint64_t rem = (uint64_t) n - tile_base;
+        const bool tile_full = rem >= (uint64_t) TILE;
+        const uint32_t tile_valid = tile_full ? (uint32_t) TILE : (uint32_t) rem;
+        if (STAMPS) tprev = __builtin_amdgcn_s_memtime();
+
+        // ---- the next tile is loaded under this one: its keys one load per rank iteration (into nkey), its values one
+        //      load per staging iteration (into the value register just staged).  The last tile of a range, or one whose
+        //      successor is partial (the last tile of the array: guarded loads at the end of this iteration), prefetches a
+        //      full tile it will not use, so that neither loop carries a branch.
+        const bool next_ok = tile + 1 < last && (uint64_t) n - (tile_base + TILE) >= (uint64_t) TILE;
+        const uint64_t next_base = (next_ok ? tile_base + TILE : (tile_full ? tile_base : 0ull)) + wave_off;
+        stamp(0);
+
+        // ---- rank inside the wave (match-any on the digit bits with one ballot per bit, wave-private counters)
+        uint32_t rank[KPT];
+        uint32_t* my_cnt = s.wcnt[wave];
+#pragma unroll
+        for (int i = 0; i < KPT; i++)
+        {
+            nkey[i] = src_keys[next_base + i * kWave];
+            const uint32_t d = digit_of<KeyT>(key[i], shift, MASK);
+            uint32_t* const cnt = my_cnt + d;
+            const uint32_t prev = *cnt;
+            uint32_t plo = ~0u, phi = ~0u;
+#pragma unroll
+            for (int bit = 0; bit < BITS; bit++)
+            {
+                int32_t sel;
+                asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(sel) : "v"(d), "n"(bit));
+                const uint64_t m = __ballot(sel < 0);
+                plo = __builtin_amdgcn_bitop3_b32(plo, (uint32_t) m, (uint32_t) sel, 0x90);
+                phi = __builtin_amdgcn_bitop3_b32(phi, (uint32_t) (m >> 32), (uint32_t) sel, 0x90);
+            }
+            const uint32_t lower = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
+            const uint32_t total = (uint32_t) __popc(plo) + (uint32_t) __popc(phi);
+            rank[i] = prev + lower;
+            asm volatile("" : "+v"(rank[i]));
+            *cnt = prev + total;
+        }
+        stamp(1);
+        __syncthreads();
+        stamp(2);
+
+        // ---- one packed block scan over (digit, wave quad): low half = elements, high half = full lines of the digit.
+        //      All four scan threads of a digit know the digit's element count n_d and carried count c_d.
+        uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0, n_d = 0, c_d = 0, nl_d = 0;
+        uint32_t excl = 0;
+        {
+            if (scan_thread)
+            {
+                c0 = s.wcnt[sw + 0][sd];
+                c1 = s.wcnt[sw + 1][sd];
+                c2 = s.wcnt[sw + 2][sd];
+                c3 = s.wcnt[sw + 3][sd];
+            }
+            const uint32_t mine = c0 + c1 + c2 + c3;
+            if (wave < SCAN_WAVES) // wave-uniform
+            {
+                // quad sum into the quad's lane 0 (row_shl moves lane i + k to lane i inside a row of 16), then broadcast
+                int t = (int) mine;
+                t += __builtin_amdgcn_update_dpp(0, t, 0x101, 0xf, 0xf, false); // row_shl:1
+                t += __builtin_amdgcn_update_dpp(0, t, 0x102, 0xf, 0xf, false); // row_shl:2
+                n_d = (uint32_t) __builtin_amdgcn_update_dpp(0, t, 0x00, 0xf, 0xf, false);                        // quad_perm:[0,0,0,0]
+                c_d = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) (digit_base - carry_start), 0x00, 0xf, 0xf, false);
+                // pads of the (partial) last tile were ranked at the end of the highest used digit: not elements
+                if (sd == MASK) n_d -= (uint32_t) TILE - tile_valid;
+                nl_d = (c_d + n_d) / LINE;
+                uint32_t wtotal;
+                excl = wave_exclusive_sum(mine + (sq == WQ - 1 ? nl_d << 16 : 0u), lane, wtotal);
+                if (lane == 0) s.scan_tmp[wave] = wtotal;
+            }
+            __syncthreads();
+            if (wave < SCAN_WAVES) excl += sum_of_preceding_waves(s.scan_tmp, SCAN_WAVES, wave, lane);
+            if (scan_thread)
+            {
+                const uint32_t pos = excl & 0xFFFFu, line0 = excl >> 16;
+                s.wcnt[sw + 0][sd] = pos;
+                s.wcnt[sw + 1][sd] = pos + c0;
+                s.wcnt[sw + 2][sd] = pos + c0 + c1;
+                s.wcnt[sw + 3][sd] = pos + c0 + c1 + c2;
+                // lines of this digit, dealt to its four scan threads
+                for (uint32_t j = sq; j < nl_d; j += WQ) s.ltab[line0 + j] = (uint16_t) sd;
+                if (sq == 0)
+                {
+                    const uint32_t m = c_d + n_d, c_new = m & (LINE - 1), k = n_d < c_new ? n_d : c_new;
+                    s.dinfo[sd] = make_uint4(carry_start, pos - c_d, line0 | (c_d << 16), owned_from);
+                    s.tail[sd] = make_uint2(pos + n_d - c_new, (c_new - k) | (c_new << 8));
+                    digit_base += n_d;
+                    carry_start += nl_d * LINE;
+                }
+                if (tid == SCAN_THREADS - 1) s.total_lines = line0 + nl_d;
+            }
+        }
+        __syncthreads();
+        stamp(3);
+
+        // ---- stage (key, val) at the ranked position
+#pragma unroll
+        for (int i = 0; i < KPT; i++)
+        {
+            const uint32_t pos = rank[i] + my_cnt[digit_of<KeyT>(key[i], shift, MASK)];
+            s.buf.put(pos, key[i], VALS ? val[i] : 0u);
+            if (VALS) val[i] = src_vals[next_base + i * kWave];
+        }
+        __syncthreads();
+        stamp(4);
+
+        // ---- write the full lines: quad = 4 consecutive elements of one line = one 16-byte store per array
+        if (ABLATE < 4)
+        {
+            const uint32_t quads = s.total_lines * (LINE / 4);
+            constexpr int QB = 3; // quads per thread and sweep (a tile of uniform keys has about 2.3 per thread)
+            for (uint32_t q_first = tid; q_first < quads; q_first += QB * THREADS)
+            {
+                uint32_t g0[QB], from_run[QB], from_carry[QB], owned[QB];
+                int in_carry[QB];
+#pragma unroll
+                for (int u = 0; u < QB; u++)
+                {
+                    uint32_t qi = q_first + u * THREADS;
+                    qi = qi < quads ? qi : q_first; // a surplus quad reads what the first one reads and stores nothing
+                    const uint32_t l = qi / (LINE / 4), sub = qi % (LINE / 4);
+                    const uint32_t d = s.ltab[l];
+                    const uint4 info = s.dinfo[d];
+                    const uint32_t line0 = info.z & 0xFFFFu, carried = info.z >> 16;
+                    const uint32_t q0 = (l - line0) * LINE + sub * 4; // index in (carry ++ run) of the quad's first element
+                    g0[u] = info.x + q0;                               // its global index (a multiple of 4)
+                    from_run[u] = info.y + q0;                         // ranked position, were it an element of the run
+                    from_carry[u] = (uint32_t) TILE + d * LINE + q0;
+                    in_carry[u] = (int) carried - (int) q0;            // elements e < in_carry of the quad are carried ones
+                    owned[u] = info.w;
+                }
+#pragma unroll
+                for (int u = 0; u < QB; u++)
+                {
+                    KeyT k[4];
+                    uint32_t v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) s.buf.get((e < in_carry[u] ? from_carry[u] : from_run[u]) + e, k[e], v[e]);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) k[e] = codec_out.decode(k[e]);
+                    const bool real = u == 0 || q_first + u * THREADS < quads;
+                    if (real && g0[u] >= owned[u] && (ABLATE == 0 || g0[u] + 3 < n))
+                    {
+                        typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+                        u32x4_t kk = {(uint32_t) k[0], (uint32_t) k[1], (uint32_t) k[2], (uint32_t) k[3]};
+                        *reinterpret_cast<u32x4_t*>(dst_keys + g0[u]) = kk;
+                        if (VALS)
+                        {
+                            u32x4_t vv = {v[0], v[1], v[2], v[3]};
+                            *reinterpret_cast<u32x4_t*>(dst_vals + g0[u]) = vv;
+                        }
+                    }
+                    else if (real && ABLATE == 0)
+                    {
+                        // first line of the digit in this workgroup's range: the slots below owned_from belong to the
+                        // workgroup before (it writes them when it flushes its carry)
+#pragma unroll
+                        for (int e = 0; e < 4; e++)
+                            if (g0[u] + e >= owned[u])
+                            {
+                                dst_keys[g0[u] + e] = k[e];
+                                if (VALS) dst_vals[g0[u] + e] = v[e];
+                            }
+                    }
+                }
+            }
+        }
+        __syncthreads(); // the carried elements have been read: their slots may be rewritten
+        stamp(5);
+
+        // ---- new carry: the elements of every digit past its last full line move to the digit's carry slots
+        {
+            constexpr int ITEMS = RADIX * (int) (LINE / 4); // (digit, quad of slots)
+#pragma unroll
+            for (int it = 0; it < (ITEMS + THREADS - 1) / THREADS; it++)
+            {
+                const uint32_t item = it * THREADS + tid;
+                if (ITEMS % THREADS == 0 || item < (uint32_t) ITEMS)
+                {
+                    const uint32_t d = item / (LINE / 4), s0 = (item % (LINE / 4)) * 4;
+                    const uint2 t = s.tail[d];
+                    const uint32_t lo = t.y & 0xFFu, hi = t.y >> 8;
+                    KeyT k[4];
+                    uint32_t v[4];
+                    // slots below lo read the element of slot lo (a valid position), slots from hi up read past the run
+                    // (inside the buffer): neither is written
+#pragma unroll
+                    for (int e = 0; e < 4; e++) s.buf.get(t.x + (s0 + e > lo ? s0 + e : lo), k[e], v[e]);
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        if (s0 + e >= lo && s0 + e < hi) s.buf.put((uint32_t) TILE + d * LINE + s0 + e, k[e], v[e]);
+                }
+            }
+        }
+        for (int i = tid; i < WAVES * Smem::WCNT_STRIDE; i += THREADS) (&s.wcnt[0][0])[i] = 0;
+#pragma unroll
+        for (int i = 0; i < KPT; i++) key[i] = codec_in.encode(nkey[i]);
+        // a partial tile is never prefetched (it is the last tile of the array): guarded loads now
+        if (tile + 1 < last && !next_ok) load_tile_guarded(tile + 1);
+        stamp(6);
+        __syncthreads();
+        stamp(7);
+    }
+
+    // ---- what is still carried at the end of this workgroup's range: the (partial) last line of every digit
+    if (digit_owner) s.dinfo[sd] = make_uint4(carry_start, digit_base - carry_start, 0u, owned_from);
+    __syncthreads();
+    if (ABLATE < 4)
+    {
+        for (uint32_t e = tid; e < (uint32_t) Smem::CARRY; e += THREADS)
+        {
+            const uint32_t d = e / LINE, slot = e % LINE;
+            const uint4 info = s.dinfo[d];
+            const uint32_t g = info.x + slot;
+            if (slot < info.y && g >= info.w && (ABLATE == 0 || g < n))
+            {
+                KeyT k;
+                uint32_t v;
+                s.buf.get((uint32_t) TILE + e, k, v);
+                dst_keys[g] = codec_out.decode(k);
+                if (VALS) dst_vals[g] = v;
+            }
+        }
+    }
+    if (STAMPS && tid == 0 && stamps)
+    {
+#pragma unroll
+        for (int i = 0; i < 8; i++) atomicAdd(&stamps[i], acc[i]);
+    }
+}
+
+} // namespace glu_hip

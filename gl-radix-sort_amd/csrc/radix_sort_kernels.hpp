@@ -380,6 +380,9 @@ struct ScatterSmem
 //   VALS        false: keys-only sort, no value arrays, LDS arrays of keys alone;
 //   FUSED_SCAN  the prologue sums the raw count table itself (<= kFusedScanMaxBlocks workgroups, no row-scan launch);
 //   ABLATE      tuning builds: 1 = write every tile back linearly (prices the scattered stores; wrong results),
+//               2 = only a workgroup's first tile is loaded (prices the exposed load phase), 4 = no carry flush and no
+//               write-out (prices them), 5 = both (what rank + offsets + staging cost alone); all wrong results,
+//               2 = only the first tile of a workgroup is loaded (prices the exposed load phase; wrong results),
 //               3 = stagger the workgroups' start;  STAMPS: wave 0 adds the s_memtime cycles of each phase to stamps[0..7];
 //   ROUNDS > 1  tile = ROUNDS x the staging area (keys, values, ranks stay in registers across the staging rounds);
 //   PREFETCH    the next tile's loads are issued one pair per rank iteration;  DMA: tile loads as LDS-DMA into the idle
@@ -521,7 +524,8 @@ __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_ker
         {
             const uint32_t e = j * THREADS + tid;
             const uint32_t g = (lo[j] & ~(BLK - 1)) + (e % BLK);
-            const bool live = g >= lo[j] && g < hi[j] && (RADIX * BLK % THREADS == 0 || e < RADIX * BLK);
+            const bool live = g >= lo[j] && g < hi[j] && (RADIX * BLK % THREADS == 0 || e < RADIX * BLK) &&
+                              (ABLATE == 0 || g < n); // ablation builds scatter with made-up keys: stay inside the arrays
             if (live)
             {
                 dst_keys[g] = codec_out.decode(fk[j]);
@@ -605,7 +609,7 @@ __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_ker
         if (STAMPS) tprev = __builtin_amdgcn_s_memtime();
 
         // ---- load (PREFETCH: already issued while the previous tile was being ranked)
-        if (!PREFETCH) load_tile(tile);
+        if (!PREFETCH && ((ABLATE != 2 && ABLATE != 5) || tile == first)) load_tile(tile); // ABLATE 2 / 5: tile loads are free
         if (STAMPS)
         {
             stamp(0); // issue
@@ -747,7 +751,7 @@ __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_ker
             if (r == 0) stamp(5); // stage + barrier
             if (CARRY && r == 0)
             {
-                flush_carry(); // old carry out before the write-out below refills the slots
+                if (ABLATE < 4) flush_carry(); // old carry out before the write-out below refills the slots
                 __syncthreads();
             }
 
@@ -762,7 +766,7 @@ __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_ker
             // 5 registers per item and was 2 % (32-bit keys, 12 items) to 17 % (64-bit keys, 16 items) slower
             constexpr int WB = (GLU_WRITE_BATCH > 0 && WI % GLU_WRITE_BATCH == 0) ? GLU_WRITE_BATCH : WI;
 #pragma unroll
-            for (int b0 = 0; b0 < WI; b0 += WB)
+            for (int b0 = 0; b0 < (ABLATE >= 4 ? 0 : WI); b0 += WB) // ABLATE 4 / 5: no write-out at all (prices it)
             {
                 KeyT wk[WB];
                 uint32_t wv[WB], wg[WB], wlim[WB];
@@ -784,7 +788,7 @@ __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_ker
                     const bool to_carry = CARRY && wg[i] >= wlim[i];
                     uint32_t g = wg[i];
                     if (ABLATE == 1) g = (uint32_t) tile_base + p;
-                    if (valid && !to_carry)
+                    if (valid && !to_carry && (ABLATE == 0 || g < n))
                     {
                         dst_keys[g] = codec_out.decode(wk[i]);
                         if (has_vals) dst_vals[g] = wv[i];

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "radix_sort_kernels.hpp"
+#include "radix_scatter_lines.hpp"
 
 using namespace glu_hip;
 
@@ -178,7 +179,8 @@ void run_variant(Ctx& c, int blocks_per_cu, uint32_t shift, uint32_t mask_overri
     constexpr int TILE = THREADS * KPT;
     using Smem = ScatterSmem<uint32_t, BITS, THREADS, KPT, CARRY, ROUNDS, VALS>;
     const uint32_t tiles = (uint32_t) ((c.n + TILE - 1) / TILE);
-    const uint32_t nb = std::min<uint32_t>(tiles, (uint32_t) (c.cus * blocks_per_cu));
+    uint32_t nb = std::min<uint32_t>(tiles, (uint32_t) (c.cus * blocks_per_cu));
+    if (getenv("SB_NB")) nb = std::min<uint32_t>(tiles, (uint32_t) atoi(getenv("SB_NB"))); // fewer workgroups than CUs: per-CU vs chip limits
     uint32_t* totals = c.table + (size_t) RADIX * nb;
     const uint32_t mask = mask_override ? mask_override : RADIX - 1;
     if (mask_override) printf("mask %u: ", mask);
@@ -243,6 +245,58 @@ void run_variant(Ctx& c, int blocks_per_cu, uint32_t shift, uint32_t mask_overri
         for (int i = 0; i < 8; i++) printf(" %s %.0f", names[i], hst[i] * per_tile);
         printf("\n");
     }
+    fflush(stdout);
+}
+
+// the 128-byte-line scatter (radix_scatter_lines.hpp) behind the production count + row scan
+template<int BITS, int THREADS, int KPT, bool VALS = true, int ABLATE = 0>
+void run_lines(Ctx& c, uint32_t shift, uint32_t mask_override = 0)
+{
+    constexpr int RADIX = 1 << BITS;
+    constexpr int TILE = THREADS * KPT;
+    using Smem = LineSmem<uint32_t, BITS, THREADS, KPT, VALS>;
+    const uint32_t tiles = (uint32_t) ((c.n + TILE - 1) / TILE);
+    uint32_t nb = std::min<uint32_t>(tiles, (uint32_t) c.cus);
+    if (getenv("SB_NB")) nb = std::min<uint32_t>(tiles, (uint32_t) atoi(getenv("SB_NB")));
+    uint32_t* totals = c.table + (size_t) RADIX * nb;
+    const uint32_t mask = mask_override ? mask_override : RADIX - 1;
+    if (mask_override) printf("mask %u: ", mask);
+    auto scatter = radix_scatter_lines_kernel<uint32_t, BITS, THREADS, KPT, false, VALS, ABLATE, false>;
+    auto scatter_st = radix_scatter_lines_kernel<uint32_t, BITS, THREADS, KPT, false, VALS, ABLATE, true>;
+    CK(hipFuncSetAttribute((const void*) scatter_st, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sizeof(Smem)));
+    CK(hipFuncSetAttribute((const void*) scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sizeof(Smem)));
+    hipLaunchKernelGGL((radix_count_kernel<uint32_t, BITS, THREADS, TILE>), dim3(nb), dim3(THREADS), 0, 0, c.keys, c.table, (uint32_t) c.n, shift, mask,
+                       tiles, 0u);
+    hipLaunchKernelGGL((radix_row_scan_kernel<256>), dim3(RADIX), dim3(256), 0, 0, c.table, totals, nb);
+    CK(hipMemset(c.keys2, 0xff, c.n * 4));
+    CK(hipMemset(c.vals2, 0xff, c.n * 4));
+    float t_scatter = time_min(c, 5, [&] {
+        hipLaunchKernelGGL(scatter, dim3(nb), dim3(THREADS), sizeof(Smem), 0, c.keys, VALS ? c.vals : nullptr, c.keys2, VALS ? c.vals2 : nullptr,
+                           c.table, totals, (uint32_t) c.n, shift, mask, tiles, (unsigned long long*) nullptr, 0u, (PassPlan*) nullptr, 0u);
+    });
+    CK(hipGetLastError());
+    CK(hipDeviceSynchronize());
+    CK(hipMemset(c.bad, 0, 8));
+    hipLaunchKernelGGL(check_kernel, dim3(4096), dim3(256), 0, 0, c.keys2, c.vals2, c.keys, c.n, shift, mask, c.bad);
+    unsigned long long bad = 0;
+    CK(hipMemcpy(&bad, c.bad, 8, hipMemcpyDeviceToHost));
+    if (!VALS) bad = 0;
+    unsigned long long* st;
+    CK(hipMalloc(&st, 64));
+    CK(hipMemset(st, 0, 64));
+    hipLaunchKernelGGL(scatter_st, dim3(nb), dim3(THREADS), sizeof(Smem), 0, c.keys, VALS ? c.vals : nullptr, c.keys2, VALS ? c.vals2 : nullptr, c.table,
+                       totals, (uint32_t) c.n, shift, mask, tiles, st, 0u, (PassPlan*) nullptr, 0u);
+    unsigned long long hst[8];
+    CK(hipMemcpy(hst, st, 64, hipMemcpyDeviceToHost));
+    CK(hipFree(st));
+    if (!VALS) printf("keys-only ");
+    if (ABLATE) printf("ABLATE %d: ", ABLATE);
+    printf("lines bits %d threads %4d kpt %2d tile %5d lds %6zu nb %5u | scatter %.3f ms (%.0f GB/s) %s\n", BITS, THREADS, KPT, TILE, sizeof(Smem), nb,
+           t_scatter, c.n * (VALS ? 16.0 : 8.0) / t_scatter / 1e6, ABLATE ? "(ablated)" : bad ? "WRONG" : "ok");
+    const char* names[8] = {"top", "rank", "bar1", "scan", "stage", "lines", "tails", "bar_end"};
+    printf("    stamps/tile:");
+    for (int i = 0; i < 8; i++) printf(" %s %.0f", names[i], hst[i] / (double) tiles);
+    printf("\n");
     fflush(stdout);
 }
 
@@ -574,6 +628,39 @@ int main(int argc, char** argv)
         run_variant<8, 512, 12, true>(c, 2, shift);
         run_variant<8, 512, 12, true>(c, 1, shift);
         run_variant<8, 1024, 12, true>(c, 1, shift);
+        return 0;
+    }
+    if (getenv("SB_DIAG"))
+    { // what bounds the production scatter: linear write-back (ABLATE 1), fewer digit values, plain
+        run_variant<8, 1024, 12, true>(c, 1, shift);
+        run_variant<8, 1024, 12, true, 1>(c, 1, shift);
+        run_variant<8, 1024, 12, true>(c, 1, shift, 15u);
+        run_variant<8, 1024, 12, true>(c, 1, shift, 63u);
+        run_variant<8, 1024, 12, false>(c, 1, shift);
+        return 0;
+    }
+    if (getenv("SB_C32"))
+    { // 128-byte carry (build with -DGLU_CARRY_ELEMS=32): 64 KiB of carry, so smaller tiles
+        run_variant<8, 1024, 8, true>(c, 1, shift);
+        run_variant<8, 1024, 9, true>(c, 1, shift);
+        run_variant<8, 1024, 8, true>(c, 1, shift, 15u);
+        run_variant<8, 1024, 8, true, 0, 1, true>(c, 1, shift);
+        run_variant<8, 1024, 9, true, 0, 1, true>(c, 1, shift);
+        run_variant<8, 1024, 9, true, 2>(c, 1, shift);
+        run_variant<8, 1024, 9, true, 4>(c, 1, shift);
+        run_variant<8, 1024, 9, true, 5>(c, 1, shift);
+        return 0;
+    }
+    if (getenv("SB_LINES"))
+    {
+        run_lines<8, 1024, 9>(c, shift);
+        run_variant<8, 1024, 12, true>(c, 1, shift);
+        run_lines<8, 1024, 9>(c, shift);
+        run_lines<8, 1024, 8>(c, shift);
+        run_lines<8, 1024, 9, true, 4>(c, shift);
+        run_lines<8, 1024, 9>(c, shift, 15u);
+        run_lines<8, 1024, 9, false>(c, shift);
+        run_lines<4, 1024, 12>(c, shift);
         return 0;
     }
     if (getenv("SB_QUICK"))
