@@ -37,7 +37,8 @@ def parse_args():
     p.add_argument("--keys", default="uniform", choices=["uniform", "zero"],
                    help="uniform = headline; zero = the reference README's benchmark input")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-sample-log2", type=int, default=26)
+    p.add_argument("--cpu-sample-log2", type=int, default=None,
+                   help="time the CPU baseline on a generated 2^this sample instead of the GPU workload's own array")
     p.add_argument("--no-verify", action="store_true")
     p.add_argument("--no-kernel-events", action="store_true",
                    help="do not record per-kernel HIP events in the timed region (roofline fields become null)")
@@ -75,8 +76,10 @@ def verify_sorted(torch, keys0, out_k, out_v, vals_are_local_iota):
     return ok
 
 
-def cpu_baseline(sample_log2):
-    """std::sort of (key, val) structs by key on the host cores (oracle/cpu_sort_baseline.cpp), bounded sample."""
+def cpu_baseline(sample_log2, keys_host=None, vals_host=None):
+    """std::sort of (key, val) structs by key on the host cores (oracle/cpu_sort_baseline.cpp).  With keys_host /
+    vals_host (the GPU workload's own input array copied to the host) it sorts exactly that
+    array, once single-threaded and once per thread count; without them a generated 2^sample_log2 sample."""
     import numpy as np
 
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -94,10 +97,16 @@ def cpu_baseline(sample_log2):
         cores = min(cores, len(os.sched_getaffinity(0)))
     except Exception:
         pass
-    n = 1 << sample_log2
-    rng = np.random.default_rng(0x5EED)
-    keys = rng.integers(0, 2**32, n, dtype=np.uint32)
-    vals = np.arange(n, dtype=np.uint32)
+    if keys_host is not None:
+        keys, vals = keys_host, vals_host
+        n = int(keys.shape[0])
+        what = "the same array as the GPU workload (copied to the host), %d pairs = 2^%.2f" % (n, np.log2(n))
+    else:
+        n = 1 << sample_log2
+        rng = np.random.default_rng(0x5EED)
+        keys = rng.integers(0, 2**32, n, dtype=np.uint32)
+        vals = np.arange(n, dtype=np.uint32)
+        what = "a generated 2^%d sample (fallback: not the GPU workload's array)" % sample_log2
     k1, v1 = keys.copy(), vals.copy()
     t1 = L.glu_cpu_sort_pairs(k1.ctypes.data, v1.ctypes.data, n, 1)
     assert (k1[1:] >= k1[:-1]).all()
@@ -121,9 +130,9 @@ def cpu_baseline(sample_log2):
         pass
     return {
         "value": round(n / tp / 1e6, 2), "unit": "Mkeys/s", "cores": best_threads, "kind": "port",
-        "sample": "std::sort of 2^%d uniform uint32 key+val structs by key (__gnu_parallel::sort, best of %s threads; "
-                  "the host has %d hardware threads); same generator family as the GPU workload"
-                  % (sample_log2, "/".join(str(t) for t in sorted(tried)), cores),
+        "sample": "%s; std::sort of uint32 key+val structs by key, one run single-threaded and one run per thread count "
+                  "(__gnu_parallel::sort, best of %s threads reported; the host has %d hardware threads)"
+                  % (what, "/".join(str(t) for t in sorted(tried)), cores),
         "host_hardware_threads": cores,
         "all_thread_counts_Mkeys_s": {str(t): round(n / tried[t] / 1e6, 2) for t in sorted(tried)},
         "single_thread_value": round(n / t1 / 1e6, 2), "cpu_model": model,
@@ -254,7 +263,7 @@ def main():
         bytes_per_pair_moved = passes_per_sort * (3 * KEY_BYTES + 2 * VAL_BYTES)
         result.update({
             "roofline": {
-                "bound": "hbm", "kernel": "radix_scatter_kernel<u32,%d>" % bits,
+                "bound": "hbm", "kernel": "radix_scatter_lines_kernel<u32,%d>" % bits,
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4),
                 "traffic": traffic["hbm_bytes_per_launch"] if traffic else None,
@@ -279,31 +288,53 @@ def main():
             # the spread is the physical placement of each copy's arrays in HBM, not noise
             result["step_device_ms"] = {"min": round(step_ms[0], 4), "median": round(step_ms[len(step_ms) // 2], 4),
                                         "max": round(step_ms[-1], 4)}
-        # the same sort with the reference's pass structure (8 x 4-bit digits, 160 B/pair), a few untimed-region
-        # steps on restored inputs: reported next to the headline, not part of `value`
+        # the same sort with the reference's pass structure (8 x 4-bit digits, 160 B/pair), measured like the headline:
+        # warm-ups, then K timed steps on restored inputs (restores outside the per-step device timing), median + min.
+        # Reported next to the headline, not part of `value`.
         if bits != 4 and not args.no_alt:
             alt = G.RadixSort(digit_bits=4)
             alt.prepare_internal_buffers(n)
-            alt_steps = min(3, copies)
-            for i in range(alt_steps):
-                sets[i][0].copy_(keys0)
-                sets[i][1].copy_(vals0)
+            alt_warm, alt_steps = max(W, 3), max(K, 10)
+
+            def restore(i):
+                sets[i % copies][0].copy_(keys0)
+                sets[i % copies][1].copy_(vals0)
+
+            for i in range(alt_warm):
+                restore(i)
+                alt.run_ptr(sets[i % copies][0].data_ptr(), sets[i % copies][1].data_ptr(), n, 0, stream)
             barrier()
             alt.set_profiling(True)
-            ta = time.perf_counter()
+            alt_events = []
             for i in range(alt_steps):
-                alt.run_ptr(sets[i][0].data_ptr(), sets[i][1].data_ptr(), n, 0, stream)
+                restore(i)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(work_stream)
+                alt.run_ptr(sets[i % copies][0].data_ptr(), sets[i % copies][1].data_ptr(), n, 0, stream)
+                e1.record(work_stream)
+                alt_events.append((e0, e1))
             barrier()
-            ta = time.perf_counter() - ta
+            alt_ms = sorted(a.elapsed_time(b) for a, b in alt_events)
             ap = alt.read_profile()
+            alt.set_profiling(False)
+            alt_verified = None
+            if not args.no_verify:
+                k, v = sets[(alt_steps - 1) % copies]
+                alt_verified = verify_sorted(torch, keys0, k, v, True)
             a_scatter_ms = ap["scatter_ms"] / max(int(ap["passes"]), 1)
+            a_med, a_min = alt_ms[len(alt_ms) // 2], alt_ms[0]
             result["reference_pass_structure"] = {
-                "digit_bits": 4, "passes": int(ap["passes"]) // alt_steps, "steps": alt_steps,
-                "ms_per_step": round(ta / alt_steps * 1e3, 4), "value": round(n * alt_steps / ta / 1e6, 1), "unit": "Mkeys/s",
-                "achieved_GBps_at_160B_per_pair": round(n * alt_steps * 160 / ta / 1e9, 1),
-                "frac_of_peak_at_160B_per_pair": round(n * alt_steps * 160 / ta / 1e9 / HBM_PEAK_GBPS, 4),
+                "digit_bits": 4, "passes": int(ap["passes"]) // alt_steps, "steps": alt_steps, "warmup": alt_warm,
+                "ms_per_step": round(a_med, 4), "ms_per_step_min": round(a_min, 4), "timing": "device time per sort (HIP events), median and min",
+                "value": round(n / (a_med * 1e-3) / 1e6, 1), "unit": "Mkeys/s",
+                "achieved_GBps_at_160B_per_pair": round(n * 160 / (a_med * 1e-3) / 1e9, 1),
+                "frac_of_peak_at_160B_per_pair": round(n * 160 / (a_med * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                "frac_of_peak_at_160B_per_pair_best": round(n * 160 / (a_min * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                "scatter_kernel": "radix_scatter_lines_kernel<u32,4>",
                 "scatter_kernel_avg_ms": round(a_scatter_ms, 4),
                 "scatter_kernel_frac_of_peak": round(alg_bytes / (a_scatter_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if a_scatter_ms > 0 else None,
+                "count_kernel_avg_ms": round(ap["count_ms"] / max(int(ap["passes"]), 1), 4),
+                "verified": alt_verified,
             }
         workload = "2^%d uint32 key + uint32 val pairs, %s keys, vals=iota, in-place stable LSD radix sort, 1x MI355X" % (
             log2n, "uniform-random full-range" if args.keys == "uniform" else "all-zero")
@@ -344,7 +375,7 @@ def main():
         if launches and scatter_ms > 0:
             achieved = alg_bytes / (scatter_ms * 1e-3) / 1e9
             result["roofline"] = {
-                "bound": "hbm", "kernel": "radix_scatter_kernel<u32,%d> (rank 0)" % sorters[0].digit_bits,
+                "bound": "hbm", "kernel": "radix_scatter_lines_kernel<u32,%d> (rank 0)" % sorters[0].digit_bits,
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                 "traffic": None, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(scatter_ms, 4),
                 "launches_timed": launches,
@@ -409,7 +440,13 @@ def main():
         }
         line.update(result)
         if world == 1 and not args.force_dist and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.cpu_sample_log2)
+            if args.cpu_sample_log2 is None:
+                # the same input array as the GPU sorted, whole, one run per configuration
+                kh = keys0.cpu().numpy().view("uint32")
+                vh = vals0.cpu().numpy().view("uint32")
+                line["cpu_baseline"] = cpu_baseline(None, kh, vh)
+            else:
+                line["cpu_baseline"] = cpu_baseline(args.cpu_sample_log2)
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(line) + "\n").encode())
 

@@ -96,6 +96,21 @@ glu_status ensure_device()
     return GLU_OK;
 }
 
+// Every public entry point runs this first: the device is initialised once per process, and every host thread that
+// calls into the library gets that device as its current HIP device (a new thread's current device is 0, so without
+// this a second thread would allocate scratch on device 0 and launch on a stream of device k).
+thread_local int t_bound_device = -1;
+glu_status enter()
+{
+    GLU_TRY(ensure_device());
+    if (t_bound_device != g_dev.id)
+    {
+        HIP_TRY(hipSetDevice(g_dev.id));
+        t_bound_device = g_dev.id;
+    }
+    return GLU_OK;
+}
+
 inline hipStream_t pick_stream(void* stream) { return stream ? (hipStream_t) stream : g_dev.queue; }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -188,7 +203,7 @@ glu_status glu_set_device(int device)
 
 glu_status glu_device_info(char* out, size_t out_size)
 {
-    GLU_TRY(ensure_device());
+    GLU_TRY(enter());
     if (!out || out_size == 0) return fail(GLU_ERROR_INVALID_ARGUMENT, "out is NULL");
     snprintf(out, out_size, "%s (%s), %d CUs, %.1f GiB, device %d", g_dev.props.name, g_dev.props.gcnArchName,
              g_dev.num_cus, (double) g_dev.props.totalGlobalMem / (1024.0 * 1024.0 * 1024.0), g_dev.id);
@@ -197,14 +212,14 @@ glu_status glu_device_info(char* out, size_t out_size)
 
 glu_status glu_device_synchronize(void)
 {
-    GLU_TRY(ensure_device());
+    GLU_TRY(enter());
     HIP_TRY(hipStreamSynchronize(g_dev.queue));
     return GLU_OK;
 }
 
 glu_status glu_queue(void** stream)
 {
-    GLU_TRY(ensure_device());
+    GLU_TRY(enter());
     if (!stream) return fail(GLU_ERROR_INVALID_ARGUMENT, "stream is NULL");
     *stream = (void*) g_dev.queue;
     return GLU_OK;
@@ -215,7 +230,7 @@ glu_status glu_queue(void** stream)
 // ------------------------------------------------------------------------------------------------------------
 glu_status glu_buffer_create(size_t size, glu_buffer* out)
 {
-    GLU_TRY(ensure_device());
+    GLU_TRY(enter());
     if (!out) return fail(GLU_ERROR_INVALID_ARGUMENT, "out is NULL");
     Buffer b;
     b.size = size;
@@ -226,6 +241,7 @@ glu_status glu_buffer_create(size_t size, glu_buffer* out)
 
 glu_status glu_buffer_create_with_data(const void* data, size_t size, glu_buffer* out)
 {
+    GLU_TRY(enter());
     if (!data) return fail(GLU_ERROR_INVALID_ARGUMENT, "data is NULL");
     if (size == 0) return fail(GLU_ERROR_INVALID_ARGUMENT, "size is 0");
     GLU_TRY(glu_buffer_create(size, out));
@@ -234,7 +250,7 @@ glu_status glu_buffer_create_with_data(const void* data, size_t size, glu_buffer
 
 glu_status glu_buffer_wrap(void* device_ptr, size_t size, glu_buffer* out)
 {
-    GLU_TRY(ensure_device());
+    GLU_TRY(enter());
     if (!out) return fail(GLU_ERROR_INVALID_ARGUMENT, "out is NULL");
     if (!device_ptr && size > 0) return fail(GLU_ERROR_INVALID_ARGUMENT, "device_ptr is NULL");
     Buffer b;
@@ -247,6 +263,7 @@ glu_status glu_buffer_wrap(void* device_ptr, size_t size, glu_buffer* out)
 
 glu_status glu_buffer_destroy(glu_buffer buffer)
 {
+    GLU_TRY(enter());
     if (buffer == 0) return GLU_OK;
     Buffer b;
     {
@@ -267,6 +284,7 @@ glu_status glu_buffer_destroy(glu_buffer buffer)
 
 glu_status glu_buffer_size(glu_buffer buffer, size_t* size)
 {
+    GLU_TRY(enter());
     Buffer b;
     GLU_TRY(lookup(buffer, b, "buffer"));
     if (!size) return fail(GLU_ERROR_INVALID_ARGUMENT, "size is NULL");
@@ -276,6 +294,7 @@ glu_status glu_buffer_size(glu_buffer buffer, size_t* size)
 
 glu_status glu_buffer_device_ptr(glu_buffer buffer, void** device_ptr)
 {
+    GLU_TRY(enter());
     Buffer b;
     GLU_TRY(lookup(buffer, b, "buffer"));
     if (!device_ptr) return fail(GLU_ERROR_INVALID_ARGUMENT, "device_ptr is NULL");
@@ -285,6 +304,7 @@ glu_status glu_buffer_device_ptr(glu_buffer buffer, void** device_ptr)
 
 glu_status glu_buffer_write(glu_buffer buffer, const void* data, size_t size, size_t offset)
 {
+    GLU_TRY(enter());
     Buffer b;
     GLU_TRY(lookup(buffer, b, "buffer"));
     if (size == 0) return GLU_OK;
@@ -299,6 +319,7 @@ glu_status glu_buffer_write(glu_buffer buffer, const void* data, size_t size, si
 
 glu_status glu_buffer_read(glu_buffer buffer, void* data, size_t size, size_t offset)
 {
+    GLU_TRY(enter());
     Buffer b;
     GLU_TRY(lookup(buffer, b, "buffer"));
     if (size == 0) return GLU_OK;
@@ -312,6 +333,7 @@ glu_status glu_buffer_read(glu_buffer buffer, void* data, size_t size, size_t of
 
 glu_status glu_buffer_fill_u32(glu_buffer buffer, uint32_t value)
 {
+    GLU_TRY(enter());
     Buffer b;
     GLU_TRY(lookup(buffer, b, "buffer"));
     if (b.size / 4 > 0) HIP_TRY(hipMemsetD32Async((hipDeviceptr_t) b.ptr, (int) value, b.size / 4, g_dev.queue));
@@ -320,6 +342,7 @@ glu_status glu_buffer_fill_u32(glu_buffer buffer, uint32_t value)
 
 glu_status glu_buffer_copy(glu_buffer src, glu_buffer dst, size_t size, size_t src_offset, size_t dst_offset)
 {
+    GLU_TRY(enter());
     Buffer s, d;
     GLU_TRY(lookup(src, s, "source buffer"));
     GLU_TRY(lookup(dst, d, "destination buffer"));
@@ -725,7 +748,7 @@ extern "C" {
 
 glu_status glu_radix_sort_create(glu_radix_sort* out)
 {
-    GLU_TRY(ensure_device());
+    GLU_TRY(enter());
     if (!out) return fail(GLU_ERROR_INVALID_ARGUMENT, "out is NULL");
     glu_radix_sort_s* s = new glu_radix_sort_s();
     if (const char* e = getenv("GLU_HIP_DIGIT_BITS"))
@@ -750,6 +773,7 @@ glu_status glu_radix_sort_create(glu_radix_sort* out)
 
 glu_status glu_radix_sort_destroy(glu_radix_sort sort)
 {
+    GLU_TRY(enter());
     if (!sort) return GLU_OK;
     (void) hipStreamSynchronize(g_dev.queue);
     sort->keys.release();
@@ -763,12 +787,22 @@ glu_status glu_radix_sort_destroy(glu_radix_sort sort)
 
 glu_status glu_radix_sort_prepare(glu_radix_sort sort, size_t count)
 {
+    GLU_TRY(enter());
     if (!sort) return fail(GLU_ERROR_INVALID_ARGUMENT, "sort is NULL");
     return sort_prepare(sort, count, sizeof(uint32_t));
 }
 
+glu_status glu_radix_sort_prepare_ex(glu_radix_sort sort, size_t count, size_t key_bytes, int with_vals)
+{
+    GLU_TRY(enter());
+    if (!sort) return fail(GLU_ERROR_INVALID_ARGUMENT, "sort is NULL");
+    if (key_bytes != 4 && key_bytes != 8) return fail(GLU_ERROR_INVALID_ARGUMENT, "key_bytes must be 4 or 8 (got %zu)", key_bytes);
+    return sort_prepare(sort, count, key_bytes, with_vals != 0);
+}
+
 glu_status glu_radix_sort_prepare_u64(glu_radix_sort sort, size_t count)
 {
+    GLU_TRY(enter());
     if (!sort) return fail(GLU_ERROR_INVALID_ARGUMENT, "sort is NULL");
     return sort_prepare(sort, count, sizeof(uint64_t));
 }
@@ -776,7 +810,9 @@ glu_status glu_radix_sort_prepare_u64(glu_radix_sort sort, size_t count)
 glu_status glu_radix_sort_run_ptr(glu_radix_sort sort, uint32_t* keys, uint32_t* vals, size_t count, size_t num_steps,
                                   void* stream)
 {
+    GLU_TRY(enter());
     if (!sort) return fail(GLU_ERROR_INVALID_ARGUMENT, "sort is NULL");
+    if (count == 0) return GLU_OK; // an empty shard: nothing to sort, NULL arrays are fine (torch gives data_ptr() == 0)
     if (!keys) return fail(GLU_ERROR_INVALID_ARGUMENT, "Invalid key buffer");
     if (!vals) return fail(GLU_ERROR_INVALID_ARGUMENT, "Invalid value buffer");
     return sort_run<uint32_t>(sort, keys, vals, count, num_steps, pick_stream(stream));
@@ -785,7 +821,9 @@ glu_status glu_radix_sort_run_ptr(glu_radix_sort sort, uint32_t* keys, uint32_t*
 glu_status glu_radix_sort_run_u64_ptr(glu_radix_sort sort, uint64_t* keys, uint32_t* vals, size_t count,
                                       size_t num_steps, void* stream)
 {
+    GLU_TRY(enter());
     if (!sort) return fail(GLU_ERROR_INVALID_ARGUMENT, "sort is NULL");
+    if (count == 0) return GLU_OK;
     if (!keys) return fail(GLU_ERROR_INVALID_ARGUMENT, "Invalid key buffer");
     if (!vals) return fail(GLU_ERROR_INVALID_ARGUMENT, "Invalid value buffer");
     return sort_run<uint64_t>(sort, keys, vals, count, num_steps, pick_stream(stream));
@@ -794,6 +832,7 @@ glu_status glu_radix_sort_run_u64_ptr(glu_radix_sort sort, uint64_t* keys, uint3
 glu_status glu_radix_sort_run(glu_radix_sort sort, glu_buffer key_buffer, glu_buffer val_buffer, size_t count,
                               size_t num_steps)
 {
+    GLU_TRY(enter());
     if (!sort) return fail(GLU_ERROR_INVALID_ARGUMENT, "sort is NULL");
     Buffer k, v;
     GLU_TRY(lookup(key_buffer, k, "key buffer"));   // RadixSort.hpp:275
@@ -806,6 +845,7 @@ glu_status glu_radix_sort_run(glu_radix_sort sort, glu_buffer key_buffer, glu_bu
 glu_status glu_radix_sort_run_u64(glu_radix_sort sort, glu_buffer key_buffer, glu_buffer val_buffer, size_t count,
                                   size_t num_steps)
 {
+    GLU_TRY(enter());
     if (!sort) return fail(GLU_ERROR_INVALID_ARGUMENT, "sort is NULL");
     Buffer k, v;
     GLU_TRY(lookup(key_buffer, k, "key buffer"));
@@ -817,6 +857,7 @@ glu_status glu_radix_sort_run_u64(glu_radix_sort sort, glu_buffer key_buffer, gl
 
 glu_status glu_radix_sort_run_keys_ptr(glu_radix_sort sort, uint32_t* keys, size_t count, size_t num_steps, void* stream)
 {
+    GLU_TRY(enter());
     if (!sort) return fail(GLU_ERROR_INVALID_ARGUMENT, "sort is NULL");
     if (!keys) return fail(GLU_ERROR_INVALID_ARGUMENT, "Invalid key buffer");
     return sort_run<uint32_t>(sort, keys, nullptr, count, num_steps, pick_stream(stream));
@@ -824,6 +865,7 @@ glu_status glu_radix_sort_run_keys_ptr(glu_radix_sort sort, uint32_t* keys, size
 
 glu_status glu_radix_sort_run_keys_u64_ptr(glu_radix_sort sort, uint64_t* keys, size_t count, size_t num_steps, void* stream)
 {
+    GLU_TRY(enter());
     if (!sort) return fail(GLU_ERROR_INVALID_ARGUMENT, "sort is NULL");
     if (!keys) return fail(GLU_ERROR_INVALID_ARGUMENT, "Invalid key buffer");
     return sort_run<uint64_t>(sort, keys, nullptr, count, num_steps, pick_stream(stream));
@@ -832,6 +874,7 @@ glu_status glu_radix_sort_run_keys_u64_ptr(glu_radix_sort sort, uint64_t* keys, 
 glu_status glu_radix_sort_run_typed_ptr(glu_radix_sort sort, void* keys, uint32_t* vals, size_t count, glu_key_type key_type,
                                         void* stream)
 {
+    GLU_TRY(enter());
     if (!sort) return fail(GLU_ERROR_INVALID_ARGUMENT, "sort is NULL");
     if (!keys) return fail(GLU_ERROR_INVALID_ARGUMENT, "Invalid key buffer");
     hipStream_t st = pick_stream(stream);
@@ -850,6 +893,7 @@ glu_status glu_radix_sort_run_typed_ptr(glu_radix_sort sort, void* keys, uint32_
 glu_status glu_radix_sort_run_bit_range_ptr(glu_radix_sort sort, void* keys, uint32_t* vals, size_t count, uint32_t key_bits,
                                             uint32_t begin_bit, uint32_t end_bit, void* stream)
 {
+    GLU_TRY(enter());
     if (!sort) return fail(GLU_ERROR_INVALID_ARGUMENT, "sort is NULL");
     if (!keys) return fail(GLU_ERROR_INVALID_ARGUMENT, "Invalid key buffer");
     if (key_bits != 32 && key_bits != 64) return fail(GLU_ERROR_INVALID_ARGUMENT, "key_bits must be 32 or 64 (got %u)", key_bits);
@@ -862,6 +906,7 @@ glu_status glu_radix_sort_run_bit_range_ptr(glu_radix_sort sort, void* keys, uin
 
 glu_status glu_radix_sort_run_keys(glu_radix_sort sort, glu_buffer key_buffer, size_t count, size_t num_steps)
 {
+    GLU_TRY(enter());
     if (!sort) return fail(GLU_ERROR_INVALID_ARGUMENT, "sort is NULL");
     Buffer k;
     GLU_TRY(lookup(key_buffer, k, "key buffer"));
@@ -874,10 +919,14 @@ glu_status glu_radix_sort_partition_ptr(glu_radix_sort sort, const uint32_t* src
                                         uint32_t* dst_keys, uint32_t* dst_vals, size_t count, uint32_t shift,
                                         uint32_t bits, uint32_t* digit_histogram, void* stream)
 {
+    GLU_TRY(enter());
     if (!sort) return fail(GLU_ERROR_INVALID_ARGUMENT, "sort is NULL");
-    if (!src_keys || !src_vals || !dst_keys || !dst_vals) return fail(GLU_ERROR_INVALID_ARGUMENT, "NULL array");
-    if (src_keys == dst_keys || src_vals == dst_vals)
-        return fail(GLU_ERROR_INVALID_ARGUMENT, "partition needs distinct source and destination");
+    if (count > 0)
+    {
+        if (!src_keys || !src_vals || !dst_keys || !dst_vals) return fail(GLU_ERROR_INVALID_ARGUMENT, "NULL array");
+        if (src_keys == dst_keys || src_vals == dst_vals)
+            return fail(GLU_ERROR_INVALID_ARGUMENT, "partition needs distinct source and destination");
+    }
     if (bits < 1 || bits > 8 || shift + bits > 32) return fail(GLU_ERROR_INVALID_ARGUMENT, "bad digit: shift %u bits %u", shift, bits);
     if (count > 0xFFFF0000ull) return fail(GLU_ERROR_INVALID_ARGUMENT, "count %zu does not fit 32-bit indexing", count);
     hipStream_t st = pick_stream(stream);
@@ -894,6 +943,7 @@ glu_status glu_radix_sort_partition_ptr(glu_radix_sort sort, const uint32_t* src
 
 glu_status glu_radix_sort_set_digit_bits(glu_radix_sort sort, uint32_t bits)
 {
+    GLU_TRY(enter());
     if (!sort) return fail(GLU_ERROR_INVALID_ARGUMENT, "sort is NULL");
     if (bits != 4 && bits != 8) return fail(GLU_ERROR_INVALID_ARGUMENT, "digit bits must be 4 or 8 (got %u)", bits);
     sort->digit_bits = bits;
@@ -902,6 +952,7 @@ glu_status glu_radix_sort_set_digit_bits(glu_radix_sort sort, uint32_t bits)
 
 glu_status glu_radix_sort_get_digit_bits(glu_radix_sort sort, uint32_t* bits)
 {
+    GLU_TRY(enter());
     if (!sort || !bits) return fail(GLU_ERROR_INVALID_ARGUMENT, "NULL argument");
     *bits = sort->digit_bits;
     return GLU_OK;
@@ -909,6 +960,7 @@ glu_status glu_radix_sort_get_digit_bits(glu_radix_sort sort, uint32_t* bits)
 
 glu_status glu_radix_sort_set_profiling(glu_radix_sort sort, int enable)
 {
+    GLU_TRY(enter());
     if (!sort) return fail(GLU_ERROR_INVALID_ARGUMENT, "sort is NULL");
     sort->profiling = enable != 0;
     if (!enable) sort->events_used = 0;
@@ -918,6 +970,7 @@ glu_status glu_radix_sort_set_profiling(glu_radix_sort sort, int enable)
 glu_status glu_radix_sort_read_profile(glu_radix_sort sort, double* count_ms, double* scan_ms, double* scatter_ms,
                                        uint64_t* passes)
 {
+    GLU_TRY(enter());
     if (!sort) return fail(GLU_ERROR_INVALID_ARGUMENT, "sort is NULL");
     double acc[3] = {0, 0, 0};
     const size_t n = sort->events_used / 4;
@@ -939,6 +992,7 @@ glu_status glu_radix_sort_read_profile(glu_radix_sort sort, double* count_ms, do
 
 glu_status glu_radix_sort_scratch_size(glu_radix_sort sort, size_t* bytes)
 {
+    GLU_TRY(enter());
     if (!sort || !bytes) return fail(GLU_ERROR_INVALID_ARGUMENT, "NULL argument");
     *bytes = sort->keys.size + sort->vals.size + sort->table.size;
     return GLU_OK;
@@ -1186,7 +1240,7 @@ extern "C" {
 
 glu_status glu_scan_create(glu_data_type data_type, glu_scan* out)
 {
-    GLU_TRY(ensure_device());
+    GLU_TRY(enter());
     if (!out) return fail(GLU_ERROR_INVALID_ARGUMENT, "out is NULL");
     if ((int) data_type < 0 || data_type >= GLU_DATA_TYPE_COUNT_)
         return fail(GLU_ERROR_INVALID_ARGUMENT, "Invalid data type: %d", (int) data_type);
@@ -1203,6 +1257,7 @@ glu_status glu_scan_create(glu_data_type data_type, glu_scan* out)
 
 glu_status glu_scan_destroy(glu_scan scan)
 {
+    GLU_TRY(enter());
     if (!scan) return GLU_OK;
     (void) hipStreamSynchronize(g_dev.queue);
     scan->sums.release();
@@ -1214,6 +1269,7 @@ glu_status glu_scan_destroy(glu_scan scan)
 
 glu_status glu_scan_prepare(glu_scan scan, size_t count, size_t num_partitions)
 {
+    GLU_TRY(enter());
     if (!scan) return fail(GLU_ERROR_INVALID_ARGUMENT, "scan is NULL");
     if (count == 0 || num_partitions == 0) return GLU_OK;
     ScanRunner r{scan, nullptr, count, num_partitions, nullptr, true};
@@ -1222,6 +1278,7 @@ glu_status glu_scan_prepare(glu_scan scan, size_t count, size_t num_partitions)
 
 glu_status glu_scan_run_ptr(glu_scan scan, void* data, size_t count, size_t num_partitions, void* stream)
 {
+    GLU_TRY(enter());
     if (!scan) return fail(GLU_ERROR_INVALID_ARGUMENT, "scan is NULL");
     if (!data) return fail(GLU_ERROR_INVALID_ARGUMENT, "Invalid buffer");
     if (count == 0) return fail(GLU_ERROR_INVALID_ARGUMENT, "Count must be greater than zero");
@@ -1234,6 +1291,7 @@ glu_status glu_scan_run_ptr(glu_scan scan, void* data, size_t count, size_t num_
 
 glu_status glu_scan_run(glu_scan scan, glu_buffer buffer, size_t count, size_t num_partitions)
 {
+    GLU_TRY(enter());
     if (!scan) return fail(GLU_ERROR_INVALID_ARGUMENT, "scan is NULL");
     Buffer b;
     GLU_TRY(lookup(buffer, b, "buffer"));                                                         // BlellochScan.hpp:132
@@ -1248,7 +1306,7 @@ glu_status glu_scan_run(glu_scan scan, glu_buffer buffer, size_t count, size_t n
 
 glu_status glu_reduce_create(glu_data_type data_type, glu_reduce_operator op, glu_reduce* out)
 {
-    GLU_TRY(ensure_device());
+    GLU_TRY(enter());
     if (!out) return fail(GLU_ERROR_INVALID_ARGUMENT, "out is NULL");
     if ((int) data_type < 0 || data_type >= GLU_DATA_TYPE_COUNT_)
         return fail(GLU_ERROR_INVALID_ARGUMENT, "Invalid data type: %d", (int) data_type);
@@ -1269,6 +1327,7 @@ glu_status glu_reduce_create(glu_data_type data_type, glu_reduce_operator op, gl
 
 glu_status glu_reduce_destroy(glu_reduce reduce)
 {
+    GLU_TRY(enter());
     if (!reduce) return GLU_OK;
     (void) hipStreamSynchronize(g_dev.queue);
     reduce->partials.release();
@@ -1278,6 +1337,7 @@ glu_status glu_reduce_destroy(glu_reduce reduce)
 
 glu_status glu_reduce_run_ptr(glu_reduce reduce, void* data, size_t count, void* stream)
 {
+    GLU_TRY(enter());
     if (!reduce) return fail(GLU_ERROR_INVALID_ARGUMENT, "reduce is NULL");
     if (!data) return fail(GLU_ERROR_INVALID_ARGUMENT, "Invalid buffer");
     if (count == 0) return fail(GLU_ERROR_INVALID_ARGUMENT, "Count must be greater than zero");
@@ -1289,6 +1349,7 @@ glu_status glu_reduce_run_ptr(glu_reduce reduce, void* data, size_t count, void*
 
 glu_status glu_reduce_run(glu_reduce reduce, glu_buffer buffer, size_t count)
 {
+    GLU_TRY(enter());
     if (!reduce) return fail(GLU_ERROR_INVALID_ARGUMENT, "reduce is NULL");
     Buffer b;
     GLU_TRY(lookup(buffer, b, "buffer"));                                                      // Reduce.hpp:113
@@ -1312,7 +1373,7 @@ extern "C" {
 
 glu_status glu_timer_begin(glu_timer* out)
 {
-    GLU_TRY(ensure_device());
+    GLU_TRY(enter());
     if (!out) return fail(GLU_ERROR_INVALID_ARGUMENT, "out is NULL");
     glu_timer_s* t = new glu_timer_s();
     if (hipEventCreate(&t->start) != hipSuccess || hipEventCreate(&t->stop) != hipSuccess)
@@ -1327,6 +1388,7 @@ glu_status glu_timer_begin(glu_timer* out)
 
 glu_status glu_timer_end(glu_timer timer, uint64_t* elapsed_ns)
 {
+    GLU_TRY(enter());
     if (!timer) return fail(GLU_ERROR_INVALID_ARGUMENT, "timer is NULL");
     HIP_TRY(hipEventRecord(timer->stop, g_dev.queue));
     HIP_TRY(hipEventSynchronize(timer->stop));

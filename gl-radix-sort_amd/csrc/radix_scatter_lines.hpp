@@ -394,10 +394,11 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
             }
         }
     }
-    if (STAMPS && tid == 0 && stamps)
+    if (STAMPS && lane == 0 && (wave == 0 || wave == WAVES - 1) && stamps)
     {
+        // first and last wave of the workgroup: between them they show what a phase costs and what the barrier hides
 #pragma unroll
-        for (int i = 0; i < 8; i++) atomicAdd(&stamps[i], acc[i]);
+        for (int i = 0; i < 8; i++) atomicAdd(&stamps[(wave == 0 ? 0 : 8) + i], acc[i]);
     }
 }
 

@@ -81,6 +81,11 @@ namespace glu
             GLU_CHECK_STATUS(glu_radix_sort_run_u64(m_impl, key_buffer, val_buffer, count, num_steps));
         }
         void prepare_internal_buffers_u64(size_t count) { GLU_CHECK_STATUS(glu_radix_sort_prepare_u64(m_impl, count)); }
+        /// Scratch for any entry point: key_bytes 4 or 8, with_vals false for the keys-only sorts.
+        void prepare_internal_buffers(size_t count, size_t key_bytes, bool with_vals)
+        {
+            GLU_CHECK_STATUS(glu_radix_sort_prepare_ex(m_impl, count, key_bytes, with_vals ? 1 : 0));
+        }
 
         /// Bits per counting pass: 4 = the reference's pass structure (8 passes), 8 = 4 passes; same output.
         void set_digit_bits(uint32_t bits) { GLU_CHECK_STATUS(glu_radix_sort_set_digit_bits(m_impl, bits)); }

@@ -50,6 +50,7 @@ SYMBOLS = [
     ("glu_radix_sort_destroy", _int, [_vp]),
     ("glu_radix_sort_prepare", _int, [_vp, _sz]),
     ("glu_radix_sort_prepare_u64", _int, [_vp, _sz]),
+    ("glu_radix_sort_prepare_ex", _int, [_vp, _sz, _sz, _int]),
     ("glu_radix_sort_run", _int, [_vp, _u32, _u32, _sz, _sz]),
     ("glu_radix_sort_run_ptr", _int, [_vp, _vp, _vp, _sz, _sz, _vp]),
     ("glu_radix_sort_run_u64", _int, [_vp, _u32, _u32, _sz, _sz]),
@@ -223,9 +224,10 @@ class RadixSort:
         check(lib().glu_radix_sort_get_digit_bits(self._h, ctypes.byref(b)))
         return b.value
 
-    def prepare_internal_buffers(self, count, key_bytes=4):
-        fn = lib().glu_radix_sort_prepare if key_bytes == 4 else lib().glu_radix_sort_prepare_u64
-        check(fn(self._h, count))
+    def prepare_internal_buffers(self, count, key_bytes=4, with_vals=True):
+        """Grow-only scratch for `count` elements (RadixSort.hpp:237-271); key_bytes 4 or 8, with_vals False for
+        keys-only sorts.  After it the matching run call allocates nothing."""
+        check(lib().glu_radix_sort_prepare_ex(self._h, count, key_bytes, 1 if with_vals else 0))
 
     def scratch_size(self):
         s = _sz(0)

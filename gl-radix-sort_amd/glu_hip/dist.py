@@ -89,10 +89,15 @@ class HipLocalOps:
     def partition(self, keys, vals, out_keys, out_vals, hist):
         """Stable partition by (key >> 24); hist: int32[256] device tensor."""
         n = keys.numel()
+        if n == 0:  # an empty local slice: torch hands out data_ptr() == 0, nothing to partition
+            hist.zero_()
+            return
         self.sorter.partition_ptr(keys.data_ptr(), vals.data_ptr(), out_keys.data_ptr(), out_vals.data_ptr(), n,
                                   32 - TOP_BITS, TOP_BITS, hist.data_ptr(), self._stream())
 
     def sort(self, keys, vals, count):
+        if count == 0:  # a rank that owns no bucket with elements (skewed keys) receives nothing
+            return
         self.sorter.run_ptr(keys.data_ptr(), vals.data_ptr(), count, 0, self._stream())
 
 

@@ -22,7 +22,9 @@
  *   - no function allocates device memory inside a sort/scan/reduce call once the matching
  *     *_prepare() has been called with a count at least as large (glu/RadixSort.hpp:237-271:
  *     grow-only scratch).
- *   - not thread-safe per handle; distinct handles may be used from distinct threads.
+ *   - not thread-safe per handle; distinct handles may be used from distinct host threads (every entry point makes the
+ *     library's device the calling thread's current HIP device; per-kernel one-time setup is guarded).  The
+ *     *_ptr entry points accept NULL arrays when count == 0 (an empty shard).
  */
 #ifndef GLU_HIP_H
 #define GLU_HIP_H
@@ -134,6 +136,12 @@ GLU_API glu_status glu_radix_sort_destroy(glu_radix_sort sort);
 GLU_API glu_status glu_radix_sort_prepare(glu_radix_sort sort, size_t count);
 /* Same for 64-bit keys (BASELINE.json config 5). */
 GLU_API glu_status glu_radix_sort_prepare_u64(glu_radix_sort sort, size_t count);
+/* The general form (RadixSort.hpp:237-271 knows one key type only): scratch for `count` elements of `key_bytes`-byte
+ * keys (4 or 8), with or without a value array.  After it, the matching run entry point (run / run_u64 / run_keys* /
+ * run_typed / run_bit_range with that key width) allocates nothing for counts up to `count`.  A run of a wider key type
+ * than prepared for still works but grows the scratch inside the call (hipFree + hipMalloc: a device-wide
+ * synchronisation, and not capturable into a graph). */
+GLU_API glu_status glu_radix_sort_prepare_ex(glu_radix_sort sort, size_t count, size_t key_bytes, int with_vals);
 /* RadixSort::operator()(key_buffer, val_buffer, count, num_steps)   (RadixSort.hpp:273-334).
  * Stable ascending sort of `count` (uint32 key, uint32 val) pairs by the low 4*num_steps key bits
  * (num_steps == 0 or > 8: all 32 bits).  count <= 1 returns immediately (:278).  count must be < 2^32.

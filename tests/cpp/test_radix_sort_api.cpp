@@ -4,6 +4,8 @@
 #include <algorithm>
 #include <cinttypes>
 #include <numeric>
+#include <random>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -255,6 +257,48 @@ TEST_CASE("RadixSort-raw-pointer-overload")
     bool paired = true;
     for (size_t i = 0; i < n; i++) paired = paired && keys[sv[i]] == sk[i];
     CHECK(paired);
+}
+
+TEST_CASE("RadixSort-two-host-threads")
+{
+    // glu_hip.h: distinct handles may be used from distinct host threads.  Two threads, each with its own sorter and
+    // buffers, start together (the first launch of a kernel instantiation does its one-time setup under both) and
+    // sort inputs large enough for the large-tile kernels and small enough for the single-workgroup kernel.
+    struct Job
+    {
+        size_t n;
+        uint32_t seed;
+        bool ok = false;
+    };
+    std::vector<Job> jobs = {{4200003, 1}, {4200003, 2}, {9001, 3}, {9001, 4}};
+    auto work = [](Job* job) {
+        std::mt19937 gen(job->seed);
+        std::vector<GLuint> keys(job->n), vals(job->n);
+        for (auto& k : keys) k = gen();
+        std::iota(vals.begin(), vals.end(), 0u);
+        std::vector<GLuint> order(vals);
+        std::stable_sort(order.begin(), order.end(), [&](GLuint a, GLuint b) { return keys[a] < keys[b]; });
+        ShaderStorageBuffer kb(keys), vb(vals);
+        RadixSort radix_sort;
+        bool same = true;
+        for (int round = 0; round < 3; round++) // the same objects again: scratch reuse from this thread
+        {
+            kb.write_data(keys.data(), job->n * sizeof(GLuint));
+            vb.write_data(vals.data(), job->n * sizeof(GLuint));
+            radix_sort(kb.handle(), vb.handle(), job->n);
+            std::vector<GLuint> out_keys = kb.get_data<GLuint>(), out_vals = vb.get_data<GLuint>();
+            for (size_t i = 0; i < job->n; i++) same = same && out_vals[i] == order[i] && out_keys[i] == keys[order[i]];
+        }
+        job->ok = same;
+    };
+    for (size_t pair = 0; pair < jobs.size(); pair += 2)
+    {
+        std::thread a(work, &jobs[pair]), b(work, &jobs[pair + 1]);
+        a.join();
+        b.join();
+        CHECK(jobs[pair].ok);
+        CHECK(jobs[pair + 1].ok);
+    }
 }
 
 int main(int argc, char** argv) { return mini_test::run(argc, argv); }

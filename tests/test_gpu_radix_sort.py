@@ -119,6 +119,121 @@ def test_key_distributions_large_tile_geometry(G, bits, kind):
     assert (gk == ek).all() and (gv == ev).all()
 
 
+@pytest.mark.parametrize("bits", DIGIT_BITS)
+@pytest.mark.parametrize("kind", ["uniform", "one_per_tile", "sparse_digits", "sawtooth", "two_values", "all_equal_no_plan"])
+def test_line_kernel_carry_cases(G, bits, kind, monkeypatch):
+    """The 128-byte-line scatter (radix_scatter_lines.hpp) keeps up to 31 elements per digit in LDS between tiles:
+    digits that get a handful of elements per tile (a carry that lives across many tiles without completing a line),
+    digits that get whole tiles, runs that end exactly on line boundaries, a partial last tile, and workgroup range
+    boundaries inside a line (n is not a multiple of anything)."""
+    n = 256 * 9216 * 2 + 4321
+    rng = np.random.default_rng(41)
+    if kind == "uniform":
+        keys = rng.integers(0, 2**32, n, dtype=np.uint32)
+    elif kind == "one_per_tile":
+        # almost everything in one digit value, every other value about once per tile
+        keys = np.full(n, 0x55555555, dtype=np.uint32)
+        idx = rng.integers(0, n, n // 40)
+        keys[idx] = rng.integers(0, 2**32, idx.size, dtype=np.uint32)
+    elif kind == "sparse_digits":
+        keys = (rng.integers(0, 5, n, dtype=np.uint32) * np.uint32(0x33333333)) ^ (rng.integers(0, 2, n, dtype=np.uint32) << 31)
+    elif kind == "sawtooth":
+        keys = (np.arange(n, dtype=np.uint64) * 32 % (1 << 32)).astype(np.uint32)  # runs of exactly one line per digit
+    elif kind == "two_values":
+        keys = np.where(rng.integers(0, 2, n) == 0, 0x80000000, 0x7FFFFFFF).astype(np.uint32)
+    else:
+        monkeypatch.setenv("GLU_HIP_SORT_NO_PLAN", "1")  # constant digits must go through the scatter, not be skipped
+        keys = np.full(n, 0xDEADBEEF, dtype=np.uint32)
+    vals = np.arange(n, dtype=np.uint32)
+    gk, gv = gpu_sort(G, keys, vals, bits=bits)
+    ek, ev = O.stable_sort_pairs(keys, vals)
+    assert (gk == ek).all() and (gv == ev).all()
+
+
+@pytest.mark.parametrize("blocks", [1, 2, 7, 100, 255])
+def test_line_kernel_with_fewer_workgroups(G, blocks, monkeypatch):
+    """GLU_HIP_SORT_BLOCKS caps the grid: other range boundaries (first / last partial lines of a range), many tiles per
+    workgroup, a single workgroup that owns everything."""
+    monkeypatch.setenv("GLU_HIP_SORT_BLOCKS", str(blocks))
+    n = 256 * 9216 * 3 // 2 + 777
+    rng = np.random.default_rng(blocks)
+    keys = rng.integers(0, 2**32, n, dtype=np.uint32)
+    keys[::5] &= np.uint32(0xFF00FFFF)
+    vals = np.arange(n, dtype=np.uint32)
+    gk, gv = gpu_sort(G, keys, vals)
+    ek, ev = O.stable_sort_pairs(keys, vals)
+    assert (gk == ek).all() and (gv == ev).all()
+
+
+def test_line_kernel_needs_aligned_arrays_and_falls_back(G):
+    """Whole-line stores need 16-byte aligned arrays; a sub-range that starts 4 bytes into an allocation takes the other
+    kernel (same result), and GLU_HIP_SORT_NO_LINES=1 gives the same output as the default."""
+    torch = pytest.importorskip("torch")
+    n = 256 * 12288 * 2 + 5
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    keys = torch.randint(-2**31, 2**31, (n + 4,), dtype=torch.int32, device="cuda", generator=g)
+    vals = torch.arange(n + 4, dtype=torch.int32, device="cuda")
+    expect = {}
+    for off in (0, 1, 3):
+        k, v = keys.clone(), vals.clone()
+        ks, vs = k[off:off + n], v[off:off + n]
+        src = keys[off:off + n].clone()
+        G.RadixSort().run_ptr(ks.data_ptr(), vs.data_ptr(), n, 0, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        flipped = ks ^ (-2**31)
+        assert bool((flipped[1:] >= flipped[:-1]).all())
+        idx = (vs.to(torch.int64) & 0xFFFFFFFF) - off
+        assert bool((src[idx] == ks).all())
+        eq = ks[1:] == ks[:-1]
+        assert bool((idx[1:][eq] > idx[:-1][eq]).all())  # stable
+        # untouched neighbours
+        assert bool((k[:off] == keys[:off]).all()) and bool((k[off + n:] == keys[off + n:]).all())
+        expect[off] = ks.clone()
+    os.environ["GLU_HIP_SORT_NO_LINES"] = "1"
+    try:
+        k, v = keys.clone(), vals.clone()
+        G.RadixSort().run_ptr(k.data_ptr(), v.data_ptr(), n, 0, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert bool((k[:n] == expect[0]).all())
+    finally:
+        del os.environ["GLU_HIP_SORT_NO_LINES"]
+
+
+def test_prepare_ex_covers_every_entry_point(G):
+    """glu_radix_sort_prepare_ex(count, key_bytes, with_vals): after it the matching run allocates nothing."""
+    n = 300000
+    rng = np.random.default_rng(9)
+    s64 = G.RadixSort()
+    s64.prepare_internal_buffers(n, key_bytes=8)
+    size0 = s64.scratch_size()
+    assert size0 >= n * 12
+    keys = rng.integers(0, 2**64, n, dtype=np.uint64)
+    vals = np.arange(n, dtype=np.uint32)
+    kb, vb = G.ShaderStorageBuffer(keys), G.ShaderStorageBuffer(vals)
+    s64(kb, vb, n, key_bytes=8)
+    order = np.argsort(keys, kind="stable")
+    assert (kb.get_data(np.uint64) == keys[order]).all() and (vb.get_data(np.uint32) == vals[order]).all()
+    assert s64.scratch_size() == size0
+    sk = G.RadixSort()
+    sk.prepare_internal_buffers(n, key_bytes=4, with_vals=False)
+    size1 = sk.scratch_size()
+    k32 = rng.integers(0, 2**32, n, dtype=np.uint32)
+    kb = G.ShaderStorageBuffer(k32)
+    sk.sort_keys(kb, n)
+    assert (kb.get_data(np.uint32) == np.sort(k32)).all()
+    assert sk.scratch_size() == size1 and size1 < n * 8
+
+
+def test_pointer_entry_points_accept_empty_inputs(G):
+    """An empty shard (torch gives data_ptr() == 0 for an empty tensor): count 0 with NULL arrays is not an error."""
+    s = G.RadixSort()
+    s.run_ptr(0, 0, 0)
+    s.run_ptr(0, 0, 0, key_bytes=8)
+    with pytest.raises(G.GluError):
+        s.run_ptr(0, 0, 5)
+
+
 def test_small_geometry_forced_matches(G, monkeypatch):
     """GLU_HIP_SORT_SMALL=1 forces the 256-thread kernels at any size; both geometries give identical output."""
     n = 4 * (1 << 20) + 99
@@ -549,11 +664,13 @@ def test_bit_range_argument_checks(G):
             sorter.sort_bit_range_ptr(kb.device_ptr(), None, 64, begin, end, None, kbytes)
 
 
-@pytest.mark.parametrize("mode,threshold", [("pairs", 256 * 12288 * 3 // 2), ("keys", 256 * 20480 * 3 // 2), ("u64", 256 * 8192 * 3 // 2)])
+@pytest.mark.parametrize("mode,threshold", [("pairs", 256 * 9216 * 3 // 2), ("keys", 256 * 16384 * 3 // 2), ("u64", 256 * 8192 * 3 // 2),
+                                            ("pairs", 256 * 12288 * 3 // 2)])
 @pytest.mark.parametrize("delta", [-1, 0, 1, 12287])
 def test_geometry_switch_points(G, mode, threshold, delta):
     """Sizes right at the small -> large geometry switch of each kernel family (3/2 large tiles per CU on 256 CUs; the
-    large tile is 12288 pairs, 20480 keys for keys-only sorts, 8192 pairs for 64-bit keys)."""
+    large tile is 9216 pairs / 16384 keys for the 128-byte-line kernel of 32-bit keys, 8192 pairs for 64-bit keys;
+    12288 pairs is the switch of the kernel that unaligned arrays fall back to)."""
     n = threshold + delta
     rng = np.random.default_rng(n)
     if mode == "u64":

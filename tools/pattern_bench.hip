@@ -91,6 +91,47 @@ __global__ __launch_bounds__(THREADS) void chunk_copy_any_kernel(const uint32_t*
     }
 }
 
+// Tile-ordered ("onesweep") write pattern: tile T of the whole input puts its chunk of region j at j * region_len +
+// T * chunk, so a chunk that is not a multiple of 32 elements shares its first and last 128-byte line with the tiles
+// T - 1 and T + 1, which another workgroup writes at about the same time.  order 0: tile k * wgs + b (neighbours on
+// different XCDs), order 1: groups of 32 consecutive tiles on the 32 CUs of one XCD (workgroup b runs on XCD b % 8), so
+// that the two halves of a shared line meet in one L2.
+template<int THREADS, int KPT>
+__global__ __launch_bounds__(THREADS) void tile_order_copy_kernel(const uint32_t* __restrict__ ka, const uint32_t* __restrict__ va,
+                                                                  uint32_t* __restrict__ kb, uint32_t* __restrict__ vb,
+                                                                  uint32_t tiles_per_wg, uint32_t chunk, uint32_t regions,
+                                                                  uint32_t region_len, int order)
+{
+    constexpr int STEP = THREADS * KPT;
+    const uint32_t b = blockIdx.x, tid = threadIdx.x, wgs = gridDim.x;
+    const uint32_t vtile = chunk * regions; // <= STEP
+    for (uint32_t k = 0; k < tiles_per_wg; k++)
+    {
+        const uint32_t T = order == 0 ? k * wgs + b : (k * 8 + (b & 7)) * (wgs / 8) + (b >> 3);
+        const size_t src = (size_t) T * vtile;
+        uint32_t kk[KPT], vv[KPT];
+#pragma unroll
+        for (int i = 0; i < KPT; i++)
+        {
+            const uint32_t e = i * THREADS + tid;
+            kk[i] = e < vtile ? ka[src + e] : 0u;
+            vv[i] = e < vtile ? va[src + e] : 0u;
+        }
+#pragma unroll
+        for (int i = 0; i < KPT; i++)
+        {
+            const uint32_t e = i * THREADS + tid;
+            if (e < vtile)
+            {
+                const uint32_t j = e / chunk, r = e - j * chunk;
+                const size_t dst = (size_t) j * region_len + (size_t) T * chunk + r;
+                kb[dst] = kk[i];
+                vb[dst] = vv[i];
+            }
+        }
+    }
+}
+
 int main(int argc, char** argv)
 {
     const int log2n = argc > 1 ? atoi(argv[1]) : 28;
@@ -98,8 +139,8 @@ int main(int argc, char** argv)
     uint32_t *ka, *va, *kb, *vb;
     CK(hipMalloc(&ka, n * 4));
     CK(hipMalloc(&va, n * 4));
-    CK(hipMalloc(&kb, n * 4));
-    CK(hipMalloc(&vb, n * 4));
+    CK(hipMalloc(&kb, n * 4 + (1 << 20)));
+    CK(hipMalloc(&vb, n * 4 + (1 << 20)));
     CK(hipMemset(ka, 1, n * 4));
     CK(hipMemset(va, 2, n * 4));
     hipEvent_t e0, e1;
@@ -157,7 +198,30 @@ int main(int argc, char** argv)
                chunk * 4, shift_elems * 4, best, moved / best / 1e6);
         fflush(stdout);
     };
-    for (int sh : {0, 16})
-        for (int ch : {16, 32, 48, 64, 80, 96, 128}) run_any(ch, 256, sh);
+    for (int ch : {16, 32, 48, 64, 80, 96, 128}) run_any(ch, 256, 0);
+    auto run_order = [&](int chunk, int order) {
+        const int wgs = 256, regions = 256;
+        const uint32_t vtile = chunk * regions;
+        const uint32_t tiles_per_wg = (uint32_t) (n / vtile / wgs);
+        const uint32_t region_len = ((uint32_t) (n / regions) + 31u) & ~31u;
+        float best = 1e9f;
+        for (int r = 0; r < 5; r++)
+        {
+            CK(hipEventRecord(e0));
+            hipLaunchKernelGGL((tile_order_copy_kernel<1024, 12>), dim3(wgs), dim3(1024), 0, 0, ka, va, kb, vb, tiles_per_wg, (uint32_t) chunk,
+                               (uint32_t) regions, region_len, order);
+            CK(hipEventRecord(e1));
+            CK(hipEventSynchronize(e1));
+            float ms;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            best = std::min(best, ms);
+        }
+        const double moved = (double) tiles_per_wg * wgs * vtile * 16.0;
+        printf("tile order %s: 256 regions x chunks of %3d elems (%4d B): %.3f ms  %.0f GB/s\n",
+               order ? "XCD groups of 32" : "round robin     ", chunk, chunk * 4, best, moved / best / 1e6);
+        fflush(stdout);
+    };
+    for (int ch : {32, 36, 40, 44, 48})
+        for (int order : {0, 1}) run_order(ch, order);
     return 0;
 }

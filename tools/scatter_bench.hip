@@ -277,26 +277,30 @@ void run_lines(Ctx& c, uint32_t shift, uint32_t mask_override = 0)
     CK(hipGetLastError());
     CK(hipDeviceSynchronize());
     CK(hipMemset(c.bad, 0, 8));
-    hipLaunchKernelGGL(check_kernel, dim3(4096), dim3(256), 0, 0, c.keys2, c.vals2, c.keys, c.n, shift, mask, c.bad);
+    if (!ABLATE) hipLaunchKernelGGL(check_kernel, dim3(4096), dim3(256), 0, 0, c.keys2, c.vals2, c.keys, c.n, shift, mask, c.bad);
     unsigned long long bad = 0;
     CK(hipMemcpy(&bad, c.bad, 8, hipMemcpyDeviceToHost));
     if (!VALS) bad = 0;
     unsigned long long* st;
-    CK(hipMalloc(&st, 64));
-    CK(hipMemset(st, 0, 64));
+    CK(hipMalloc(&st, 128));
+    CK(hipMemset(st, 0, 128));
     hipLaunchKernelGGL(scatter_st, dim3(nb), dim3(THREADS), sizeof(Smem), 0, c.keys, VALS ? c.vals : nullptr, c.keys2, VALS ? c.vals2 : nullptr, c.table,
                        totals, (uint32_t) c.n, shift, mask, tiles, st, 0u, (PassPlan*) nullptr, 0u);
-    unsigned long long hst[8];
-    CK(hipMemcpy(hst, st, 64, hipMemcpyDeviceToHost));
+    unsigned long long hst[16];
+    CK(hipMemcpy(hst, st, 128, hipMemcpyDeviceToHost));
     CK(hipFree(st));
     if (!VALS) printf("keys-only ");
     if (ABLATE) printf("ABLATE %d: ", ABLATE);
     printf("lines bits %d threads %4d kpt %2d tile %5d lds %6zu nb %5u | scatter %.3f ms (%.0f GB/s) %s\n", BITS, THREADS, KPT, TILE, sizeof(Smem), nb,
            t_scatter, c.n * (VALS ? 16.0 : 8.0) / t_scatter / 1e6, ABLATE ? "(ablated)" : bad ? "WRONG" : "ok");
     const char* names[8] = {"top", "rank", "bar1", "scan", "stage", "lines", "tails", "bar_end"};
-    printf("    stamps/tile:");
-    for (int i = 0; i < 8; i++) printf(" %s %.0f", names[i], hst[i] / (double) tiles);
-    printf("\n");
+    for (int w = 0; w < 2; w++)
+    {
+        double sum = 0;
+        printf("    stamps/tile wave %2d:", w ? THREADS / 64 - 1 : 0);
+        for (int i = 0; i < 8; i++) printf(" %s %.0f", names[i], hst[w * 8 + i] / (double) tiles), sum += hst[w * 8 + i] / (double) tiles;
+        printf(" | sum %.0f\n", sum);
+    }
     fflush(stdout);
 }
 
