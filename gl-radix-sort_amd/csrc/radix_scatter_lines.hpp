@@ -47,8 +47,10 @@ struct LineSmem
     uint32_t total_lines;
 };
 
-// ABLATE (tuning builds, wrong results): 4 = nothing is written out.
-template<typename KeyT, int BITS, int THREADS, int KPT, bool XF = false, bool VALS = true, int ABLATE = 0, bool STAMPS = false>
+// ABLATE (tuning builds, wrong results): 4 = nothing is written out.  RANK_SPLIT: how many of a tile's KPT items are
+// ranked right after the staging of the tile before (the rest after that tile's tail copy).
+template<typename KeyT, int BITS, int THREADS, int KPT, bool XF = false, bool VALS = true, int ABLATE = 0, bool STAMPS = false,
+         int RANK_SPLIT = (KPT + 2) / 3, bool STAGGER = true>
 __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
     const KeyT* __restrict__ keys_a, const uint32_t* __restrict__ vals_a, KeyT* __restrict__ keys_b,
     uint32_t* __restrict__ vals_b, const uint32_t* __restrict__ table, const uint32_t* __restrict__ totals, uint32_t n,
@@ -122,6 +124,7 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
 
     uint32_t first, last;
     block_tile_range(b, nb, tiles_total, first, last);
+    const uint32_t last_tile_of_range = last;
     const uint32_t wave_off = wave * WAVE_TILE + lane; // wave-striped: item i of lane l of wave w = element w*64*KPT + i*64 + l
 
     unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -137,6 +140,8 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
 
     KeyT key[KPT], nkey[KPT];
     uint32_t val[KPT];
+    uint32_t rank[KPT];
+    uint32_t* const my_cnt = s.wcnt[wave];
     // guarded loads of a partial tile: positions past the end of the array read as pads (highest digit, after all keys)
     auto load_tile_guarded = [&](uint32_t t) {
         const uint64_t base = (uint64_t) t * TILE;
@@ -149,6 +154,49 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
             if (VALS) val[i] = p < left ? src_vals[base + p] : 0u;
         }
     };
+    // full tile t, or tile 0 when t is not a full tile of this range (a harmless prefetch of something that is not used:
+    // the loops that prefetch carry no branch)
+    auto prefetch_base = [&](uint32_t t) -> uint64_t {
+        const bool ok = t < last_tile_of_range && (uint64_t) n - (uint64_t) t * TILE >= (uint64_t) TILE;
+        return (ok ? (uint64_t) t * TILE : 0ull) + wave_off;
+    };
+    // Ranks items [I0, I1) of the tile in key[] inside the wave (match-any on the digit bits with one ballot per bit,
+    // wave-private running counters) and loads the same items of the tile after it into nkey[].  Touches nothing but the
+    // wave's own counter row, so it needs no workgroup barrier against the phases of the tile before.
+    // (Tried: ballots for all items first, then the counters with one read and one leader-only atomic add per item, so
+    // that the ballots carry no LDS dependency: 6 % slower, the adds and their exec-mask branches cost more than the
+    // dependency they remove.)
+    auto rank_items = [&](auto i0, auto i1, uint64_t pf_base) {
+#pragma unroll
+        for (int i = decltype(i0)::value; i < decltype(i1)::value; i++)
+        {
+            nkey[i] = src_keys[pf_base + i * kWave];
+            const uint32_t d = digit_of<KeyT>(key[i], shift, MASK);
+            uint32_t* const cnt = my_cnt + d;
+            const uint32_t prev = *cnt; // issued first: its LDS latency hides under the ballots below
+            uint32_t plo = ~0u, phi = ~0u;
+#pragma unroll
+            for (int bit = 0; bit < BITS; bit++)
+            {
+                int32_t sel; // asm: keeps bit 0 from being rewritten as -(d & 1) and a compare chain
+                asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(sel) : "v"(d), "n"(bit));
+                const uint64_t m = __ballot(sel < 0);
+                plo = __builtin_amdgcn_bitop3_b32(plo, (uint32_t) m, (uint32_t) sel, 0x90);
+                phi = __builtin_amdgcn_bitop3_b32(phi, (uint32_t) (m >> 32), (uint32_t) sel, 0x90);
+            }
+            const uint32_t lower = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
+            const uint32_t total = (uint32_t) __popc(plo) + (uint32_t) __popc(phi);
+            rank[i] = prev + lower;
+            asm volatile("" : "+v"(rank[i])); // keep the rank (1 register), not the two peer masks, live
+            *cnt = prev + total;              // every peer stores the same new count (no leader election)
+        }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using ISplit = std::integral_constant<int, RANK_SPLIT>;
+    using IEnd = std::integral_constant<int, KPT>;
+
+    // ---- prologue of the software pipeline: the first tile is loaded and ranked here; every later tile is loaded and
+    //      ranked under the phases of the tile before it
     if (first < last)
     {
         if ((uint64_t) n - (uint64_t) first * TILE >= (uint64_t) TILE)
@@ -164,53 +212,19 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
         }
         else
             load_tile_guarded(first);
+        rank_items(I0(), IEnd(), prefetch_base(first + 1));
     }
 
     for (uint32_t tile = first; tile < last; tile++)
     {
         const uint64_t tile_base = (uint64_t) tile * TILE;
         const uint64_t rem = (uint64_t) n - tile_base;
-        const bool tile_full = rem >= (uint64_t) TILE;
-        const uint32_t tile_valid = tile_full ? (uint32_t) TILE : (uint32_t) rem;
+        const uint32_t tile_valid = rem >= (uint64_t) TILE ? (uint32_t) TILE : (uint32_t) rem;
+        const bool has_next = tile + 1 < last;
+        const bool next_full = has_next && (uint64_t) n - (tile_base + TILE) >= (uint64_t) TILE;
         if (STAMPS) tprev = __builtin_amdgcn_s_memtime();
-
-        // ---- the next tile is loaded under this one: its keys one load per rank iteration (into nkey), its values one
-        //      load per staging iteration (into the value register just staged).  The last tile of a range, or one whose
-        //      successor is partial (the last tile of the array: guarded loads at the end of this iteration), prefetches a
-        //      full tile it will not use, so that neither loop carries a branch.
-        const bool next_ok = tile + 1 < last && (uint64_t) n - (tile_base + TILE) >= (uint64_t) TILE;
-        const uint64_t next_base = (next_ok ? tile_base + TILE : (tile_full ? tile_base : 0ull)) + wave_off;
+        __syncthreads(); // every wave has ranked this tile
         stamp(0);
-
-        // ---- rank inside the wave (match-any on the digit bits with one ballot per bit, wave-private counters)
-        uint32_t rank[KPT];
-        uint32_t* my_cnt = s.wcnt[wave];
-#pragma unroll
-        for (int i = 0; i < KPT; i++)
-        {
-            nkey[i] = src_keys[next_base + i * kWave];
-            const uint32_t d = digit_of<KeyT>(key[i], shift, MASK);
-            uint32_t* const cnt = my_cnt + d;
-            const uint32_t prev = *cnt;
-            uint32_t plo = ~0u, phi = ~0u;
-#pragma unroll
-            for (int bit = 0; bit < BITS; bit++)
-            {
-                int32_t sel;
-                asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(sel) : "v"(d), "n"(bit));
-                const uint64_t m = __ballot(sel < 0);
-                plo = __builtin_amdgcn_bitop3_b32(plo, (uint32_t) m, (uint32_t) sel, 0x90);
-                phi = __builtin_amdgcn_bitop3_b32(phi, (uint32_t) (m >> 32), (uint32_t) sel, 0x90);
-            }
-            const uint32_t lower = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
-            const uint32_t total = (uint32_t) __popc(plo) + (uint32_t) __popc(phi);
-            rank[i] = prev + lower;
-            asm volatile("" : "+v"(rank[i]));
-            *cnt = prev + total;
-        }
-        stamp(1);
-        __syncthreads();
-        stamp(2);
 
         // ---- one packed block scan over (digit, wave quad): low half = elements, high half = full lines of the digit.
         //      All four scan threads of a digit know the digit's element count n_d and carried count c_d.
@@ -263,18 +277,39 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
             }
         }
         __syncthreads();
-        stamp(3);
+        stamp(1);
 
-        // ---- stage (key, val) at the ranked position
-#pragma unroll
-        for (int i = 0; i < KPT; i++)
+        // ---- stage (key, val) at the ranked position; the value register just staged takes the next tile's value
         {
-            const uint32_t pos = rank[i] + my_cnt[digit_of<KeyT>(key[i], shift, MASK)];
-            s.buf.put(pos, key[i], VALS ? val[i] : 0u);
-            if (VALS) val[i] = src_vals[next_base + i * kWave];
+            const uint64_t next_base = prefetch_base(tile + 1);
+#pragma unroll
+            for (int i = 0; i < KPT; i++)
+            {
+                const uint32_t pos = rank[i] + my_cnt[digit_of<KeyT>(key[i], shift, MASK)];
+                s.buf.put(pos, key[i], VALS ? val[i] : 0u);
+                if (VALS) val[i] = src_vals[next_base + i * kWave];
+            }
         }
+        // ---- this wave is done with its counter row: zero it and start ranking the next tile (keys prefetched into nkey
+        //      while this tile was ranked; a partial next tile, the last of the array, takes guarded loads now).  The
+        //      ranking is VALU work on wave-private state: no barrier separates it from this tile's later phases, the
+        //      rest of it follows the tail copy below.
+        for (int i = lane; i < Smem::WCNT_STRIDE; i += kWave) my_cnt[i] = 0;
+        const uint64_t pf_base = prefetch_base(tile + 2);
+        if (has_next)
+        {
+            if (next_full)
+            {
+#pragma unroll
+                for (int i = 0; i < KPT; i++) key[i] = codec_in.encode(nkey[i]);
+            }
+            else
+                load_tile_guarded(tile + 1);
+            rank_items(I0(), ISplit(), pf_base);
+        }
+        stamp(2);
         __syncthreads();
-        stamp(4);
+        stamp(3);
 
         // ---- write the full lines: quad = 4 consecutive elements of one line = one 16-byte store per array
         if (ABLATE < 4)
@@ -337,41 +372,52 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
                 }
             }
         }
+        stamp(4);
         __syncthreads(); // the carried elements have been read: their slots may be rewritten
         stamp(5);
 
         // ---- new carry: the elements of every digit past its last full line move to the digit's carry slots
-        {
-            constexpr int ITEMS = RADIX * (int) (LINE / 4); // (digit, quad of slots)
-#pragma unroll
-            for (int it = 0; it < (ITEMS + THREADS - 1) / THREADS; it++)
+        auto copy_tails = [&]() {
             {
-                const uint32_t item = it * THREADS + tid;
-                if (ITEMS % THREADS == 0 || item < (uint32_t) ITEMS)
+                constexpr int ITEMS = RADIX * (int) (LINE / 4); // (digit, quad of slots)
+    #pragma unroll
+                for (int it = 0; it < (ITEMS + THREADS - 1) / THREADS; it++)
                 {
-                    const uint32_t d = item / (LINE / 4), s0 = (item % (LINE / 4)) * 4;
-                    const uint2 t = s.tail[d];
-                    const uint32_t lo = t.y & 0xFFu, hi = t.y >> 8;
-                    KeyT k[4];
-                    uint32_t v[4];
-                    // slots below lo read the element of slot lo (a valid position), slots from hi up read past the run
-                    // (inside the buffer): neither is written
-#pragma unroll
-                    for (int e = 0; e < 4; e++) s.buf.get(t.x + (s0 + e > lo ? s0 + e : lo), k[e], v[e]);
-#pragma unroll
-                    for (int e = 0; e < 4; e++)
-                        if (s0 + e >= lo && s0 + e < hi) s.buf.put((uint32_t) TILE + d * LINE + s0 + e, k[e], v[e]);
+                    const uint32_t item = it * THREADS + tid;
+                    if (ITEMS % THREADS == 0 || item < (uint32_t) ITEMS)
+                    {
+                        const uint32_t d = item / (LINE / 4), s0 = (item % (LINE / 4)) * 4;
+                        const uint2 t = s.tail[d];
+                        const uint32_t lo = t.y & 0xFFu, hi = t.y >> 8;
+                        KeyT k[4];
+                        uint32_t v[4];
+                        // slots below lo read the element of slot lo (a valid position), slots from hi up read past the run
+                        // (inside the buffer): neither is written
+    #pragma unroll
+                        for (int e = 0; e < 4; e++) s.buf.get(t.x + (s0 + e > lo ? s0 + e : lo), k[e], v[e]);
+    #pragma unroll
+                        for (int e = 0; e < 4; e++)
+                            if (s0 + e >= lo && s0 + e < hi) s.buf.put((uint32_t) TILE + d * LINE + s0 + e, k[e], v[e]);
+                    }
                 }
             }
+        };
+        // ---- tail copy (LDS-bound) and the rest of the next tile's ranking (VALU-bound, wave-private state: nobody else
+        //      touches this wave's counter row between this tile's staging and the scan of the next tile, so the tile
+        //      ends without a barrier).  The two are independent: on every SIMD two waves copy first and two rank first, so
+        //      that the LDS and the vector ALUs are busy at the same time (waves run in lockstep behind a barrier; the
+        //      second four of every eight waves are the SIMD partners of the first four).
+        if (STAGGER && (wave & 4u))
+        {
+            if (has_next) rank_items(ISplit(), IEnd(), pf_base);
+            copy_tails();
         }
-        for (int i = tid; i < WAVES * Smem::WCNT_STRIDE; i += THREADS) (&s.wcnt[0][0])[i] = 0;
-#pragma unroll
-        for (int i = 0; i < KPT; i++) key[i] = codec_in.encode(nkey[i]);
-        // a partial tile is never prefetched (it is the last tile of the array): guarded loads now
-        if (tile + 1 < last && !next_ok) load_tile_guarded(tile + 1);
+        else
+        {
+            copy_tails();
+            if (has_next) rank_items(ISplit(), IEnd(), pf_base);
+        }
         stamp(6);
-        __syncthreads();
-        stamp(7);
     }
 
     // ---- what is still carried at the end of this workgroup's range: the (partial) last line of every digit

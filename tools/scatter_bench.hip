@@ -249,7 +249,7 @@ void run_variant(Ctx& c, int blocks_per_cu, uint32_t shift, uint32_t mask_overri
 }
 
 // the 128-byte-line scatter (radix_scatter_lines.hpp) behind the production count + row scan
-template<int BITS, int THREADS, int KPT, bool VALS = true, int ABLATE = 0>
+template<int BITS, int THREADS, int KPT, bool VALS = true, int ABLATE = 0, int RS = (KPT + 2) / 3, bool STAGGER = true>
 void run_lines(Ctx& c, uint32_t shift, uint32_t mask_override = 0)
 {
     constexpr int RADIX = 1 << BITS;
@@ -261,8 +261,8 @@ void run_lines(Ctx& c, uint32_t shift, uint32_t mask_override = 0)
     uint32_t* totals = c.table + (size_t) RADIX * nb;
     const uint32_t mask = mask_override ? mask_override : RADIX - 1;
     if (mask_override) printf("mask %u: ", mask);
-    auto scatter = radix_scatter_lines_kernel<uint32_t, BITS, THREADS, KPT, false, VALS, ABLATE, false>;
-    auto scatter_st = radix_scatter_lines_kernel<uint32_t, BITS, THREADS, KPT, false, VALS, ABLATE, true>;
+    auto scatter = radix_scatter_lines_kernel<uint32_t, BITS, THREADS, KPT, false, VALS, ABLATE, false, RS, STAGGER>;
+    auto scatter_st = radix_scatter_lines_kernel<uint32_t, BITS, THREADS, KPT, false, VALS, ABLATE, true, RS, STAGGER>;
     CK(hipFuncSetAttribute((const void*) scatter_st, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sizeof(Smem)));
     CK(hipFuncSetAttribute((const void*) scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sizeof(Smem)));
     hipLaunchKernelGGL((radix_count_kernel<uint32_t, BITS, THREADS, TILE>), dim3(nb), dim3(THREADS), 0, 0, c.keys, c.table, (uint32_t) c.n, shift, mask,
@@ -277,7 +277,7 @@ void run_lines(Ctx& c, uint32_t shift, uint32_t mask_override = 0)
     CK(hipGetLastError());
     CK(hipDeviceSynchronize());
     CK(hipMemset(c.bad, 0, 8));
-    if (!ABLATE) hipLaunchKernelGGL(check_kernel, dim3(4096), dim3(256), 0, 0, c.keys2, c.vals2, c.keys, c.n, shift, mask, c.bad);
+    if (!ABLATE && VALS) hipLaunchKernelGGL(check_kernel, dim3(4096), dim3(256), 0, 0, c.keys2, c.vals2, c.keys, c.n, shift, mask, c.bad);
     unsigned long long bad = 0;
     CK(hipMemcpy(&bad, c.bad, 8, hipMemcpyDeviceToHost));
     if (!VALS) bad = 0;
@@ -291,9 +291,9 @@ void run_lines(Ctx& c, uint32_t shift, uint32_t mask_override = 0)
     CK(hipFree(st));
     if (!VALS) printf("keys-only ");
     if (ABLATE) printf("ABLATE %d: ", ABLATE);
-    printf("lines bits %d threads %4d kpt %2d tile %5d lds %6zu nb %5u | scatter %.3f ms (%.0f GB/s) %s\n", BITS, THREADS, KPT, TILE, sizeof(Smem), nb,
+    printf("lines %ssplit %d bits %d threads %4d kpt %2d tile %5d lds %6zu nb %5u | scatter %.3f ms (%.0f GB/s) %s\n", STAGGER ? "stagger " : "", RS, BITS, THREADS, KPT, TILE, sizeof(Smem), nb,
            t_scatter, c.n * (VALS ? 16.0 : 8.0) / t_scatter / 1e6, ABLATE ? "(ablated)" : bad ? "WRONG" : "ok");
-    const char* names[8] = {"top", "rank", "bar1", "scan", "stage", "lines", "tails", "bar_end"};
+    const char* names[8] = {"bar1", "scan", "stage+rankA", "bar4", "lines", "bar5", "tails+rankB", "-"};
     for (int w = 0; w < 2; w++)
     {
         double sum = 0;
@@ -659,11 +659,14 @@ int main(int argc, char** argv)
     {
         run_lines<8, 1024, 9>(c, shift);
         run_variant<8, 1024, 12, true>(c, 1, shift);
-        run_lines<8, 1024, 9>(c, shift);
-        run_lines<8, 1024, 8>(c, shift);
+        run_lines<8, 1024, 9, true, 0, 0>(c, shift);
+        run_lines<8, 1024, 9, true, 0, 3>(c, shift);
+        run_lines<8, 1024, 9, true, 0, 0, false>(c, shift);
+        run_lines<8, 1024, 9, true, 0, 3, false>(c, shift);
+        run_lines<8, 1024, 9, true, 0, 2>(c, shift);
         run_lines<8, 1024, 9, true, 4>(c, shift);
         run_lines<8, 1024, 9>(c, shift, 15u);
-        run_lines<8, 1024, 9, false>(c, shift);
+        run_lines<8, 1024, 16, false>(c, shift);
         run_lines<4, 1024, 12>(c, shift);
         return 0;
     }
