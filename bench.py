@@ -44,7 +44,10 @@ def parse_args():
                    help="do not record per-kernel HIP events in the timed region (roofline fields become null)")
     p.add_argument("--no-alt", action="store_true", help="skip the extra 4-bit-digit (reference pass structure) measurement")
     p.add_argument("--pipeline-depth", type=int, default=2,
-                   help="N>1: consecutive sorts in flight (own stream + buffers each); 1 = strictly one after the other")
+                   help="N>1: besides the headline (one sort at a time) also measure this many consecutive sorts in flight "
+                        "(own stream, buffers and communicator each); 1 = skip")
+    p.add_argument("--reserved-cus", type=int, default=8,
+                   help="N>1, pipelined measurement: CUs the sort kernels leave to the RCCL kernels of the other sort in flight")
     p.add_argument("--force-dist", action="store_true",
                    help="run the multi-GPU code path (partition + all-to-all + local sort) even with one rank")
     return p.parse_args()
@@ -342,32 +345,60 @@ def main():
     else:
         from glu_hip import dist as D
 
-        # consecutive sorts are independent batches: with pipeline depth 2 each runs on its own stream / buffers, so the
-        # all-to-all of step i+1 (RCCL) can proceed under the local sort of step i; every step is still a complete sort
-        depth = max(1, args.pipeline_depth)
-        dsort = D.DistributedRadixSort(local_ops_factory=lambda: D.HipLocalOps(digit_bits=args.digit_bits), slots=depth,
-                                       profile=not args.no_kernel_events)
         keys0, vals0 = make_input(torch, n, args.keys, rank, device, index_base=rank * n)
-        for i in range(W):
-            dsort.sort_async(keys0, vals0)
-        barrier()
-        dsort.phase_times()  # drop the warm-up stamps
-        sorters = [slot["ops"].sorter for slot in dsort._slots]
-        for srt in sorters:
-            srt.set_profiling(not args.no_kernel_events)
-        t0 = time.perf_counter()
-        handle = None
-        for i in range(K):
-            handle = dsort.sort_async(keys0, vals0)
-        barrier()
-        elapsed = time.perf_counter() - t0
+
+        def run_depth(depth):
+            """W warm-up sorts, then K timed sorts with `depth` sorts in flight (depth 1 = strictly one after the other, the
+            same regime as the N = 1 line; depth 2 = consecutive independent sorts on two streams / buffer sets /
+            communicators, so that the exchange of sort i+1 can run under the local sort of sort i)."""
+            dsort = D.DistributedRadixSort(slots=depth, profile=not args.no_kernel_events)
+            if args.digit_bits is not None:
+                for srt in dsort.local_sorters():
+                    srt.set_digit_bits(args.digit_bits)
+            if dsort.native and depth > 1 and args.reserved_cus:
+                for slot in dsort._slots:  # leave CUs to the RCCL kernels of the other sort in flight
+                    slot["native"].set_reserved_cus(args.reserved_cus)
+            for i in range(W):
+                dsort.sort_async(keys0, vals0)
+            barrier()
+            dsort.phase_times()  # drop the warm-up stamps
+            sorters = dsort.local_sorters()
+            for srt in sorters:
+                srt.set_profiling(not args.no_kernel_events)
+            t0 = time.perf_counter()
+            handle = None
+            for i in range(K):
+                handle = dsort.sort_async(keys0, vals0)
+            barrier()
+            dt = time.perf_counter() - t0
+            profs = [srt.read_profile() for srt in sorters]
+            for srt in sorters:
+                srt.set_profiling(False)
+            return {"dsort": dsort, "elapsed": dt, "handle": handle, "profs": profs, "sorters": sorters,
+                    "phases": dsort.phase_times()}
+
+        def max_over_ranks(x):
+            tt = torch.tensor([x], dtype=torch.float64, device=device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return float(tt.item())
+
+        # the timed region of the line (`value`, `ms_per_step`): one sort at a time, like N = 1
+        r1 = run_depth(1)
+        elapsed = r1["elapsed"]
+        result["pipeline_depth"] = 1
+        result["value_depth1"] = round(n * world * K / max_over_ranks(elapsed) / 1e6, 1)
+        depth = max(1, args.pipeline_depth)
+        if depth > 1:
+            # batch throughput with `depth` independent sorts in flight: a different regime, reported beside the headline
+            r2 = run_depth(depth)
+            result["value_depth%d" % depth] = round(n * world * K / max_over_ranks(r2["elapsed"]) / 1e6, 1)
+            result["phases_ms_rank0_depth%d" % depth] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in r2["phases"].items()}
+            del r2
+        dsort, handle, profs, sorters = r1["dsort"], r1["handle"], r1["profs"], r1["sorters"]
+        result["native_c_abi"] = bool(dsort.native)
         rk, rv, cnt = handle.synchronize()
-        result["pipeline_depth"] = depth
         # rank 0's view: the scatter kernel (1 partition launch over n pairs + 4 sort launches over its shard per sort)
-        # and the device time of every phase of a sort (they overlap between the sorts in flight)
-        profs = [srt.read_profile() for srt in sorters]
-        for srt in sorters:
-            srt.set_profiling(False)
+        # and the device time of every phase of a sort
         launches = sum(int(pf["passes"]) for pf in profs)
         scatter_ms = sum(pf["scatter_ms"] for pf in profs) / max(launches, 1)
         per_sort = max(launches // max(K, 1), 1)
@@ -381,7 +412,7 @@ def main():
                 "launches_timed": launches,
                 "count_kernel_avg_ms": round(sum(pf["count_ms"] for pf in profs) / launches, 4),
             }
-        phases = dsort.phase_times()
+        phases = r1["phases"]
         result["phases_ms_rank0"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in phases.items()}
         units = n * world * K
         verified = None
@@ -413,7 +444,7 @@ def main():
         result["shard_pairs_rank0"] = int(cnt)
         workload = ("2^%d uint32 key+val pairs per GPU (%d GPUs, 2^%.2f total), uniform-random keys; top-8-bit bucket "
                     "partition + one RCCL all-to-all over xGMI + local sort") % (log2n, world, log2n + __import__("math").log2(world))
-        parallelism = "bucket-sharded x%d (1 all-to-all), %d sorts in flight" % (world, depth)
+        parallelism = "bucket-sharded x%d (1 grouped RCCL exchange), one sort at a time (value_depth%d: %d in flight)" % (world, depth, depth)
 
     # max over ranks
     if dist is not None:

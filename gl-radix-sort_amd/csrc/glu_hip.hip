@@ -415,6 +415,8 @@ struct glu_radix_sort_s
     bool no_fused_scan = false;   // GLU_HIP_SORT_NO_FUSED_SCAN=1: always launch the row-scan kernel (tests / tuning)
     bool no_plan = false;         // GLU_HIP_SORT_NO_PLAN=1: never skip constant-digit passes (tests / tuning)
     bool no_lines = false;        // GLU_HIP_SORT_NO_LINES=1: never use the 128-byte-line scatter kernel (tests / tuning)
+    hipEvent_t after_histogram_event = nullptr; // partition passes: recorded once the digit histogram has been copied out
+                                                // (after the row scan, before the scatter): glu_dist uses it
     size_t large_min = 0;         // GLU_HIP_SORT_LARGE_MIN=N: element count from which the large geometry is used (tuning)
     // optional per-kernel timing: 4 events per pass (before count, after count, after scan, after scatter)
     bool profiling = false;
@@ -504,8 +506,11 @@ glu_status launch_pass(glu_radix_sort_s* s, const KeyT* src_k, const uint32_t* s
                            pa.may_skip ? pa.plan : (PassPlan*) nullptr, pa.pass);
     s->mark(stream);
     if (histogram_out)
+    {
         HIP_TRY(hipMemcpyAsync(histogram_out, totals, ((size_t) 1 << bits) * sizeof(uint32_t), hipMemcpyDeviceToDevice,
                                stream));
+        if (s->after_histogram_event) HIP_TRY(hipEventRecord(s->after_histogram_event, stream));
+    }
     hipLaunchKernelGGL(fused ? scatter_fused : scatter, dim3(nb), dim3(G::THREADS), sizeof(Smem), stream, src_k, src_v, dst_k,
                        dst_v, (const uint32_t*) table, (const uint32_t*) totals, (uint32_t) count, shift, mask, tiles,
                        (unsigned long long*) nullptr, xform, pa.plan, pa.pass);
@@ -550,8 +555,11 @@ glu_status launch_pass_lines(glu_radix_sort_s* s, const KeyT* src_k, const uint3
     HIP_TRY(hipGetLastError());
     s->mark(stream);
     if (histogram_out)
+    {
         HIP_TRY(hipMemcpyAsync(histogram_out, totals, ((size_t) 1 << bits) * sizeof(uint32_t), hipMemcpyDeviceToDevice,
                                stream));
+        if (s->after_histogram_event) HIP_TRY(hipEventRecord(s->after_histogram_event, stream));
+    }
     hipLaunchKernelGGL(scatter, dim3(nb), dim3(G::THREADS), sizeof(Smem), stream, src_k, src_v, dst_k, dst_v,
                        (const uint32_t*) table, (const uint32_t*) totals, (uint32_t) count, shift, mask, tiles,
                        (unsigned long long*) nullptr, xform, pa.plan, pa.pass);
@@ -1360,6 +1368,8 @@ glu_status glu_reduce_run(glu_reduce reduce, glu_buffer buffer, size_t count)
 }
 
 } // extern "C"
+
+#include "glu_dist_impl.hpp"
 
 // ------------------------------------------------------------------------------------------------------------
 // timer

@@ -75,6 +75,20 @@ SYMBOLS = [
     ("glu_reduce_destroy", _int, [_vp]),
     ("glu_reduce_run", _int, [_vp, _u32, _sz]),
     ("glu_reduce_run_ptr", _int, [_vp, _vp, _sz, _vp]),
+    ("glu_dist_unique_id", _int, [_vp, _sz]),
+    ("glu_dist_create", _int, [_vp, _sz, _int, _int, _P(_vp)]),
+    ("glu_dist_destroy", _int, [_vp]),
+    ("glu_dist_world", _int, [_vp, _P(_int), _P(_int)]),
+    ("glu_dist_local_sorter", _int, [_vp, _P(_vp)]),
+    ("glu_dist_prepare", _int, [_vp, _sz, _sz]),
+    ("glu_dist_sort_begin", _int, [_vp, _vp, _vp, _sz, _vp, _P(_sz)]),
+    ("glu_dist_sort_finish", _int, [_vp, _vp, _vp, _sz, _vp]),
+    ("glu_dist_sort_ptr", _int, [_vp, _vp, _vp, _sz, _vp, _P(_vp), _P(_vp), _P(_sz)]),
+    ("glu_dist_set_reserved_cus", _int, [_vp, _int]),
+    ("glu_dist_set_profiling", _int, [_vp, _int]),
+    ("glu_dist_phase_times", _int, [_vp, _P(ctypes.c_double), _P(_u64)]),
+    ("glu_dist_plan_buckets", _int, [_P(_u32), _int, _P(_int)]),
+    ("glu_dist_plan_counts", _int, [_P(_u32), _int, _int, _P(_int), _P(_u64), _P(_u64)]),
     ("glu_timer_begin", _int, [_P(_vp)]),
     ("glu_timer_end", _int, [_vp, _P(_u64)]),
 ]
@@ -218,6 +232,9 @@ class RadixSort:
         if digit_bits is not None:
             check(lib().glu_radix_sort_set_digit_bits(self._h, digit_bits))
 
+    def set_digit_bits(self, bits):
+        check(lib().glu_radix_sort_set_digit_bits(self._h, bits))
+
     @property
     def digit_bits(self):
         b = _u32(0)
@@ -282,7 +299,7 @@ class RadixSort:
                                                  count, shift, bits, _vp(histogram_ptr), _vp(stream)))
 
     def destroy(self):
-        if self._h and _lib is not None:
+        if self._h and _lib is not None and not getattr(self, "_borrowed", False):
             _lib.glu_radix_sort_destroy(self._h)
         self._h = _vp()
 
@@ -353,3 +370,87 @@ def measure_elapsed_time(callback):
     ns = _u64(0)
     check(lib().glu_timer_end(t, ctypes.byref(ns)))
     return ns.value
+
+
+DIST_UNIQUE_ID_BYTES = 128
+DIST_BUCKETS = 256
+
+
+def dist_unique_id():
+    """Rank 0: the RCCL unique id (bytes) to hand to every rank's Dist(...)."""
+    buf = ctypes.create_string_buffer(DIST_UNIQUE_ID_BYTES)
+    check(lib().glu_dist_unique_id(buf, DIST_UNIQUE_ID_BYTES))
+    return buf.raw
+
+
+def dist_plan(all_hist, world_size, rank):
+    """The C ABI's plan (host only): (bucket_owner[256], send_counts[world], recv_counts[world]) as Python lists."""
+    flat = [int(x) for row in all_hist for x in row]
+    assert len(flat) == world_size * DIST_BUCKETS
+    h = (_u32 * len(flat))(*flat)
+    owner = (_int * DIST_BUCKETS)()
+    check(lib().glu_dist_plan_buckets(h, world_size, owner))
+    send, recv = (_u64 * world_size)(), (_u64 * world_size)()
+    check(lib().glu_dist_plan_counts(h, world_size, rank, owner, send, recv))
+    return list(owner), list(send), list(recv)
+
+
+class Dist:
+    """glu_dist over the C ABI: the sharded sort of one rank (RCCL communicator + local sorter inside the library)."""
+
+    def __init__(self, unique_id, world_size, rank):
+        self._h = _vp()
+        check(lib().glu_dist_create(unique_id, len(unique_id), world_size, rank, ctypes.byref(self._h)))
+        self.world_size, self.rank = world_size, rank
+
+    def prepare(self, local_count, recv_capacity=0):
+        check(lib().glu_dist_prepare(self._h, local_count, recv_capacity))
+
+    @property
+    def sorter(self):
+        """The local RadixSort inside the object (borrowed: profiling / digit width, never destroyed from here)."""
+        h = _vp()
+        check(lib().glu_dist_local_sorter(self._h, ctypes.byref(h)))
+        s = RadixSort.__new__(RadixSort)
+        s._h = h
+        s._borrowed = True
+        return s
+
+    def sort_begin(self, keys_ptr, vals_ptr, local_count, stream=None):
+        n = _sz(0)
+        check(lib().glu_dist_sort_begin(self._h, _vp(keys_ptr), _vp(vals_ptr), local_count, _vp(stream), ctypes.byref(n)))
+        return n.value
+
+    def sort_finish(self, recv_keys_ptr, recv_vals_ptr, capacity, stream=None):
+        check(lib().glu_dist_sort_finish(self._h, _vp(recv_keys_ptr), _vp(recv_vals_ptr), capacity, _vp(stream)))
+
+    def sort_ptr(self, keys_ptr, vals_ptr, local_count, stream=None):
+        """-> (device pointer of the shard's keys, of its values, count); the arrays belong to the object."""
+        k, v, n = _vp(), _vp(), _sz(0)
+        check(lib().glu_dist_sort_ptr(self._h, _vp(keys_ptr), _vp(vals_ptr), local_count, _vp(stream), ctypes.byref(k),
+                                      ctypes.byref(v), ctypes.byref(n)))
+        return k.value or 0, v.value or 0, n.value
+
+    def set_reserved_cus(self, cus):
+        check(lib().glu_dist_set_reserved_cus(self._h, cus))
+
+    def set_profiling(self, enable):
+        check(lib().glu_dist_set_profiling(self._h, 1 if enable else 0))
+
+    def phase_times(self):
+        ms = (ctypes.c_double * 4)()
+        n = _u64(0)
+        check(lib().glu_dist_phase_times(self._h, ms, ctypes.byref(n)))
+        names = ("partition", "histogram_exchange_and_plan", "all_to_all", "local_sort")
+        return {"sorts": int(n.value), **{k: float(ms[i]) for i, k in enumerate(names)}}
+
+    def destroy(self):
+        if self._h and _lib is not None:
+            _lib.glu_dist_destroy(self._h)
+        self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass

@@ -6,9 +6,15 @@ for.  Rank r holds slice r of the global array.  Steps:
   1. each rank: stable partition of its slice by the top-8-bit bucket (one counting pass of the local sort
      kernels, glu_radix_sort_partition_ptr) + the 256-bin bucket histogram;
   2. all-gather of the R x 256 histogram -> every rank derives the same contiguous bucket -> rank assignment;
-  3. one all-to-all of keys and one of values (RCCL: all_to_all_single with split sizes), receive segments
-     ordered by source rank;
+  3. ONE grouped exchange of keys and values (RCCL: ncclSend / ncclRecv to and from every peer inside one
+     ncclGroupStart / ncclGroupEnd), receive segments ordered by source rank;
   4. each rank: full local stable sort of what it received.
+
+On the GPU (process group backend "nccl" = RCCL) all of it happens inside libglu_hip.so: this module is a binding of
+the glu_dist_* entry points of include/glu_hip.h (the library makes its own RCCL communicator from a unique id that is
+broadcast through the torch process group; torch only owns the tensors).  The pure-Python transport below survives for
+process groups without RCCL (gloo): the CPU tests with an oracle-backed stand-in for the device work, and the GPU tests
+that run several ranks on one GPU, which RCCL refuses.
 
 The concatenation of the rank outputs in rank order equals the single-device stable sort: a bucket is never
 split across ranks, equal keys share a bucket, the local partition and the local sort are stable and receive
@@ -135,16 +141,38 @@ class DistributedRadixSort:
         self.torch, self.dist, self.group = torch, dist, group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
-        if local_ops_factory is None:
-            local_ops_factory = (lambda: local_ops) if local_ops is not None else HipLocalOps
+        # RCCL process group and no injected device ops: the whole sort runs inside the C library (glu_dist_*)
+        self.native = (local_ops is None and local_ops_factory is None and torch.cuda.is_available()
+                       and dist.get_backend(group) == "nccl")
         self.capacity_factor = capacity_factor
-        self._slots = [{"ops": local_ops_factory(), "bufs": None, "stream": None} for _ in range(max(1, slots))]
+        if self.native:
+            self._slots = [{"ops": None, "native": self._make_native(profile), "bufs": None, "stream": None}
+                           for _ in range(max(1, slots))]
+        else:
+            if local_ops_factory is None:
+                local_ops_factory = (lambda: local_ops) if local_ops is not None else HipLocalOps
+            self._slots = [{"ops": local_ops_factory(), "bufs": None, "stream": None} for _ in range(max(1, slots))]
         self._next_slot = 0
         self.last_plan = None
         # profile=True: device-time stamps around the phases of every sort (events on the slot's stream), summed by
         # phase_times(); they are what tells a slow exchange from a slow local sort in a multi-GPU run
         self.profile = profile
         self._stamps = []
+
+    def _make_native(self, profile):
+        """One glu_dist per slot: rank 0 draws the RCCL unique id, the torch process group carries it to the others."""
+        from . import Dist, dist_unique_id
+
+        ids = [dist_unique_id() if self.rank == 0 else None]
+        src = self.dist.get_global_rank(self.group, 0) if self.group is not None else 0
+        self.dist.broadcast_object_list(ids, src=src, group=self.group)
+        d = Dist(ids[0], self.world, self.rank)
+        d.set_profiling(profile)
+        return d
+
+    def local_sorters(self):
+        """The local RadixSort object of every slot (kernel-level profiling in bench.py)."""
+        return [s["native"].sorter if self.native else s["ops"].sorter for s in self._slots]
 
     @property
     def ops(self):
@@ -223,6 +251,10 @@ class DistributedRadixSort:
     def phase_times(self, reset=True):
         """Average device milliseconds per sort of each phase (profile=True; call after synchronising)."""
         names = ("partition", "histogram_exchange_and_plan", "all_to_all", "local_sort")
+        if self.native:
+            per = [s["native"].phase_times() for s in self._slots]
+            count = sum(p["sorts"] for p in per)
+            return {"sorts": count, **{n: (sum(p[n] * p["sorts"] for p in per) / count if count else 0.0) for n in names}}
         sums, count = [0.0] * len(names), 0
         for marks in self._stamps:
             if len(marks) != len(names) + 1:
@@ -234,7 +266,33 @@ class DistributedRadixSort:
             self._stamps = []
         return {"sorts": count, **{n: (sums[i] / count if count else 0.0) for i, n in enumerate(names)}}
 
+    def _sort_native(self, slot, keys, vals):
+        """The sort inside libglu_hip.so: partition + histogram exchange + plan, then (receive arrays sized by the plan)
+        the grouped exchange and the local sort.  Only the receive arrays are torch's."""
+        t = self.torch
+        nd = slot["native"]
+        n_local = keys.numel()
+        stream = t.cuda.current_stream(keys.device).cuda_stream
+        b = slot["bufs"]
+        if b is None or b["n_local"] < n_local:
+            cap = int(n_local * self.capacity_factor) + 4096
+            b = {"n_local": n_local, "cap": cap,
+                 "recv_k": t.empty(cap, dtype=t.int32, device=keys.device),
+                 "recv_v": t.empty(cap, dtype=t.int32, device=keys.device)}
+            slot["bufs"] = b
+            nd.prepare(n_local, cap)
+        n_recv = nd.sort_begin(keys.data_ptr() if n_local else 0, vals.data_ptr() if n_local else 0, n_local, stream)
+        if n_recv > b["cap"]:  # a skewed plan: this rank owns more than its share (buckets are never split)
+            b["cap"] = int(n_recv * 1.1) + 4096
+            b["recv_k"] = t.empty(b["cap"], dtype=t.int32, device=keys.device)
+            b["recv_v"] = t.empty(b["cap"], dtype=t.int32, device=keys.device)
+            nd.prepare(n_local, b["cap"])
+        nd.sort_finish(b["recv_k"].data_ptr(), b["recv_v"].data_ptr(), b["cap"], stream)
+        return b["recv_k"][:n_recv], b["recv_v"][:n_recv], n_recv
+
     def _sort(self, slot, keys, vals):
+        if self.native and keys.is_cuda:
+            return self._sort_native(slot, keys, vals)
         t, dist = self.torch, self.dist
         ops = slot["ops"]
         n_local = keys.numel()
@@ -259,7 +317,8 @@ class DistributedRadixSort:
         self.last_plan = {"owner": owner, "send": send_counts, "recv": recv_counts}
         self._stamp(marks, keys.device)
 
-        # 4. one exchange for keys, one for values; receive segments ordered by source rank
+        # 4. keys and values to every peer (this transport: gloo point-to-point or two torch all-to-alls; the native path
+        #    posts one grouped RCCL exchange); receive segments ordered by source rank
         recv_k = b["recv_k"][:n_recv]
         recv_v = b["recv_v"][:n_recv]
         self._all_to_all(recv_k, b["part_k"][:n_local], recv_counts, send_counts)

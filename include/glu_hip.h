@@ -86,6 +86,7 @@ typedef struct glu_radix_sort_s* glu_radix_sort;
 typedef struct glu_scan_s* glu_scan;
 typedef struct glu_reduce_s* glu_reduce;
 typedef struct glu_timer_s* glu_timer;
+typedef struct glu_dist_s* glu_dist;
 
 /* ---- library / device ---------------------------------------------------------------------------- */
 
@@ -231,6 +232,55 @@ GLU_API glu_status glu_reduce_destroy(glu_reduce reduce);
  * some of them; only data[0] is contract).  Checks kept (:113-114): buffer != 0, count > 0. */
 GLU_API glu_status glu_reduce_run(glu_reduce reduce, glu_buffer buffer, size_t count);
 GLU_API glu_status glu_reduce_run_ptr(glu_reduce reduce, void* data, size_t count, void* stream);
+
+/* ---- sharded sort over the GPUs of one node ---------------------------------------------------------
+ * The reference is single-device (one GL context, no communication code: SURVEY.md section 2 row C1); this is the
+ * sharded form of glu::RadixSort::operator() (glu/RadixSort.hpp:273-334) that BASELINE.json configs[3] asks for.
+ * One process per GPU, rank r holds slice r of the array.  A sort = stable partition of the slice by the top 8 key
+ * bits -> ncclAllGather of the R x 256 bucket histograms -> identical contiguous bucket -> rank plan on every rank (a
+ * bucket is never split) -> ONE grouped RCCL exchange of keys and values (receive segments in source-rank order) ->
+ * local stable sort.  The ranks' outputs concatenated in rank order equal the single-device stable sort; shard sizes
+ * follow the data.  RCCL is loaded with dlopen at first use (GLU_HIP_RCCL_LIB overrides the name).
+ * Every rank must issue the same sequence of glu_dist calls (they contain collectives). */
+
+#define GLU_DIST_UNIQUE_ID_BYTES 128
+/* Rank 0: ncclGetUniqueId; the caller carries the bytes to the other ranks (MPI, torch.distributed, a file ...). */
+GLU_API glu_status glu_dist_unique_id(void* id_out, size_t id_bytes);
+/* ncclCommInitRank on the library's device (glu_set_device) + a local glu_radix_sort; collective over all ranks. */
+GLU_API glu_status glu_dist_create(const void* unique_id, size_t id_bytes, int world_size, int rank, glu_dist* out);
+GLU_API glu_status glu_dist_destroy(glu_dist dist);
+GLU_API glu_status glu_dist_world(glu_dist dist, int* world_size, int* rank);
+/* The local glu_radix_sort that `dist` partitions and sorts with (owned by `dist`, do not destroy): for
+ * glu_radix_sort_set_digit_bits / set_profiling / read_profile. */
+GLU_API glu_status glu_dist_local_sorter(glu_dist dist, glu_radix_sort* out);
+/* Grow-only buffers for slices of `local_count` pairs and (for glu_dist_sort_ptr) shards of `recv_capacity` pairs: after
+ * it a sort whose slice / shard fit allocates nothing (the analogue of RadixSort::prepare_internal_buffers, :237-271). */
+GLU_API glu_status glu_dist_prepare(glu_dist dist, size_t local_count, size_t recv_capacity);
+/* First half of a sort: partition + histogram exchange + plan.  The partition is enqueued on `stream`; the call returns
+ * when the host has the plan (it waits for the histogram exchange, which runs on a side stream beside the partition's
+ * scatter kernel, not for the partition).  *recv_count = pairs this rank will receive. */
+GLU_API glu_status glu_dist_sort_begin(glu_dist dist, const uint32_t* keys, const uint32_t* vals, size_t local_count,
+                                       void* stream, size_t* recv_count);
+/* Second half: the grouped exchange into the caller's arrays (capacity >= the count glu_dist_sort_begin returned) and the
+ * local sort, enqueued on `stream` (no host synchronisation). */
+GLU_API glu_status glu_dist_sort_finish(glu_dist dist, uint32_t* recv_keys, uint32_t* recv_vals, size_t capacity, void* stream);
+/* Both halves with receive arrays owned by `dist` (grown if the shard does not fit); *out_keys / *out_vals are device
+ * pointers valid until the next sort on `dist`. */
+GLU_API glu_status glu_dist_sort_ptr(glu_dist dist, const uint32_t* keys, const uint32_t* vals, size_t local_count,
+                                     void* stream, uint32_t** out_keys, uint32_t** out_vals, size_t* out_count);
+/* CUs that the sort kernels of `dist` leave free (for RCCL kernels of another sort in flight; the partition pass always
+ * leaves two when world_size > 1, for the histogram all-gather). */
+GLU_API glu_status glu_dist_set_reserved_cus(glu_dist dist, int cus);
+/* Device time per phase, averaged over the sorts since the last call (after glu_dist_set_profiling(dist, 1)):
+ * ms4 = {partition, histogram exchange + plan (side stream), exchange, local sort}. */
+GLU_API glu_status glu_dist_set_profiling(glu_dist dist, int enable);
+GLU_API glu_status glu_dist_phase_times(glu_dist dist, double* ms4, uint64_t* sorts);
+/* The plan as pure host functions (no device, no RCCL needed: unit-testable with simulated ranks).
+ * all_hist: [world_size][256] bucket histograms; bucket_owner: [256] rank of every bucket (contiguous, monotone, balanced
+ * on the boundary nearest to r * N / R); send_counts / recv_counts: [world_size] for `rank`. */
+GLU_API glu_status glu_dist_plan_buckets(const uint32_t* all_hist, int world_size, int* bucket_owner);
+GLU_API glu_status glu_dist_plan_counts(const uint32_t* all_hist, int world_size, int rank, const int* bucket_owner,
+                                        uint64_t* send_counts, uint64_t* recv_counts);
 
 /* ---- timing: replaces glu::measure_gl_elapsed_time (glu/gl_utils.hpp:249-265) ---------------------- */
 

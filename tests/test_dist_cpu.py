@@ -59,6 +59,31 @@ def test_plan_is_contiguous_monotone_and_balanced(world):
     assert (owner == (np.arange(256) * world) // 256).all()
 
 
+@pytest.mark.parametrize("world", [1, 2, 3, 8, 16])
+def test_c_abi_plan_equals_the_python_plan(world):
+    """glu_dist_plan_buckets / glu_dist_plan_counts (host-only entry points of libglu_hip.so: what the native sharded
+    sort plans with) against the numpy plan of this module, on random, hot-bucket, empty and one-sided histograms."""
+    import glu_hip as G
+
+    rng = np.random.default_rng(world)
+    for trial in range(12):
+        h = rng.integers(0, 5000, (world, 256))
+        if trial % 4 == 1:
+            h[:, rng.integers(0, 256)] += 3000000
+        if trial % 4 == 2:
+            h[:, 1:] = 0
+        if trial % 4 == 3:
+            h[1:, :] = 0
+        if trial == 11:
+            h[:] = 0
+        owner = D.plan_bucket_to_rank(h.sum(axis=0), world)
+        for rank in range(world):
+            send, recv = D.split_counts(h, owner, rank)
+            c_owner, c_send, c_recv = G.dist_plan(h, world, rank)
+            assert c_owner == [int(x) for x in owner]
+            assert c_send == [int(x) for x in send] and c_recv == [int(x) for x in recv]
+
+
 def test_plan_skew_never_splits_a_bucket():
     totals = np.zeros(256, dtype=np.int64)
     totals[77] = 10**6

@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("prog", ["test_radix_sort_api", "test_scan_api", "test_reduce_api"])
+@pytest.mark.parametrize("prog", ["test_radix_sort_api", "test_scan_api", "test_reduce_api", "test_dist_api"])
 def test_cpp_program(built, prog):
     exe = os.path.join(ROOT, "tests", "cpp", "bin", prog)
     p = subprocess.run([exe], capture_output=True, text=True, timeout=900)
