@@ -1,0 +1,79 @@
+"""Builds profiles/traffic_r02*.json and profiles/r02/traffic_all_kernels.json from the per-kernel PMC summaries that
+tools/refresh_profiles_r02.sh leaves in profiles/r02/ (FETCH_SIZE and WRITE_SIZE were collected in separate rocprofv3
+--pmc passes; on gfx950 FETCH_SIZE counts half of a coalesced streaming read, MI355X_MICROARCH.md HBM section, so it is
+doubled -- the count kernel, which reads exactly 4 B per key and writes nothing, calibrates that in the same run).
+usage: python tools/make_traffic_json.py"""
+import json, os, re
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P = os.path.join(ROOT, "profiles", "r02")
+
+
+def parse(path):
+    out, name = {}, None
+    for line in open(path):
+        if line.startswith("void "):
+            name = line.strip()
+        elif name and "avg=" in line:
+            m = re.search(r"n=\s*(\d+) avg=([0-9.e+]+)", line)
+            out[name] = (int(m.group(1)), float(m.group(2)))
+    return out
+
+
+def find(d, *subs):
+    for k, v in d.items():
+        if all(s in k for s in subs):
+            return k, v
+    raise KeyError(subs)
+
+
+N = 1 << 28
+rows = []
+for tag in ("bench", "configs"):
+    f = parse(os.path.join(P, "pmc_fetch_size_%s.txt" % tag))
+    w = parse(os.path.join(P, "pmc_write_size_%s.txt" % tag))
+    rows.append((tag, f, w))
+bench_f, bench_w = rows[0][1], rows[0][2]
+cfg_f, cfg_w = rows[1][1], rows[1][2]
+
+
+def entry(f, w, subs, alg_bytes, what, launches_note=""):
+    k, (nf, fk) = find(f, *subs)
+    _, (nw, wk) = find(w, *subs)
+    rd, wr = int(fk * 1024 * 2), int(wk * 1024)
+    return {"kernel": k.split("(")[0].replace("void ", ""), "what": what, "dispatches_averaged": nf,
+            "fetch_size_kb_avg": fk, "write_size_kb_avg": wk, "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr,
+            "hbm_bytes_per_launch": rd + wr, "algorithmic_bytes_per_launch": alg_bytes, "ratio": round((rd + wr) / alg_bytes, 4),
+            "note": launches_note}
+
+
+corr = ("FETCH_SIZE is doubled (MI355X_MICROARCH.md, HBM section: on gfx950 FETCH_SIZE reads 1/2 of a coalesced streaming "
+        "read; the count kernel of the same run, which reads 4 B per key and nothing else, reports 524323 KB for 2^28 keys "
+        "= 1/2 of 1 GiB). WRITE_SIZE is exact. Units: KB = 1024 B.")
+src = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, tools/refresh_profiles_r02.sh), MI355X, round 2; "
+       "per-dispatch averages in profiles/r02/pmc_{fetch,write}_size_{bench,configs}.txt")
+e8 = entry(bench_f, bench_w, ("radix_scatter_lines_kernel<unsigned int, 8",), N * 16, "dominant kernel of the headline sort (2^28 u32 pairs, 8-bit digits)")
+e4 = entry(bench_f, bench_w, ("radix_scatter_lines_kernel<unsigned int, 4",), N * 16, "scatter of the reference pass structure (4-bit digits)")
+all_k = {
+    "source": src, "corrections": corr,
+    "kernels": [
+        e8, e4,
+        entry(bench_f, bench_w, ("radix_count_kernel<unsigned int, 8, 1024, 9216",), N * 4, "count pass of the headline sort (reads the keys)"),
+        entry(cfg_f, cfg_w, ("radix_scatter_kernel<unsigned long, 8, 512, 16",), N * 24, "scatter of BASELINE.json configs[4] (2^28 u64 keys + u32 vals, 8-bit digits)"),
+        entry(cfg_f, cfg_w, ("radix_scatter_kernel<unsigned long, 4, 1024, 8",), N * 24, "same, 4-bit digits"),
+        entry(cfg_f, cfg_w, ("radix_count_kernel<unsigned long, 8",), N * 8, "count pass, 64-bit keys"),
+        entry(cfg_f, cfg_w, ("scan_chunks_kernel",), N * 8, "glu::BlellochScan 2^28 u32 (chained single pass)"),
+    ],
+}
+k, (nf, fk) = find(cfg_f, "reduce_kernel")
+all_k["kernels"].append({"kernel": "glu_hip::reduce_kernel<0, unsigned int, 1, true>", "what": "glu::Reduce 2^28 u32 sum",
+                         "dispatches_averaged": nf, "fetch_size_kb_avg": fk,
+                         "note": "average over the two launches of a reduce (the second reads 2 KiB): the first launch fetches 2 x avg",
+                         "hbm_read_bytes_per_launch": int(fk * 2 * 1024 * 2), "algorithmic_bytes_per_launch": N * 4,
+                         "ratio": round(fk * 2 * 1024 * 2 / (N * 4), 4)})
+json.dump(all_k, open(os.path.join(P, "traffic_all_kernels.json"), "w"), indent=1)
+for e, key, name in ((e8, "radix_sort_u32_pairs_2^28_uniform_bits8", "traffic_r02.json"), (e4, "radix_sort_u32_pairs_2^28_uniform_bits4", "traffic_r02_bits4.json")):
+    d = {"workload_key": key, "source": src, "corrections": corr}
+    d.update(e)
+    json.dump(d, open(os.path.join(ROOT, "profiles", name), "w"), indent=1)
+for e in all_k["kernels"]:
+    print("%-70s ratio %s" % (e["kernel"][:70], e["ratio"]))
