@@ -23,19 +23,22 @@
 
 namespace glu_hip
 {
-constexpr int kLineElems = 32; // 4-byte elements per 128-byte line
+// Elements per carry granule = keys per 128-byte line: 32 for 4-byte keys (values then fill whole lines too), 16 for
+// 8-byte keys (whole lines of keys, 64-byte halves of value lines: a 32-element granule would need 96 KiB of carry).
+template<typename KeyT>
+constexpr int line_elems() { return 128 / (int) sizeof(KeyT); }
 
 template<typename KeyT, int BITS, int THREADS, int KPT, bool VALS = true>
 struct LineSmem
 {
-    static_assert(sizeof(KeyT) == 4, "the line kernel handles 4-byte keys");
     static constexpr int RADIX = 1 << BITS;
     static constexpr int WAVES = THREADS / kWave;
     static constexpr int TILE = THREADS * KPT;
-    static constexpr int CARRY = RADIX * kLineElems;
-    static constexpr int MAXLINES = (TILE + RADIX * (kLineElems - 1)) / kLineElems + 2;
+    static constexpr int LINE = line_elems<KeyT>();
+    static constexpr int CARRY = RADIX * LINE;
+    static constexpr int MAXLINES = (TILE + RADIX * (LINE - 1)) / LINE + 2;
     static_assert(TILE < 65536 && MAXLINES < 65536, "ranked positions and line numbers share one 32-bit scan word");
-    PairArray<KeyT, TILE + CARRY, VALS> buf; // [0, TILE): the tile in ranked order;  [TILE + d * 32, +32): carry of digit d
+    PairArray<KeyT, TILE + CARRY, VALS> buf; // [0, TILE): the tile in ranked order;  [TILE + d * LINE, + LINE): carry of digit d
     static constexpr int WCNT_STRIDE = RADIX + wcnt_row_pad(WAVES);
     uint32_t wcnt[WAVES][WCNT_STRIDE]; // wave-private running digit counters -> first ranked position of (wave, digit)
     uint4 dinfo[RADIX];  // .x global index of the digit's first line this tile (= of its carried elements), .y ranked position
@@ -50,7 +53,7 @@ struct LineSmem
 // ABLATE (tuning builds, wrong results): 4 = nothing is written out.  RANK_SPLIT: how many of a tile's KPT items are
 // ranked right after the staging of the tile before (the rest after that tile's tail copy).
 template<typename KeyT, int BITS, int THREADS, int KPT, bool XF = false, bool VALS = true, int ABLATE = 0, bool STAMPS = false,
-         int RANK_SPLIT = (KPT + 2) / 3, bool STAGGER = true>
+         int RANK_SPLIT = (KPT + 2) / 3, bool STAGGER = true, bool NT_STORES = false>
 __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
     const KeyT* __restrict__ keys_a, const uint32_t* __restrict__ vals_a, KeyT* __restrict__ keys_b,
     uint32_t* __restrict__ vals_b, const uint32_t* __restrict__ table, const uint32_t* __restrict__ totals, uint32_t n,
@@ -83,7 +86,7 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
     constexpr int WQ = WAVES / 4;            // scan threads per digit (4 waves' counters each)
     constexpr int SCAN_THREADS = RADIX * WQ;
     constexpr int SCAN_WAVES = (SCAN_THREADS + kWave - 1) / kWave;
-    constexpr uint32_t LINE = kLineElems;
+    constexpr uint32_t LINE = Smem::LINE;
     static_assert(WQ == 4, "the digit bookkeeping below is written for 16 waves (quads of scan threads)");
     static_assert(SCAN_THREADS <= THREADS, "one scan thread per (digit, 4 waves)");
     const uint32_t MASK = mask; // <= RADIX - 1
@@ -349,12 +352,36 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
                     if (real && g0[u] >= owned[u] && (ABLATE == 0 || g0[u] + 3 < n))
                     {
                         typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-                        u32x4_t kk = {(uint32_t) k[0], (uint32_t) k[1], (uint32_t) k[2], (uint32_t) k[3]};
-                        *reinterpret_cast<u32x4_t*>(dst_keys + g0[u]) = kk;
+                        if constexpr (sizeof(KeyT) == 4)
+                        {
+                            u32x4_t kk = {(uint32_t) k[0], (uint32_t) k[1], (uint32_t) k[2], (uint32_t) k[3]};
+                            if (NT_STORES)
+                                __builtin_nontemporal_store(kk, reinterpret_cast<u32x4_t*>(dst_keys + g0[u]));
+                            else
+                                *reinterpret_cast<u32x4_t*>(dst_keys + g0[u]) = kk;
+                        }
+                        else
+                        {
+                            typedef uint64_t u64x2_t __attribute__((ext_vector_type(2)));
+                            u64x2_t k01 = {(uint64_t) k[0], (uint64_t) k[1]}, k23 = {(uint64_t) k[2], (uint64_t) k[3]};
+                            if (NT_STORES)
+                            {
+                                __builtin_nontemporal_store(k01, reinterpret_cast<u64x2_t*>(dst_keys + g0[u]));
+                                __builtin_nontemporal_store(k23, reinterpret_cast<u64x2_t*>(dst_keys + g0[u] + 2));
+                            }
+                            else
+                            {
+                                *reinterpret_cast<u64x2_t*>(dst_keys + g0[u]) = k01;
+                                *reinterpret_cast<u64x2_t*>(dst_keys + g0[u] + 2) = k23;
+                            }
+                        }
                         if (VALS)
                         {
                             u32x4_t vv = {v[0], v[1], v[2], v[3]};
-                            *reinterpret_cast<u32x4_t*>(dst_vals + g0[u]) = vv;
+                            if (NT_STORES)
+                                __builtin_nontemporal_store(vv, reinterpret_cast<u32x4_t*>(dst_vals + g0[u]));
+                            else
+                                *reinterpret_cast<u32x4_t*>(dst_vals + g0[u]) = vv;
                         }
                     }
                     else if (real && ABLATE == 0)

@@ -150,6 +150,28 @@ def test_line_kernel_carry_cases(G, bits, kind, monkeypatch):
     assert (gk == ek).all() and (gv == ev).all()
 
 
+@pytest.mark.parametrize("bits", DIGIT_BITS)
+@pytest.mark.parametrize("kind", ["uniform", "one_per_tile", "low_word_only", "two_values"])
+def test_line_kernel_u64_carry_cases(G, bits, kind):
+    """64-bit keys through the line kernel (16-element granules): the same carry situations as the 32-bit test."""
+    n = 256 * 7168 * 2 + 999
+    rng = np.random.default_rng(43)
+    if kind == "uniform":
+        keys = rng.integers(0, 2**64, n, dtype=np.uint64)
+    elif kind == "one_per_tile":
+        keys = np.full(n, 0x5555555555555555, dtype=np.uint64)
+        idx = rng.integers(0, n, n // 40)
+        keys[idx] = rng.integers(0, 2**64, idx.size, dtype=np.uint64)
+    elif kind == "low_word_only":
+        keys = rng.integers(0, 2**20, n, dtype=np.uint64)  # the high passes are constant (skipped by the plan)
+    else:
+        keys = np.where(rng.integers(0, 2, n) == 0, 0x8000000000000000, 0x7FFFFFFFFFFFFFFF).astype(np.uint64)
+    vals = np.arange(n, dtype=np.uint32)
+    gk, gv = gpu_sort(G, keys, vals, bits=bits, key_bytes=8)
+    order = np.argsort(keys, kind="stable")
+    assert (gk == keys[order]).all() and (gv == vals[order]).all()
+
+
 @pytest.mark.parametrize("blocks", [1, 2, 7, 100, 255])
 def test_line_kernel_with_fewer_workgroups(G, blocks, monkeypatch):
     """GLU_HIP_SORT_BLOCKS caps the grid: other range boundaries (first / last partial lines of a range), many tiles per
@@ -664,13 +686,13 @@ def test_bit_range_argument_checks(G):
             sorter.sort_bit_range_ptr(kb.device_ptr(), None, 64, begin, end, None, kbytes)
 
 
-@pytest.mark.parametrize("mode,threshold", [("pairs", 256 * 9216 * 3 // 2), ("keys", 256 * 16384 * 3 // 2), ("u64", 256 * 8192 * 3 // 2),
-                                            ("pairs", 256 * 12288 * 3 // 2)])
+@pytest.mark.parametrize("mode,threshold", [("pairs", 256 * 9216 * 3 // 2), ("keys", 256 * 16384 * 3 // 2), ("u64", 256 * 7168 * 3 // 2),
+                                            ("pairs", 256 * 12288 * 3 // 2), ("u64", 256 * 8192 * 3 // 2)])
 @pytest.mark.parametrize("delta", [-1, 0, 1, 12287])
 def test_geometry_switch_points(G, mode, threshold, delta):
     """Sizes right at the small -> large geometry switch of each kernel family (3/2 large tiles per CU on 256 CUs; the
-    large tile is 9216 pairs / 16384 keys for the 128-byte-line kernel of 32-bit keys, 8192 pairs for 64-bit keys;
-    12288 pairs is the switch of the kernel that unaligned arrays fall back to)."""
+    large tile is 9216 pairs / 16384 keys for the 128-byte-line kernel of 32-bit keys, 7168 pairs for 64-bit keys;
+    12288 pairs / 8192 pairs are the switches of the kernel that unaligned arrays fall back to)."""
     n = threshold + delta
     rng = np.random.default_rng(n)
     if mode == "u64":
