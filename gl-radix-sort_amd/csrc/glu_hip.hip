@@ -506,10 +506,14 @@ glu_status launch_pass(glu_radix_sort_s* s, const KeyT* src_k, const uint32_t* s
     constexpr int COUNT_THREADS = LARGE ? 1024 : G::THREADS;
     hipLaunchKernelGGL((radix_count_kernel<KeyT, BITS, COUNT_THREADS, G::TILE, XF>), dim3(nb), dim3(COUNT_THREADS), 0, stream,
                        src_k, table, (uint32_t) count, shift, mask, tiles, xform, (const KeyT*) dst_k, pa.plan, pa.pass);
+    HIP_TRY(hipGetLastError()); // every launch is checked where it happens: a failed count launch is reported as such
     s->mark(stream);
     if (!fused)
+    {
         hipLaunchKernelGGL((radix_row_scan_kernel<256>), dim3(RADIX), dim3(256), 0, stream, table, totals, nb, (uint32_t) count,
                            pa.may_skip ? pa.plan : (PassPlan*) nullptr, pa.pass);
+        HIP_TRY(hipGetLastError());
+    }
     s->mark(stream);
     if (histogram_out)
     {
@@ -1184,7 +1188,12 @@ struct ScanRunner
             const size_t chunks = (count + ScanCfg<T, kChainGroups, kChainThreads>::CHUNK - 1) / ScanCfg<T, kChainGroups, kChainThreads>::CHUNK;
             // Below about one chunk per CU the ticket chain is latency-bound and the three-launch reduce-then-scan
             // wins (measured crossover between 2^22 and 2^24 elements, tools/scan_probe.py).
-            if (scan->chained && chunks > 1 && chunks * partitions >= scan->chain_min_chunks && chunks * partitions <= 0x7FFFFFFFull)
+            // A captured launch would bake this call's epoch into the graph: every replay would accept the chain words of the
+            // replay before as ready.  Under stream capture the scan takes the reduce-then-scan path (capturable: no host state).
+            hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+            if (!size_only) (void) hipStreamIsCapturing(stream, &capturing);
+            if (scan->chained && chunks > 1 && chunks * partitions >= scan->chain_min_chunks && chunks * partitions <= 0x7FFFFFFFull &&
+                capturing == hipStreamCaptureStatusNone)
             {
                 if (size_only)
                 {
@@ -1195,9 +1204,10 @@ struct ScanRunner
                         HIP_TRY(hipMemset(scan->chain.ptr, 0, scan->chain.size));
                         scan->epoch = 0;
                     }
-                    return GLU_OK;
+                    // no return: a captured run of the same scan takes the other path and needs its scratch too
                 }
-                return scan_chained<S, N>(scan, (T*) data, count, partitions, stream);
+                else
+                    return scan_chained<S, N>(scan, (T*) data, count, partitions, stream);
             }
         }
         size_t need = scan_scratch_elems<T>(count, partitions) * sizeof(T);

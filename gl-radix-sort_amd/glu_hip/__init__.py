@@ -321,6 +321,10 @@ class BlellochScan:
         b = buffer.handle() if isinstance(buffer, ShaderStorageBuffer) else buffer
         check(lib().glu_scan_run(self._h, b, count, num_partitions))
 
+    def prepare(self, count, num_partitions=1):
+        """Scratch for scans of `count` x `num_partitions` elements: after it a scan allocates nothing (capturable)."""
+        check(lib().glu_scan_prepare(self._h, count, num_partitions))
+
     def run_ptr(self, data_ptr, count, num_partitions=1, stream=None):
         check(lib().glu_scan_run_ptr(self._h, _vp(data_ptr), count, num_partitions, _vp(stream)))
 

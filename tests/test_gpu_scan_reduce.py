@@ -295,3 +295,34 @@ def test_reduce_beyond_32_bit_counts_on_device(G, count):
         del work
     del data
     torch.cuda.empty_cache()
+
+
+def test_scan_captured_into_a_graph_replays_correctly(G):
+    """The single-pass chained scan keeps a host-side epoch and is not capturable; a scan issued under stream capture takes
+    the reduce-then-scan path instead (after glu_scan_prepare nothing is allocated), so replays give fresh results even
+    at a size where the chained kernel would run (2^24 elements)."""
+    import torch
+
+    n = 1 << 24
+    scan = G.BlellochScan(G.DataType_Uint)
+    scan.prepare(n)
+    t = torch.empty(n, dtype=torch.int32, device="cuda")
+    side = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    rng = np.random.default_rng(5)
+    with torch.cuda.stream(side):
+        data = rng.integers(0, 1000, n, dtype=np.uint32)
+        t.copy_(torch.from_numpy(data.view(np.int32)))
+        scan.run_ptr(t.data_ptr(), n, 1, side.cuda_stream)  # warm-up outside the capture (chained path)
+        side.synchronize()
+        expect = np.concatenate([[0], np.cumsum(data[:-1], dtype=np.uint64)]).astype(np.uint32)
+        assert (t.cpu().numpy().view(np.uint32) == expect).all()
+        with torch.cuda.graph(graph, stream=side):
+            scan.run_ptr(t.data_ptr(), n, 1, torch.cuda.current_stream().cuda_stream)
+        for rep in range(3):
+            data = rng.integers(0, 1000 + rep, n, dtype=np.uint32)
+            t.copy_(torch.from_numpy(data.view(np.int32)))
+            graph.replay()
+            side.synchronize()
+            expect = np.concatenate([[0], np.cumsum(data[:-1], dtype=np.uint64)]).astype(np.uint32)
+            assert (t.cpu().numpy().view(np.uint32) == expect).all()
