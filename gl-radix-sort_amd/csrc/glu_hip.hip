@@ -393,15 +393,21 @@ struct GeometryFor : PairGeometry<KeyT, BITS, LARGE> {};
 template<> struct GeometryFor<uint32_t, 8, true, false> : Geometry<1024, 20, 1, true> {};
 
 // 128-byte-line scatter (radix_scatter_lines.hpp): 4-byte keys, large inputs, 16-byte aligned arrays.  The carry is
-// RADIX x 32 elements of LDS (64 KiB for 8-bit digits of pairs), so the tile is what is left of the 160 KiB: 9 pairs per
-// thread (1024 x 9 = 9216), 16 keys per thread for keys-only sorts.
-// 8-byte keys: 16-element granules (whole lines of keys, half lines of values), 48 KiB of carry, 7 pairs per thread.
+// RADIX x 32 elements of LDS (64 KiB for 8-bit digits of pairs), so the tile is what is left of the 160 KiB: 10 pairs per
+// thread (1024 x 10 = 10240), 16 keys per thread for keys-only sorts.
+// 8-byte keys: 16-element granules (whole lines of keys, half lines of values), 48 KiB of carry, 8 pairs per thread.
+#ifndef GLU_LINES_KPT_U32
+#define GLU_LINES_KPT_U32 10 // pairs per thread of the line kernel, 4-byte keys, 8-bit digits (tuning builds override)
+#endif
+#ifndef GLU_LINES_KPT_U64
+#define GLU_LINES_KPT_U64 8 // same, 8-byte keys
+#endif
 template<typename KeyT, int BITS, bool VALS>
-struct LinesGeometry : Geometry<1024, 9, 1, true> {};
+struct LinesGeometry : Geometry<1024, GLU_LINES_KPT_U32, 1, true> {};
 template<> struct LinesGeometry<uint32_t, 8, false> : Geometry<1024, 16, 1, true> {};
 template<> struct LinesGeometry<uint32_t, 4, true> : Geometry<1024, 12, 1, true> {};
 template<> struct LinesGeometry<uint32_t, 4, false> : Geometry<1024, 16, 1, true> {};
-template<> struct LinesGeometry<uint64_t, 8, true> : Geometry<1024, 7, 1, true> {};
+template<> struct LinesGeometry<uint64_t, 8, true> : Geometry<1024, GLU_LINES_KPT_U64, 1, true> {};
 template<> struct LinesGeometry<uint64_t, 8, false> : Geometry<1024, 10, 1, true> {};
 template<> struct LinesGeometry<uint64_t, 4, true> : Geometry<1024, 8, 1, true> {};
 template<> struct LinesGeometry<uint64_t, 4, false> : Geometry<1024, 10, 1, true> {};

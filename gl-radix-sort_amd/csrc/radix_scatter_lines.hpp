@@ -39,8 +39,10 @@ struct LineSmem
     static constexpr int MAXLINES = (TILE + RADIX * (LINE - 1)) / LINE + 2;
     static_assert(TILE < 65536 && MAXLINES < 65536, "ranked positions and line numbers share one 32-bit scan word");
     PairArray<KeyT, TILE + CARRY, VALS> buf; // [0, TILE): the tile in ranked order;  [TILE + d * LINE, + LINE): carry of digit d
-    static constexpr int WCNT_STRIDE = RADIX + wcnt_row_pad(WAVES);
-    uint32_t wcnt[WAVES][WCNT_STRIDE]; // wave-private running digit counters -> first ranked position of (wave, digit)
+    // 16-bit counters (a wave ranks at most 64 * KPT elements of a tile, positions stay below TILE < 65536): half the LDS
+    // of 32-bit ones, which the tile gets.  Rows of RADIX + 4 halfwords: the scan's four rows per thread land 8 banks apart.
+    static constexpr int WCNT_STRIDE = RADIX + 4;
+    uint16_t wcnt[WAVES][WCNT_STRIDE]; // wave-private running digit counters -> first ranked position of (wave, digit)
     uint4 dinfo[RADIX];  // .x global index of the digit's first line this tile (= of its carried elements), .y ranked position
                          // of combined element 0 (= first ranked position - carried count), .z first line | carried << 16,
                          // .w first global index of the digit that this workgroup owns
@@ -122,7 +124,8 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
             carry_start = digit_base & ~(LINE - 1); // the slots below digit_base are never written (another workgroup's)
         }
     }
-    for (int i = tid; i < WAVES * Smem::WCNT_STRIDE; i += THREADS) (&s.wcnt[0][0])[i] = 0;
+    static_assert(Smem::WCNT_STRIDE % 2 == 0, "counter rows are zeroed as 32-bit words");
+    for (int i = tid; i < WAVES * Smem::WCNT_STRIDE / 2; i += THREADS) reinterpret_cast<uint32_t*>(&s.wcnt[0][0])[i] = 0;
     __syncthreads();
 
     uint32_t first, last;
@@ -144,7 +147,7 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
     KeyT key[KPT], nkey[KPT];
     uint32_t val[KPT];
     uint32_t rank[KPT];
-    uint32_t* const my_cnt = s.wcnt[wave];
+    uint16_t* const my_cnt = s.wcnt[wave];
     // guarded loads of a partial tile: positions past the end of the array read as pads (highest digit, after all keys)
     auto load_tile_guarded = [&](uint32_t t) {
         const uint64_t base = (uint64_t) t * TILE;
@@ -175,7 +178,7 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
         {
             nkey[i] = src_keys[pf_base + i * kWave];
             const uint32_t d = digit_of<KeyT>(key[i], shift, MASK);
-            uint32_t* const cnt = my_cnt + d;
+            uint16_t* const cnt = my_cnt + d;
             const uint32_t prev = *cnt; // issued first: its LDS latency hides under the ballots below
             uint32_t plo = ~0u, phi = ~0u;
 #pragma unroll
@@ -187,11 +190,13 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
                 plo = __builtin_amdgcn_bitop3_b32(plo, (uint32_t) m, (uint32_t) sel, 0x90);
                 phi = __builtin_amdgcn_bitop3_b32(phi, (uint32_t) (m >> 32), (uint32_t) sel, 0x90);
             }
-            const uint32_t lower = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
-            const uint32_t total = (uint32_t) __popc(plo) + (uint32_t) __popc(phi);
-            rank[i] = prev + lower;
+            // v_mbcnt and v_bcnt add into an accumulator operand: rank and new count come out of two instructions each
+            rank[i] = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, prev)); // prev + lower peers
             asm volatile("" : "+v"(rank[i])); // keep the rank (1 register), not the two peer masks, live
-            *cnt = prev + total;              // every peer stores the same new count (no leader election)
+            uint32_t new_count; // prev + number of peers; asm: hipcc does not fold the additions into v_bcnt's accumulator
+            asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(new_count) : "v"(plo), "v"(prev));
+            asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(new_count) : "v"(phi), "v"(new_count));
+            *cnt = (uint16_t) new_count; // every peer stores the same new count (no leader election)
         }
     };
     using I0 = std::integral_constant<int, 0>;
@@ -262,10 +267,10 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
             if (scan_thread)
             {
                 const uint32_t pos = excl & 0xFFFFu, line0 = excl >> 16;
-                s.wcnt[sw + 0][sd] = pos;
-                s.wcnt[sw + 1][sd] = pos + c0;
-                s.wcnt[sw + 2][sd] = pos + c0 + c1;
-                s.wcnt[sw + 3][sd] = pos + c0 + c1 + c2;
+                s.wcnt[sw + 0][sd] = (uint16_t) pos;
+                s.wcnt[sw + 1][sd] = (uint16_t) (pos + c0);
+                s.wcnt[sw + 2][sd] = (uint16_t) (pos + c0 + c1);
+                s.wcnt[sw + 3][sd] = (uint16_t) (pos + c0 + c1 + c2);
                 // lines of this digit, dealt to its four scan threads
                 for (uint32_t j = sq; j < nl_d; j += WQ) s.ltab[line0 + j] = (uint16_t) sd;
                 if (sq == 0)
@@ -297,7 +302,7 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
         //      while this tile was ranked; a partial next tile, the last of the array, takes guarded loads now).  The
         //      ranking is VALU work on wave-private state: no barrier separates it from this tile's later phases, the
         //      rest of it follows the tail copy below.
-        for (int i = lane; i < Smem::WCNT_STRIDE; i += kWave) my_cnt[i] = 0;
+        for (int i = lane; i < Smem::WCNT_STRIDE / 2; i += kWave) reinterpret_cast<uint32_t*>(my_cnt)[i] = 0;
         const uint64_t pf_base = prefetch_base(tile + 2);
         if (has_next)
         {

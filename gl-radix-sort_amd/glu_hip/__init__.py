@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG_DIR, "lib", "libglu_hip.so")
+LIB_PATH = os.environ.get("GLU_HIP_LIB_PATH") or os.path.join(_PKG_DIR, "lib", "libglu_hip.so")  # override: tuning builds
 
 # glu/data_types.hpp:8-22 and glu/Reduce.hpp:42-48 (same numeric values)
 DataType_Float, DataType_Double, DataType_Int, DataType_Uint, DataType_Vec2, DataType_Vec4, DataType_DVec2, \

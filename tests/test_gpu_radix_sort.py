@@ -126,7 +126,7 @@ def test_line_kernel_carry_cases(G, bits, kind, monkeypatch):
     digits that get a handful of elements per tile (a carry that lives across many tiles without completing a line),
     digits that get whole tiles, runs that end exactly on line boundaries, a partial last tile, and workgroup range
     boundaries inside a line (n is not a multiple of anything)."""
-    n = 256 * 9216 * 2 + 4321
+    n = 256 * 10240 * 2 + 4321
     rng = np.random.default_rng(41)
     if kind == "uniform":
         keys = rng.integers(0, 2**32, n, dtype=np.uint32)
@@ -154,7 +154,7 @@ def test_line_kernel_carry_cases(G, bits, kind, monkeypatch):
 @pytest.mark.parametrize("kind", ["uniform", "one_per_tile", "low_word_only", "two_values"])
 def test_line_kernel_u64_carry_cases(G, bits, kind):
     """64-bit keys through the line kernel (16-element granules): the same carry situations as the 32-bit test."""
-    n = 256 * 7168 * 2 + 999
+    n = 256 * 8192 * 2 + 999
     rng = np.random.default_rng(43)
     if kind == "uniform":
         keys = rng.integers(0, 2**64, n, dtype=np.uint64)
@@ -177,7 +177,7 @@ def test_line_kernel_with_fewer_workgroups(G, blocks, monkeypatch):
     """GLU_HIP_SORT_BLOCKS caps the grid: other range boundaries (first / last partial lines of a range), many tiles per
     workgroup, a single workgroup that owns everything."""
     monkeypatch.setenv("GLU_HIP_SORT_BLOCKS", str(blocks))
-    n = 256 * 9216 * 3 // 2 + 777
+    n = 256 * 10240 * 3 // 2 + 777
     rng = np.random.default_rng(blocks)
     keys = rng.integers(0, 2**32, n, dtype=np.uint32)
     keys[::5] &= np.uint32(0xFF00FFFF)
@@ -686,12 +686,12 @@ def test_bit_range_argument_checks(G):
             sorter.sort_bit_range_ptr(kb.device_ptr(), None, 64, begin, end, None, kbytes)
 
 
-@pytest.mark.parametrize("mode,threshold", [("pairs", 256 * 9216 * 3 // 2), ("keys", 256 * 16384 * 3 // 2), ("u64", 256 * 7168 * 3 // 2),
-                                            ("pairs", 256 * 12288 * 3 // 2), ("u64", 256 * 8192 * 3 // 2)])
+@pytest.mark.parametrize("mode,threshold", [("pairs", 256 * 10240 * 3 // 2), ("keys", 256 * 16384 * 3 // 2), ("u64", 256 * 8192 * 3 // 2),
+                                            ("pairs", 256 * 12288 * 3 // 2), ("pairs", 256 * 9216 * 3 // 2)])
 @pytest.mark.parametrize("delta", [-1, 0, 1, 12287])
 def test_geometry_switch_points(G, mode, threshold, delta):
     """Sizes right at the small -> large geometry switch of each kernel family (3/2 large tiles per CU on 256 CUs; the
-    large tile is 9216 pairs / 16384 keys for the 128-byte-line kernel of 32-bit keys, 7168 pairs for 64-bit keys;
+    large tile is 10240 pairs / 16384 keys for the 128-byte-line kernel of 32-bit keys, 8192 pairs for 64-bit keys;
     12288 pairs / 8192 pairs are the switches of the kernel that unaligned arrays fall back to)."""
     n = threshold + delta
     rng = np.random.default_rng(n)

@@ -315,7 +315,7 @@ def test_scan_captured_into_a_graph_replays_correctly(G):
         t.copy_(torch.from_numpy(data.view(np.int32)))
         scan.run_ptr(t.data_ptr(), n, 1, side.cuda_stream)  # warm-up outside the capture (chained path)
         side.synchronize()
-        expect = np.concatenate([[0], np.cumsum(data[:-1], dtype=np.uint64)]).astype(np.uint32)
+        expect = np.concatenate([np.zeros(1, np.uint64), np.cumsum(data[:-1], dtype=np.uint64)]).astype(np.uint32)
         assert (t.cpu().numpy().view(np.uint32) == expect).all()
         with torch.cuda.graph(graph, stream=side):
             scan.run_ptr(t.data_ptr(), n, 1, torch.cuda.current_stream().cuda_stream)
@@ -324,5 +324,5 @@ def test_scan_captured_into_a_graph_replays_correctly(G):
             t.copy_(torch.from_numpy(data.view(np.int32)))
             graph.replay()
             side.synchronize()
-            expect = np.concatenate([[0], np.cumsum(data[:-1], dtype=np.uint64)]).astype(np.uint32)
+            expect = np.concatenate([np.zeros(1, np.uint64), np.cumsum(data[:-1], dtype=np.uint64)]).astype(np.uint32)
             assert (t.cpu().numpy().view(np.uint32) == expect).all()

@@ -674,15 +674,14 @@ int main(int argc, char** argv)
     }
     if (getenv("SB_LINES"))
     {
-        run_lines<8, 1024, 9>(c, shift);
+        run_lines<8, 1024, 9, true, 0, 3, true, true>(c, shift);
         run_variant<8, 1024, 12, true>(c, 1, shift);
-        run_lines<8, 1024, 9, true, 0, 0>(c, shift);
-        run_lines<8, 1024, 9, true, 0, 3>(c, shift);
+        run_lines<8, 1024, 10, true, 0, 3, true, true>(c, shift);
+        run_lines<8, 1024, 10, true, 0, 4, true, true>(c, shift);
         run_lines<8, 1024, 9, true, 0, 3, true, true>(c, shift);
-        run_lines<8, 1024, 9, true, 0, 3, true, false>(c, shift);
-        run_lines<8, 1024, 9, true, 0, 3, true, true>(c, shift);
-        run_lines<8, 1024, 9, true, 4>(c, shift);
-        run_lines<8, 1024, 9>(c, shift, 15u);
+        run_lines<8, 1024, 10, true, 0, 3, true, true>(c, shift);
+        run_lines<8, 1024, 10, true, 4>(c, shift);
+        run_lines<8, 1024, 10>(c, shift, 15u);
         run_lines<8, 1024, 16, false>(c, shift);
         run_lines<4, 1024, 12>(c, shift);
         return 0;

@@ -13,7 +13,7 @@ keys = rng.integers(0, 2**64, n, dtype=np.uint64)
 vals = np.arange(n, dtype=np.uint32)
 k0, v0 = G.ShaderStorageBuffer(keys), G.ShaderStorageBuffer(vals)
 k, v = G.ShaderStorageBuffer(size=keys.nbytes), G.ShaderStorageBuffer(size=vals.nbytes)
-for label, env in (("lines", None), ("element-granular", "1"), ("lines", None)):
+for label, env in (("lines", None),):
     if env:
         os.environ["GLU_HIP_SORT_NO_LINES"] = env
     else:
