@@ -608,7 +608,8 @@ glu_status launch_pass_sized(glu_radix_sort_s* s, const KeyT* src_k, const uint3
         // because a planned sort swaps their roles on the device.  Same size rule as the large geometry, with its tile.
         const size_t lines_tile = vals ? LinesGeometry<KeyT, BITS, true>::TILE : LinesGeometry<KeyT, BITS, false>::TILE;
         const bool aligned = (((uintptr_t) src_k | (uintptr_t) src_v | (uintptr_t) dst_k | (uintptr_t) dst_v) & 15u) == 0;
-        const bool lines = aligned && !s->no_lines && !s->force_small &&
+        // (at least one whole tile: the kernel's branch-free prefetch reads tile 0 when it has nothing better to read)
+        const bool lines = aligned && !s->no_lines && !s->force_small && count >= lines_tile &&
                            count >= (s->large_min ? s->large_min : (size_t) g_dev.num_cus * lines_tile * 3 / 2);
         if (lines)
         {

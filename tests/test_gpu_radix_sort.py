@@ -187,6 +187,30 @@ def test_line_kernel_with_fewer_workgroups(G, blocks, monkeypatch):
     assert (gk == ek).all() and (gv == ev).all()
 
 
+@pytest.mark.parametrize("bits", DIGIT_BITS)
+@pytest.mark.parametrize("n", [10240, 10241, 12288, 20480, 30001, 123457, 1000003])
+def test_line_kernel_forced_on_small_inputs(G, bits, n, monkeypatch):
+    """GLU_HIP_SORT_LARGE_MIN=1 sends every input of at least one tile through the line kernel: grids of 1 .. 100
+    workgroups, one or two tiles per workgroup, a partial tile right behind the only full one (pairs, keys only, 64-bit)."""
+    monkeypatch.setenv("GLU_HIP_SORT_LARGE_MIN", "1")
+    monkeypatch.setenv("GLU_HIP_SORT_NO_SINGLE_BLOCK", "1")
+    rng = np.random.default_rng(n)
+    keys = rng.integers(0, 2**32, n, dtype=np.uint32)
+    keys[::3] = keys[1]
+    vals = np.arange(n, dtype=np.uint32)
+    gk, gv = gpu_sort(G, keys, vals, bits=bits)
+    ek, ev = O.stable_sort_pairs(keys, vals)
+    assert (gk == ek).all() and (gv == ev).all()
+    kb = G.ShaderStorageBuffer(keys)
+    G.RadixSort(digit_bits=bits).sort_keys(kb, n)
+    assert (kb.get_data(np.uint32) == ek).all()
+    k64 = rng.integers(0, 2**64, n, dtype=np.uint64)
+    k64[::5] = k64[2]
+    gk, gv = gpu_sort(G, k64, vals, bits=bits, key_bytes=8)
+    order = np.argsort(k64, kind="stable")
+    assert (gk == k64[order]).all() and (gv == vals[order]).all()
+
+
 def test_line_kernel_needs_aligned_arrays_and_falls_back(G):
     """Whole-line stores need 16-byte aligned arrays; a sub-range that starts 4 bytes into an allocation takes the other
     kernel (same result), and GLU_HIP_SORT_NO_LINES=1 gives the same output as the default."""
