@@ -146,9 +146,16 @@ class DistributedRadixSort:
                        and dist.get_backend(group) == "nccl")
         self.capacity_factor = capacity_factor
         if self.native:
-            self._slots = [{"ops": None, "native": self._make_native(profile), "bufs": None, "stream": None}
-                           for _ in range(max(1, slots))]
-        else:
+            try:
+                self._slots = [{"ops": None, "native": self._make_native(profile), "bufs": None, "stream": None}
+                               for _ in range(max(1, slots))]
+            except Exception as e:  # e.g. no usable librccl for dlopen: every rank fails alike -> torch transport
+                import warnings
+
+                warnings.warn("glu_dist is not available (%s): using the torch.distributed transport" % (e,))
+                self.native = False
+                self.native_error = str(e)
+        if not self.native:
             if local_ops_factory is None:
                 local_ops_factory = (lambda: local_ops) if local_ops is not None else HipLocalOps
             self._slots = [{"ops": local_ops_factory(), "bufs": None, "stream": None} for _ in range(max(1, slots))]
