@@ -147,8 +147,16 @@ struct glu_dist_s
     ncclComm_t comm = nullptr;
     glu_radix_sort_s* sorter = nullptr; // partition pass + local sort (its scratch is sized for the receive side)
     hipStream_t aux = nullptr;          // histogram all-gather + copy to the host, beside the partition's scatter kernel
-    hipEvent_t ev_hist = nullptr, ev_plan = nullptr, ev_aux_begin = nullptr;
-    hipEvent_t marks[4] = {nullptr, nullptr, nullptr, nullptr}; // start, after partition, after exchange, after local sort
+    hipEvent_t ev_hist = nullptr, ev_plan = nullptr;
+    // profiling: one set of events per sort since the last glu_dist_phase_times (start, after partition, after exchange,
+    // after local sort on the sort's stream; begin / end of the histogram exchange on the side stream); nothing waits
+    // for them before glu_dist_phase_times does
+    struct Marks
+    {
+        hipEvent_t e[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    };
+    std::vector<Marks> marks;
+    size_t marks_used = 0;
     Scratch part_k, part_v;             // the local slice grouped by bucket (send side)
     Scratch recv_k, recv_v;             // receive side of glu_dist_sort_ptr (glu_dist_sort_finish takes the caller's)
     Scratch hist;                       // [256] local bucket histogram, [world * 256] gathered
@@ -160,24 +168,26 @@ struct glu_dist_s
     bool began = false;
     bool profiling = false;
     int reserved_cus = 0;               // glu_dist_set_reserved_cus
-    double phase_ms[4] = {0, 0, 0, 0};  // partition, histogram exchange + plan (side stream), exchange, local sort
-    uint64_t phase_sorts = 0;
-    bool marks_pending = false;
 };
 
 namespace
 {
-void dist_collect_marks(glu_dist_s* d)
+// the event set of the sort that is being enqueued (profiling on), or nullptr
+glu_dist_s::Marks* dist_marks(glu_dist_s* d, bool begin_new)
 {
-    if (!d->marks_pending) return;
-    d->marks_pending = false;
-    float ms;
-    if (hipEventSynchronize(d->marks[3]) != hipSuccess) return;
-    if (hipEventElapsedTime(&ms, d->marks[0], d->marks[1]) == hipSuccess) d->phase_ms[0] += ms;
-    if (hipEventElapsedTime(&ms, d->ev_aux_begin, d->ev_plan) == hipSuccess) d->phase_ms[1] += ms;
-    if (hipEventElapsedTime(&ms, d->marks[1], d->marks[2]) == hipSuccess) d->phase_ms[2] += ms;
-    if (hipEventElapsedTime(&ms, d->marks[2], d->marks[3]) == hipSuccess) d->phase_ms[3] += ms;
-    d->phase_sorts++;
+    if (!d->profiling) return nullptr;
+    if (begin_new)
+    {
+        if (d->marks_used == d->marks.size())
+        {
+            glu_dist_s::Marks m;
+            for (hipEvent_t& e : m.e)
+                if (hipEventCreate(&e) != hipSuccess) return nullptr;
+            d->marks.push_back(m);
+        }
+        d->marks_used++;
+    }
+    return d->marks_used ? &d->marks[d->marks_used - 1] : nullptr;
 }
 } // namespace
 
@@ -223,9 +233,7 @@ glu_status glu_dist_create(const void* unique_id, size_t id_bytes, int world_siz
     }
     hipError_t e = hipStreamCreateWithFlags(&d->aux, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&d->ev_hist, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreate(&d->ev_plan);
-    if (e == hipSuccess) e = hipEventCreate(&d->ev_aux_begin);
-    for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipEventCreate(&d->marks[i]);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&d->ev_plan, hipEventDisableTiming);
     if (e == hipSuccess) e = hipHostMalloc((void**) &d->all_hist_host, (size_t) world_size * kDistBuckets * sizeof(uint32_t));
     if (e != hipSuccess) return cleanup(fail(GLU_ERROR_DEVICE, "glu_dist_create: %s", hipGetErrorString(e)));
     if (glu_status st = d->hist.reserve((size_t) (world_size + 1) * kDistBuckets * sizeof(uint32_t)); st != GLU_OK) return cleanup(st);
@@ -242,9 +250,9 @@ glu_status glu_dist_destroy(glu_dist d)
     if (d->aux) (void) hipStreamDestroy(d->aux);
     if (d->ev_hist) (void) hipEventDestroy(d->ev_hist);
     if (d->ev_plan) (void) hipEventDestroy(d->ev_plan);
-    if (d->ev_aux_begin) (void) hipEventDestroy(d->ev_aux_begin);
-    for (hipEvent_t e : d->marks)
-        if (e) (void) hipEventDestroy(e);
+    for (glu_dist_s::Marks& m : d->marks)
+        for (hipEvent_t e : m.e)
+            if (e) (void) hipEventDestroy(e);
     if (d->all_hist_host) (void) hipHostFree(d->all_hist_host);
     d->part_k.release();
     d->part_v.release();
@@ -306,14 +314,23 @@ glu_status glu_dist_phase_times(glu_dist d, double* ms4, uint64_t* sorts)
 {
     GLU_TRY(enter());
     if (!d) return fail(GLU_ERROR_INVALID_ARGUMENT, "dist is NULL");
-    dist_collect_marks(d);
-    for (int i = 0; i < 4; i++)
+    double sum[4] = {0, 0, 0, 0};
+    uint64_t n = 0;
+    for (size_t i = 0; i < d->marks_used; i++)
     {
-        if (ms4) ms4[i] = d->phase_sorts ? d->phase_ms[i] / (double) d->phase_sorts : 0.0;
-        d->phase_ms[i] = 0;
+        hipEvent_t* e = d->marks[i].e;
+        if (hipEventSynchronize(e[3]) != hipSuccess || hipEventSynchronize(e[5]) != hipSuccess) continue;
+        float a, b, c, f;
+        if (hipEventElapsedTime(&a, e[0], e[1]) != hipSuccess || hipEventElapsedTime(&b, e[4], e[5]) != hipSuccess ||
+            hipEventElapsedTime(&c, e[1], e[2]) != hipSuccess || hipEventElapsedTime(&f, e[2], e[3]) != hipSuccess)
+            continue;
+        sum[0] += a, sum[1] += b, sum[2] += c, sum[3] += f;
+        n++;
     }
-    if (sorts) *sorts = d->phase_sorts;
-    d->phase_sorts = 0;
+    d->marks_used = 0;
+    for (int i = 0; i < 4; i++)
+        if (ms4) ms4[i] = n ? sum[i] / (double) n : 0.0;
+    if (sorts) *sorts = n;
     return GLU_OK;
 }
 
@@ -346,12 +363,12 @@ glu_status glu_dist_sort_begin(glu_dist d, const uint32_t* keys, const uint32_t*
     if (local_count > 0 && (!keys || !vals)) return fail(GLU_ERROR_INVALID_ARGUMENT, "NULL array");
     if (local_count > 0xFFFF0000ull) return fail(GLU_ERROR_INVALID_ARGUMENT, "count %zu does not fit 32-bit indexing", local_count);
     hipStream_t st = pick_stream(stream);
-    dist_collect_marks(d);
+    glu_dist_s::Marks* marks = dist_marks(d, true);
     GLU_TRY(d->part_k.reserve(std::max<size_t>(local_count, 1) * sizeof(uint32_t)));
     GLU_TRY(d->part_v.reserve(std::max<size_t>(local_count, 1) * sizeof(uint32_t)));
     uint32_t* hist = (uint32_t*) d->hist.ptr;
     uint32_t* all_hist = hist + kDistBuckets;
-    if (d->profiling) HIP_TRY(hipEventRecord(d->marks[0], st));
+    if (marks) HIP_TRY(hipEventRecord(marks->e[0], st));
 
     // 1. stable partition by the top-8-bit bucket; the histogram is ready (and ev_hist recorded) after the row scan,
     //    before the scatter; the scatter leaves two CUs to the RCCL kernel of step 2
@@ -365,7 +382,10 @@ glu_status glu_dist_sort_begin(glu_dist d, const uint32_t* keys, const uint32_t*
         uint64_t cap = (uint64_t) g_dev.num_cus * kMaxBlocksPerCu;
         GLU_TRY(d->sorter->table.reserve((kMaxRadix * cap + kMaxRadix) * sizeof(uint32_t)));
         const uint32_t saved_blocks = d->sorter->max_blocks;
-        const int leave = std::max(d->reserved_cus, d->world > 1 ? 2 : 0);
+        // The histogram exchange of step 2 needs a CU beside the scatter, and workgroups are dealt round-robin to the 8 XCDs:
+        // with 254 workgroups six XCDs are full and a one-workgroup kernel bound for one of them waits for the scatter to
+        // end (measured: 0.40 ms for the exchange with 2 CUs left, 0.016 ms with 8 = one per XCD).
+        const int leave = std::max(d->reserved_cus, 8);
         if (leave > 0 && g_dev.num_cus > 4 * leave && (saved_blocks == 0 || saved_blocks > (uint32_t) (g_dev.num_cus - leave)))
             d->sorter->max_blocks = (uint32_t) (g_dev.num_cus - leave);
         d->sorter->after_histogram_event = d->ev_hist;
@@ -375,13 +395,14 @@ glu_status glu_dist_sort_begin(glu_dist d, const uint32_t* keys, const uint32_t*
         d->sorter->max_blocks = saved_blocks;
         GLU_TRY(ps);
     }
-    if (d->profiling) HIP_TRY(hipEventRecord(d->marks[1], st));
+    if (marks) HIP_TRY(hipEventRecord(marks->e[1], st));
 
     // 2. every rank learns every rank's histogram (R x 256 words): side stream, beside the scatter kernel
     HIP_TRY(hipStreamWaitEvent(d->aux, d->ev_hist, 0));
-    HIP_TRY(hipEventRecord(d->ev_aux_begin, d->aux));
+    if (marks) HIP_TRY(hipEventRecord(marks->e[4], d->aux));
     NCCL_TRY(rccl().AllGather(hist, all_hist, kDistBuckets, ncclUint32, d->comm, d->aux));
     HIP_TRY(hipMemcpyAsync(d->all_hist_host, all_hist, (size_t) d->world * kDistBuckets * sizeof(uint32_t), hipMemcpyDeviceToHost, d->aux));
+    if (marks) HIP_TRY(hipEventRecord(marks->e[5], d->aux));
     HIP_TRY(hipEventRecord(d->ev_plan, d->aux));
     HIP_TRY(hipEventSynchronize(d->ev_plan));
 
@@ -449,15 +470,12 @@ glu_status glu_dist_sort_finish(glu_dist d, uint32_t* recv_keys, uint32_t* recv_
         HIP_TRY(hipMemcpyAsync(recv_keys + roff[d->rank], part_k + soff[d->rank], bytes, hipMemcpyDeviceToDevice, st));
         HIP_TRY(hipMemcpyAsync(recv_vals + roff[d->rank], part_v + soff[d->rank], bytes, hipMemcpyDeviceToDevice, st));
     }
-    if (d->profiling) HIP_TRY(hipEventRecord(d->marks[2], st));
+    glu_dist_s::Marks* marks = dist_marks(d, false);
+    if (marks) HIP_TRY(hipEventRecord(marks->e[2], st));
 
     // 5. local stable sort of the received pairs
     if (n_recv > 1) GLU_TRY(sort_run<uint32_t>(d->sorter, recv_keys, recv_vals, n_recv, 0, st));
-    if (d->profiling)
-    {
-        HIP_TRY(hipEventRecord(d->marks[3], st));
-        d->marks_pending = true;
-    }
+    if (marks) HIP_TRY(hipEventRecord(marks->e[3], st));
     return GLU_OK;
 }
 

@@ -269,7 +269,7 @@ GLU_API glu_status glu_dist_sort_finish(glu_dist dist, uint32_t* recv_keys, uint
 GLU_API glu_status glu_dist_sort_ptr(glu_dist dist, const uint32_t* keys, const uint32_t* vals, size_t local_count,
                                      void* stream, uint32_t** out_keys, uint32_t** out_vals, size_t* out_count);
 /* CUs that the sort kernels of `dist` leave free (for RCCL kernels of another sort in flight; the partition pass always
- * leaves two when world_size > 1, for the histogram all-gather). */
+ * leaves 8, one per XCD, for the histogram all-gather that runs beside its scatter kernel). */
 GLU_API glu_status glu_dist_set_reserved_cus(glu_dist dist, int cus);
 /* Device time per phase, averaged over the sorts since the last call (after glu_dist_set_profiling(dist, 1)):
  * ms4 = {partition, histogram exchange + plan (side stream), exchange, local sort}. */
