@@ -47,7 +47,7 @@ def entry(f, w, subs, alg_bytes, what, launches_note=""):
 
 
 corr = ("FETCH_SIZE is doubled (MI355X_MICROARCH.md, HBM section: on gfx950 FETCH_SIZE reads 1/2 of a coalesced streaming "
-        "read; the count kernel of the same run, which reads 4 B per key and nothing else, reports 524323 KB for 2^28 keys "
+        "read; the count kernel of the same run, which reads 4 B per key and nothing else, reports 524 32x KB for 2^28 keys "
         "= 1/2 of 1 GiB). WRITE_SIZE is exact. Units: KB = 1024 B.")
 src = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, tools/refresh_profiles_r02.sh), MI355X, round 2; "
        "per-dispatch averages in profiles/r02/pmc_{fetch,write}_size_{bench,configs}.txt")
@@ -57,9 +57,9 @@ all_k = {
     "source": src, "corrections": corr,
     "kernels": [
         e8, e4,
-        entry(bench_f, bench_w, ("radix_count_kernel<unsigned int, 8, 1024, 9216",), N * 4, "count pass of the headline sort (reads the keys)"),
-        entry(cfg_f, cfg_w, ("radix_scatter_kernel<unsigned long, 8, 512, 16",), N * 24, "scatter of BASELINE.json configs[4] (2^28 u64 keys + u32 vals, 8-bit digits)"),
-        entry(cfg_f, cfg_w, ("radix_scatter_kernel<unsigned long, 4, 1024, 8",), N * 24, "same, 4-bit digits"),
+        entry(bench_f, bench_w, ("radix_count_kernel<unsigned int, 8, 1024",), N * 4, "count pass of the headline sort (reads the keys)"),
+        entry(cfg_f, cfg_w, ("radix_scatter_lines_kernel<unsigned long, 8",), N * 24, "scatter of BASELINE.json configs[4] (2^28 u64 keys + u32 vals, 8-bit digits)"),
+        entry(cfg_f, cfg_w, ("radix_scatter_lines_kernel<unsigned long, 4",), N * 24, "same, 4-bit digits"),
         entry(cfg_f, cfg_w, ("radix_count_kernel<unsigned long, 8",), N * 8, "count pass, 64-bit keys"),
         entry(cfg_f, cfg_w, ("scan_chunks_kernel",), N * 8, "glu::BlellochScan 2^28 u32 (chained single pass)"),
     ],
