@@ -55,7 +55,7 @@ struct LineSmem
 // ABLATE (tuning builds, wrong results): 4 = nothing is written out.  RANK_SPLIT: how many of a tile's KPT items are
 // ranked right after the staging of the tile before (the rest after that tile's tail copy).
 template<typename KeyT, int BITS, int THREADS, int KPT, bool XF = false, bool VALS = true, int ABLATE = 0, bool STAMPS = false,
-         int RANK_SPLIT = (KPT + 2) / 3, bool STAGGER = true, bool NT_STORES = false>
+         int RANK_SPLIT = (KPT + 2) / 3, bool STAGGER = true, bool NT_STORES = false, int PRIO = 0>
 __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
     const KeyT* __restrict__ keys_a, const uint32_t* __restrict__ vals_a, KeyT* __restrict__ keys_b,
     uint32_t* __restrict__ vals_b, const uint32_t* __restrict__ table, const uint32_t* __restrict__ totals, uint32_t n,
@@ -290,6 +290,7 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
         // ---- stage (key, val) at the ranked position; the value register just staged takes the next tile's value
         {
             const uint64_t next_base = prefetch_base(tile + 1);
+            if (PRIO & 1) __builtin_amdgcn_s_setprio(2); // tuning: LDS-bound phases ahead of the ranking of other waves
 #pragma unroll
             for (int i = 0; i < KPT; i++)
             {
@@ -297,6 +298,7 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
                 s.buf.put(pos, key[i], VALS ? val[i] : 0u);
                 if (VALS) val[i] = src_vals[next_base + i * kWave];
             }
+            if (PRIO & 1) __builtin_amdgcn_s_setprio(0);
         }
         // ---- this wave is done with its counter row: zero it and start ranking the next tile (keys prefetched into nkey
         //      while this tile was ranked; a partial next tile, the last of the array, takes guarded loads now).  The
@@ -410,9 +412,10 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
 
         // ---- new carry: the elements of every digit past its last full line move to the digit's carry slots
         auto copy_tails = [&]() {
+            if (PRIO & 2) __builtin_amdgcn_s_setprio(2);
             {
                 constexpr int ITEMS = RADIX * (int) (LINE / 4); // (digit, quad of slots)
-    #pragma unroll
+#pragma unroll
                 for (int it = 0; it < (ITEMS + THREADS - 1) / THREADS; it++)
                 {
                     const uint32_t item = it * THREADS + tid;
@@ -425,14 +428,15 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
                         uint32_t v[4];
                         // slots below lo read the element of slot lo (a valid position), slots from hi up read past the run
                         // (inside the buffer): neither is written
-    #pragma unroll
+#pragma unroll
                         for (int e = 0; e < 4; e++) s.buf.get(t.x + (s0 + e > lo ? s0 + e : lo), k[e], v[e]);
-    #pragma unroll
+#pragma unroll
                         for (int e = 0; e < 4; e++)
                             if (s0 + e >= lo && s0 + e < hi) s.buf.put((uint32_t) TILE + d * LINE + s0 + e, k[e], v[e]);
                     }
                 }
             }
+            if (PRIO & 2) __builtin_amdgcn_s_setprio(0);
         };
         // ---- tail copy (LDS-bound) and the rest of the next tile's ranking (VALU-bound, wave-private state: nobody else
         //      touches this wave's counter row between this tile's staging and the scan of the next tile, so the tile

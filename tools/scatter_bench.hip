@@ -249,7 +249,7 @@ void run_variant(Ctx& c, int blocks_per_cu, uint32_t shift, uint32_t mask_overri
 }
 
 // the 128-byte-line scatter (radix_scatter_lines.hpp) behind the production count + row scan
-template<int BITS, int THREADS, int KPT, bool VALS = true, int ABLATE = 0, int RS = (KPT + 2) / 3, bool STAGGER = true, bool NT = false>
+template<int BITS, int THREADS, int KPT, bool VALS = true, int ABLATE = 0, int RS = (KPT + 2) / 3, bool STAGGER = true, bool NT = false, int PRIO = 0>
 void run_lines(Ctx& c, uint32_t shift, uint32_t mask_override = 0)
 {
     constexpr int RADIX = 1 << BITS;
@@ -261,8 +261,8 @@ void run_lines(Ctx& c, uint32_t shift, uint32_t mask_override = 0)
     uint32_t* totals = c.table + (size_t) RADIX * nb;
     const uint32_t mask = mask_override ? mask_override : RADIX - 1;
     if (mask_override) printf("mask %u: ", mask);
-    auto scatter = radix_scatter_lines_kernel<uint32_t, BITS, THREADS, KPT, false, VALS, ABLATE, false, RS, STAGGER, NT>;
-    auto scatter_st = radix_scatter_lines_kernel<uint32_t, BITS, THREADS, KPT, false, VALS, ABLATE, true, RS, STAGGER, NT>;
+    auto scatter = radix_scatter_lines_kernel<uint32_t, BITS, THREADS, KPT, false, VALS, ABLATE, false, RS, STAGGER, NT, PRIO>;
+    auto scatter_st = radix_scatter_lines_kernel<uint32_t, BITS, THREADS, KPT, false, VALS, ABLATE, true, RS, STAGGER, NT, PRIO>;
     CK(hipFuncSetAttribute((const void*) scatter_st, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sizeof(Smem)));
     CK(hipFuncSetAttribute((const void*) scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sizeof(Smem)));
     hipLaunchKernelGGL((radix_count_kernel<uint32_t, BITS, THREADS, TILE>), dim3(nb), dim3(THREADS), 0, 0, c.keys, c.table, (uint32_t) c.n, shift, mask,
@@ -306,7 +306,7 @@ void run_lines(Ctx& c, uint32_t shift, uint32_t mask_override = 0)
             CK(hipEventElapsedTime(&ms, c.ev[0], c.ev[1]));
             best = std::min(best, ms);
         }
-        printf("%s[count right behind it: %.3f ms] ", NT ? "nt-stores " : "", best);
+        printf("%s%s[count right behind it: %.3f ms] ", NT ? "nt-stores " : "", PRIO == 1 ? "prio-stage " : PRIO == 2 ? "prio-tails " : PRIO == 3 ? "prio-both " : "", best);
     }
     printf("lines %ssplit %d bits %d threads %4d kpt %2d tile %5d lds %6zu nb %5u | scatter %.3f ms (%.0f GB/s) %s\n", STAGGER ? "stagger " : "", RS, BITS, THREADS, KPT, TILE, sizeof(Smem), nb,
            t_scatter, c.n * (VALS ? 16.0 : 8.0) / t_scatter / 1e6, ABLATE ? "(ablated)" : bad ? "WRONG" : "ok");
@@ -674,12 +674,12 @@ int main(int argc, char** argv)
     }
     if (getenv("SB_LINES"))
     {
-        run_lines<8, 1024, 9, true, 0, 3, true, true>(c, shift);
-        run_variant<8, 1024, 12, true>(c, 1, shift);
-        run_lines<8, 1024, 10, true, 0, 3, true, true>(c, shift);
         run_lines<8, 1024, 10, true, 0, 4, true, true>(c, shift);
-        run_lines<8, 1024, 9, true, 0, 3, true, true>(c, shift);
-        run_lines<8, 1024, 10, true, 0, 3, true, true>(c, shift);
+        run_variant<8, 1024, 12, true>(c, 1, shift);
+        run_lines<8, 1024, 10, true, 0, 4, true, true, 1>(c, shift);
+        run_lines<8, 1024, 10, true, 0, 4, true, true, 2>(c, shift);
+        run_lines<8, 1024, 10, true, 0, 4, true, true, 3>(c, shift);
+        run_lines<8, 1024, 10, true, 0, 4, true, true>(c, shift);
         run_lines<8, 1024, 10, true, 4>(c, shift);
         run_lines<8, 1024, 10>(c, shift, 15u);
         run_lines<8, 1024, 16, false>(c, shift);
