@@ -1,7 +1,8 @@
 // radix_scatter_lines.hpp -- the large-input scatter pass of the LSD radix sort, written around whole 128-byte lines.
 //
-// Replaces k_radix_sort_reordering_shader (reference glu/RadixSort.hpp:60-183) for 4-byte keys on inputs large enough for
-// one persistent 1024-thread workgroup per CU (the other geometries keep radix_scatter_kernel of radix_sort_kernels.hpp).
+// Replaces k_radix_sort_reordering_shader (reference glu/RadixSort.hpp:60-183) on inputs large enough for one persistent
+// 1024-thread workgroup per CU, in 16-byte aligned arrays (the other cases keep radix_scatter_kernel of
+// radix_sort_kernels.hpp).
 // Same contract: a stable counting pass on one digit, dst = digit base + block offset + local rank (RadixSort.hpp:174-177).
 //
 // Why a second kernel.  On MI355X what the memory system delivers for a streaming read + scattered write mix depends on
@@ -15,8 +16,10 @@
 //   * the write-out walks LINES, not elements: a packed block scan gives every digit its first ranked position (low half)
 //     and its first line (high half) at once; a line -> digit table makes a quad of 4 elements = 1 lane-store;
 //   * the only partial lines are at the two ends of a workgroup's range of a digit (element-wise stores).
-// The next tile's keys are loaded while the current tile is ranked, its values at the top of the tile: both are in flight
-// under the rank / scan phases instead of in front of them.
+// The tile loop is a software pipeline: the next tile's keys are loaded while the current one is ranked, its values while the
+// current one is staged, and the next tile is ranked (VALU-bound, wave-private state) beside the LDS-bound staging and tail
+// copy of the current one; 5 barriers per tile, none at its end.  The line stores are non-temporal (the count kernel of the
+// next pass reads them once: it runs 25 % faster when they do not sit dirty in L2 / Infinity Cache).
 #pragma once
 
 #include "radix_sort_kernels.hpp"
@@ -53,7 +56,10 @@ struct LineSmem
 };
 
 // ABLATE (tuning builds, wrong results): 4 = nothing is written out.  RANK_SPLIT: how many of a tile's KPT items are
-// ranked right after the staging of the tile before (the rest after that tile's tail copy).
+// ranked right after the staging of the tile before (the rest after that tile's tail copy).  STAGGER: SIMD partner waves
+// take tail copy and ranking in opposite order.  NT_STORES: non-temporal line stores (what the library runs).  PRIO:
+// tuning only (s_setprio around the LDS-bound phases: measured, no effect).  STAMPS: s_memtime per phase of the first and
+// the last wave into stamps[0..15] (tools/scatter_bench.hip).
 template<typename KeyT, int BITS, int THREADS, int KPT, bool XF = false, bool VALS = true, int ABLATE = 0, bool STAMPS = false,
          int RANK_SPLIT = (KPT + 2) / 3, bool STAGGER = true, bool NT_STORES = false, int PRIO = 0>
 __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
