@@ -128,6 +128,19 @@ void dist_plan_buckets(const uint32_t* all_hist, int world, int* owner)
         for (int b = cuts[r]; b < cuts[r + 1]; b++) owner[b] = r;
 }
 
+// true if at most one bucket is non-empty over all ranks: a partition on this digit would send everything to one rank
+bool dist_single_bucket(const uint32_t* all_hist, int world)
+{
+    int used = 0;
+    for (int b = 0; b < kDistBuckets && used < 2; b++)
+    {
+        bool any = false;
+        for (int r = 0; r < world && !any; r++) any = all_hist[(size_t) r * kDistBuckets + b] != 0;
+        used += any ? 1 : 0;
+    }
+    return used < 2;
+}
+
 // send[d] = elements of `rank` whose bucket belongs to rank d; recv[s] = elements of rank s whose bucket belongs to `rank`
 void dist_plan_counts(const uint32_t* all_hist, int world, int rank, const int* owner, uint64_t* send, uint64_t* recv)
 {
@@ -165,6 +178,8 @@ struct glu_dist_s
     std::vector<uint64_t> send_counts, recv_counts;
     size_t local_count = 0;
     uint64_t recv_total = 0;
+    uint32_t partition_shift = 24;      // the key byte the last sort was partitioned on
+    bool repartition_at_world_1 = false; // GLU_HIP_DIST_TEST_REPARTITION=1: take the lower-byte fallback with one rank too (tests)
     bool began = false;
     bool profiling = false;
     int reserved_cus = 0;               // glu_dist_set_reserved_cus
@@ -217,6 +232,7 @@ glu_status glu_dist_create(const void* unique_id, size_t id_bytes, int world_siz
     d->world = world_size;
     d->rank = rank;
     d->owner.assign(kDistBuckets, 0);
+    if (const char* e = getenv("GLU_HIP_DIST_TEST_REPARTITION")) d->repartition_at_world_1 = atoi(e) != 0;
     d->send_counts.assign(world_size, 0);
     d->recv_counts.assign(world_size, 0);
     auto cleanup = [&](glu_status st) {
@@ -260,6 +276,13 @@ glu_status glu_dist_destroy(glu_dist d)
     d->recv_v.release();
     d->hist.release();
     delete d;
+    return GLU_OK;
+}
+
+glu_status glu_dist_partition_shift(glu_dist d, uint32_t* shift)
+{
+    if (!d || !shift) return fail(GLU_ERROR_INVALID_ARGUMENT, "NULL argument");
+    *shift = d->partition_shift;
     return GLU_OK;
 }
 
@@ -370,41 +393,52 @@ glu_status glu_dist_sort_begin(glu_dist d, const uint32_t* keys, const uint32_t*
     uint32_t* all_hist = hist + kDistBuckets;
     if (marks) HIP_TRY(hipEventRecord(marks->e[0], st));
 
-    // 1. stable partition by the top-8-bit bucket; the histogram is ready (and ev_hist recorded) after the row scan,
-    //    before the scatter; the scatter leaves two CUs to the RCCL kernel of step 2
-    if (local_count == 0)
+    // 1 + 2, on the top key byte first.  If every key of every rank shares that byte (24-bit keys, small integers ...) all
+    // the data would land on one rank: the partition is repeated on the next lower byte, down to the lowest.  The bytes
+    // above the chosen one are constant over the whole input, so bucket order is still key order and a rank's shard is a
+    // contiguous key range.  (The first attempt was then an identity copy of the slice: 0.6 ms at 2^27, paid only by such
+    // inputs.)  Every rank sees the same gathered histograms and takes the same decision.
+    for (uint32_t shift = 32 - kDistTopBits;; shift -= kDistTopBits)
     {
-        HIP_TRY(hipMemsetAsync(hist, 0, kDistBuckets * sizeof(uint32_t), st));
-        HIP_TRY(hipEventRecord(d->ev_hist, st));
-    }
-    else
-    {
-        uint64_t cap = (uint64_t) g_dev.num_cus * kMaxBlocksPerCu;
-        GLU_TRY(d->sorter->table.reserve((kMaxRadix * cap + kMaxRadix) * sizeof(uint32_t)));
-        const uint32_t saved_blocks = d->sorter->max_blocks;
-        // The histogram exchange of step 2 needs a CU beside the scatter, and workgroups are dealt round-robin to the 8 XCDs:
-        // with 254 workgroups six XCDs are full and a one-workgroup kernel bound for one of them waits for the scatter to
-        // end (measured: 0.40 ms for the exchange with 2 CUs left, 0.016 ms with 8 = one per XCD).
-        const int leave = std::max(d->reserved_cus, 8);
-        if (leave > 0 && g_dev.num_cus > 4 * leave && (saved_blocks == 0 || saved_blocks > (uint32_t) (g_dev.num_cus - leave)))
-            d->sorter->max_blocks = (uint32_t) (g_dev.num_cus - leave);
-        d->sorter->after_histogram_event = d->ev_hist;
-        glu_status ps = dispatch_pass<uint32_t>(d->sorter, keys, vals, (uint32_t*) d->part_k.ptr, (uint32_t*) d->part_v.ptr, local_count,
-                                                32 - kDistTopBits, kDistTopBits, hist, st);
-        d->sorter->after_histogram_event = nullptr;
-        d->sorter->max_blocks = saved_blocks;
-        GLU_TRY(ps);
-    }
-    if (marks) HIP_TRY(hipEventRecord(marks->e[1], st));
+        // 1. stable partition by the bucket (key >> shift) & 255; the histogram is ready (and ev_hist recorded) after the
+        //    row scan, before the scatter
+        if (local_count == 0)
+        {
+            HIP_TRY(hipMemsetAsync(hist, 0, kDistBuckets * sizeof(uint32_t), st));
+            HIP_TRY(hipEventRecord(d->ev_hist, st));
+        }
+        else
+        {
+            uint64_t cap = (uint64_t) g_dev.num_cus * kMaxBlocksPerCu;
+            GLU_TRY(d->sorter->table.reserve((kMaxRadix * cap + kMaxRadix) * sizeof(uint32_t)));
+            const uint32_t saved_blocks = d->sorter->max_blocks;
+            // The histogram exchange of step 2 needs a CU beside the scatter, and workgroups are dealt round-robin to the 8
+            // XCDs: with 254 workgroups six XCDs are full and a one-workgroup kernel bound for one of them waits for the
+            // scatter to end (measured: 0.40 ms for the exchange with 2 CUs left, 0.016 ms with 8 = one per XCD).
+            const int leave = std::max(d->reserved_cus, 8);
+            if (leave > 0 && g_dev.num_cus > 4 * leave && (saved_blocks == 0 || saved_blocks > (uint32_t) (g_dev.num_cus - leave)))
+                d->sorter->max_blocks = (uint32_t) (g_dev.num_cus - leave);
+            d->sorter->after_histogram_event = d->ev_hist;
+            glu_status ps = dispatch_pass<uint32_t>(d->sorter, keys, vals, (uint32_t*) d->part_k.ptr, (uint32_t*) d->part_v.ptr,
+                                                    local_count, shift, kDistTopBits, hist, st);
+            d->sorter->after_histogram_event = nullptr;
+            d->sorter->max_blocks = saved_blocks;
+            GLU_TRY(ps);
+        }
+        if (marks && shift == 32 - kDistTopBits) HIP_TRY(hipEventRecord(marks->e[1], st));
 
-    // 2. every rank learns every rank's histogram (R x 256 words): side stream, beside the scatter kernel
-    HIP_TRY(hipStreamWaitEvent(d->aux, d->ev_hist, 0));
-    if (marks) HIP_TRY(hipEventRecord(marks->e[4], d->aux));
-    NCCL_TRY(rccl().AllGather(hist, all_hist, kDistBuckets, ncclUint32, d->comm, d->aux));
-    HIP_TRY(hipMemcpyAsync(d->all_hist_host, all_hist, (size_t) d->world * kDistBuckets * sizeof(uint32_t), hipMemcpyDeviceToHost, d->aux));
-    if (marks) HIP_TRY(hipEventRecord(marks->e[5], d->aux));
-    HIP_TRY(hipEventRecord(d->ev_plan, d->aux));
-    HIP_TRY(hipEventSynchronize(d->ev_plan));
+        // 2. every rank learns every rank's histogram (R x 256 words): side stream, beside the scatter kernel
+        HIP_TRY(hipStreamWaitEvent(d->aux, d->ev_hist, 0));
+        if (marks && shift == 32 - kDistTopBits) HIP_TRY(hipEventRecord(marks->e[4], d->aux));
+        NCCL_TRY(rccl().AllGather(hist, all_hist, kDistBuckets, ncclUint32, d->comm, d->aux));
+        HIP_TRY(hipMemcpyAsync(d->all_hist_host, all_hist, (size_t) d->world * kDistBuckets * sizeof(uint32_t), hipMemcpyDeviceToHost, d->aux));
+        if (marks) HIP_TRY(hipEventRecord(marks->e[5], d->aux));
+        HIP_TRY(hipEventRecord(d->ev_plan, d->aux));
+        HIP_TRY(hipEventSynchronize(d->ev_plan));
+        d->partition_shift = shift;
+        if (shift == 0 || (d->world == 1 && !d->repartition_at_world_1) || !dist_single_bucket(d->all_hist_host, d->world)) break;
+        if (marks) HIP_TRY(hipEventRecord(marks->e[1], st)); // the repeated partition counts as partition time
+    }
 
     // 3. identical plan on every rank
     dist_plan_buckets(d->all_hist_host, d->world, d->owner.data());

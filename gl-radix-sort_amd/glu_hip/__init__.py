@@ -79,6 +79,7 @@ SYMBOLS = [
     ("glu_dist_create", _int, [_vp, _sz, _int, _int, _P(_vp)]),
     ("glu_dist_destroy", _int, [_vp]),
     ("glu_dist_world", _int, [_vp, _P(_int), _P(_int)]),
+    ("glu_dist_partition_shift", _int, [_vp, _P(_u32)]),
     ("glu_dist_local_sorter", _int, [_vp, _P(_vp)]),
     ("glu_dist_prepare", _int, [_vp, _sz, _sz]),
     ("glu_dist_sort_begin", _int, [_vp, _vp, _vp, _sz, _vp, _P(_sz)]),
@@ -434,6 +435,11 @@ class Dist:
         check(lib().glu_dist_sort_ptr(self._h, _vp(keys_ptr), _vp(vals_ptr), local_count, _vp(stream), ctypes.byref(k),
                                       ctypes.byref(v), ctypes.byref(n)))
         return k.value or 0, v.value or 0, n.value
+
+    def partition_shift(self):
+        sh = _u32(0)
+        check(lib().glu_dist_partition_shift(self._h, ctypes.byref(sh)))
+        return sh.value
 
     def set_reserved_cus(self, cus):
         check(lib().glu_dist_set_reserved_cus(self._h, cus))

@@ -219,7 +219,10 @@ GLU_API glu_status glu_scan_prepare(glu_scan scan, size_t count, size_t num_part
  * `+` scan (identity 0) of num_partitions adjacent partitions of `count` elements each.  The reference's
  * argument checks are kept (:132-135): buffer != 0, count > 0, count a power of two, num_partitions >= 1. */
 GLU_API glu_status glu_scan_run(glu_scan scan, glu_buffer buffer, size_t count, size_t num_partitions);
-/* Raw-pointer form; additionally accepts any count > 0 (no power-of-two requirement). */
+/* Raw-pointer form; additionally accepts any count > 0 (no power-of-two requirement).  From 2^23 4-byte elements up a
+ * single-pass chained scan runs (not under stream capture, where the three-launch form is used): its order of additions
+ * follows the arrival order of the chunks, so float sums are not bitwise reproducible from run to run there (integer
+ * results are exact either way); GLU_HIP_SCAN_CHAINED=0 selects the reproducible form. */
 GLU_API glu_status glu_scan_run_ptr(glu_scan scan, void* data, size_t count, size_t num_partitions, void* stream);
 
 /* ---- reduce: replaces glu::Reduce (glu/Reduce.hpp:51-136) ----------------------------------------- */
@@ -240,7 +243,8 @@ GLU_API glu_status glu_reduce_run_ptr(glu_reduce reduce, void* data, size_t coun
  * bits -> ncclAllGather of the R x 256 bucket histograms -> identical contiguous bucket -> rank plan on every rank (a
  * bucket is never split) -> ONE grouped RCCL exchange of keys and values (receive segments in source-rank order) ->
  * local stable sort.  The ranks' outputs concatenated in rank order equal the single-device stable sort; shard sizes
- * follow the data.  RCCL is loaded with dlopen at first use (GLU_HIP_RCCL_LIB overrides the name).
+ * follow the data.  If all keys of all ranks share the top byte (24-bit keys ...), the partition falls back to the next lower
+ * byte, so that small-range keys still spread over the ranks; one hot bucket still bounds the balance.  RCCL is loaded with dlopen at first use (GLU_HIP_RCCL_LIB overrides the name).
  * Every rank must issue the same sequence of glu_dist calls (they contain collectives). */
 
 #define GLU_DIST_UNIQUE_ID_BYTES 128
@@ -250,6 +254,8 @@ GLU_API glu_status glu_dist_unique_id(void* id_out, size_t id_bytes);
 GLU_API glu_status glu_dist_create(const void* unique_id, size_t id_bytes, int world_size, int rank, glu_dist* out);
 GLU_API glu_status glu_dist_destroy(glu_dist dist);
 GLU_API glu_status glu_dist_world(glu_dist dist, int* world_size, int* rank);
+/* The bit position of the key byte the last sort on `dist` was partitioned on (24 unless the fallback ran). */
+GLU_API glu_status glu_dist_partition_shift(glu_dist dist, uint32_t* shift);
 /* The local glu_radix_sort that `dist` partitions and sorts with (owned by `dist`, do not destroy): for
  * glu_radix_sort_set_digit_bits / set_profiling / read_profile. */
 GLU_API glu_status glu_dist_local_sorter(glu_dist dist, glu_radix_sort* out);

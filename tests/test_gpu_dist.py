@@ -58,6 +58,75 @@ def test_single_rank_nccl_distributed_sort(built):
         dist.destroy_process_group()
 
 
+def _repartition_worker(q):
+    """Own process: GLU_HIP_DIST_TEST_REPARTITION makes a one-rank glu_dist take the lower-byte fallback that a multi-rank
+    sort takes when all keys share the top byte."""
+    import os
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (os.path.join(root, "gl-radix-sort_amd"), os.path.join(root, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["GLU_HIP_DIST_TEST_REPARTITION"] = "1"
+    import numpy as np
+    import torch
+    import glu_hip as G
+    import oracle as O
+
+    torch.cuda.set_device(0)
+    G.set_device(0)
+    d = G.Dist(G.dist_unique_id(), 1, 0)
+    out = []
+    for bits, expect_shift in ((32, 24), (24, 16), (13, 8), (5, 0), (0, 0)):
+        n = 700001
+        rng = np.random.default_rng(bits)
+        keys = (rng.integers(0, 2**32, n, dtype=np.uint64) & ((1 << bits) - 1)).astype(np.uint32)
+        vals = np.arange(n, dtype=np.uint32)
+        kt = torch.from_numpy(keys.view(np.int32)).cuda()
+        vt = torch.from_numpy(vals.view(np.int32)).cuda()
+        stream = torch.cuda.Stream()
+        with torch.cuda.stream(stream):
+            kp, vp, cnt = d.sort_ptr(kt.data_ptr(), vt.data_ptr(), n, stream.cuda_stream)
+        stream.synchronize()
+        import ctypes
+
+        def read_back(ptr):  # the shard lives in the library's own arrays: wrap the pointer as a buffer and read it
+            h = ctypes.c_uint32(0)
+            G.check(G.lib().glu_buffer_wrap(ctypes.c_void_p(ptr), n * 4, ctypes.byref(h)))
+            host = np.empty(n, dtype=np.uint32)
+            G.check(G.lib().glu_buffer_read(h, host.ctypes.data_as(ctypes.c_void_p), n * 4, 0))
+            G.check(G.lib().glu_buffer_destroy(h))
+            return host
+
+        gk, gv = read_back(kp), read_back(vp)
+        ek, ev = O.stable_sort_pairs(keys, vals)
+        ok = cnt == n and (gk == ek).all() and (gv == ev).all()
+        out.append((bits, d.partition_shift(), expect_shift, bool(ok)))
+    q.put(out)
+
+
+def test_small_range_keys_fall_back_to_a_lower_partition_byte(built):
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_repartition_worker, args=(q,))
+    p.start()
+    import queue
+
+    try:
+        out = q.get(timeout=120)
+    except queue.Empty:
+        p.join(timeout=5)
+        raise AssertionError("worker produced nothing (exit code %s)" % p.exitcode)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    for bits, shift, expect_shift, ok in out:
+        assert ok, bits
+        assert shift == expect_shift, (bits, shift, expect_shift)
+
+
 def _gpu_worker(rank, world, port, n_local, q):
     """One of `world` processes sharing GPU 0: real device ops (HipLocalOps), gloo as the transport (RCCL refuses two
     ranks on one GPU) -- exercises uneven splits, the plan and the receive ordering with the real kernels."""
