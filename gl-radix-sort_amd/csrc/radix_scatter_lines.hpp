@@ -91,12 +91,9 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
     constexpr int WAVES = Smem::WAVES;
     constexpr int TILE = Smem::TILE;
     constexpr int WAVE_TILE = kWave * KPT;
-    constexpr int WQ = WAVES / 4;            // scan threads per digit (4 waves' counters each)
-    constexpr int SCAN_THREADS = RADIX * WQ;
-    constexpr int SCAN_WAVES = (SCAN_THREADS + kWave - 1) / kWave;
+    constexpr int SCAN_WAVES = (RADIX + kWave - 1) / kWave; // the waves that hold one digit per lane in the scan phase
     constexpr uint32_t LINE = Smem::LINE;
-    static_assert(WQ == 4, "the digit bookkeeping below is written for 16 waves (quads of scan threads)");
-    static_assert(SCAN_THREADS <= THREADS, "one scan thread per (digit, 4 waves)");
+    static_assert(RADIX <= THREADS, "one scan thread per digit");
     const uint32_t MASK = mask; // <= RADIX - 1
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -106,11 +103,9 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
     const uint32_t nb = gridDim.x, b = blockIdx.x;
     const KeyCodec<KeyT, XF> codec_in(xform & 3u), codec_out((xform >> 2) & 3u);
 
-    // scan-thread coordinates: thread t < SCAN_THREADS owns digit t / 4, waves 4 * (t % 4) .. + 3; the q == 0 thread of a
-    // digit also owns the digit's running state (registers):
-    const uint32_t sd = tid / WQ, sq = tid % WQ, sw = sq * 4;
-    const bool scan_thread = tid < SCAN_THREADS;
-    const bool digit_owner = scan_thread && sq == 0;
+    // thread d < RADIX owns digit d in the scan phase and keeps the digit's running state in registers:
+    const uint32_t sd = tid;
+    const bool digit_owner = tid < (uint32_t) RADIX;
     uint32_t digit_base = 0;  // global index of the digit's next element
     uint32_t carry_start = 0; // 32-aligned global index of the digit's first carried element; carried = digit_base - carry_start
     uint32_t owned_from = 0;  // first global index of the digit inside this workgroup's range
@@ -240,54 +235,68 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
         __syncthreads(); // every wave has ranked this tile
         stamp(0);
 
-        // ---- one packed block scan over (digit, wave quad): low half = elements, high half = full lines of the digit.
-        //      All four scan threads of a digit know the digit's element count n_d and carried count c_d.
-        uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0, n_d = 0, c_d = 0, nl_d = 0;
-        uint32_t excl = 0;
+        // ---- one packed block scan over the digits: low half = elements (first ranked position of the digit), high half =
+        //      full lines of the digit.  Only the RADIX / 64 waves that hold a digit per lane work here (the whole kernel is
+        //      bound by vector-instruction issue: what the other waves do not execute is time the SIMDs get back); each of
+        //      their threads reads the digit's WAVES counters, and writes back WAVES prefixes after the scan.
         {
-            if (scan_thread)
-            {
-                c0 = s.wcnt[sw + 0][sd];
-                c1 = s.wcnt[sw + 1][sd];
-                c2 = s.wcnt[sw + 2][sd];
-                c3 = s.wcnt[sw + 3][sd];
-            }
-            const uint32_t mine = c0 + c1 + c2 + c3;
+            uint32_t c[WAVES];
+            uint32_t n_d = 0, c_d = 0, nl_d = 0, excl = 0;
             if (wave < SCAN_WAVES) // wave-uniform
             {
-                // quad sum into the quad's lane 0 (row_shl moves lane i + k to lane i inside a row of 16), then broadcast
-                int t = (int) mine;
-                t += __builtin_amdgcn_update_dpp(0, t, 0x101, 0xf, 0xf, false); // row_shl:1
-                t += __builtin_amdgcn_update_dpp(0, t, 0x102, 0xf, 0xf, false); // row_shl:2
-                n_d = (uint32_t) __builtin_amdgcn_update_dpp(0, t, 0x00, 0xf, 0xf, false);                        // quad_perm:[0,0,0,0]
-                c_d = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) (digit_base - carry_start), 0x00, 0xf, 0xf, false);
-                // pads of the (partial) last tile were ranked at the end of the highest used digit: not elements
-                if (sd == MASK) n_d -= (uint32_t) TILE - tile_valid;
-                nl_d = (c_d + n_d) / LINE;
+                uint32_t n_raw = 0;
+                if (digit_owner)
+                {
+#pragma unroll
+                    for (int w = 0; w < WAVES; w++) c[w] = s.wcnt[w][sd];
+#pragma unroll
+                    for (int w = 0; w < WAVES; w++) n_raw += c[w];
+                    // pads of the (partial) last tile were ranked at the end of the highest used digit: not elements
+                    n_d = n_raw - (sd == MASK ? (uint32_t) TILE - tile_valid : 0u);
+                    c_d = digit_base - carry_start;
+                    nl_d = (c_d + n_d) / LINE;
+                }
                 uint32_t wtotal;
-                excl = wave_exclusive_sum(mine + (sq == WQ - 1 ? nl_d << 16 : 0u), lane, wtotal);
+                excl = wave_exclusive_sum(n_raw | (nl_d << 16), lane, wtotal);
                 if (lane == 0) s.scan_tmp[wave] = wtotal;
             }
             __syncthreads();
-            if (wave < SCAN_WAVES) excl += sum_of_preceding_waves(s.scan_tmp, SCAN_WAVES, wave, lane);
-            if (scan_thread)
+            if (wave < SCAN_WAVES)
             {
+                if (SCAN_WAVES > 1) excl += sum_of_preceding_waves(s.scan_tmp, SCAN_WAVES, wave, lane);
                 const uint32_t pos = excl & 0xFFFFu, line0 = excl >> 16;
-                s.wcnt[sw + 0][sd] = (uint16_t) pos;
-                s.wcnt[sw + 1][sd] = (uint16_t) (pos + c0);
-                s.wcnt[sw + 2][sd] = (uint16_t) (pos + c0 + c1);
-                s.wcnt[sw + 3][sd] = (uint16_t) (pos + c0 + c1 + c2);
-                // lines of this digit, dealt to its four scan threads
-                for (uint32_t j = sq; j < nl_d; j += WQ) s.ltab[line0 + j] = (uint16_t) sd;
-                if (sq == 0)
+                if (digit_owner)
                 {
+                    uint32_t running = pos;
+#pragma unroll
+                    for (int w = 0; w < WAVES; w++)
+                    {
+                        s.wcnt[w][sd] = (uint16_t) running;
+                        running += c[w];
+                    }
                     const uint32_t m = c_d + n_d, c_new = m & (LINE - 1), k = n_d < c_new ? n_d : c_new;
                     s.dinfo[sd] = make_uint4(carry_start, pos - c_d, line0 | (c_d << 16), owned_from);
                     s.tail[sd] = make_uint2(pos + n_d - c_new, (c_new - k) | (c_new << 8));
                     digit_base += n_d;
                     carry_start += nl_d * LINE;
+                    if (tid == (uint32_t) RADIX - 1) s.total_lines = line0 + nl_d;
                 }
-                if (tid == SCAN_THREADS - 1) s.total_lines = line0 + nl_d;
+                // line -> digit table.  Every lane writes the first lines of its digit itself (one or two for uniform keys, 24
+                // per digit with 16 digit values: the lanes loop in parallel); what a digit has beyond kOwnLines lines (a digit
+                // that holds a large part of the tile: at most TILE / 32 / kOwnLines of them) the wave fills together.
+                constexpr uint32_t kOwnLines = 32;
+                if (digit_owner)
+                    for (uint32_t j = 0; j < (nl_d < kOwnLines ? nl_d : kOwnLines); j++) s.ltab[line0 + j] = (uint16_t) sd;
+                uint64_t big = __ballot(digit_owner && nl_d > kOwnLines);
+                while (big)
+                {
+                    const int l = __builtin_ctzll(big);
+                    big &= big - 1;
+                    const uint32_t bd = (uint32_t) __builtin_amdgcn_readlane((int) sd, l);
+                    const uint32_t b0 = (uint32_t) __builtin_amdgcn_readlane((int) line0, l);
+                    const uint32_t bn = (uint32_t) __builtin_amdgcn_readlane((int) nl_d, l);
+                    for (uint32_t j = kOwnLines + lane; j < bn; j += kWave) s.ltab[b0 + j] = (uint16_t) bd;
+                }
             }
         }
         __syncthreads();
