@@ -340,8 +340,11 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
         if (ABLATE < 4)
         {
             const uint32_t quads = s.total_lines * (LINE / 4);
-            constexpr int QB = 3; // quads per thread and sweep (a tile of uniform keys has about 2.3 per thread)
-            for (uint32_t q_first = tid; q_first < quads; q_first += QB * THREADS)
+            // Quads per thread and sweep: a tile of uniform keys has about 2.5 per thread, so the waves whose third quad would
+            // lie past the end (wave-uniform test) take two (the kernel is bound by instruction issue: no surplus work).
+            auto write_lines = [&](auto qb, uint32_t q_begin) {
+                constexpr int QB = decltype(qb)::value;
+            for (uint32_t q_first = q_begin; q_first < quads; q_first += QB * THREADS)
             {
                 uint32_t g0[QB], from_run[QB], from_carry[QB], owned[QB];
                 int in_carry[QB];
@@ -420,6 +423,11 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
                     }
                 }
             }
+            };
+            if (__builtin_amdgcn_readfirstlane((int) tid) + 2 * THREADS < (int) quads)
+                write_lines(std::integral_constant<int, 3>(), tid);
+            else
+                write_lines(std::integral_constant<int, 2>(), tid);
         }
         stamp(4);
         __syncthreads(); // the carried elements have been read: their slots may be rewritten
