@@ -560,13 +560,15 @@ def test_full_size_2_28_duplicate_heavy(G):
     _check_sorted_properties(keys, gk, gv)
 
 
-def test_full_size_2_28_u64(G):
-    """BASELINE.json config 5: N = 2^28 uint64 keys + uint32 payload."""
+@pytest.mark.parametrize("bits", [8, 4])
+def test_full_size_2_28_u64(G, bits):
+    """BASELINE.json config 5: N = 2^28 uint64 keys + uint32 payload; 8-bit digits (8 passes) and the reference's
+    4-bit digits (16 passes)."""
     n = 1 << 28
     rng = np.random.default_rng(5)
     keys = rng.integers(0, 2**64, n, dtype=np.uint64)
     vals = np.arange(n, dtype=np.uint32)
-    gk, gv = gpu_sort(G, keys, vals, key_bytes=8)
+    gk, gv = gpu_sort(G, keys, vals, key_bytes=8, bits=bits)
     _check_sorted_properties(keys, gk, gv)
 
 
