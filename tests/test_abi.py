@@ -106,3 +106,22 @@ def test_standalone_dist_headers_are_current_and_compile(tmp_path):
     tu.write_text('#include "RadixSort.hpp"\n#include "BlellochScan.hpp"\n#include "Reduce.hpp"\n'
                   "int main() { return glu::is_power_of_2(8) ? 0 : 1; }\n")
     subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-I", os.path.join(ROOT, "dist"), str(tu)])
+
+
+def test_rccl_test_double_exports_what_the_library_binds(built):
+    """tests/cpp/mock_rccl.cpp (the file transport of the multi-rank GPU tests) must define every librccl entry point
+    glu_dist_* looks up with dlsym -- and the product must not mention it."""
+    import re
+
+    src = open(os.path.join(ROOT, "gl-radix-sort_amd", "csrc", "glu_dist_impl.hpp")).read()
+    bound = set(re.findall(r'sym\("(nccl\w+)"\)', src))
+    assert len(bound) == 9
+    mock = os.path.join(ROOT, "tests", "cpp", "bin", "libmock_rccl.so")
+    assert os.path.exists(mock)
+    out = subprocess.run(["nm", "-D", "--defined-only", mock], capture_output=True, text=True).stdout
+    exported = {line.split()[-1] for line in out.splitlines() if " T " in line}
+    assert bound <= exported, bound - exported
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "gl-radix-sort_amd")):
+        for f in files:
+            if f.endswith((".py", ".hpp", ".hip", ".h")):
+                assert "mock_rccl" not in open(os.path.join(dirpath, f), errors="ignore").read(), f

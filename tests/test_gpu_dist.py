@@ -283,3 +283,151 @@ def test_two_ranks_2p26_each_skewed_plan_grows_receive_buffers(built):
     assert results[0][6] <= results[1][5]  # rank 0's last key <= rank 1's first key
     heavy = max(results, key=lambda r: r[1])
     assert heavy[1] > 1.25 * (1 << log2n) and heavy[8] == 1  # the skewed shard really grew the receive arrays
+
+
+# ---- the multi-rank code of the C ABI, on one GPU: processes as ranks, tests/cpp/mock_rccl.cpp as the transport ---------
+# RCCL refuses two ranks on one GPU, so glu_dist_* binds a test double for the nine librccl entry points
+# (GLU_HIP_RCCL_LIB) that exchanges through files.  Everything else is the product: partition kernels, the histogram
+# gather, the plan, the send / receive offsets of the grouped exchange, the local sort.
+
+def _mock_cases(world):
+    """(name, expected partition shift or None, per-rank (keys, vals)) -- vals are global indices."""
+    cases = []
+
+    def build(name, shift, key_fn, sizes):
+        per_rank, base = [], 0
+        for r, n in enumerate(sizes):
+            keys = key_fn(r, n).astype(np.uint32)
+            per_rank.append((keys, np.arange(base, base + n, dtype=np.uint32)))
+            base += n
+        cases.append((name, shift, per_rank))
+
+    sizes = [150001 + 1000 * r for r in range(world)]
+
+    def uniform(r, n):
+        k = np.random.default_rng(100 + r).integers(0, 2**32, n, dtype=np.uint32)
+        k[::9] = np.uint32(0x80000000 | r)  # duplicates within and across ranks
+        return k
+
+    def hot_bucket(r, n):
+        k = np.random.default_rng(200 + r).integers(0, 2**32, n, dtype=np.uint32)
+        hot = np.arange(n) % 10 < 7
+        k[hot] = (k[hot] & np.uint32(0x00FFFFFF)) | np.uint32(0xC0000000)
+        return k
+
+    def small_range(r, n):  # every key below 2^24 on every rank: the ranks agree on the next byte down
+        return np.random.default_rng(300 + r).integers(0, 2**24, n, dtype=np.uint32) & np.uint32(0xFFFF0F)
+
+    def small_on_rank0(r, n):  # only rank 0's keys are small: no fallback
+        k = np.random.default_rng(400 + r).integers(0, 2**32, n, dtype=np.uint32)
+        return k & np.uint32(0xFFFFFF) if r == 0 else k
+
+    build("uniform", 24, uniform, sizes)
+    build("hot_bucket", 24, hot_bucket, sizes)
+    build("all_equal", 0, lambda r, n: np.full(n, 0xDEADBEEF, dtype=np.uint32), sizes)  # one rank receives everything
+    build("small_range", 16, small_range, sizes)
+    build("small_on_rank0", 24, small_on_rank0, sizes)
+    build("rank0_empty", 24, uniform, [0] + sizes[1:])
+    build("only_last_rank_has_keys", 24, uniform, [0] * (world - 1) + [70001])
+    build("two_keys", None, lambda r, n: np.array([5, 3][:n], dtype=np.uint32), [2] + [0] * (world - 1))
+    build("line_kernel_sizes", 24, uniform, [3 * (1 << 20) + 17 + 4096 * r for r in range(world)])
+    return cases
+
+
+def _mock_rank_worker(rank, world, unique_id, mock_lib, mock_dir, q):
+    import os
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (os.path.join(root, "gl-radix-sort_amd"), os.path.join(root, "oracle"), os.path.join(root, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["GLU_HIP_RCCL_LIB"] = mock_lib
+    os.environ["GLU_MOCK_RCCL_DIR"] = mock_dir
+    import ctypes
+
+    import numpy as np
+    import glu_hip as G
+    from test_gpu_dist import _mock_cases
+
+    G.set_device(0)
+    first = G.Dist(unique_id, world, rank)
+    second = G.Dist(unique_id[::-1], world, rank)  # a second communicator: two sorts in flight below
+    out = []
+
+    def read_back(ptr, n):
+        host = np.empty(n, dtype=np.uint32)
+        if n:
+            h = ctypes.c_uint32(0)
+            G.check(G.lib().glu_buffer_wrap(ctypes.c_void_p(ptr), n * 4, ctypes.byref(h)))
+            G.check(G.lib().glu_buffer_read(h, host.ctypes.data_as(ctypes.c_void_p), n * 4, 0))
+            G.check(G.lib().glu_buffer_destroy(h))
+        return host
+
+    for name, shift, per_rank in _mock_cases(world):
+        keys, vals = per_rank[rank]
+        kb, vb = G.ShaderStorageBuffer(keys) if keys.size else None, G.ShaderStorageBuffer(vals) if vals.size else None
+        kp, vp = (kb.device_ptr(), vb.device_ptr()) if keys.size else (None, None)
+        gk_ptr, gv_ptr, cnt = first.sort_ptr(kp, vp, keys.size)
+        G.synchronize()
+        gk, gv = read_back(gk_ptr, cnt), read_back(gv_ptr, cnt)
+        # the same sort as begin / finish on two objects at once (what bench.py's depth 2 does), into caller arrays
+        n1 = first.sort_begin(kp, vp, keys.size)
+        n2 = second.sort_begin(kp, vp, keys.size)
+        rk1, rv1 = G.ShaderStorageBuffer(size=max(n1, 1) * 4), G.ShaderStorageBuffer(size=max(n1, 1) * 4)
+        rk2, rv2 = G.ShaderStorageBuffer(size=max(n2, 1) * 4), G.ShaderStorageBuffer(size=max(n2, 1) * 4)
+        first.sort_finish(rk1.device_ptr(), rv1.device_ptr(), n1)
+        second.sort_finish(rk2.device_ptr(), rv2.device_ptr(), n2)
+        G.synchronize()
+        same = n1 == cnt and n2 == cnt
+        for b, ref in ((rk1, gk), (rv1, gv), (rk2, gk), (rv2, gv)):
+            same = same and bool((b.get_data(np.uint32)[:cnt] == ref).all())
+        if keys.size:  # the input is untouched
+            same = same and bool((kb.get_data(np.uint32) == keys).all()) and bool((vb.get_data(np.uint32) == vals).all())
+        out.append((name, first.partition_shift(), gk, gv, same))
+    first.destroy()
+    second.destroy()
+    q.put((rank, out))
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_native_multi_rank_sort_over_mock_transport(built, world, tmp_path):
+    import torch.multiprocessing as mp
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    mock_lib = os.path.join(root, "tests", "cpp", "bin", "libmock_rccl.so")
+    assert os.path.exists(mock_lib), "tests/cpp/bin/libmock_rccl.so is not built (make -C tests/cpp)"
+    unique_id = os.urandom(128)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_mock_rank_worker, args=(r, world, unique_id, mock_lib, str(tmp_path), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    import queue
+
+    try:
+        results = dict(q.get(timeout=600) for _ in range(world))
+    except queue.Empty:
+        for p in procs:
+            p.join(timeout=5)
+        raise AssertionError("a rank produced nothing (exit codes %s)" % [p.exitcode for p in procs])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for ci, (name, shift, per_rank) in enumerate(_mock_cases(world)):
+        all_keys = np.concatenate([k for k, _ in per_rank])
+        all_vals = np.concatenate([v for _, v in per_rank])
+        ek, ev = O.stable_sort_pairs(all_keys, all_vals)
+        got = [results[r][ci] for r in range(world)]
+        assert all(g[0] == name for g in got)
+        gk = np.concatenate([g[2] for g in got])
+        gv = np.concatenate([g[3] for g in got])
+        assert gk.size == ek.size, name
+        assert (gk == ek).all() and (gv == ev).all(), name  # rank outputs in rank order = the single-device stable sort
+        assert all(g[4] for g in got), name                 # begin / finish on two communicators gave the same shards
+        if shift is not None:
+            assert all(g[1] == shift for g in got), (name, [g[1] for g in got])
+        if name == "uniform":  # the plan balances: a shard exceeds its share by less than the hottest (unsplittable) bucket
+            sizes = [g[2].size for g in got]
+            hottest = int(np.bincount(all_keys >> 24, minlength=256).max())
+            assert max(sizes) <= ek.size / world + hottest, (sizes, hottest)
