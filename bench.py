@@ -50,6 +50,10 @@ def parse_args():
                    help="N>1, pipelined measurement: CUs the sort kernels leave to the RCCL kernels of the other sort in flight")
     p.add_argument("--force-dist", action="store_true",
                    help="run the multi-GPU code path (partition + all-to-all + local sort) even with one rank")
+    p.add_argument("--rehearse-one-gpu", action="store_true",
+                   help="NOT a measurement: run the N>1 code path with all ranks on GPU 0 (gloo process group, glu_dist over "
+                        "the file transport named by GLU_HIP_RCCL_LIB, tests/cpp/mock_rccl.cpp) to check that the launch, the "
+                        "collectives and the JSON line work before an 8-GPU node runs them")
     return p.parse_args()
 
 
@@ -179,6 +183,10 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libglu_hip has no CPU fallback")
 
+    if args.rehearse_one_gpu:
+        local_rank = 0
+        if not os.environ.get("GLU_HIP_RCCL_LIB"):
+            raise SystemExit("--rehearse-one-gpu needs GLU_HIP_RCCL_LIB=tests/cpp/bin/libmock_rccl.so (RCCL refuses two ranks on one GPU)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     import glu_hip as G
@@ -191,7 +199,10 @@ def main():
         if "MASTER_ADDR" not in os.environ:
             os.environ["MASTER_ADDR"] = "127.0.0.1"
             os.environ.setdefault("MASTER_PORT", "29577")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.rehearse_one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     log2n = args.log2_keys if args.log2_keys is not None else (28 if world == 1 else 27)
     n = 1 << log2n
@@ -351,7 +362,8 @@ def main():
             """W warm-up sorts, then K timed sorts with `depth` sorts in flight (depth 1 = strictly one after the other, the
             same regime as the N = 1 line; depth 2 = consecutive independent sorts on two streams / buffer sets /
             communicators, so that the exchange of sort i+1 can run under the local sort of sort i)."""
-            dsort = D.DistributedRadixSort(slots=depth, profile=not args.no_kernel_events)
+            dsort = D.DistributedRadixSort(slots=depth, profile=not args.no_kernel_events,
+                                           native=True if args.rehearse_one_gpu else None)
             if args.digit_bits is not None:
                 for srt in dsort.local_sorters():
                     srt.set_digit_bits(args.digit_bits)
@@ -396,6 +408,8 @@ def main():
             del r2
         dsort, handle, profs, sorters = r1["dsort"], r1["handle"], r1["profs"], r1["sorters"]
         result["native_c_abi"] = bool(dsort.native)
+        if args.rehearse_one_gpu:
+            result["rehearsal"] = "NOT A MEASUREMENT: %d ranks share one GPU and exchange through files (tests/cpp/mock_rccl.cpp)" % world
         rk, rv, cnt = handle.synchronize()
         # rank 0's view: the scatter kernel (1 partition launch over n pairs + 4 sort launches over its shard per sort)
         # and the device time of every phase of a sort

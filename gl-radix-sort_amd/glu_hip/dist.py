@@ -134,7 +134,8 @@ class DistributedRadixSort:
     device-op object, so the all-to-all of sort i+1 (RCCL, few CUs) can run under the local sort of sort i.  The order
     of collectives is the call order on every rank, so ranks must issue the same sequence of sorts."""
 
-    def __init__(self, group=None, local_ops=None, capacity_factor=1.25, slots=1, local_ops_factory=None, profile=False):
+    def __init__(self, group=None, local_ops=None, capacity_factor=1.25, slots=1, local_ops_factory=None, profile=False,
+                 native=None):
         import torch
         import torch.distributed as dist
 
@@ -142,8 +143,10 @@ class DistributedRadixSort:
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         # RCCL process group and no injected device ops: the whole sort runs inside the C library (glu_dist_*)
+        # (native=True asks for it under any backend: the rehearsal of bench.py, where the ranks share one GPU, the torch
+        # group is gloo and GLU_HIP_RCCL_LIB names the test transport)
         self.native = (local_ops is None and local_ops_factory is None and torch.cuda.is_available()
-                       and dist.get_backend(group) == "nccl")
+                       and (dist.get_backend(group) == "nccl" if native is None else bool(native)))
         self.capacity_factor = capacity_factor
         if self.native:
             try:

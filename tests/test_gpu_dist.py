@@ -431,3 +431,23 @@ def test_native_multi_rank_sort_over_mock_transport(built, world, tmp_path):
             sizes = [g[2].size for g in got]
             hottest = int(np.bincount(all_keys >> 24, minlength=256).max())
             assert max(sizes) <= ek.size / world + hottest, (sizes, hottest)
+
+
+def test_bench_multi_gpu_command_line_rehearsal(built):
+    """The driver's N > 1 bench launch (torchrun, one rank per process) with 2 ranks sharing the GPU: gloo process group,
+    glu_dist over the file transport.  Not a measurement -- it checks that the launch, the collectives, the verification
+    and the JSON line of bench.py's multi-GPU branch work."""
+    import json
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GRAFT_REPO_ROOT=root)
+    p = subprocess.run(["bash", os.path.join(root, "tools", "rehearse_multi_gpu.sh"), "2", "20"], capture_output=True, text=True,
+                       env=env, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["verified"] is True and line["native_c_abi"] is True
+    assert line["value"] == line["value_depth1"] and "value_depth2" in line and "rehearsal" in line
+    assert line["phases_ms_rank0"]["sorts"] == line["steps"]
