@@ -15,6 +15,7 @@
 #include "glu_hip.h"
 #include "radix_sort_kernels.hpp"
 #include "radix_scatter_lines.hpp"
+#include "radix_pair_passes.hpp"
 #include "scan_reduce_kernels.hpp"
 
 using namespace glu_hip;
@@ -419,6 +420,9 @@ struct glu_radix_sort_s
     Scratch vals;
     Scratch table;  // [RADIX][num_blocks] digit counts -> scanned offsets, + RADIX digit totals
     Scratch plan;   // PassPlan of large sorts (which arrays hold the data before each pass, which passes are identities)
+    Scratch pair_t2;     // paired passes (radix_pair_passes.hpp): [256][num_blocks][256] 16-bit two-digit counters,
+    Scratch pair_table;  // the follower's count table + digit totals,
+    Scratch pair_ranges; // and the element range of every follower workgroup
     uint32_t digit_bits = 8;
     uint32_t max_blocks = 0;   // GLU_HIP_SORT_BLOCKS: cap on the number of workgroups (tuning)
     bool force_small = false;  // GLU_HIP_SORT_SMALL=1: always use the small-tile geometry (tests / tuning)
@@ -427,6 +431,9 @@ struct glu_radix_sort_s
     bool no_plan = false;         // GLU_HIP_SORT_NO_PLAN=1: never skip constant-digit passes (tests / tuning)
     bool no_lines = false;        // GLU_HIP_SORT_NO_LINES=1: never use the 128-byte-line scatter kernel (tests / tuning)
     bool nt_stores = true;        // GLU_HIP_SORT_NT_STORES=0: plain instead of non-temporal line stores in the line scatter (tuning)
+    bool pairs = true;            // GLU_HIP_SORT_PAIRS=0: every pass of a large sort counts for itself (tests / tuning)
+    uint32_t pair_unit_div = 16;  // GLU_HIP_SORT_PAIR_UNIT_DIV: a follower counts for itself when a unit of its leader is longer
+                                  // than 1 / this of a workgroup's share (0 = never: tests reach the counter-overflow check that way)
     hipEvent_t after_histogram_event = nullptr; // partition passes: recorded once the digit histogram has been copied out
                                                 // (after the row scan, before the scatter): glu_dist uses it
     size_t large_min = 0;         // GLU_HIP_SORT_LARGE_MIN=N: element count from which the large geometry is used (tuning)
@@ -453,6 +460,10 @@ struct glu_radix_sort_s
 
 namespace
 {
+// paired passes need the line kernel and the device-side plan; below this count neither runs (the exact conditions are
+// checked per sort: pairs_applicable)
+constexpr size_t kPairMinCount = (size_t) 1 << 22;
+
 glu_status sort_prepare(glu_radix_sort_s* s, size_t count, size_t key_size, bool with_vals = true)
 {
     if (count <= 1) return GLU_OK;
@@ -461,6 +472,13 @@ glu_status sort_prepare(glu_radix_sort_s* s, size_t count, size_t key_size, bool
     uint64_t cap = (uint64_t) g_dev.num_cus * kMaxBlocksPerCu;
     GLU_TRY(s->table.reserve((kMaxRadix * cap + kMaxRadix) * sizeof(uint32_t)));
     GLU_TRY(s->plan.reserve(sizeof(PassPlan)));
+    if (count >= kPairMinCount && s->pairs && !s->no_plan && !s->no_lines && !s->force_small)
+    {
+        const size_t nb = (size_t) g_dev.num_cus;
+        GLU_TRY(s->pair_t2.reserve((size_t) kPairRadix * nb * kPairRowWords * sizeof(uint32_t)));
+        GLU_TRY(s->pair_table.reserve(((size_t) kPairRadix * nb + kPairRadix) * sizeof(uint32_t)));
+        GLU_TRY(s->pair_ranges.reserve(nb * sizeof(uint2)));
+    }
     return GLU_OK;
 }
 
@@ -473,6 +491,10 @@ struct PlanArgs
     PassPlan* plan = nullptr;
     uint32_t pass = 0;
     bool may_skip = false;
+    // paired passes (radix_pair_passes.hpp): 1 = leader (its count kernel also builds the two-digit table on the digit
+    // [shift2, shift2 + bits2) of the pass after it), 2 = follower (its count table comes from that)
+    int pair_role = 0;
+    uint32_t shift2 = 0, bits2 = 0;
 };
 
 // XF: this pass encodes keys on load and / or decodes them on store (first / last pass of a typed sort); every other
@@ -569,13 +591,51 @@ glu_status launch_pass_lines(glu_radix_sort_s* s, const KeyT* src_k, const uint3
     HIP_TRY(lds_opt_in_result);
     auto scatter = s->nt_stores ? scatter_nt : scatter_plain;
 
+    const uint2* ranges = nullptr;
     s->mark(stream);
-    hipLaunchKernelGGL((radix_count_kernel<KeyT, BITS, 1024, G::TILE, XF>), dim3(nb), dim3(1024), 0, stream, src_k, table,
-                       (uint32_t) count, shift, mask, tiles, xform, (const KeyT*) dst_k, pa.plan, pa.pass);
-    HIP_TRY(hipGetLastError());
+    if constexpr (BITS == 8 && !XF)
+    {
+        if (pa.pair_role == 1)
+        {
+            // leader: one read of the keys for this pass's table and the two-digit table the follower's comes from
+            auto count2 = radix_pair_count_kernel<KeyT, G::TILE, false>;
+            static std::once_flag count2_opt_in;
+            static hipError_t count2_opt_in_result = hipSuccess;
+            std::call_once(count2_opt_in, [&] {
+                count2_opt_in_result = hipFuncSetAttribute((const void*) count2, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sizeof(PairCountSmem));
+            });
+            HIP_TRY(count2_opt_in_result);
+            hipLaunchKernelGGL(count2, dim3(nb), dim3(1024), sizeof(PairCountSmem), stream, src_k, table, (uint32_t*) s->pair_t2.ptr,
+                               (uint32_t) count, shift, mask, pa.shift2, (1u << pa.bits2) - 1, tiles, xform, (const KeyT*) dst_k, pa.plan,
+                               pa.pass);
+            HIP_TRY(hipGetLastError());
+        }
+    }
+    if (pa.pair_role == 2)
+    {
+        // follower: unit runs and their digit counts from the leader's tables (s->table still holds them); its own table
+        // lives in pair_table.  The count kernel behind it runs only if a kernel before it asked for that.
+        uint32_t* leader_table = table;
+        table = (uint32_t*) s->pair_table.ptr;
+        totals = table + (size_t) RADIX * nb;
+        ranges = (const uint2*) s->pair_ranges.ptr;
+        hipLaunchKernelGGL(radix_pair_unitsum_kernel, dim3(nb), dim3(1024), 0, stream, (const uint32_t*) s->pair_t2.ptr,
+                           (const uint32_t*) leader_table, (const uint32_t*) (leader_table + (size_t) RADIX * nb), table,
+                           (uint2*) s->pair_ranges.ptr, (uint32_t) count, pa.plan, pa.pass);
+        HIP_TRY(hipGetLastError());
+    }
+    if (pa.pair_role != 1)
+    {
+        hipLaunchKernelGGL((radix_count_kernel<KeyT, BITS, 1024, G::TILE, XF>), dim3(nb), dim3(1024), 0, stream, src_k, table,
+                           (uint32_t) count, shift, mask, tiles, xform, (const KeyT*) dst_k, pa.plan, pa.pass, pa.pair_role == 2);
+        HIP_TRY(hipGetLastError());
+    }
     s->mark(stream);
+    // (leader: a unit longer than 1/16 of a workgroup's share makes the follower count for itself)
     hipLaunchKernelGGL((radix_row_scan_kernel<256>), dim3(RADIX), dim3(256), 0, stream, table, totals, nb, (uint32_t) count,
-                       pa.may_skip ? pa.plan : (PassPlan*) nullptr, pa.pass);
+                       pa.may_skip ? pa.plan : (PassPlan*) nullptr, pa.pass,
+                       pa.pair_role == 1 ? (s->pair_unit_div ? std::max<uint32_t>(1u, (uint32_t) (count / nb / s->pair_unit_div)) : 0xFFFFFFFFu) : 0u,
+                       pa.plan);
     HIP_TRY(hipGetLastError());
     s->mark(stream);
     if (histogram_out)
@@ -586,10 +646,24 @@ glu_status launch_pass_lines(glu_radix_sort_s* s, const KeyT* src_k, const uint3
     }
     hipLaunchKernelGGL(scatter, dim3(nb), dim3(G::THREADS), sizeof(Smem), stream, src_k, src_v, dst_k, dst_v,
                        (const uint32_t*) table, (const uint32_t*) totals, (uint32_t) count, shift, mask, tiles,
-                       (unsigned long long*) nullptr, xform, pa.plan, pa.pass);
+                       (unsigned long long*) nullptr, xform, pa.plan, pa.pass, ranges);
     s->mark(stream);
     HIP_TRY(hipGetLastError());
     return GLU_OK;
+}
+
+// does a pass over these arrays run the line kernel?  (launch_pass_sized and the pairing of passes in sort_bits)
+template<typename KeyT, int BITS>
+bool lines_applicable(const glu_radix_sort_s* s, const void* src_k, const void* src_v, const void* dst_k, const void* dst_v, size_t count)
+{
+    const bool vals = src_v != nullptr;
+    // whole-line stores need 16-byte aligned destinations (hipMalloc gives 256); both pairs of arrays are checked
+    // because a planned sort swaps their roles on the device.  Same size rule as the large geometry, with its tile.
+    const size_t lines_tile = vals ? LinesGeometry<KeyT, BITS, true>::TILE : LinesGeometry<KeyT, BITS, false>::TILE;
+    const bool aligned = (((uintptr_t) src_k | (uintptr_t) src_v | (uintptr_t) dst_k | (uintptr_t) dst_v) & 15u) == 0;
+    // (at least one whole tile: the kernel's branch-free prefetch reads tile 0 when it has nothing better to read)
+    return aligned && !s->no_lines && !s->force_small && count >= lines_tile &&
+           count >= (s->large_min ? s->large_min : (size_t) g_dev.num_cus * lines_tile * 3 / 2);
 }
 
 template<typename KeyT, int BITS>
@@ -604,14 +678,7 @@ glu_status launch_pass_sized(glu_radix_sort_s* s, const KeyT* src_k, const uint3
     const size_t large_tile = vals ? GeometryFor<KeyT, BITS, true, true>::TILE : GeometryFor<KeyT, BITS, true, false>::TILE;
     const bool large = count >= (s->large_min ? s->large_min : (size_t) g_dev.num_cus * large_tile * 3 / 2) && !s->force_small;
     {
-        // whole-line stores need 16-byte aligned destinations (hipMalloc gives 256); both pairs of arrays are checked
-        // because a planned sort swaps their roles on the device.  Same size rule as the large geometry, with its tile.
-        const size_t lines_tile = vals ? LinesGeometry<KeyT, BITS, true>::TILE : LinesGeometry<KeyT, BITS, false>::TILE;
-        const bool aligned = (((uintptr_t) src_k | (uintptr_t) src_v | (uintptr_t) dst_k | (uintptr_t) dst_v) & 15u) == 0;
-        // (at least one whole tile: the kernel's branch-free prefetch reads tile 0 when it has nothing better to read)
-        const bool lines = aligned && !s->no_lines && !s->force_small && count >= lines_tile &&
-                           count >= (s->large_min ? s->large_min : (size_t) g_dev.num_cus * lines_tile * 3 / 2);
-        if (lines)
+        if (lines_applicable<KeyT, BITS>(s, src_k, src_v, dst_k, dst_v, count))
         {
 #define GLU_LAUNCH_LINES(XF_, VALS_) \
     launch_pass_lines<KeyT, BITS, XF_, VALS_>(s, src_k, src_v, dst_k, dst_v, count, shift, bits, histogram_out, stream, XF_ ? xform : 0u, pa)
@@ -714,22 +781,62 @@ glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t cou
     KeyT* kbuf[2] = {keys, (KeyT*) s->keys.ptr};
     uint32_t* vbuf[2] = {vals, vals ? (uint32_t*) s->vals.ptr : nullptr};
     int cur = 0;
-    uint32_t shift = first_bit;
     // large sorts: device-side pass plan (constant-digit passes are skipped, the arrays' roles follow on the device)
     const bool planned = count >= kPlanMinCount && !s->no_plan;
-    uint32_t pass = 0;
-    while (shift < end_bit)
+    // the passes: digit positions, key transforms (typed keys: encode on the first pass's loads, decode on the last
+    // pass's stores), and which passes share one count kernel (radix_pair_passes.hpp)
+    struct PassDesc
+    {
+        uint32_t shift, bits, xform;
+        int pair_role;
+    };
+    PassDesc passes[kPlanMaxPasses];
+    uint32_t num_passes = 0;
+    for (uint32_t shift = first_bit; shift < end_bit;)
     {
         uint32_t bits = std::min<uint32_t>(s->digit_bits, end_bit - shift);
         if (sizeof(KeyT) == 8 && shift < 32 && shift + bits > 32) bits = 32 - shift; // a digit stays inside one key word
-        // typed keys: encode on the first pass's loads, decode on the last pass's stores
         const uint32_t xform = (shift == first_bit ? key_xf : 0u) | (shift + bits >= end_bit ? key_xf << 2 : 0u);
+        if (num_passes == kPlanMaxPasses) return fail(GLU_ERROR_INVALID_ARGUMENT, "too many passes");
+        passes[num_passes++] = PassDesc{shift, bits, xform, 0};
+        shift += bits;
+    }
+    // A leader is a pass of the 8-bit line kernel that does not encode keys on load; its follower is the pass after it,
+    // also of the 8-bit line kernel.
+    const bool pairs_ok = planned && s->pairs && s->pair_t2.ptr && s->max_blocks == 0 &&
+                          lines_applicable<KeyT, 8>(s, kbuf[0], vbuf[0], kbuf[1], vbuf[1], count);
+    if (pairs_ok)
+    {
+        for (uint32_t i = 0; i + 1 < num_passes;)
+        {
+            if (passes[i].bits > 4 && passes[i + 1].bits > 4 && (passes[i].xform & 3u) == 0)
+            {
+                passes[i].pair_role = 1;
+                passes[i + 1].pair_role = 2;
+                i += 2;
+            }
+            else
+                i += 1;
+        }
+        PassPlan* plan = (PassPlan*) s->plan.ptr;
+        HIP_TRY(hipMemsetAsync(plan->pair_fallback, 0, sizeof(plan->pair_fallback), stream));
+    }
+    uint32_t pass = 0;
+    for (; pass < num_passes; pass++)
+    {
+        const uint32_t shift = passes[pass].shift, bits = passes[pass].bits, xform = passes[pass].xform;
         if (planned)
         {
             PlanArgs pa;
             pa.plan = (PassPlan*) s->plan.ptr;
             pa.pass = pass;
             pa.may_skip = xform == 0; // encode / decode passes run whatever the data looks like
+            pa.pair_role = passes[pass].pair_role;
+            if (pa.pair_role == 1)
+            {
+                pa.shift2 = passes[pass + 1].shift;
+                pa.bits2 = passes[pass + 1].bits;
+            }
             GLU_TRY(dispatch_pass<KeyT>(s, kbuf[0], vbuf[0], kbuf[1], vbuf[1], count, shift, bits, nullptr, stream, xform, pa));
         }
         else
@@ -738,8 +845,6 @@ glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t cou
                                         stream, xform));
             cur ^= 1;
         }
-        pass++;
-        shift += bits;
     }
     if (planned)
     {
@@ -798,6 +903,12 @@ glu_status glu_radix_sort_create(glu_radix_sort* out)
     if (const char* e = getenv("GLU_HIP_SORT_NO_FUSED_SCAN")) s->no_fused_scan = atoi(e) != 0;
     if (const char* e = getenv("GLU_HIP_SORT_NO_PLAN")) s->no_plan = atoi(e) != 0;
     if (const char* e = getenv("GLU_HIP_SORT_NO_LINES")) s->no_lines = atoi(e) != 0;
+    if (const char* e = getenv("GLU_HIP_SORT_PAIRS")) s->pairs = atoi(e) != 0;
+    if (const char* e = getenv("GLU_HIP_SORT_PAIR_UNIT_DIV"))
+    {
+        int v = atoi(e); // 0: no limit
+        if (v >= 0) s->pair_unit_div = (uint32_t) v;
+    }
     if (const char* e = getenv("GLU_HIP_SORT_NT_STORES")) s->nt_stores = atoi(e) != 0;
     if (const char* e = getenv("GLU_HIP_SORT_LARGE_MIN")) s->large_min = (size_t) atoll(e);
     *out = s;
@@ -997,6 +1108,22 @@ glu_status glu_radix_sort_set_profiling(glu_radix_sort sort, int enable)
     if (!sort) return fail(GLU_ERROR_INVALID_ARGUMENT, "sort is NULL");
     sort->profiling = enable != 0;
     if (!enable) sort->events_used = 0;
+    return GLU_OK;
+}
+
+glu_status glu_radix_sort_read_plan(glu_radix_sort sort, uint32_t* skipped, uint32_t* counted_alone, size_t passes)
+{
+    GLU_TRY(enter());
+    if (!sort) return fail(GLU_ERROR_INVALID_ARGUMENT, "sort is NULL");
+    if (passes > (size_t) kPlanMaxPasses) return fail(GLU_ERROR_INVALID_ARGUMENT, "at most %d passes", kPlanMaxPasses);
+    if (!sort->plan.ptr) return fail(GLU_ERROR_INVALID_STATE, "no planned sort has run on this object");
+    PassPlan host;
+    HIP_TRY(hipMemcpy(&host, sort->plan.ptr, sizeof(host), hipMemcpyDeviceToHost));
+    for (size_t p = 0; p < passes; p++)
+    {
+        if (skipped) skipped[p] = host.skip[p];
+        if (counted_alone) counted_alone[p] = host.pair_fallback[p];
+    }
     return GLU_OK;
 }
 

@@ -1,0 +1,272 @@
+// radix_pair_passes.hpp -- one read of the keys for the digit tables of TWO counting passes (large sorts, 8-bit digits).
+//
+// The count pass (k_radix_sort_counting_shader, reference glu/RadixSort.hpp:11-58) reads every key once per pass: 4 x 0.165
+// ms of a 4.3 ms sort of 2^28 pairs.  The table of pass p + 1 cannot be counted before pass p has run, because its blocks
+// are ranges of pass p's OUTPUT -- unless the blocks of pass p + 1 are chosen to be what pass p's output is made of:
+//
+//   pass p ("leader") cuts its input into nb blocks; its output is the concatenation, digit value d major and block b
+//   minor, of the UNITS (d, b) = the keys of block b whose digit p is d, in input order.  A unit's position and length are
+//   the scanned count table of pass p.  A pass p + 1 ("follower") whose workgroup w takes a run of whole units
+//   [U_w, U_w+1) needs, per digit value e of digit p + 1, the number of keys with that value in its run = the sum over its
+//   units of T2[d][b][e] = #keys of block b with digit p = d and digit p + 1 = e: a two-digit histogram per block, which
+//   the leader's count kernel builds from the keys it is reading anyway (256 x 256 16-bit counters = 128 KiB of LDS).
+//
+// radix_pair_count_kernel: the leader's count kernel, T1 (the usual table) and T2.
+// radix_pair_unitsum_kernel: instead of the follower's count kernel: unit runs balanced on elements, their digit counts
+// summed from T2 (64 MiB of table traffic per pair of passes instead of 1 GiB of keys).
+// The follower's row scan and scatter are the usual kernels; the scatter takes its element range from `ranges`.
+//
+// Two things send a follower back to its own count kernel (PassPlan::pair_fallback, decided on the device; the launch
+// sequence is the same either way, the kernels that are not needed return at once):
+//   * a 16-bit counter of T2 overflowed (more than 65535 keys of one block share both digit values): found by comparing
+//     every row sum of T2 with T1;
+//   * a unit is longer than 1/16 of a workgroup's share: runs of whole units could not be balanced (a digit value that
+//     holds more than 6 % of a block's keys);
+//   * a workgroup's run has more than 2048 units (a region of very rare digit values): summing their rows in one
+//     workgroup would take longer than counting.
+#pragma once
+
+#include "radix_sort_kernels.hpp"
+
+namespace glu_hip
+{
+constexpr uint32_t kPairRadix = 256;               // 8-bit digits only
+constexpr uint32_t kPairRowWords = kPairRadix / 2; // a T2 row: 256 16-bit counters in 128 words
+constexpr uint32_t kPairMaxRunUnits = 2048;       // a follower workgroup sums at most this many T2 rows (1 MiB)
+
+// physical LDS word of the counter pair holding (d, e): the row's words are permuted by d so that a wave whose keys share
+// one of the two digit values still spreads over all banks
+__device__ __forceinline__ uint32_t pair_word(uint32_t d, uint32_t e) { return d * kPairRowWords + ((e >> 1) ^ (d & 63u)); }
+
+struct PairCountSmem
+{
+    static constexpr int WAVES = 16;
+    uint32_t hist1[WAVES][kPairRadix];        // wave-private counters of digit p (as in radix_count_kernel)
+    uint32_t hist2[kPairRadix * kPairRowWords]; // shared 16-bit counters of (digit p, digit p + 1)
+};
+
+// t2 row of unit (d, b): words [(d * nb + b) * 128, + 128), counter e in the low (e even) / high (e odd) half of word e / 2
+template<typename KeyT, int TILE, bool XF = false>
+__global__ __launch_bounds__(1024) void radix_pair_count_kernel(const KeyT* __restrict__ keys_a, uint32_t* __restrict__ table,
+                                                                uint32_t* __restrict__ t2, uint32_t n, uint32_t shift,
+                                                                uint32_t mask, uint32_t shift2, uint32_t mask2,
+                                                                uint32_t tiles_total, uint32_t xform, const KeyT* keys_b,
+                                                                PassPlan* plan, uint32_t pass)
+{
+    constexpr int THREADS = 1024;
+    constexpr int WAVES = PairCountSmem::WAVES;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    PairCountSmem& s = *reinterpret_cast<PairCountSmem*>(smem_raw);
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const KeyT* __restrict__ keys = keys_a;
+    if (plan)
+    {
+        if (pass > 0 && plan->flip[pass]) keys = keys_b;
+        if (blockIdx.x == 0 && tid == 0) plan->skip[pass] = 0;
+    }
+    for (uint32_t i = tid; i < sizeof(PairCountSmem) / 4; i += THREADS) reinterpret_cast<uint32_t*>(&s)[i] = 0;
+    __syncthreads();
+
+    uint32_t first, last;
+    block_tile_range(blockIdx.x, gridDim.x, tiles_total, first, last);
+    const uint64_t begin = (uint64_t) first * TILE;
+    uint64_t end = (uint64_t) last * TILE;
+    if (end > n) end = n;
+    uint32_t* my_hist = s.hist1[wave];
+    const KeyCodec<KeyT, XF> codec_in(xform & 3u);
+
+    // every lane of the wave is active when this runs
+    auto tally = [&](KeyT raw) {
+        const KeyT k = codec_in.encode(raw);
+        const uint32_t d = digit_of<KeyT>(k, shift, mask), e = digit_of<KeyT>(k, shift2, mask2);
+        const uint32_t de = d | (e << 8);
+        const uint32_t de0 = __builtin_amdgcn_readfirstlane(de);
+        if (__ballot(de != de0) == 0) // the whole wave on one counter (constant / heavily duplicated keys): one add each
+        {
+            if (lane == 0)
+            {
+                atomicAdd(&my_hist[de0 & 255u], 64u);
+                atomicAdd(&s.hist2[pair_word(de0 & 255u, de0 >> 8)], 64u << (16u * ((de0 >> 8) & 1u)));
+            }
+        }
+        else
+        {
+            atomicAdd(&my_hist[d], 1u);
+            atomicAdd(&s.hist2[pair_word(d, e)], 1u << (16u * (e & 1u)));
+        }
+    };
+    auto tally_one = [&](KeyT raw) { // lanes may be inactive
+        const KeyT k = codec_in.encode(raw);
+        const uint32_t d = digit_of<KeyT>(k, shift, mask), e = digit_of<KeyT>(k, shift2, mask2);
+        atomicAdd(&my_hist[d], 1u);
+        atomicAdd(&s.hist2[pair_word(d, e)], 1u << (16u * (e & 1u)));
+    };
+
+    constexpr int VEC = 16 / sizeof(KeyT);
+    using VecT = typename std::conditional<sizeof(KeyT) == 4, uint4, ulonglong2>::type;
+    const bool vec_ok = (reinterpret_cast<uintptr_t>(keys) & 15u) == 0;
+    const uint64_t nvec = vec_ok ? (end - begin) / VEC : 0;
+    const VecT* vkeys = reinterpret_cast<const VecT*>(keys + begin);
+    auto tally_vec = [&](const VecT& a) {
+        if constexpr (sizeof(KeyT) == 4)
+        {
+            tally(a.x); tally(a.y); tally(a.z); tally(a.w);
+        }
+        else
+        {
+            tally(a.x); tally(a.y);
+        }
+    };
+    uint64_t vbase = 0;
+    for (; vbase + 4 * THREADS <= nvec; vbase += 4 * THREADS) // block-uniform trip count, 4 x 16 B in flight per lane
+    {
+        VecT a = load_streaming(&vkeys[vbase + tid]);
+        VecT b = load_streaming(&vkeys[vbase + tid + THREADS]);
+        VecT c = load_streaming(&vkeys[vbase + tid + 2 * THREADS]);
+        VecT d = load_streaming(&vkeys[vbase + tid + 3 * THREADS]);
+        tally_vec(a);
+        tally_vec(b);
+        tally_vec(c);
+        tally_vec(d);
+    }
+    uint64_t i = begin + vbase * VEC + tid;
+    for (; i + 7ull * THREADS < end; i += 8ull * THREADS)
+    {
+        KeyT k[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) k[j] = keys[i + (uint64_t) j * THREADS];
+#pragma unroll
+        for (int j = 0; j < 8; j++) tally_one(k[j]);
+    }
+    for (; i < end; i += THREADS) tally_one(keys[i]);
+    __syncthreads();
+
+    // T1: the usual table entry; kept in hist1[0] for the row check below
+    const uint32_t nb = gridDim.x, b = blockIdx.x;
+    if (tid < kPairRadix)
+    {
+        uint32_t c = 0;
+#pragma unroll
+        for (int w = 0; w < WAVES; w++) c += s.hist1[w][tid];
+        table[(size_t) tid * nb + b] = c;
+        s.hist1[0][tid] = c; // (thread tid is the only reader of column tid)
+    }
+    __syncthreads();
+    // T2: every wave writes the rows d = wave, wave + 16, ...; a row whose counters do not add up to T1[d] had an overflow
+    bool bad = false;
+    for (uint32_t d = wave; d < kPairRadix; d += WAVES)
+    {
+        const uint32_t j0 = lane ^ (d & 63u); // the counter pair this lane's two physical words hold: j0 and 64 + j0
+        const uint32_t w0 = s.hist2[d * kPairRowWords + lane], w1 = s.hist2[d * kPairRowWords + 64 + lane];
+        uint32_t sum = (w0 & 0xFFFFu) + (w0 >> 16) + (w1 & 0xFFFFu) + (w1 >> 16);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        bad = bad || sum != s.hist1[0][d];
+        uint32_t* row = t2 + ((size_t) d * nb + b) * kPairRowWords;
+        row[j0] = w0;
+        row[64 + j0] = w1;
+    }
+    if (bad && lane == 0 && plan) plan->pair_fallback[pass + 1] = 1;
+}
+
+// Follower pass `pass`: workgroup w's run of units and its digit counts.  table_l / totals_l: the leader's scanned table
+// and digit totals; table_f: the follower's count table (as radix_count_kernel would write it); ranges[w] = the element
+// range of workgroup w.  Returns at once when the follower counts for itself.
+__global__ __launch_bounds__(1024) void radix_pair_unitsum_kernel(const uint32_t* __restrict__ t2,
+                                                                  const uint32_t* __restrict__ table_l,
+                                                                  const uint32_t* __restrict__ totals_l,
+                                                                  uint32_t* __restrict__ table_f, uint2* __restrict__ ranges,
+                                                                  uint32_t n, PassPlan* plan, uint32_t pass)
+{
+    constexpr int THREADS = 1024;
+    if (plan->pair_fallback[pass]) return; // (kernel-uniform)
+    __shared__ uint32_t base[kPairRadix + 1];
+    __shared__ uint32_t tmp[16];
+    __shared__ uint32_t found[2];
+    __shared__ uint32_t part[32][kPairRadix];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t nb = gridDim.x, w = blockIdx.x;
+    if (w == 0 && tid == 0) plan->skip[pass] = 0;
+
+    // exclusive scan of the leader's digit totals: where every digit value's units start
+    {
+        const uint32_t t = tid < kPairRadix ? totals_l[tid] : 0u;
+        uint32_t wtotal;
+        uint32_t excl = wave_exclusive_sum(t, lane, wtotal);
+        if (lane == 0) tmp[wave] = wtotal;
+        __syncthreads();
+        excl += sum_of_preceding_waves(tmp, 4, wave < 4 ? wave : 0, lane);
+        if (tid < kPairRadix) base[tid] = excl;
+        if (tid == 0) base[kPairRadix] = n;
+        __syncthreads();
+    }
+    // U(P) = number of units that start before element P (unit index u = d * nb + b, starts ascend with u): all units of
+    // the digit values below d*, the last one whose units start before P, and of d* those whose scanned entry is below.
+    uint32_t edge[2]; // first unit of this workgroup, first unit of the next
+    uint32_t edge_start[2];
+#pragma unroll
+    for (int side = 0; side < 2; side++)
+    {
+        const uint32_t P = (uint32_t) ((uint64_t) n * (w + side) / nb);
+        if (w + side == nb)
+        {
+            edge[side] = kPairRadix * nb;
+            edge_start[side] = n;
+            continue;
+        }
+        if (tid < 2) found[tid] = 0;
+        __syncthreads();
+        // d* + 1 = number of digit values whose units start before P
+        if (tid < kPairRadix && base[tid] < P) atomicAdd(&found[0], 1u);
+        __syncthreads();
+        const uint32_t below = found[0];
+        if (below == 0) // P == 0
+        {
+            edge[side] = 0;
+            edge_start[side] = 0;
+            continue;
+        }
+        const uint32_t ds = below - 1;
+        for (uint32_t bb = tid; bb < nb; bb += THREADS)
+            if (base[ds] + table_l[(size_t) ds * nb + bb] < P) atomicAdd(&found[1], 1u);
+        __syncthreads();
+        const uint32_t in_row = found[1]; // >= 1: the row's first unit starts at base[ds] < P
+        const uint32_t u = ds * nb + in_row;
+        edge[side] = u;
+        // start of unit u (the first one not before P); past the row's end it is the next digit value's first unit
+        edge_start[side] = in_row < nb ? base[ds] + table_l[(size_t) ds * nb + in_row] : base[ds + 1];
+        __syncthreads();
+    }
+
+    // a run of very many (tiny) units would be a long chain of table reads in this one workgroup: count instead
+    if (edge[1] - edge[0] > kPairMaxRunUnits)
+    {
+        if (tid == 0) plan->pair_fallback[pass] = 1;
+        return;
+    }
+    // digit counts of the run: sum of its T2 rows; 32 rows at a time, thread (g, q) adds words 4q .. 4q + 3 of the rows
+    // g, g + 32, ...
+    const uint32_t g = tid >> 5, q = tid & 31u;
+    uint32_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const uint4* rows = reinterpret_cast<const uint4*>(t2);
+#pragma unroll 4
+    for (uint32_t u = edge[0] + g; u < edge[1]; u += 32)
+    {
+        const uint4 v = rows[(size_t) u * (kPairRowWords / 4) + q];
+        acc[0] += v.x & 0xFFFFu, acc[1] += v.x >> 16, acc[2] += v.y & 0xFFFFu, acc[3] += v.y >> 16;
+        acc[4] += v.z & 0xFFFFu, acc[5] += v.z >> 16, acc[6] += v.w & 0xFFFFu, acc[7] += v.w >> 16;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) part[g][8 * q + k] = acc[k];
+    __syncthreads();
+    if (tid < kPairRadix)
+    {
+        uint32_t c = 0;
+#pragma unroll
+        for (int k = 0; k < 32; k++) c += part[k][tid];
+        table_f[(size_t) tid * nb + w] = c;
+    }
+    if (tid == 0) ranges[w] = make_uint2(edge_start[0], edge_start[1]);
+}
+
+} // namespace glu_hip

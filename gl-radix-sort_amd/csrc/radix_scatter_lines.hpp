@@ -66,7 +66,7 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
     const KeyT* __restrict__ keys_a, const uint32_t* __restrict__ vals_a, KeyT* __restrict__ keys_b,
     uint32_t* __restrict__ vals_b, const uint32_t* __restrict__ table, const uint32_t* __restrict__ totals, uint32_t n,
     uint32_t shift, uint32_t mask, uint32_t tiles_total, unsigned long long* stamps = nullptr, uint32_t xform = 0,
-    PassPlan* plan = nullptr, uint32_t pass = 0)
+    PassPlan* plan = nullptr, uint32_t pass = 0, const uint2* __restrict__ ranges = nullptr)
 {
     const KeyT* __restrict__ src_keys = keys_a;
     const uint32_t* __restrict__ src_vals = vals_a;
@@ -129,8 +129,25 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
     for (int i = tid; i < WAVES * Smem::WCNT_STRIDE / 2; i += THREADS) reinterpret_cast<uint32_t*>(&s.wcnt[0][0])[i] = 0;
     __syncthreads();
 
-    uint32_t first, last;
-    block_tile_range(b, nb, tiles_total, first, last);
+    // The workgroup's element range [r0, r1), cut into tiles from r0: a run of whole tiles of the array, or -- the
+    // follower of a pair of passes (radix_pair_passes.hpp) -- a run of whole units of the pass before, which starts and
+    // ends at any element.  Only the last tile of a range can be partial.
+    uint64_t r0, r1;
+    if (ranges && !plan->pair_fallback[pass])
+    {
+        const uint2 r = ranges[b];
+        r0 = r.x;
+        r1 = r.y;
+    }
+    else
+    {
+        uint32_t first_tile, end_tile;
+        block_tile_range(b, nb, tiles_total, first_tile, end_tile);
+        r0 = (uint64_t) first_tile * TILE;
+        r1 = (uint64_t) end_tile * TILE;
+        if (r1 > n) r1 = n;
+    }
+    const uint32_t first = 0, last = (uint32_t) ((r1 - r0 + (uint64_t) TILE - 1) / (uint64_t) TILE);
     const uint32_t last_tile_of_range = last;
     const uint32_t wave_off = wave * WAVE_TILE + lane; // wave-striped: item i of lane l of wave w = element w*64*KPT + i*64 + l
 
@@ -151,8 +168,8 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
     uint16_t* const my_cnt = s.wcnt[wave];
     // guarded loads of a partial tile: positions past the end of the array read as pads (highest digit, after all keys)
     auto load_tile_guarded = [&](uint32_t t) {
-        const uint64_t base = (uint64_t) t * TILE;
-        const uint32_t left = (uint32_t) ((uint64_t) n - base);
+        const uint64_t base = r0 + (uint64_t) t * TILE;
+        const uint32_t left = (uint32_t) (r1 - base);
 #pragma unroll
         for (int i = 0; i < KPT; i++)
         {
@@ -161,11 +178,12 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
             if (VALS) val[i] = p < left ? src_vals[base + p] : 0u;
         }
     };
-    // full tile t, or tile 0 when t is not a full tile of this range (a harmless prefetch of something that is not used:
-    // the loops that prefetch carry no branch)
+    // full tile t, or the first tile of the array when t is not a full tile of this range (a harmless prefetch of
+    // something that is not used: the loops that prefetch carry no branch)
     auto prefetch_base = [&](uint32_t t) -> uint64_t {
-        const bool ok = t < last_tile_of_range && (uint64_t) n - (uint64_t) t * TILE >= (uint64_t) TILE;
-        return (ok ? (uint64_t) t * TILE : 0ull) + wave_off;
+        const uint64_t tb = r0 + (uint64_t) t * TILE;
+        const bool ok = t < last_tile_of_range && r1 - tb >= (uint64_t) TILE;
+        return (ok ? tb : 0ull) + wave_off;
     };
     // Ranks items [I0, I1) of the tile in key[] inside the wave (match-any on the digit bits with one ballot per bit,
     // wave-private running counters) and loads the same items of the tile after it into nkey[].  Touches nothing but the
@@ -208,9 +226,9 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
     //      ranked under the phases of the tile before it
     if (first < last)
     {
-        if ((uint64_t) n - (uint64_t) first * TILE >= (uint64_t) TILE)
+        if (r1 - r0 >= (uint64_t) TILE)
         {
-            const uint64_t base = (uint64_t) first * TILE + wave_off;
+            const uint64_t base = r0 + wave_off;
 #pragma unroll
             for (int i = 0; i < KPT; i++) key[i] = codec_in.encode(src_keys[base + i * kWave]);
             if (VALS)
@@ -226,11 +244,11 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
 
     for (uint32_t tile = first; tile < last; tile++)
     {
-        const uint64_t tile_base = (uint64_t) tile * TILE;
-        const uint64_t rem = (uint64_t) n - tile_base;
+        const uint64_t tile_base = r0 + (uint64_t) tile * TILE;
+        const uint64_t rem = r1 - tile_base;
         const uint32_t tile_valid = rem >= (uint64_t) TILE ? (uint32_t) TILE : (uint32_t) rem;
         const bool has_next = tile + 1 < last;
-        const bool next_full = has_next && (uint64_t) n - (tile_base + TILE) >= (uint64_t) TILE;
+        const bool next_full = has_next && r1 - (tile_base + TILE) >= (uint64_t) TILE;
         if (STAMPS) tprev = __builtin_amdgcn_s_memtime();
         __syncthreads(); // every wave has ranked this tile
         stamp(0);

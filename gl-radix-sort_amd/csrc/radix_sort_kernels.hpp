@@ -133,6 +133,9 @@ struct PassPlan
 {
     uint32_t flip[kPlanMaxPasses + 1];
     uint32_t skip[kPlanMaxPasses];
+    // paired passes (radix_pair_passes.hpp): 1 = pass p counts for itself although its table was to come from the
+    // two-digit histogram of pass p - 1; zeroed at the start of every sort, set by kernels that run before pass p
+    uint32_t pair_fallback[kPlanMaxPasses + 1];
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -144,12 +147,16 @@ __global__ __launch_bounds__(THREADS) void radix_count_kernel(const KeyT* __rest
                                                               uint32_t* __restrict__ table, uint32_t n,
                                                               uint32_t shift, uint32_t mask, uint32_t tiles_total,
                                                               uint32_t xform = 0, const KeyT* keys_b = nullptr,
-                                                              PassPlan* plan = nullptr, uint32_t pass = 0)
+                                                              PassPlan* plan = nullptr, uint32_t pass = 0,
+                                                              bool pair_follower = false)
 {
     constexpr int RADIX = 1 << BITS;
     constexpr int WAVES = THREADS / kWave;
     const uint32_t MASK = mask; // <= RADIX - 1 (narrower digits reuse the next wider instantiation)
     __shared__ uint32_t hist[WAVES][RADIX];
+    // the follower of a pair of passes has its table from the two-digit histogram of the pass before it
+    // (radix_pair_passes.hpp) unless a kernel before this one found that it cannot (kernel-uniform)
+    if (pair_follower && !plan->pair_fallback[pass]) return;
 
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // planned sorts: read whichever pair of arrays holds the data before this pass; arm the pass's skip flag
@@ -246,11 +253,13 @@ __global__ __launch_bounds__(THREADS) void radix_count_kernel(const KeyT* __rest
 // (The reference scans 16 partitions of nbp2 entries with 2*log2(nbp2) dispatches and keeps the 16 digit
 //  totals in a separate buffer that the reorder shader scans itself: RadixSort.hpp:148-152, 311.)
 // ---------------------------------------------------------------------------------------------------------
+// pair_limit > 0 (the leader of a pair of passes): a table entry above it sends the follower back to its own count kernel.
 template<int THREADS>
 __global__ __launch_bounds__(THREADS) void radix_row_scan_kernel(uint32_t* __restrict__ table,
                                                                  uint32_t* __restrict__ totals, uint32_t num_blocks,
                                                                  uint32_t n = 0, PassPlan* plan = nullptr,
-                                                                 uint32_t pass = 0)
+                                                                 uint32_t pass = 0, uint32_t pair_limit = 0,
+                                                                 PassPlan* pair_plan = nullptr)
 {
     constexpr int WAVES = THREADS / kWave;
     __shared__ uint32_t wave_sums[WAVES];
@@ -261,6 +270,7 @@ __global__ __launch_bounds__(THREADS) void radix_row_scan_kernel(uint32_t* __res
     {
         uint32_t i = base + tid;
         uint32_t v = i < num_blocks ? row[i] : 0;
+        if (pair_limit && v > pair_limit) pair_plan->pair_fallback[pass + 1] = 1;
         uint32_t wtotal;
         uint32_t excl = wave_exclusive_sum(v, lane, wtotal);
         if (lane == 0) wave_sums[wave] = wtotal;

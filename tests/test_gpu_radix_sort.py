@@ -867,3 +867,164 @@ def test_planned_sort_inside_a_captured_graph(G):
             side.synchronize()
             order = np.argsort(keys, kind="stable")
             assert (kt.cpu().numpy().view(np.uint32) == keys[order]).all() and (vt.cpu().numpy().view(np.uint32) == vals[order]).all()
+
+
+# ---- paired passes (radix_pair_passes.hpp): sorts of >= 2^22 elements with 8-bit digits read the keys once per PAIR of
+# passes; the second pass of a pair ("follower") takes its count table from the two-digit histogram of the first, unless
+# the data sends it back to its own count kernel.  glu_radix_sort_read_plan says what happened.
+
+def _sort_and_plan(G, keys, vals, passes, key_bytes=4, env=None, run=None):
+    old = {}
+    for k, v in (env or {}).items():
+        old[k] = os.environ.get(k)
+        os.environ[k] = v
+    try:
+        sorter = G.RadixSort()  # reads the environment switches
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    kb = G.ShaderStorageBuffer(keys)
+    vb = G.ShaderStorageBuffer(vals) if vals is not None else None
+    if run is not None:
+        run(sorter, kb, vb)
+    elif vals is None:
+        sorter.sort_keys_ptr(kb.device_ptr(), keys.size, 0, None, key_bytes=key_bytes)
+    else:
+        sorter(kb, vb, keys.size, 0, key_bytes=key_bytes)
+    G.synchronize()
+    skipped, alone = sorter.read_plan(passes)
+    return kb.get_data(keys.dtype), (vb.get_data(np.uint32) if vb is not None else None), skipped, alone
+
+
+PAIR_N = (1 << 24) + 4321
+
+
+def _check_against_oracle(keys, vals, gk, gv):
+    ek, ev = O.stable_sort_pairs(keys, vals)
+    assert (gk == ek).all() and (gv == ev).all()
+
+
+def test_paired_passes_uniform_keys_take_every_table_from_the_leader(G):
+    rng = np.random.default_rng(31)
+    keys = rng.integers(0, 2**32, PAIR_N, dtype=np.uint32)
+    vals = np.arange(PAIR_N, dtype=np.uint32)
+    gk, gv, skipped, alone = _sort_and_plan(G, keys, vals, 4)
+    _check_against_oracle(keys, vals, gk, gv)
+    assert skipped == [0, 0, 0, 0] and alone == [0, 0, 0, 0]
+    # and with the switch off the same result from four counting kernels
+    gk2, gv2, _, alone2 = _sort_and_plan(G, keys, vals, 4, env={"GLU_HIP_SORT_PAIRS": "0"})
+    assert (gk2 == gk).all() and (gv2 == gv).all() and alone2 == [0, 0, 0, 0]
+
+
+def test_paired_passes_common_digit_value_sends_the_follower_back_to_counting(G):
+    """10 % of the keys share one low byte: the leader's units of that digit value are longer than 1/16 of a workgroup's
+    share, runs of whole units cannot be balanced, pass 1 counts for itself; the second pair is unaffected."""
+    rng = np.random.default_rng(32)
+    keys = rng.integers(0, 2**32, PAIR_N, dtype=np.uint32)
+    hot = rng.random(PAIR_N) < 0.10
+    keys[hot] = (keys[hot] & np.uint32(0xFFFFFF00)) | np.uint32(0x77)
+    vals = np.arange(PAIR_N, dtype=np.uint32)
+    gk, gv, skipped, alone = _sort_and_plan(G, keys, vals, 4)
+    _check_against_oracle(keys, vals, gk, gv)
+    assert alone == [0, 1, 0, 0] and skipped == [0, 0, 0, 0]
+
+
+def test_paired_passes_counter_overflow_is_found(G):
+    """The first 200 000 keys share their low 16 bits: the 16-bit counter of that digit pair overflows in the first
+    workgroups' two-digit histograms.  With the unit-length rule switched off, the row-sum check is what sends pass 1
+    back to counting."""
+    rng = np.random.default_rng(33)
+    keys = rng.integers(0, 2**32, PAIR_N, dtype=np.uint32)
+    keys[:200000] = (keys[:200000] & np.uint32(0xFFFF0000)) | np.uint32(0x1234)
+    vals = np.arange(PAIR_N, dtype=np.uint32)
+    gk, gv, skipped, alone = _sort_and_plan(G, keys, vals, 4, env={"GLU_HIP_SORT_PAIR_UNIT_DIV": "0"})
+    _check_against_oracle(keys, vals, gk, gv)
+    assert alone == [0, 1, 0, 0]
+    # the default rule catches the same input earlier (those units are long)
+    gk, gv, skipped, alone = _sort_and_plan(G, keys, vals, 4)
+    _check_against_oracle(keys, vals, gk, gv)
+    assert alone == [0, 1, 0, 0]
+
+
+def test_paired_passes_run_of_many_tiny_units_counts_instead(G):
+    """Half of the low-byte values are rare (1 key in 256 has one of them): their 128 x 256 units hold about two keys each
+    and one follower workgroup's run would span ten thousands of them."""
+    rng = np.random.default_rng(34)
+    keys = rng.integers(0, 2**32, PAIR_N, dtype=np.uint32)
+    rare = rng.random(PAIR_N) < 1.0 / 256
+    keys[~rare] &= np.uint32(0xFFFFFF7F)
+    keys[rare] |= np.uint32(0x80)
+    vals = np.arange(PAIR_N, dtype=np.uint32)
+    gk, gv, skipped, alone = _sort_and_plan(G, keys, vals, 4)
+    _check_against_oracle(keys, vals, gk, gv)
+    assert alone == [0, 1, 0, 0]
+
+
+@pytest.mark.parametrize("case", ["sorted", "reverse", "all_equal", "two_values", "low_16_bits_only", "high_16_bits_only",
+                                  "byte_1_constant", "few_distinct"])
+def test_paired_passes_structured_inputs(G, case):
+    n = PAIR_N
+    rng = np.random.default_rng(35)
+    if case == "sorted":
+        keys = np.arange(n, dtype=np.uint32) * np.uint32(251)
+    elif case == "reverse":
+        keys = (np.uint32(0xFFFFFFFF) - np.arange(n, dtype=np.uint32) * np.uint32(17))
+    elif case == "all_equal":
+        keys = np.full(n, 0xA5A5A5A5, dtype=np.uint32)
+    elif case == "two_values":
+        keys = np.where(rng.random(n) < 0.5, np.uint32(0x01020304), np.uint32(0xF1F2F3F4)).astype(np.uint32)
+    elif case == "low_16_bits_only":
+        keys = rng.integers(0, 2**16, n, dtype=np.uint32)
+    elif case == "high_16_bits_only":
+        keys = rng.integers(0, 2**16, n, dtype=np.uint32) << np.uint32(16)
+    elif case == "byte_1_constant":
+        keys = (rng.integers(0, 2**32, n, dtype=np.uint32) & np.uint32(0xFFFF00FF)) | np.uint32(0x4200)
+    else:
+        keys = rng.integers(0, 40, n, dtype=np.uint32) * np.uint32(0x01010101)
+    vals = np.arange(n, dtype=np.uint32)
+    gk, gv, skipped, alone = _sort_and_plan(G, keys, vals, 4)
+    _check_against_oracle(keys, vals, gk, gv)
+    if case == "low_16_bits_only":
+        assert skipped == [0, 0, 1, 1] and alone[:2] == [0, 0]
+    if case == "high_16_bits_only":
+        assert skipped == [1, 1, 0, 0]
+    if case == "byte_1_constant":
+        assert skipped == [0, 1, 0, 0]
+    if case == "all_equal":
+        assert skipped == [1, 1, 1, 1]
+
+
+def test_paired_passes_u64_keys_only_and_bit_ranges(G):
+    n = (1 << 23) + 99
+    rng = np.random.default_rng(36)
+    k64 = rng.integers(0, 2**64, n, dtype=np.uint64)
+    k64[::5] &= np.uint64(0x0000FFFFFFFFFFFF)
+    vals = np.arange(n, dtype=np.uint32)
+    gk, gv, skipped, alone = _sort_and_plan(G, k64, vals, 8, key_bytes=8)
+    order = np.argsort(k64, kind="stable")
+    assert (gk == k64[order]).all() and (gv == vals[order]).all()
+    # (a fifth of the keys has zero top bytes: the last leader's units of digit value 0 are long, pass 7 counts for itself)
+    assert alone == [0, 0, 0, 0, 0, 0, 0, 1] and skipped == [0] * 8
+    # 64-bit keys whose upper word is zero: the last two pairs of passes are identities
+    small = k64 & np.uint64(0xFFFFFFFF)
+    gk, gv, skipped, alone = _sort_and_plan(G, small, vals, 8, key_bytes=8)
+    order = np.argsort(small, kind="stable")
+    assert (gk == small[order]).all() and (gv == vals[order]).all()
+    assert skipped == [0, 0, 0, 0, 1, 1, 1, 1]
+    # keys only
+    gk, _, skipped, alone = _sort_and_plan(G, k64, None, 8, key_bytes=8)
+    assert (gk == np.sort(k64)).all() and alone == [0, 0, 0, 0, 0, 0, 0, 1]
+    k32 = rng.integers(0, 2**32, n, dtype=np.uint32)
+    gk, _, skipped, alone = _sort_and_plan(G, k32, None, 4)
+    assert (gk == np.sort(k32)).all() and alone == [0] * 4
+    # bit ranges: [4, 28) = three 8-bit passes (a pair and a single), [8, 21) = 8 + 5 bits (a pair with a narrow follower)
+    for begin, end, passes in ((4, 28, 3), (8, 21, 2), (0, 12, 2)):
+        field = (k32 >> np.uint32(begin)) & np.uint32((1 << (end - begin)) - 1)
+        order = np.argsort(field, kind="stable")
+        gk, gv, skipped, alone = _sort_and_plan(
+            G, k32, vals, passes, run=lambda s, kb, vb: s.sort_bit_range_ptr(kb.device_ptr(), vb.device_ptr(), n, begin, end, None, 4))
+        assert (gk == k32[order]).all() and (gv == vals[order]).all(), (begin, end)
+        assert alone[:passes] == [0] * passes

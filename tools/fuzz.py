@@ -19,7 +19,12 @@ SWITCH = [1024, 4096, 8192, 12288, 256 * 4096, 768 * 4096, 256 * 12288, 256 * 20
           256 * 10240 * 3 // 2, 256 * 16384 * 3 // 2, 256 * 8192 * 3 // 2, 256 * 10240 * 2, 256 * 10240 * 2 + 10240]  # + line-kernel switch points
 
 
+LARGE = os.environ.get("FUZZ_LARGE") == "1"  # most sizes in [2^22, 2^23]: the sorts that pair their passes
+
+
 def draw_n(limit=1 << 23):
+    if LARGE and rng.random() < 0.8:
+        return int(rng.integers(1 << 22, limit + 1))
     if rng.random() < 0.3:
         n = int(rng.choice(SWITCH)) + int(rng.integers(-3, 4))
     else:
@@ -29,8 +34,21 @@ def draw_n(limit=1 << 23):
 
 def draw_keys(n, bits):
     dt = np.uint32 if bits == 32 else np.uint64
-    kind = rng.integers(0, 8)
+    kind = rng.integers(0, 11)
     full = rng.integers(0, 2 ** bits, n, dtype=dt)
+    if kind == 8:  # one byte takes one value in a tenth to a half of the keys (paired passes: units too long to balance)
+        b = dt(8 * int(rng.integers(0, bits // 8)))
+        hot = rng.random(n) < rng.uniform(0.05, 0.5)
+        return np.where(hot, (full & ~(dt(0xFF) << b)) | (dt(int(rng.integers(0, 256))) << b), full).astype(dt)
+    if kind == 9:  # half of one byte's values are rare (paired passes: runs of very many tiny units)
+        b = dt(8 * int(rng.integers(0, bits // 8)))
+        rare = rng.random(n) < 1.0 / int(rng.integers(64, 2048))
+        return np.where(rare, full | (dt(0x80) << b), full & ~(dt(0x80) << b)).astype(dt)
+    if kind == 10:  # a long prefix of the array shares its low 16 bits (paired passes: 16-bit counter overflow)
+        m = int(rng.integers(0, n + 1))
+        out = full.copy()
+        out[:m] = (out[:m] & ~dt(0xFFFF)) | dt(int(rng.integers(0, 1 << 16)))
+        return out
     if kind == 0:
         return full
     if kind == 1:

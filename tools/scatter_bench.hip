@@ -255,7 +255,14 @@ void run_lines(Ctx& c, uint32_t shift, uint32_t mask_override = 0)
     constexpr int RADIX = 1 << BITS;
     constexpr int TILE = THREADS * KPT;
     using Smem = LineSmem<uint32_t, BITS, THREADS, KPT, VALS>;
-    const uint32_t tiles = (uint32_t) ((c.n + TILE - 1) / TILE);
+    // SB_SRCOFF=k: the source arrays start k elements into their allocations (what an unaligned source costs: the
+    // arrays of a pass whose workgroup ranges start at arbitrary elements); the element count is n - 32 either way
+    const size_t src_off = getenv("SB_SRCOFF") ? (size_t) atoi(getenv("SB_SRCOFF")) : 0;
+    const uint32_t* skeys = c.keys + src_off;
+    const uint32_t* svals = c.vals + src_off;
+    const size_t n_eff = getenv("SB_SRCOFF") ? c.n - 32 : c.n;
+    if (getenv("SB_SRCOFF")) printf("src offset %zu: ", src_off);
+    const uint32_t tiles = (uint32_t) ((n_eff + TILE - 1) / TILE);
     uint32_t nb = std::min<uint32_t>(tiles, (uint32_t) c.cus);
     if (getenv("SB_NB")) nb = std::min<uint32_t>(tiles, (uint32_t) atoi(getenv("SB_NB")));
     uint32_t* totals = c.table + (size_t) RADIX * nb;
@@ -265,27 +272,27 @@ void run_lines(Ctx& c, uint32_t shift, uint32_t mask_override = 0)
     auto scatter_st = radix_scatter_lines_kernel<uint32_t, BITS, THREADS, KPT, false, VALS, ABLATE, true, RS, STAGGER, NT, PRIO>;
     CK(hipFuncSetAttribute((const void*) scatter_st, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sizeof(Smem)));
     CK(hipFuncSetAttribute((const void*) scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sizeof(Smem)));
-    hipLaunchKernelGGL((radix_count_kernel<uint32_t, BITS, THREADS, TILE>), dim3(nb), dim3(THREADS), 0, 0, c.keys, c.table, (uint32_t) c.n, shift, mask,
+    hipLaunchKernelGGL((radix_count_kernel<uint32_t, BITS, THREADS, TILE>), dim3(nb), dim3(THREADS), 0, 0, skeys, c.table, (uint32_t) n_eff, shift, mask,
                        tiles, 0u);
     hipLaunchKernelGGL((radix_row_scan_kernel<256>), dim3(RADIX), dim3(256), 0, 0, c.table, totals, nb);
     CK(hipMemset(c.keys2, 0xff, c.n * 4));
     CK(hipMemset(c.vals2, 0xff, c.n * 4));
     float t_scatter = time_min(c, 5, [&] {
-        hipLaunchKernelGGL(scatter, dim3(nb), dim3(THREADS), sizeof(Smem), 0, c.keys, VALS ? c.vals : nullptr, c.keys2, VALS ? c.vals2 : nullptr,
-                           c.table, totals, (uint32_t) c.n, shift, mask, tiles, (unsigned long long*) nullptr, 0u, (PassPlan*) nullptr, 0u);
+        hipLaunchKernelGGL(scatter, dim3(nb), dim3(THREADS), sizeof(Smem), 0, skeys, VALS ? svals : nullptr, c.keys2, VALS ? c.vals2 : nullptr,
+                           c.table, totals, (uint32_t) n_eff, shift, mask, tiles, (unsigned long long*) nullptr, 0u, (PassPlan*) nullptr, 0u);
     });
     CK(hipGetLastError());
     CK(hipDeviceSynchronize());
     CK(hipMemset(c.bad, 0, 8));
-    if (!ABLATE && VALS) hipLaunchKernelGGL(check_kernel, dim3(4096), dim3(256), 0, 0, c.keys2, c.vals2, c.keys, c.n, shift, mask, c.bad);
+    if (!ABLATE && VALS) hipLaunchKernelGGL(check_kernel, dim3(4096), dim3(256), 0, 0, c.keys2, c.vals2, c.keys, n_eff, shift, mask, c.bad);
     unsigned long long bad = 0;
     CK(hipMemcpy(&bad, c.bad, 8, hipMemcpyDeviceToHost));
     if (!VALS) bad = 0;
     unsigned long long* st;
     CK(hipMalloc(&st, 128));
     CK(hipMemset(st, 0, 128));
-    hipLaunchKernelGGL(scatter_st, dim3(nb), dim3(THREADS), sizeof(Smem), 0, c.keys, VALS ? c.vals : nullptr, c.keys2, VALS ? c.vals2 : nullptr, c.table,
-                       totals, (uint32_t) c.n, shift, mask, tiles, st, 0u, (PassPlan*) nullptr, 0u);
+    hipLaunchKernelGGL(scatter_st, dim3(nb), dim3(THREADS), sizeof(Smem), 0, skeys, VALS ? svals : nullptr, c.keys2, VALS ? c.vals2 : nullptr, c.table,
+                       totals, (uint32_t) n_eff, shift, mask, tiles, st, 0u, (PassPlan*) nullptr, 0u);
     unsigned long long hst[16];
     CK(hipMemcpy(hst, st, 128, hipMemcpyDeviceToHost));
     CK(hipFree(st));
@@ -295,10 +302,10 @@ void run_lines(Ctx& c, uint32_t shift, uint32_t mask_override = 0)
         float best = 1e9f;
         for (int r = 0; r < 5; r++)
         {
-            hipLaunchKernelGGL(scatter, dim3(nb), dim3(THREADS), sizeof(Smem), 0, c.keys, VALS ? c.vals : nullptr, c.keys2, VALS ? c.vals2 : nullptr,
-                               c.table, totals, (uint32_t) c.n, shift, mask, tiles, (unsigned long long*) nullptr, 0u, (PassPlan*) nullptr, 0u);
+            hipLaunchKernelGGL(scatter, dim3(nb), dim3(THREADS), sizeof(Smem), 0, skeys, VALS ? svals : nullptr, c.keys2, VALS ? c.vals2 : nullptr,
+                               c.table, totals, (uint32_t) n_eff, shift, mask, tiles, (unsigned long long*) nullptr, 0u, (PassPlan*) nullptr, 0u);
             CK(hipEventRecord(c.ev[0]));
-            hipLaunchKernelGGL((radix_count_kernel<uint32_t, BITS, THREADS, TILE>), dim3(nb), dim3(THREADS), 0, 0, c.keys2, c.table + (1 << 20), (uint32_t) c.n,
+            hipLaunchKernelGGL((radix_count_kernel<uint32_t, BITS, THREADS, TILE>), dim3(nb), dim3(THREADS), 0, 0, c.keys2, c.table + (1 << 20), (uint32_t) n_eff,
                                shift + BITS, mask, tiles, 0u);
             CK(hipEventRecord(c.ev[1]));
             CK(hipEventSynchronize(c.ev[1]));
@@ -309,7 +316,7 @@ void run_lines(Ctx& c, uint32_t shift, uint32_t mask_override = 0)
         printf("%s%s[count right behind it: %.3f ms] ", NT ? "nt-stores " : "", PRIO == 1 ? "prio-stage " : PRIO == 2 ? "prio-tails " : PRIO == 3 ? "prio-both " : "", best);
     }
     printf("lines %ssplit %d bits %d threads %4d kpt %2d tile %5d lds %6zu nb %5u | scatter %.3f ms (%.0f GB/s) %s\n", STAGGER ? "stagger " : "", RS, BITS, THREADS, KPT, TILE, sizeof(Smem), nb,
-           t_scatter, c.n * (VALS ? 16.0 : 8.0) / t_scatter / 1e6, ABLATE ? "(ablated)" : bad ? "WRONG" : "ok");
+           t_scatter, n_eff * (VALS ? 16.0 : 8.0) / t_scatter / 1e6, ABLATE ? "(ablated)" : bad ? "WRONG" : "ok");
     const char* names[8] = {"bar1", "scan", "stage+rankA", "bar4", "lines", "bar5", "tails+rankB", "-"};
     for (int w = 0; w < 2; w++)
     {
@@ -670,6 +677,11 @@ int main(int argc, char** argv)
         run_variant<8, 1024, 9, true, 2>(c, 1, shift);
         run_variant<8, 1024, 9, true, 4>(c, 1, shift);
         run_variant<8, 1024, 9, true, 5>(c, 1, shift);
+        return 0;
+    }
+    if (getenv("SB_SRCOFF"))
+    {
+        run_lines<8, 1024, 10, true, 0, 4, true, true>(c, shift);
         return 0;
     }
     if (getenv("SB_LINES"))
