@@ -274,7 +274,14 @@ def main():
         workload_key = "radix_sort_u32_pairs_2^%d_%s_bits%d" % (log2n, args.keys, bits)
         traffic = load_traffic(workload_key)
         passes_per_sort = passes // K
-        bytes_per_pair_moved = passes_per_sort * (3 * KEY_BYTES + 2 * VAL_BYTES)
+        # bytes the sort really moves per pair: every pass reads and writes key + val in its scatter; a pass reads the keys
+        # once more in its count kernel unless it is the second pass of a pair that took its count table from the first
+        # pass's two-digit histogram (then the pair moves that table instead: 256 x workgroups x 512 B written and read)
+        skipped, alone, roles = sorter.read_plan(passes_per_sort, roles=True)
+        from_table = sum(1 for p in range(passes_per_sort) if roles[p] == 2 and not alone[p])
+        pair_table_bytes = sum(1 for p in range(passes_per_sort) if roles[p] == 1) * 2 * 256 * 256 * 512
+        bytes_per_pair_moved = round(passes_per_sort * 2 * (KEY_BYTES + VAL_BYTES) + (passes_per_sort - from_table) * KEY_BYTES
+                                     + pair_table_bytes / n, 2)
         result.update({
             "roofline": {
                 "bound": "hbm", "kernel": "radix_scatter_lines_kernel<u32,%d>" % bits,
@@ -289,6 +296,7 @@ def main():
             },
             "whole_sort": {
                 "passes": passes_per_sort, "digit_bits": bits,
+                "count_kernels_reading_keys": passes_per_sort - from_table,
                 "bytes_per_pair_moved": bytes_per_pair_moved,
                 "achieved_GBps_own_bytes": round(units * bytes_per_pair_moved / elapsed / 1e9, 1),
                 "frac_of_peak_own_bytes": round(units * bytes_per_pair_moved / elapsed / 1e9 / HBM_PEAK_GBPS, 4),

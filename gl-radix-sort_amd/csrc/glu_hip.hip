@@ -432,6 +432,8 @@ struct glu_radix_sort_s
     bool no_lines = false;        // GLU_HIP_SORT_NO_LINES=1: never use the 128-byte-line scatter kernel (tests / tuning)
     bool nt_stores = true;        // GLU_HIP_SORT_NT_STORES=0: plain instead of non-temporal line stores in the line scatter (tuning)
     bool pairs = true;            // GLU_HIP_SORT_PAIRS=0: every pass of a large sort counts for itself (tests / tuning)
+    uint32_t last_pair_roles[kPlanMaxPasses] = {}; // host-side record of the last planned sort (glu_radix_sort_read_plan)
+    size_t pair_min = 0;          // GLU_HIP_SORT_PAIR_MIN=N: element count from which passes are paired (tests / tuning)
     uint32_t pair_unit_div = 16;  // GLU_HIP_SORT_PAIR_UNIT_DIV: a follower counts for itself when a unit of its leader is longer
                                   // than 1 / this of a workgroup's share (0 = never: tests reach the counter-overflow check that way)
     hipEvent_t after_histogram_event = nullptr; // partition passes: recorded once the digit histogram has been copied out
@@ -460,9 +462,11 @@ struct glu_radix_sort_s
 
 namespace
 {
-// paired passes need the line kernel and the device-side plan; below this count neither runs (the exact conditions are
-// checked per sort: pairs_applicable)
-constexpr size_t kPairMinCount = (size_t) 1 << 22;
+// paired passes need the line kernel and the device-side plan, and pay 64 MiB of table traffic and two launches per pair
+// of passes whatever the input size: below this many bytes of keys a second read of the keys is cheaper
+// (tools/pairs_ladder.py; GLU_HIP_SORT_PAIR_MIN=elements overrides: tests, tuning)
+constexpr size_t kPairMinKeyBytes = (size_t) 1 << 28;
+constexpr size_t kPlanMinCount = (size_t) 1 << 22; // planned sorts: see PlanArgs below
 
 glu_status sort_prepare(glu_radix_sort_s* s, size_t count, size_t key_size, bool with_vals = true)
 {
@@ -472,7 +476,8 @@ glu_status sort_prepare(glu_radix_sort_s* s, size_t count, size_t key_size, bool
     uint64_t cap = (uint64_t) g_dev.num_cus * kMaxBlocksPerCu;
     GLU_TRY(s->table.reserve((kMaxRadix * cap + kMaxRadix) * sizeof(uint32_t)));
     GLU_TRY(s->plan.reserve(sizeof(PassPlan)));
-    if (count >= kPairMinCount && s->pairs && !s->no_plan && !s->no_lines && !s->force_small)
+    if (count >= kPlanMinCount && count >= (s->pair_min ? s->pair_min : kPairMinKeyBytes / key_size) && s->pairs && !s->no_plan &&
+        !s->no_lines && !s->force_small)
     {
         const size_t nb = (size_t) g_dev.num_cus;
         GLU_TRY(s->pair_t2.reserve((size_t) kPairRadix * nb * kPairRowWords * sizeof(uint32_t)));
@@ -485,7 +490,6 @@ glu_status sort_prepare(glu_radix_sort_s* s, size_t count, size_t key_size, bool
 // Planned sorts (count >= kPlanMinCount): the kernels pick source / destination from the device-side PassPlan and skip
 // the scatter of passes whose digit is constant over the input (radix_sort_kernels.hpp).  `may_skip` is false for the
 // passes that must run whatever the data looks like (key encode / decode passes of typed sorts).
-constexpr size_t kPlanMinCount = (size_t) 1 << 22;
 struct PlanArgs
 {
     PassPlan* plan = nullptr;
@@ -804,6 +808,7 @@ glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t cou
     // A leader is a pass of the 8-bit line kernel that does not encode keys on load; its follower is the pass after it,
     // also of the 8-bit line kernel.
     const bool pairs_ok = planned && s->pairs && s->pair_t2.ptr && s->max_blocks == 0 &&
+                          count >= (s->pair_min ? s->pair_min : kPairMinKeyBytes / sizeof(KeyT)) &&
                           lines_applicable<KeyT, 8>(s, kbuf[0], vbuf[0], kbuf[1], vbuf[1], count);
     if (pairs_ok)
     {
@@ -821,6 +826,8 @@ glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t cou
         PassPlan* plan = (PassPlan*) s->plan.ptr;
         HIP_TRY(hipMemsetAsync(plan->pair_fallback, 0, sizeof(plan->pair_fallback), stream));
     }
+    if (planned)
+        for (uint32_t i = 0; i < (uint32_t) kPlanMaxPasses; i++) s->last_pair_roles[i] = i < num_passes ? (uint32_t) passes[i].pair_role : 0u;
     uint32_t pass = 0;
     for (; pass < num_passes; pass++)
     {
@@ -904,6 +911,7 @@ glu_status glu_radix_sort_create(glu_radix_sort* out)
     if (const char* e = getenv("GLU_HIP_SORT_NO_PLAN")) s->no_plan = atoi(e) != 0;
     if (const char* e = getenv("GLU_HIP_SORT_NO_LINES")) s->no_lines = atoi(e) != 0;
     if (const char* e = getenv("GLU_HIP_SORT_PAIRS")) s->pairs = atoi(e) != 0;
+    if (const char* e = getenv("GLU_HIP_SORT_PAIR_MIN")) s->pair_min = (size_t) atoll(e);
     if (const char* e = getenv("GLU_HIP_SORT_PAIR_UNIT_DIV"))
     {
         int v = atoi(e); // 0: no limit
@@ -1111,7 +1119,7 @@ glu_status glu_radix_sort_set_profiling(glu_radix_sort sort, int enable)
     return GLU_OK;
 }
 
-glu_status glu_radix_sort_read_plan(glu_radix_sort sort, uint32_t* skipped, uint32_t* counted_alone, size_t passes)
+glu_status glu_radix_sort_read_plan(glu_radix_sort sort, uint32_t* skipped, uint32_t* counted_alone, uint32_t* pair_role, size_t passes)
 {
     GLU_TRY(enter());
     if (!sort) return fail(GLU_ERROR_INVALID_ARGUMENT, "sort is NULL");
@@ -1123,6 +1131,7 @@ glu_status glu_radix_sort_read_plan(glu_radix_sort sort, uint32_t* skipped, uint
     {
         if (skipped) skipped[p] = host.skip[p];
         if (counted_alone) counted_alone[p] = host.pair_fallback[p];
+        if (pair_role) pair_role[p] = sort->last_pair_roles[p];
     }
     return GLU_OK;
 }

@@ -66,7 +66,7 @@ SYMBOLS = [
     ("glu_radix_sort_scratch_size", _int, [_vp, _P(_sz)]),
     ("glu_radix_sort_set_profiling", _int, [_vp, _int]),
     ("glu_radix_sort_read_profile", _int, [_vp, _P(ctypes.c_double), _P(ctypes.c_double), _P(ctypes.c_double), _P(_u64)]),
-    ("glu_radix_sort_read_plan", _int, [_vp, _P(_u32), _P(_u32), _sz]),
+    ("glu_radix_sort_read_plan", _int, [_vp, _P(_u32), _P(_u32), _P(_u32), _sz]),
     ("glu_scan_create", _int, [_int, _P(_vp)]),
     ("glu_scan_destroy", _int, [_vp]),
     ("glu_scan_prepare", _int, [_vp, _sz, _sz]),
@@ -264,11 +264,12 @@ class RadixSort:
                                                 ctypes.byref(n)))
         return {"count_ms": c.value, "scan_ms": s.value, "scatter_ms": x.value, "passes": n.value}
 
-    def read_plan(self, passes):
-        """(skipped[passes], counted_alone[passes]) of the last planned sort (>= 2^22 elements); synchronise first."""
-        sk, ca = (_u32 * passes)(), (_u32 * passes)()
-        check(lib().glu_radix_sort_read_plan(self._h, sk, ca, passes))
-        return list(sk), list(ca)
+    def read_plan(self, passes, roles=False):
+        """(skipped[passes], counted_alone[passes]) -- with roles=True also pair_role[passes] -- of the last planned sort
+        (>= 2^22 elements); synchronise first."""
+        sk, ca, ro = (_u32 * passes)(), (_u32 * passes)(), (_u32 * passes)()
+        check(lib().glu_radix_sort_read_plan(self._h, sk, ca, ro, passes))
+        return (list(sk), list(ca), list(ro)) if roles else (list(sk), list(ca))
 
     def __call__(self, key_buffer, val_buffer, count, num_steps=0, key_bytes=4):
         kb = key_buffer.handle() if isinstance(key_buffer, ShaderStorageBuffer) else key_buffer

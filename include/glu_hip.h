@@ -209,10 +209,13 @@ GLU_API glu_status glu_radix_sort_read_profile(glu_radix_sort sort, double* coun
                                                double* scatter_ms, uint64_t* passes);
 /* Diagnostics of the last sort of >= 2^22 elements on this object, whose passes are planned on the device (the caller has
  * synchronised the sort's stream): for pass p < passes, skipped[p] = 1 if the pass was an identity (every key had the same
- * digit value: its scatter did not run), counted_alone[p] = 1 if the pass was to take its count table from the
- * two-digit histogram of the pass before it (large sorts with 8-bit digits read the keys once per PAIR of passes) but
- * counted for itself (skewed digit values, a 16-bit counter overflow).  Either array may be NULL; passes <= 32. */
-GLU_API glu_status glu_radix_sort_read_plan(glu_radix_sort sort, uint32_t* skipped, uint32_t* counted_alone, size_t passes);
+ * digit value: its scatter did not run); pair_role[p] = 1 / 2 if the pass was the first / second of a pair of passes that
+ * share one read of the keys (large sorts with 8-bit digits: the first pass's count kernel also builds a two-digit
+ * histogram, the second pass takes its count table from it), 0 if it stood alone; counted_alone[p] = 1 if a second pass
+ * of a pair counted for itself after all (skewed digit values, a 16-bit counter overflow).  Any array may be NULL;
+ * passes <= 32. */
+GLU_API glu_status glu_radix_sort_read_plan(glu_radix_sort sort, uint32_t* skipped, uint32_t* counted_alone,
+                                            uint32_t* pair_role, size_t passes);
 
 /* ---- exclusive scan: replaces glu::BlellochScan (glu/BlellochScan.hpp:80-191) ---------------------- */
 

@@ -875,7 +875,9 @@ def test_planned_sort_inside_a_captured_graph(G):
 
 def _sort_and_plan(G, keys, vals, passes, key_bytes=4, env=None, run=None):
     old = {}
-    for k, v in (env or {}).items():
+    env = dict(env or {})
+    env.setdefault("GLU_HIP_SORT_PAIR_MIN", "1")  # pair from the smallest planned sort up (default: from 2^28 bytes of keys)
+    for k, v in env.items():
         old[k] = os.environ.get(k)
         os.environ[k] = v
     try:
@@ -895,7 +897,8 @@ def _sort_and_plan(G, keys, vals, passes, key_bytes=4, env=None, run=None):
     else:
         sorter(kb, vb, keys.size, 0, key_bytes=key_bytes)
     G.synchronize()
-    skipped, alone = sorter.read_plan(passes)
+    skipped, alone, roles = sorter.read_plan(passes, roles=True)
+    _sort_and_plan.last_roles = roles
     return kb.get_data(keys.dtype), (vb.get_data(np.uint32) if vb is not None else None), skipped, alone
 
 
@@ -913,10 +916,13 @@ def test_paired_passes_uniform_keys_take_every_table_from_the_leader(G):
     vals = np.arange(PAIR_N, dtype=np.uint32)
     gk, gv, skipped, alone = _sort_and_plan(G, keys, vals, 4)
     _check_against_oracle(keys, vals, gk, gv)
-    assert skipped == [0, 0, 0, 0] and alone == [0, 0, 0, 0]
+    assert skipped == [0, 0, 0, 0] and alone == [0, 0, 0, 0] and _sort_and_plan.last_roles == [1, 2, 1, 2]
     # and with the switch off the same result from four counting kernels
     gk2, gv2, _, alone2 = _sort_and_plan(G, keys, vals, 4, env={"GLU_HIP_SORT_PAIRS": "0"})
-    assert (gk2 == gk).all() and (gv2 == gv).all() and alone2 == [0, 0, 0, 0]
+    assert (gk2 == gk).all() and (gv2 == gv).all() and alone2 == [0, 0, 0, 0] and _sort_and_plan.last_roles == [0, 0, 0, 0]
+    # by default a sort of this size (2^26 bytes of keys) does not pair either: the tables would cost more than the keys
+    gk3, gv3, _, _ = _sort_and_plan(G, keys, vals, 4, env={"GLU_HIP_SORT_PAIR_MIN": "0"})
+    assert (gk3 == gk).all() and (gv3 == gv).all() and _sort_and_plan.last_roles == [0, 0, 0, 0]
 
 
 def test_paired_passes_common_digit_value_sends_the_follower_back_to_counting(G):
@@ -1028,3 +1034,32 @@ def test_paired_passes_u64_keys_only_and_bit_ranges(G):
             G, k32, vals, passes, run=lambda s, kb, vb: s.sort_bit_range_ptr(kb.device_ptr(), vb.device_ptr(), n, begin, end, None, 4))
         assert (gk == k32[order]).all() and (gv == vals[order]).all(), (begin, end)
         assert alone[:passes] == [0] * passes
+
+
+@pytest.mark.parametrize("dtype", ["float32", "int32", "float64", "int64"])
+def test_paired_passes_typed_keys(G, dtype):
+    """Signed / float keys: the first pass encodes on load (it counts alone), the passes after it pair up, the last one
+    decodes on store."""
+    n = (1 << 22) + 12345
+    rng = np.random.default_rng(37)
+    dt = np.dtype(dtype)
+    if dt.kind == "f":
+        keys = (rng.standard_normal(n) * 1e3).astype(dt)
+        keys[::50] = 0.0
+        keys[1::50] = -0.0
+    else:
+        info = np.iinfo(dt)
+        keys = rng.integers(info.min, info.max, n, dtype=dt, endpoint=True)
+    vals = np.arange(n, dtype=np.uint32)
+    passes = dt.itemsize
+    gk, gv, skipped, alone = _sort_and_plan(
+        G, keys, vals, passes, run=lambda s, kb, vb: s.sort_typed_ptr(kb.device_ptr(), vb.device_ptr(), n, dtype))
+    u = keys.view(np.uint32 if dt.itemsize == 4 else np.uint64)
+    sign = u.dtype.type(1) << u.dtype.type(dt.itemsize * 8 - 1)
+    image = (u ^ sign) if dt.kind == "i" else np.where(u & sign, ~u, u ^ sign)
+    order = np.argsort(image, kind="stable")
+    assert (gk.view(u.dtype) == u[order]).all() and (gv == vals[order]).all()
+    assert skipped == [0] * passes
+    assert _sort_and_plan.last_roles == ([0, 1, 2, 0] if passes == 4 else [0, 1, 2, 1, 2, 1, 2, 0])
+    if dt.kind == "i":
+        assert alone == [0] * passes  # uniform digits: every follower took its table from its leader

@@ -19,7 +19,9 @@ SWITCH = [1024, 4096, 8192, 12288, 256 * 4096, 768 * 4096, 256 * 12288, 256 * 20
           256 * 10240 * 3 // 2, 256 * 16384 * 3 // 2, 256 * 8192 * 3 // 2, 256 * 10240 * 2, 256 * 10240 * 2 + 10240]  # + line-kernel switch points
 
 
-LARGE = os.environ.get("FUZZ_LARGE") == "1"  # most sizes in [2^22, 2^23]: the sorts that pair their passes
+LARGE = os.environ.get("FUZZ_LARGE") == "1"  # most sizes in [2^22, 2^23], passes paired from 2^22 elements up
+if LARGE:
+    os.environ["GLU_HIP_SORT_PAIR_MIN"] = "1"  # (default: from 2^28 bytes of keys)
 
 
 def draw_n(limit=1 << 23):
