@@ -807,7 +807,7 @@ glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t cou
     }
     // A leader is a pass of the 8-bit line kernel that does not encode keys on load; its follower is the pass after it,
     // also of the 8-bit line kernel.
-    const bool pairs_ok = planned && s->pairs && s->pair_t2.ptr && s->max_blocks == 0 &&
+    const bool pairs_ok = planned && s->pairs && s->pair_t2.ptr &&
                           count >= (s->pair_min ? s->pair_min : kPairMinKeyBytes / sizeof(KeyT)) &&
                           lines_applicable<KeyT, 8>(s, kbuf[0], vbuf[0], kbuf[1], vbuf[1], count);
     if (pairs_ok)

@@ -1063,3 +1063,16 @@ def test_paired_passes_typed_keys(G, dtype):
     assert _sort_and_plan.last_roles == ([0, 1, 2, 0] if passes == 4 else [0, 1, 2, 1, 2, 1, 2, 0])
     if dt.kind == "i":
         assert alone == [0] * passes  # uniform digits: every follower took its table from its leader
+
+
+@pytest.mark.parametrize("blocks", ["3", "37", "255"])
+def test_paired_passes_fewer_workgroups_than_cus(G, blocks):
+    """GLU_HIP_SORT_BLOCKS caps the grid (what glu_dist does to leave CUs to RCCL): units, runs and tables follow the grid."""
+    rng = np.random.default_rng(38)
+    n = (1 << 23) + 5
+    keys = rng.integers(0, 2**32, n, dtype=np.uint32)
+    keys[::13] = keys[5]
+    vals = np.arange(n, dtype=np.uint32)
+    gk, gv, skipped, alone = _sort_and_plan(G, keys, vals, 4, env={"GLU_HIP_SORT_BLOCKS": blocks})
+    _check_against_oracle(keys, vals, gk, gv)
+    assert _sort_and_plan.last_roles == [1, 2, 1, 2]
