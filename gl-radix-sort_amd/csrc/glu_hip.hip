@@ -422,7 +422,8 @@ struct glu_radix_sort_s
     Scratch plan;   // PassPlan of large sorts (which arrays hold the data before each pass, which passes are identities)
     Scratch pair_t2;     // paired passes (radix_pair_passes.hpp): [256][num_blocks][256] 16-bit two-digit counters,
     Scratch pair_table;  // the follower's count table + digit totals,
-    Scratch pair_ranges; // and the element range of every follower workgroup
+    Scratch pair_ranges; // the element range of every follower workgroup,
+    Scratch pair_sub;    // and (4-bit digits) the leader's table per sub-block: [16][num_blocks * 16]
     uint32_t digit_bits = 8;
     uint32_t max_blocks = 0;   // GLU_HIP_SORT_BLOCKS: cap on the number of workgroups (tuning)
     bool force_small = false;  // GLU_HIP_SORT_SMALL=1: always use the small-tile geometry (tests / tuning)
@@ -483,6 +484,7 @@ glu_status sort_prepare(glu_radix_sort_s* s, size_t count, size_t key_size, bool
         GLU_TRY(s->pair_t2.reserve((size_t) kPairRadix * nb * kPairRowWords * sizeof(uint32_t)));
         GLU_TRY(s->pair_table.reserve(((size_t) kPairRadix * nb + kPairRadix) * sizeof(uint32_t)));
         GLU_TRY(s->pair_ranges.reserve(nb * sizeof(uint2)));
+        GLU_TRY(s->pair_sub.reserve((size_t) kPair4Radix * nb * kPairSub * sizeof(uint32_t)));
     }
     return GLU_OK;
 }
@@ -597,35 +599,48 @@ glu_status launch_pass_lines(glu_radix_sort_s* s, const KeyT* src_k, const uint3
 
     const uint2* ranges = nullptr;
     s->mark(stream);
-    if constexpr (BITS == 8 && !XF)
+    uint32_t* const sub_table = (uint32_t*) s->pair_sub.ptr; // 4-bit digits: the leader's table per sub-block
+    if constexpr (!XF)
     {
         if (pa.pair_role == 1)
         {
             // leader: one read of the keys for this pass's table and the two-digit table the follower's comes from
-            auto count2 = radix_pair_count_kernel<KeyT, G::TILE, false>;
-            static std::once_flag count2_opt_in;
-            static hipError_t count2_opt_in_result = hipSuccess;
-            std::call_once(count2_opt_in, [&] {
-                count2_opt_in_result = hipFuncSetAttribute((const void*) count2, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sizeof(PairCountSmem));
-            });
-            HIP_TRY(count2_opt_in_result);
-            hipLaunchKernelGGL(count2, dim3(nb), dim3(1024), sizeof(PairCountSmem), stream, src_k, table, (uint32_t*) s->pair_t2.ptr,
-                               (uint32_t) count, shift, mask, pa.shift2, (1u << pa.bits2) - 1, tiles, xform, (const KeyT*) dst_k, pa.plan,
-                               pa.pass);
+            if constexpr (BITS == 8)
+            {
+                auto count2 = radix_pair_count_kernel<KeyT, G::TILE, false>;
+                static std::once_flag count2_opt_in;
+                static hipError_t count2_opt_in_result = hipSuccess;
+                std::call_once(count2_opt_in, [&] {
+                    count2_opt_in_result = hipFuncSetAttribute((const void*) count2, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sizeof(PairCountSmem));
+                });
+                HIP_TRY(count2_opt_in_result);
+                hipLaunchKernelGGL(count2, dim3(nb), dim3(1024), sizeof(PairCountSmem), stream, src_k, table, (uint32_t*) s->pair_t2.ptr,
+                                   (uint32_t) count, shift, mask, pa.shift2, (1u << pa.bits2) - 1, tiles, xform, (const KeyT*) dst_k,
+                                   pa.plan, pa.pass);
+            }
+            else
+                hipLaunchKernelGGL((radix_pair4_count_kernel<KeyT, G::TILE, false>), dim3(nb * kPairSub), dim3(256), 0, stream, src_k,
+                                   sub_table, (uint32_t*) s->pair_t2.ptr, (uint32_t) count, shift, mask, pa.shift2,
+                                   (1u << pa.bits2) - 1, tiles, xform, (const KeyT*) dst_k, pa.plan, pa.pass);
             HIP_TRY(hipGetLastError());
         }
     }
     if (pa.pair_role == 2)
     {
-        // follower: unit runs and their digit counts from the leader's tables (s->table still holds them); its own table
-        // lives in pair_table.  The count kernel behind it runs only if a kernel before it asked for that.
+        // follower: unit runs and their digit counts from the leader's tables (s->table / pair_sub still hold them); its own
+        // table lives in pair_table.  The count kernel behind it runs only if a kernel before it asked for that.
         uint32_t* leader_table = table;
         table = (uint32_t*) s->pair_table.ptr;
         totals = table + (size_t) RADIX * nb;
         ranges = (const uint2*) s->pair_ranges.ptr;
-        hipLaunchKernelGGL(radix_pair_unitsum_kernel, dim3(nb), dim3(1024), 0, stream, (const uint32_t*) s->pair_t2.ptr,
-                           (const uint32_t*) leader_table, (const uint32_t*) (leader_table + (size_t) RADIX * nb), table,
-                           (uint2*) s->pair_ranges.ptr, (uint32_t) count, pa.plan, pa.pass);
+        if constexpr (BITS == 8)
+            hipLaunchKernelGGL(radix_pair_unitsum_kernel, dim3(nb), dim3(1024), 0, stream, (const uint32_t*) s->pair_t2.ptr,
+                               (const uint32_t*) leader_table, (const uint32_t*) (leader_table + (size_t) RADIX * nb), table,
+                               (uint2*) s->pair_ranges.ptr, (uint32_t) count, pa.plan, pa.pass);
+        else
+            hipLaunchKernelGGL(radix_pair4_unitsum_kernel, dim3(nb), dim3(1024), 0, stream, (const uint32_t*) s->pair_t2.ptr,
+                               (const uint32_t*) sub_table, (const uint32_t*) (leader_table + (size_t) RADIX * nb), table,
+                               (uint2*) s->pair_ranges.ptr, (uint32_t) count, pa.plan, pa.pass);
         HIP_TRY(hipGetLastError());
     }
     if (pa.pair_role != 1)
@@ -635,11 +650,25 @@ glu_status launch_pass_lines(glu_radix_sort_s* s, const KeyT* src_k, const uint3
         HIP_TRY(hipGetLastError());
     }
     s->mark(stream);
-    // (leader: a unit longer than 1/16 of a workgroup's share makes the follower count for itself)
-    hipLaunchKernelGGL((radix_row_scan_kernel<256>), dim3(RADIX), dim3(256), 0, stream, table, totals, nb, (uint32_t) count,
-                       pa.may_skip ? pa.plan : (PassPlan*) nullptr, pa.pass,
-                       pa.pair_role == 1 ? (s->pair_unit_div ? std::max<uint32_t>(1u, (uint32_t) (count / nb / s->pair_unit_div)) : 0xFFFFFFFFu) : 0u,
-                       pa.plan);
+    if (BITS == 4 && pa.pair_role == 1)
+    {
+        // 4-bit leader: its count kernel wrote the table per sub-block; one scan gives where every (digit value, sub-block)
+        // unit starts, the digit totals, and -- every kPairSub-th entry -- the usual per-block table of the scatter
+        hipLaunchKernelGGL((radix_row_scan_kernel<256>), dim3(RADIX), dim3(256), 0, stream, sub_table, totals, nb * kPairSub,
+                           (uint32_t) count, pa.may_skip ? pa.plan : (PassPlan*) nullptr, pa.pass, 0u, (PassPlan*) nullptr, table,
+                           kPairSub);
+    }
+    else
+    {
+        // (8-bit leader: a unit longer than 1/16 of a workgroup's share makes the follower count for itself; the units of a
+        // 4-bit leader are parts of sub-blocks, which are that short by construction)
+        hipLaunchKernelGGL((radix_row_scan_kernel<256>), dim3(RADIX), dim3(256), 0, stream, table, totals, nb, (uint32_t) count,
+                           pa.may_skip ? pa.plan : (PassPlan*) nullptr, pa.pass,
+                           pa.pair_role == 1 && BITS == 8
+                               ? (s->pair_unit_div ? std::max<uint32_t>(1u, (uint32_t) (count / nb / s->pair_unit_div)) : 0xFFFFFFFFu)
+                               : 0u,
+                           pa.plan);
+    }
     HIP_TRY(hipGetLastError());
     s->mark(stream);
     if (histogram_out)
@@ -805,16 +834,18 @@ glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t cou
         passes[num_passes++] = PassDesc{shift, bits, xform, 0};
         shift += bits;
     }
-    // A leader is a pass of the 8-bit line kernel that does not encode keys on load; its follower is the pass after it,
-    // also of the 8-bit line kernel.
+    // A leader is a pass of the line kernel that does not encode keys on load; its follower is the pass after it, of the
+    // line kernel of the same digit width (wider than 4 bits: the 8-bit kernels, else the 4-bit ones).
     const bool pairs_ok = planned && s->pairs && s->pair_t2.ptr &&
-                          count >= (s->pair_min ? s->pair_min : kPairMinKeyBytes / sizeof(KeyT)) &&
-                          lines_applicable<KeyT, 8>(s, kbuf[0], vbuf[0], kbuf[1], vbuf[1], count);
+                          count >= (s->pair_min ? s->pair_min : kPairMinKeyBytes / sizeof(KeyT));
     if (pairs_ok)
     {
+        const bool lines8 = lines_applicable<KeyT, 8>(s, kbuf[0], vbuf[0], kbuf[1], vbuf[1], count);
+        const bool lines4 = lines_applicable<KeyT, 4>(s, kbuf[0], vbuf[0], kbuf[1], vbuf[1], count);
         for (uint32_t i = 0; i + 1 < num_passes;)
         {
-            if (passes[i].bits > 4 && passes[i + 1].bits > 4 && (passes[i].xform & 3u) == 0)
+            const bool wide = passes[i].bits > 4;
+            if (wide == (passes[i + 1].bits > 4) && (wide ? lines8 : lines4) && (passes[i].xform & 3u) == 0)
             {
                 passes[i].pair_role = 1;
                 passes[i + 1].pair_role = 2;

@@ -1,4 +1,4 @@
-// radix_pair_passes.hpp -- one read of the keys for the digit tables of TWO counting passes (large sorts, 8-bit digits).
+// radix_pair_passes.hpp -- one read of the keys for the digit tables of TWO counting passes (large sorts).
 //
 // The count pass (k_radix_sort_counting_shader, reference glu/RadixSort.hpp:11-58) reads every key once per pass: 4 x 0.165
 // ms of a 4.3 ms sort of 2^28 pairs.  The table of pass p + 1 cannot be counted before pass p has run, because its blocks
@@ -16,7 +16,7 @@
 // summed from T2 (64 MiB of table traffic per pair of passes instead of 1 GiB of keys).
 // The follower's row scan and scatter are the usual kernels; the scatter takes its element range from `ranges`.
 //
-// Two things send a follower back to its own count kernel (PassPlan::pair_fallback, decided on the device; the launch
+// Three things send a follower back to its own count kernel (PassPlan::pair_fallback, decided on the device; the launch
 // sequence is the same either way, the kernels that are not needed return at once):
 //   * a 16-bit counter of T2 overflowed (more than 65535 keys of one block share both digit values): found by comparing
 //     every row sum of T2 with T1;
@@ -169,55 +169,49 @@ __global__ __launch_bounds__(1024) void radix_pair_count_kernel(const KeyT* __re
     if (bad && lane == 0 && plan) plan->pair_fallback[pass + 1] = 1;
 }
 
-// Follower pass `pass`: workgroup w's run of units and its digit counts.  table_l / totals_l: the leader's scanned table
-// and digit totals; table_f: the follower's count table (as radix_count_kernel would write it); ranges[w] = the element
-// range of workgroup w.  Returns at once when the follower counts for itself.
-__global__ __launch_bounds__(1024) void radix_pair_unitsum_kernel(const uint32_t* __restrict__ t2,
-                                                                  const uint32_t* __restrict__ table_l,
-                                                                  const uint32_t* __restrict__ totals_l,
-                                                                  uint32_t* __restrict__ table_f, uint2* __restrict__ ranges,
-                                                                  uint32_t n, PassPlan* plan, uint32_t pass)
-{
-    constexpr int THREADS = 1024;
-    if (plan->pair_fallback[pass]) return; // (kernel-uniform)
-    __shared__ uint32_t base[kPairRadix + 1];
-    __shared__ uint32_t tmp[16];
-    __shared__ uint32_t found[2];
-    __shared__ uint32_t part[32][kPairRadix];
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t nb = gridDim.x, w = blockIdx.x;
-    if (w == 0 && tid == 0) plan->skip[pass] = 0;
+// ---- what the unit-sum kernels of both digit widths share ----------------------------------------------------------------
 
-    // exclusive scan of the leader's digit totals: where every digit value's units start
-    {
-        const uint32_t t = tid < kPairRadix ? totals_l[tid] : 0u;
-        uint32_t wtotal;
-        uint32_t excl = wave_exclusive_sum(t, lane, wtotal);
-        if (lane == 0) tmp[wave] = wtotal;
-        __syncthreads();
-        excl += sum_of_preceding_waves(tmp, 4, wave < 4 ? wave : 0, lane);
-        if (tid < kPairRadix) base[tid] = excl;
-        if (tid == 0) base[kPairRadix] = n;
-        __syncthreads();
-    }
-    // U(P) = number of units that start before element P (unit index u = d * nb + b, starts ascend with u): all units of
-    // the digit values below d*, the last one whose units start before P, and of d* those whose scanned entry is below.
-    uint32_t edge[2]; // first unit of this workgroup, first unit of the next
-    uint32_t edge_start[2];
+// base[d] = first element of digit value d's units (exclusive scan of the leader's digit totals), base[RADIX] = n.
+// All 1024 threads call; RADIX <= 256.
+template<int RADIX>
+__device__ __forceinline__ void pair_unit_bases(const uint32_t* __restrict__ totals_l, uint32_t n, uint32_t* base, uint32_t* tmp)
+{
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t t = tid < (uint32_t) RADIX ? totals_l[tid] : 0u;
+    uint32_t wtotal;
+    uint32_t excl = wave_exclusive_sum(t, lane, wtotal);
+    if (lane == 0) tmp[wave] = wtotal;
+    __syncthreads();
+    excl += sum_of_preceding_waves(tmp, 4, wave < 4 ? wave : 0, lane);
+    if (tid < (uint32_t) RADIX) base[tid] = excl;
+    if (tid == 0) base[RADIX] = n;
+    __syncthreads();
+}
+
+// The run of units of follower workgroup w of nb: edge[0] = its first unit, edge[1] = the first unit of the next
+// workgroup, edge_start[] = the elements they start at.  Units are numbered u = d * row_len + i (digit value d of the
+// leader, i-th block or sub-block), start at base[d] + scanned[d * row_len + i], and starts ascend with u.  The first unit
+// of workgroup w is the first one that starts at or after element P = n * w / nb: U(P) = all units of the digit values
+// below d* (the last one whose units start before P) plus those of d* whose scanned entry is below P - base[d*].
+template<int RADIX>
+__device__ __forceinline__ void pair_find_run(const uint32_t* __restrict__ scanned, uint32_t row_len, const uint32_t* base,
+                                              uint32_t* found, uint32_t n, uint32_t w, uint32_t nb, uint32_t (&edge)[2],
+                                              uint32_t (&edge_start)[2])
+{
+    const uint32_t tid = threadIdx.x;
 #pragma unroll
     for (int side = 0; side < 2; side++)
     {
         const uint32_t P = (uint32_t) ((uint64_t) n * (w + side) / nb);
-        if (w + side == nb)
+        if (w + side == nb) // (block-uniform branches throughout)
         {
-            edge[side] = kPairRadix * nb;
+            edge[side] = (uint32_t) RADIX * row_len;
             edge_start[side] = n;
             continue;
         }
         if (tid < 2) found[tid] = 0;
         __syncthreads();
-        // d* + 1 = number of digit values whose units start before P
-        if (tid < kPairRadix && base[tid] < P) atomicAdd(&found[0], 1u);
+        if (tid < (uint32_t) RADIX && base[tid] < P) atomicAdd(&found[0], 1u); // d* + 1
         __syncthreads();
         const uint32_t below = found[0];
         if (below == 0) // P == 0
@@ -227,16 +221,39 @@ __global__ __launch_bounds__(1024) void radix_pair_unitsum_kernel(const uint32_t
             continue;
         }
         const uint32_t ds = below - 1;
-        for (uint32_t bb = tid; bb < nb; bb += THREADS)
-            if (base[ds] + table_l[(size_t) ds * nb + bb] < P) atomicAdd(&found[1], 1u);
+        uint32_t mine = 0;
+        for (uint32_t i = tid; i < row_len; i += blockDim.x)
+            if (base[ds] + scanned[(size_t) ds * row_len + i] < P) mine++;
+        if (mine) atomicAdd(&found[1], mine);
         __syncthreads();
         const uint32_t in_row = found[1]; // >= 1: the row's first unit starts at base[ds] < P
-        const uint32_t u = ds * nb + in_row;
-        edge[side] = u;
-        // start of unit u (the first one not before P); past the row's end it is the next digit value's first unit
-        edge_start[side] = in_row < nb ? base[ds] + table_l[(size_t) ds * nb + in_row] : base[ds + 1];
+        edge[side] = ds * row_len + in_row;
+        // the first unit not before P; past the row's end it is the next digit value's first unit
+        edge_start[side] = in_row < row_len ? base[ds] + scanned[(size_t) ds * row_len + in_row] : base[ds + 1];
         __syncthreads();
     }
+}
+
+// Follower pass `pass` (8-bit digits): workgroup w's run of units and its digit counts.  table_l / totals_l: the leader's
+// scanned table and digit totals; table_f: the follower's count table (as radix_count_kernel would write it); ranges[w] =
+// the element range of workgroup w.  Returns at once when the follower counts for itself.
+__global__ __launch_bounds__(1024) void radix_pair_unitsum_kernel(const uint32_t* __restrict__ t2,
+                                                                  const uint32_t* __restrict__ table_l,
+                                                                  const uint32_t* __restrict__ totals_l,
+                                                                  uint32_t* __restrict__ table_f, uint2* __restrict__ ranges,
+                                                                  uint32_t n, PassPlan* plan, uint32_t pass)
+{
+    if (plan->pair_fallback[pass]) return; // (kernel-uniform)
+    __shared__ uint32_t base[kPairRadix + 1];
+    __shared__ uint32_t tmp[16];
+    __shared__ uint32_t found[2];
+    __shared__ uint32_t part[32][kPairRadix];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t nb = gridDim.x, w = blockIdx.x;
+    if (w == 0 && tid == 0) plan->skip[pass] = 0;
+    pair_unit_bases<kPairRadix>(totals_l, n, base, tmp);
+    uint32_t edge[2], edge_start[2];
+    pair_find_run<kPairRadix>(table_l, nb, base, found, n, w, nb, edge, edge_start);
 
     // a run of very many (tiny) units would be a long chain of table reads in this one workgroup: count instead
     if (edge[1] - edge[0] > kPairMaxRunUnits)
@@ -264,6 +281,157 @@ __global__ __launch_bounds__(1024) void radix_pair_unitsum_kernel(const uint32_t
         uint32_t c = 0;
 #pragma unroll
         for (int k = 0; k < 32; k++) c += part[k][tid];
+        table_f[(size_t) tid * nb + w] = c;
+    }
+    if (tid == 0) ranges[w] = make_uint2(edge_start[0], edge_start[1]);
+}
+
+// ---- 4-bit digits (the reference's pass structure) -------------------------------------------------------------------------
+// 16 digit values x nb blocks are too few units to balance runs on (a unit would be 1/16 of a workgroup's share), so a
+// leader's block is cut into kPairSub sub-blocks (whole tiles, in order) and the units are (digit value, sub-block): as many
+// and as small as with 8-bit digits.  The two-digit histogram of a sub-block is 16 x 16 32-bit counters -- nothing overflows,
+// and no unit is longer than 1/16 of a share, so the only way back to counting is a run of very many tiny units.
+constexpr uint32_t kPairSub = 16;
+constexpr uint32_t kPair4Radix = 16;
+
+// Leader's count kernel, 4-bit digits: one 256-thread workgroup per SUB-BLOCK (grid = nb * kPairSub; sub-block j of block b
+// = the j-th sixteenth of block b's tiles), so that no workgroup drains its loads sixteen times.  table_sub: [16][nb *
+// kPairSub] counts per (digit value, sub-block); the row-scan kernel behind this one scans it and copies every kPairSub-th
+// entry into the leader's usual [16][nb] table (the scanned count of a block = that of its first sub-block).  t2: per
+// sub-block 256 words, word d * 16 + e = #keys with digit p = d and digit p + 1 = e.
+template<typename KeyT, int TILE, bool XF = false>
+__global__ __launch_bounds__(256) void radix_pair4_count_kernel(const KeyT* __restrict__ keys_a, uint32_t* __restrict__ table_sub,
+                                                                uint32_t* __restrict__ t2, uint32_t n, uint32_t shift,
+                                                                uint32_t mask, uint32_t shift2, uint32_t mask2,
+                                                                uint32_t tiles_total, uint32_t xform, const KeyT* keys_b,
+                                                                PassPlan* plan, uint32_t pass)
+{
+    constexpr int THREADS = 256;
+    constexpr int WAVES = THREADS / kWave;
+    __shared__ uint32_t hist[WAVES][256]; // wave-private counters of the combined digit d | e << 4
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t nb = gridDim.x / kPairSub, b = blockIdx.x / kPairSub, j = blockIdx.x % kPairSub;
+    const KeyT* __restrict__ keys = keys_a;
+    if (plan)
+    {
+        if (pass > 0 && plan->flip[pass]) keys = keys_b;
+        if (blockIdx.x == 0 && tid == 0) plan->skip[pass] = 0;
+    }
+    for (int i = tid; i < WAVES * 256; i += THREADS) (&hist[0][0])[i] = 0;
+    __syncthreads();
+    uint32_t first, last, sf, sl;
+    block_tile_range(b, nb, tiles_total, first, last);
+    block_tile_range(j, kPairSub, last - first, sf, sl);
+    const uint64_t begin = (uint64_t) (first + sf) * TILE;
+    uint64_t end = (uint64_t) (first + sl) * TILE;
+    if (end > n) end = n;
+    uint32_t* my_hist = hist[wave];
+    const KeyCodec<KeyT, XF> codec_in(xform & 3u);
+    auto combined = [&](KeyT raw) {
+        const KeyT k = codec_in.encode(raw);
+        return digit_of<KeyT>(k, shift, mask) | (digit_of<KeyT>(k, shift2, mask2) << 4);
+    };
+    // every lane of the wave is active when this runs
+    auto tally = [&](KeyT raw) {
+        const uint32_t c = combined(raw);
+        const uint32_t c0 = __builtin_amdgcn_readfirstlane(c);
+        if (__ballot(c != c0) == 0)
+        {
+            if (lane == 0) atomicAdd(&my_hist[c0], 64u);
+        }
+        else
+            atomicAdd(&my_hist[c], 1u);
+    };
+    constexpr int VEC = 16 / sizeof(KeyT);
+    using VecT = typename std::conditional<sizeof(KeyT) == 4, uint4, ulonglong2>::type;
+    const bool vec_ok = (reinterpret_cast<uintptr_t>(keys) & 15u) == 0;
+    auto tally_vec = [&](const VecT& a) {
+        if constexpr (sizeof(KeyT) == 4)
+        {
+            tally(a.x); tally(a.y); tally(a.z); tally(a.w);
+        }
+        else
+        {
+            tally(a.x); tally(a.y);
+        }
+    };
+    if (begin < end) // (block-uniform)
+    {
+        const uint64_t nvec = vec_ok ? (end - begin) / VEC : 0;
+        const VecT* vkeys = reinterpret_cast<const VecT*>(keys + begin);
+        uint64_t vbase = 0;
+        for (; vbase + 4 * THREADS <= nvec; vbase += 4 * THREADS) // block-uniform trip count, 4 x 16 B in flight per lane
+        {
+            VecT a = load_streaming(&vkeys[vbase + tid]);
+            VecT bq = load_streaming(&vkeys[vbase + tid + THREADS]);
+            VecT c = load_streaming(&vkeys[vbase + tid + 2 * THREADS]);
+            VecT d = load_streaming(&vkeys[vbase + tid + 3 * THREADS]);
+            tally_vec(a);
+            tally_vec(bq);
+            tally_vec(c);
+            tally_vec(d);
+        }
+        for (uint64_t i = begin + vbase * VEC + tid; i < end; i += THREADS) atomicAdd(&my_hist[combined(keys[i])], 1u);
+    }
+    __syncthreads();
+    // thread = combined value: d = tid & 15, e = tid >> 4
+    uint32_t c = 0;
+#pragma unroll
+    for (int wv = 0; wv < WAVES; wv++) c += hist[wv][tid];
+    t2[(size_t) blockIdx.x * 256 + (tid & 15u) * 16 + (tid >> 4)] = c;
+    // the sub-block's count of digit value d = sum over e: the lanes d, d + 16, d + 32, d + 48 of the four waves
+    uint32_t sum = c;
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    __syncthreads(); // every thread has read its column of hist
+    if (lane < 16) hist[wave][lane] = sum;
+    __syncthreads();
+    if (tid < kPair4Radix)
+        table_sub[(size_t) tid * gridDim.x + blockIdx.x] = hist[0][tid] + hist[1][tid] + hist[2][tid] + hist[3][tid];
+}
+
+// Follower pass `pass` (4-bit digits): as radix_pair_unitsum_kernel, units = (digit value, sub-block).
+// sub_scanned: the leader's per-sub-block table after its row scan; totals_l: the leader's digit totals.
+__global__ __launch_bounds__(1024) void radix_pair4_unitsum_kernel(const uint32_t* __restrict__ t2,
+                                                                   const uint32_t* __restrict__ sub_scanned,
+                                                                   const uint32_t* __restrict__ totals_l,
+                                                                   uint32_t* __restrict__ table_f, uint2* __restrict__ ranges,
+                                                                   uint32_t n, PassPlan* plan, uint32_t pass)
+{
+    if (plan->pair_fallback[pass]) return; // (kernel-uniform)
+    __shared__ uint32_t base[kPair4Radix + 1];
+    __shared__ uint32_t tmp[16];
+    __shared__ uint32_t found[2];
+    __shared__ uint32_t part[64][kPair4Radix];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t nb = gridDim.x, w = blockIdx.x;
+    const uint32_t row_len = nb * kPairSub;
+    if (w == 0 && tid == 0) plan->skip[pass] = 0;
+    pair_unit_bases<kPair4Radix>(totals_l, n, base, tmp);
+    uint32_t edge[2], edge_start[2];
+    pair_find_run<kPair4Radix>(sub_scanned, row_len, base, found, n, w, nb, edge, edge_start);
+    if (edge[1] - edge[0] > kPairMaxRunUnits * 4) // (rows of 64 bytes here: four times as many cost the same)
+    {
+        if (tid == 0) plan->pair_fallback[pass] = 1;
+        return;
+    }
+    // unit u = d * row_len + i: the 16 words d * 16 .. d * 16 + 15 of sub-block i's T2 row; thread (g, e) adds word e of the
+    // units g, g + 64, ...
+    const uint32_t g = tid >> 4, e = tid & 15u;
+    uint32_t acc = 0;
+#pragma unroll 4
+    for (uint32_t u = edge[0] + g; u < edge[1]; u += 64)
+    {
+        const uint32_t d = u / row_len, i = u % row_len;
+        acc += t2[(size_t) i * 256 + d * 16 + e];
+    }
+    part[g][e] = acc;
+    __syncthreads();
+    if (tid < kPair4Radix)
+    {
+        uint32_t c = 0;
+#pragma unroll
+        for (int k = 0; k < 64; k++) c += part[k][tid];
         table_f[(size_t) tid * nb + w] = c;
     }
     if (tid == 0) ranges[w] = make_uint2(edge_start[0], edge_start[1]);

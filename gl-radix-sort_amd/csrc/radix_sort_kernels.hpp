@@ -254,12 +254,14 @@ __global__ __launch_bounds__(THREADS) void radix_count_kernel(const KeyT* __rest
 //  totals in a separate buffer that the reorder shader scans itself: RadixSort.hpp:148-152, 311.)
 // ---------------------------------------------------------------------------------------------------------
 // pair_limit > 0 (the leader of a pair of passes): a table entry above it sends the follower back to its own count kernel.
+// coarse != nullptr: every coarse_step-th scanned entry is also written to coarse[row][i / coarse_step].
 template<int THREADS>
 __global__ __launch_bounds__(THREADS) void radix_row_scan_kernel(uint32_t* __restrict__ table,
                                                                  uint32_t* __restrict__ totals, uint32_t num_blocks,
                                                                  uint32_t n = 0, PassPlan* plan = nullptr,
                                                                  uint32_t pass = 0, uint32_t pair_limit = 0,
-                                                                 PassPlan* pair_plan = nullptr)
+                                                                 PassPlan* pair_plan = nullptr,
+                                                                 uint32_t* __restrict__ coarse = nullptr, uint32_t coarse_step = 1)
 {
     constexpr int WAVES = THREADS / kWave;
     __shared__ uint32_t wave_sums[WAVES];
@@ -283,7 +285,13 @@ __global__ __launch_bounds__(THREADS) void radix_row_scan_kernel(uint32_t* __res
             if ((uint32_t) w < wave) woff += s;
             all += s;
         }
-        if (i < num_blocks) row[i] = carry + woff + excl;
+        if (i < num_blocks)
+        {
+            row[i] = carry + woff + excl;
+            // (4-bit leader of a pair of passes: the table is per sub-block; the scatter's per-block table is every
+            // coarse_step-th scanned entry)
+            if (coarse && i % coarse_step == 0) coarse[(size_t) blockIdx.x * (num_blocks / coarse_step) + i / coarse_step] = carry + woff + excl;
+        }
         carry += all;
         __syncthreads();
     }

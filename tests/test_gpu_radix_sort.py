@@ -873,7 +873,7 @@ def test_planned_sort_inside_a_captured_graph(G):
 # passes; the second pass of a pair ("follower") takes its count table from the two-digit histogram of the first, unless
 # the data sends it back to its own count kernel.  glu_radix_sort_read_plan says what happened.
 
-def _sort_and_plan(G, keys, vals, passes, key_bytes=4, env=None, run=None):
+def _sort_and_plan(G, keys, vals, passes, key_bytes=4, env=None, run=None, bits=8):
     old = {}
     env = dict(env or {})
     env.setdefault("GLU_HIP_SORT_PAIR_MIN", "1")  # pair from the smallest planned sort up (default: from 2^28 bytes of keys)
@@ -881,7 +881,7 @@ def _sort_and_plan(G, keys, vals, passes, key_bytes=4, env=None, run=None):
         old[k] = os.environ.get(k)
         os.environ[k] = v
     try:
-        sorter = G.RadixSort()  # reads the environment switches
+        sorter = G.RadixSort(digit_bits=bits)  # reads the environment switches
     finally:
         for k, v in old.items():
             if v is None:
@@ -1076,3 +1076,96 @@ def test_paired_passes_fewer_workgroups_than_cus(G, blocks):
     gk, gv, skipped, alone = _sort_and_plan(G, keys, vals, 4, env={"GLU_HIP_SORT_BLOCKS": blocks})
     _check_against_oracle(keys, vals, gk, gv)
     assert _sort_and_plan.last_roles == [1, 2, 1, 2]
+
+
+# ---- the same with the reference's 4-bit digits: units are (digit value, sub-block of 1/16 of a workgroup's block) -------
+
+def test_paired_passes_4bit_uniform_and_switch(G):
+    rng = np.random.default_rng(41)
+    keys = rng.integers(0, 2**32, PAIR_N, dtype=np.uint32)
+    vals = np.arange(PAIR_N, dtype=np.uint32)
+    gk, gv, skipped, alone = _sort_and_plan(G, keys, vals, 8, bits=4)
+    _check_against_oracle(keys, vals, gk, gv)
+    assert skipped == [0] * 8 and alone == [0] * 8 and _sort_and_plan.last_roles == [1, 2] * 4
+    gk2, gv2, _, _ = _sort_and_plan(G, keys, vals, 8, bits=4, env={"GLU_HIP_SORT_PAIRS": "0"})
+    assert (gk2 == gk).all() and (gv2 == gv).all() and _sort_and_plan.last_roles == [0] * 8
+
+
+@pytest.mark.parametrize("case", ["sorted", "reverse", "all_equal", "two_values", "low_16_bits_only", "nibble_2_constant",
+                                  "hot_nibble", "rare_nibbles", "duplicates"])
+def test_paired_passes_4bit_structured_inputs(G, case):
+    n = PAIR_N
+    rng = np.random.default_rng(42)
+    keys = rng.integers(0, 2**32, n, dtype=np.uint32)
+    expect_alone = None
+    if case == "sorted":
+        keys = np.arange(n, dtype=np.uint32) * np.uint32(251)
+    elif case == "reverse":
+        keys = (np.uint32(0xFFFFFFFF) - np.arange(n, dtype=np.uint32) * np.uint32(17))
+    elif case == "all_equal":
+        keys = np.full(n, 0xA5A5A5A5, dtype=np.uint32)
+    elif case == "two_values":
+        keys = np.where(rng.random(n) < 0.5, np.uint32(0x01020304), np.uint32(0xF1F2F3F4)).astype(np.uint32)
+    elif case == "low_16_bits_only":
+        keys = rng.integers(0, 2**16, n, dtype=np.uint32)
+    elif case == "nibble_2_constant":
+        keys = (keys & np.uint32(0xFFFFF0FF)) | np.uint32(0x300)
+    elif case == "hot_nibble":  # 60 % of the keys share the lowest nibble: no way back to counting with 4-bit digits
+        hot = rng.random(n) < 0.6
+        keys[hot] = (keys[hot] & np.uint32(0xFFFFFFF0)) | np.uint32(0x7)
+        expect_alone = [0] * 8
+    elif case == "rare_nibbles":  # half of the values of the lowest nibble are rare: one run of ten thousands of tiny units
+        rare = rng.random(n) < 1.0 / 256
+        keys[~rare] &= np.uint32(0xFFFFFFF7)
+        keys[rare] |= np.uint32(0x8)
+        expect_alone = [0, 1, 0, 0, 0, 0, 0, 0]
+    else:
+        keys = np.repeat(keys[: n // 64 + 1], 64)[:n].copy()
+    vals = np.arange(n, dtype=np.uint32)
+    gk, gv, skipped, alone = _sort_and_plan(G, keys, vals, 8, bits=4)
+    _check_against_oracle(keys, vals, gk, gv)
+    assert _sort_and_plan.last_roles == [1, 2] * 4
+    if expect_alone is not None:
+        assert alone == expect_alone
+    if case == "low_16_bits_only":
+        assert skipped == [0, 0, 0, 0, 1, 1, 1, 1]
+    if case == "nibble_2_constant":
+        assert skipped == [0, 0, 1, 0, 0, 0, 0, 0]
+    if case == "all_equal":
+        assert skipped == [1] * 8
+
+
+def test_paired_passes_4bit_u64_typed_keys_only_bit_ranges_and_capped_grid(G):
+    n = (1 << 23) + 99
+    rng = np.random.default_rng(43)
+    k64 = rng.integers(0, 2**64, n, dtype=np.uint64)
+    vals = np.arange(n, dtype=np.uint32)
+    gk, gv, skipped, alone = _sort_and_plan(G, k64, vals, 16, key_bytes=8, bits=4)
+    order = np.argsort(k64, kind="stable")
+    assert (gk == k64[order]).all() and (gv == vals[order]).all()
+    assert alone == [0] * 16 and skipped == [0] * 16 and _sort_and_plan.last_roles == [1, 2] * 8
+    gk, _, _, _ = _sort_and_plan(G, k64, None, 16, key_bytes=8, bits=4)
+    assert (gk == np.sort(k64)).all()
+    k32 = rng.integers(0, 2**32, n, dtype=np.uint32)
+    gk, _, _, alone = _sort_and_plan(G, k32, None, 8, bits=4)
+    assert (gk == np.sort(k32)).all() and alone == [0] * 8
+    # float keys: the first pass encodes on load and stands alone, the last one decodes on store
+    f = (rng.standard_normal(n) * 1e3).astype(np.float32)
+    gk, gv, _, _ = _sort_and_plan(G, f, vals, 8, bits=4,
+                                  run=lambda s, kb, vb: s.sort_typed_ptr(kb.device_ptr(), vb.device_ptr(), n, "float32"))
+    u = f.view(np.uint32)
+    image = np.where(u & np.uint32(0x80000000), ~u, u ^ np.uint32(0x80000000))
+    order = np.argsort(image, kind="stable")
+    assert (gk.view(np.uint32) == u[order]).all() and (gv == vals[order]).all()
+    assert _sort_and_plan.last_roles == [0, 1, 2, 1, 2, 1, 2, 0]
+    # bit ranges: [3, 17) = 4 + 4 + 4 + 2 bits
+    for begin, end, passes in ((3, 17, 4), (0, 7, 2), (20, 32, 3)):
+        field = (k32 >> np.uint32(begin)) & np.uint32((1 << (end - begin)) - 1)
+        order = np.argsort(field, kind="stable")
+        gk, gv, _, _ = _sort_and_plan(
+            G, k32, vals, passes, bits=4, run=lambda s, kb, vb: s.sort_bit_range_ptr(kb.device_ptr(), vb.device_ptr(), n, begin, end, None, 4))
+        assert (gk == k32[order]).all() and (gv == vals[order]).all(), (begin, end)
+    for blocks in ("3", "37"):
+        gk, gv, _, _ = _sort_and_plan(G, k32, vals, 8, bits=4, env={"GLU_HIP_SORT_BLOCKS": blocks})
+        _check_against_oracle(k32, vals, gk, gv)
+        assert _sort_and_plan.last_roles == [1, 2] * 4

@@ -1,11 +1,12 @@
 """Sort time over sizes with paired passes on / off (from which size is the two-digit table cheaper than a second read of
-the keys?): python tools/pairs_ladder.py [pairs|keys|u64|u64keys]"""
+the keys?): python tools/pairs_ladder.py [pairs|keys|u64|u64keys] [digit bits: 8|4]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "gl-radix-sort_amd"))
 import numpy as np, glu_hip as G
 
 mode = sys.argv[1] if len(sys.argv) > 1 else "pairs"
+bits = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 u64 = mode.startswith("u64")
 keys_only = mode.endswith("keys")
 os.environ["GLU_HIP_SORT_PAIR_MIN"] = "1"
@@ -24,7 +25,7 @@ for log2n in (22, 23, 24, 25, 26, 27, 28):
         row = []
         for pairs in ("1", "0"):
             os.environ["GLU_HIP_SORT_PAIRS"] = pairs
-            s = G.RadixSort()
+            s = G.RadixSort(digit_bits=bits)
             s.prepare_internal_buffers(m, key_bytes=8 if u64 else 4, with_vals=not keys_only)
             best = 1e18
             for r in range(6):
@@ -35,5 +36,5 @@ for log2n in (22, 23, 24, 25, 26, 27, 28):
                 else:
                     best = min(best, G.measure_elapsed_time(lambda: s(kb, vb, m, 0, key_bytes=8 if u64 else 4)))
             row.append(best * 1e-3)
-        print("%-8s n %10d (2^%.2f): paired %9.1f us   every pass counts %9.1f us   %+.1f %%" % (
-            mode, m, np.log2(m), row[0], row[1], (row[0] / row[1] - 1) * 100), flush=True)
+        print("%-8s %d-bit n %10d (2^%.2f): paired %9.1f us   every pass counts %9.1f us   %+.1f %%" % (
+            mode, bits, m, np.log2(m), row[0], row[1], (row[0] / row[1] - 1) * 100), flush=True)
