@@ -345,6 +345,13 @@ def main():
                 alt_verified = verify_sorted(torch, keys0, k, v, True)
             a_scatter_ms = ap["scatter_ms"] / max(int(ap["passes"]), 1)
             a_med, a_min = alt_ms[len(alt_ms) // 2], alt_ms[0]
+            # bytes this sort really moved per pair (second passes of pairs that took their table from the first pass's
+            # two-digit histogram did not read the keys again; a 4-bit pair's tables are 4 MiB + 256 KiB, written and read)
+            a_passes = int(ap["passes"]) // alt_steps
+            _, a_alone, a_roles = alt.read_plan(a_passes, roles=True)
+            a_from_table = sum(1 for p in range(a_passes) if a_roles[p] == 2 and not a_alone[p])
+            a_tables = sum(1 for p in range(a_passes) if a_roles[p] == 1) * 2 * (256 * 16 * 1024 + 16 * 256 * 16 * 4)
+            a_moved = round(a_passes * 2 * (KEY_BYTES + VAL_BYTES) + (a_passes - a_from_table) * KEY_BYTES + a_tables / n, 2)
             result["reference_pass_structure"] = {
                 "digit_bits": 4, "passes": int(ap["passes"]) // alt_steps, "steps": alt_steps, "warmup": alt_warm,
                 "ms_per_step": round(a_med, 4), "ms_per_step_min": round(a_min, 4), "timing": "device time per sort (HIP events), median and min",
@@ -352,6 +359,9 @@ def main():
                 "achieved_GBps_at_160B_per_pair": round(n * 160 / (a_med * 1e-3) / 1e9, 1),
                 "frac_of_peak_at_160B_per_pair": round(n * 160 / (a_med * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                 "frac_of_peak_at_160B_per_pair_best": round(n * 160 / (a_min * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                "count_kernels_reading_keys": a_passes - a_from_table,
+                "bytes_per_pair_moved": a_moved,
+                "frac_of_peak_own_bytes": round(n * a_moved / (a_med * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                 "scatter_kernel": "radix_scatter_lines_kernel<u32,4>",
                 "scatter_kernel_avg_ms": round(a_scatter_ms, 4),
                 "scatter_kernel_frac_of_peak": round(alg_bytes / (a_scatter_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if a_scatter_ms > 0 else None,

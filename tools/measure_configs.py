@@ -29,7 +29,8 @@ def time_sort(keys, vals, bits, key_bytes=4, reps=5):
         skipped, alone, roles = s.read_plan(passes, roles=True)
         from_table = sum(1 for p in range(passes) if roles[p] == 2 and not alone[p])
         leaders = sum(1 for p in range(passes) if roles[p] == 1)
-        moved = passes * 2 * (key_bytes + 4) + (passes - from_table) * key_bytes + leaders * 2 * 256 * 256 * 512 / n
+        tables = 2 * 256 * 256 * 512 if bits == 8 else 2 * (256 * 16 * 1024 + 16 * 256 * 16 * 4)  # written and read once
+        moved = passes * 2 * (key_bytes + 4) + (passes - from_table) * key_bytes + leaders * tables / n
     return best * 1e-9, moved
 
 
