@@ -1194,7 +1194,8 @@ glu_status glu_radix_sort_scratch_size(glu_radix_sort sort, size_t* bytes)
 {
     GLU_TRY(enter());
     if (!sort || !bytes) return fail(GLU_ERROR_INVALID_ARGUMENT, "NULL argument");
-    *bytes = sort->keys.size + sort->vals.size + sort->table.size;
+    *bytes = sort->keys.size + sort->vals.size + sort->table.size + sort->plan.size + sort->pair_t2.size + sort->pair_table.size +
+             sort->pair_ranges.size + sort->pair_sub.size;
     return GLU_OK;
 }
 

@@ -623,13 +623,18 @@ def test_maximum_count_on_device(G, n, bits):
     torch.cuda.empty_cache()
 
 
-def test_sort_is_graph_capturable_and_replayable(G):
+@pytest.mark.parametrize("n,bits", [(300001, 8), ((1 << 23) + 77, 8), ((1 << 23) + 77, 4)])
+def test_sort_is_graph_capturable_and_replayable(G, n, bits):
     """run_ptr only enqueues kernels (and, for odd pass counts, one device copy) on the caller's stream once the scratch is
-    prepared: it can be captured into a HIP graph and replayed on new data in the same buffers."""
+    prepared: it can be captured into a HIP graph and replayed on new data in the same buffers -- also a planned sort
+    whose passes run in pairs (which pass counts for itself is decided on the device in every replay)."""
     import torch
 
-    n = 300001
-    sorter = G.RadixSort()
+    os.environ["GLU_HIP_SORT_PAIR_MIN"] = "1"
+    try:
+        sorter = G.RadixSort(digit_bits=bits)
+    finally:
+        os.environ.pop("GLU_HIP_SORT_PAIR_MIN", None)
     sorter.prepare_internal_buffers(n)
     kt = torch.empty(n, dtype=torch.int32, device="cuda")
     vt = torch.empty(n, dtype=torch.int32, device="cuda")
