@@ -28,6 +28,7 @@ def find(d, *subs):
 
 N = 1 << 28
 T2 = 256 * 256 * 512  # the two-digit table of a pair of passes: [256][workgroups][256] 16-bit counters
+T2_4 = 256 * 16 * 1024 + 16 * 256 * 16 * 4  # 4-bit digits: 16 x 16 counters per sub-block + the per-sub-block table
 rows = []
 for tag in ("bench", "configs"):
     f = parse(os.path.join(P, "pmc_fetch_size_%s.txt" % tag))
@@ -48,7 +49,7 @@ def entry(f, w, subs, alg_bytes, what, launches_note=""):
 
 
 corr = ("FETCH_SIZE is doubled (MI355X_MICROARCH.md, HBM section: on gfx950 FETCH_SIZE reads 1/2 of a coalesced streaming "
-        "read; the count kernel of the 4-bit sort of the same run, which reads 4 B per key and nothing else, reports 524 3xx KB for 2^28 keys "
+        "read; the count kernel of the 4-bit sort of the same run, which reads 4 B per key and little else, reports 52x xxx KB for 2^28 keys "
         "= 1/2 of 1 GiB). WRITE_SIZE is exact. Units: KB = 1024 B.")
 src = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, tools/refresh_profiles_r02.sh), MI355X, round 2; "
        "per-dispatch averages in profiles/r02/pmc_{fetch,write}_size_{bench,configs}.txt")
@@ -60,11 +61,12 @@ all_k = {
         e8, e4,
         entry(bench_f, bench_w, ("radix_pair_count_kernel<unsigned int",), N * 4 + T2, "count kernel of a pair of passes of the headline sort (reads the keys, writes the two-digit table)"),
         entry(bench_f, bench_w, ("radix_pair_unitsum_kernel",), T2, "count table of the second pass of a pair (reads the two-digit table)"),
-        entry(bench_f, bench_w, ("radix_count_kernel<unsigned int, 4, 1024",), N * 4, "count pass of the 4-bit sort (reads the keys: the calibration of the FETCH_SIZE factor)"),
+        entry(bench_f, bench_w, ("radix_pair4_count_kernel<unsigned int",), N * 4 + T2_4, "count kernel of a pair of passes of the 4-bit sort (reads the keys -- the calibration of the FETCH_SIZE factor -- and writes 4.25 MiB of tables)"),
+        entry(bench_f, bench_w, ("radix_pair4_unitsum_kernel",), 256 * 16 * 1024, "count table of the second pass of a 4-bit pair"),
         entry(cfg_f, cfg_w, ("radix_scatter_lines_kernel<unsigned long, 8",), N * 24, "scatter of BASELINE.json configs[4] (2^28 u64 keys + u32 vals, 8-bit digits)"),
         entry(cfg_f, cfg_w, ("radix_scatter_lines_kernel<unsigned long, 4",), N * 24, "same, 4-bit digits"),
         entry(cfg_f, cfg_w, ("radix_pair_count_kernel<unsigned long",), N * 8 + T2, "count kernel of a pair of passes, 64-bit keys"),
-        entry(cfg_f, cfg_w, ("radix_count_kernel<unsigned long, 4",), N * 8, "count pass, 64-bit keys, 4-bit digits"),
+        entry(cfg_f, cfg_w, ("radix_pair4_count_kernel<unsigned long",), N * 8 + T2_4, "count kernel of a pair of passes, 64-bit keys, 4-bit digits"),
         entry(cfg_f, cfg_w, ("scan_chunks_kernel",), N * 8, "glu::BlellochScan 2^28 u32 (chained single pass)"),
     ],
 }
