@@ -277,11 +277,13 @@ def main():
         # bytes the sort really moves per pair: every pass reads and writes key + val in its scatter; a pass reads the keys
         # once more in its count kernel unless it is the second pass of a pair that took its count table from the first
         # pass's two-digit histogram (then the pair moves that table instead: 256 x workgroups x 512 B written and read)
+        # (skipped[p]: 1 = an identity pass found by its count kernel, 2 = known before counting: no key read at all)
         skipped, alone, roles = sorter.read_plan(passes_per_sort, roles=True)
-        from_table = sum(1 for p in range(passes_per_sort) if roles[p] == 2 and not alone[p])
-        pair_table_bytes = sum(1 for p in range(passes_per_sort) if roles[p] == 1) * 2 * 256 * 256 * 512
-        bytes_per_pair_moved = round(passes_per_sort * 2 * (KEY_BYTES + VAL_BYTES) + (passes_per_sort - from_table) * KEY_BYTES
-                                     + pair_table_bytes / n, 2)
+        from_table = sum(1 for p in range(passes_per_sort) if roles[p] == 2 and not alone[p] and skipped[p] != 2)
+        key_reads = sum(1 for p in range(passes_per_sort) if skipped[p] != 2) - from_table
+        scatters = sum(1 for p in range(passes_per_sort) if not skipped[p])
+        pair_table_bytes = sum(1 for p in range(passes_per_sort) if roles[p] == 1 and skipped[p] != 2) * 2 * 256 * 256 * 512
+        bytes_per_pair_moved = round(scatters * 2 * (KEY_BYTES + VAL_BYTES) + key_reads * KEY_BYTES + pair_table_bytes / n, 2)
         result.update({
             "roofline": {
                 "bound": "hbm", "kernel": "radix_scatter_lines_kernel<u32,%d>" % bits,
@@ -296,7 +298,7 @@ def main():
             },
             "whole_sort": {
                 "passes": passes_per_sort, "digit_bits": bits,
-                "count_kernels_reading_keys": passes_per_sort - from_table,
+                "count_kernels_reading_keys": key_reads, "scatter_passes_run": scatters,
                 "bytes_per_pair_moved": bytes_per_pair_moved,
                 "achieved_GBps_own_bytes": round(units * bytes_per_pair_moved / elapsed / 1e9, 1),
                 "frac_of_peak_own_bytes": round(units * bytes_per_pair_moved / elapsed / 1e9 / HBM_PEAK_GBPS, 4),
@@ -348,10 +350,12 @@ def main():
             # bytes this sort really moved per pair (second passes of pairs that took their table from the first pass's
             # two-digit histogram did not read the keys again; a 4-bit pair's tables are 4 MiB + 256 KiB, written and read)
             a_passes = int(ap["passes"]) // alt_steps
-            _, a_alone, a_roles = alt.read_plan(a_passes, roles=True)
-            a_from_table = sum(1 for p in range(a_passes) if a_roles[p] == 2 and not a_alone[p])
-            a_tables = sum(1 for p in range(a_passes) if a_roles[p] == 1) * 2 * (256 * 16 * 1024 + 16 * 256 * 16 * 4)
-            a_moved = round(a_passes * 2 * (KEY_BYTES + VAL_BYTES) + (a_passes - a_from_table) * KEY_BYTES + a_tables / n, 2)
+            a_skipped, a_alone, a_roles = alt.read_plan(a_passes, roles=True)
+            a_from_table = sum(1 for p in range(a_passes) if a_roles[p] == 2 and not a_alone[p] and a_skipped[p] != 2)
+            a_key_reads = sum(1 for p in range(a_passes) if a_skipped[p] != 2) - a_from_table
+            a_scatters = sum(1 for p in range(a_passes) if not a_skipped[p])
+            a_tables = sum(1 for p in range(a_passes) if a_roles[p] == 1 and a_skipped[p] != 2) * 2 * (256 * 16 * 1024 + 16 * 256 * 16 * 4)
+            a_moved = round(a_scatters * 2 * (KEY_BYTES + VAL_BYTES) + a_key_reads * KEY_BYTES + a_tables / n, 2)
             result["reference_pass_structure"] = {
                 "digit_bits": 4, "passes": int(ap["passes"]) // alt_steps, "steps": alt_steps, "warmup": alt_warm,
                 "ms_per_step": round(a_med, 4), "ms_per_step_min": round(a_min, 4), "timing": "device time per sort (HIP events), median and min",
@@ -359,7 +363,7 @@ def main():
                 "achieved_GBps_at_160B_per_pair": round(n * 160 / (a_med * 1e-3) / 1e9, 1),
                 "frac_of_peak_at_160B_per_pair": round(n * 160 / (a_med * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                 "frac_of_peak_at_160B_per_pair_best": round(n * 160 / (a_min * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                "count_kernels_reading_keys": a_passes - a_from_table,
+                "count_kernels_reading_keys": a_key_reads,
                 "bytes_per_pair_moved": a_moved,
                 "frac_of_peak_own_bytes": round(n * a_moved / (a_med * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                 "scatter_kernel": "radix_scatter_lines_kernel<u32,4>",

@@ -432,6 +432,7 @@ struct glu_radix_sort_s
     bool no_plan = false;         // GLU_HIP_SORT_NO_PLAN=1: never skip constant-digit passes (tests / tuning)
     bool no_lines = false;        // GLU_HIP_SORT_NO_LINES=1: never use the 128-byte-line scatter kernel (tests / tuning)
     bool nt_stores = true;        // GLU_HIP_SORT_NT_STORES=0: plain instead of non-temporal line stores in the line scatter (tuning)
+    bool no_bit_shortcut = false; // GLU_HIP_SORT_NO_BIT_SHORTCUT=1: passes on key bits that do not vary still count (tests / tuning)
     bool pairs = true;            // GLU_HIP_SORT_PAIRS=0: every pass of a large sort counts for itself (tests / tuning)
     uint32_t last_pair_roles[kPlanMaxPasses] = {}; // host-side record of the last planned sort (glu_radix_sort_read_plan)
     size_t pair_min = 0;          // GLU_HIP_SORT_PAIR_MIN=N: element count from which passes are paired (tests / tuning)
@@ -501,6 +502,7 @@ struct PlanArgs
     // [shift2, shift2 + bits2) of the pass after it), 2 = follower (its count table comes from that)
     int pair_role = 0;
     uint32_t shift2 = 0, bits2 = 0;
+    uint32_t flags = 0; // kPlanCollectBits / kPlanShortcut for the pass's count kernel
 };
 
 // XF: this pass encodes keys on load and / or decodes them on store (first / last pass of a typed sort); every other
@@ -539,7 +541,8 @@ glu_status launch_pass(glu_radix_sort_s* s, const KeyT* src_k, const uint32_t* s
     // when there is one workgroup per CU
     constexpr int COUNT_THREADS = LARGE ? 1024 : G::THREADS;
     hipLaunchKernelGGL((radix_count_kernel<KeyT, BITS, COUNT_THREADS, G::TILE, XF>), dim3(nb), dim3(COUNT_THREADS), 0, stream,
-                       src_k, table, (uint32_t) count, shift, mask, tiles, xform, (const KeyT*) dst_k, pa.plan, pa.pass);
+                       src_k, table, (uint32_t) count, shift, mask, tiles, xform, (const KeyT*) dst_k, pa.plan, pa.pass, false,
+                       pa.flags);
     HIP_TRY(hipGetLastError()); // every launch is checked where it happens: a failed count launch is reported as such
     s->mark(stream);
     if (!fused)
@@ -616,12 +619,12 @@ glu_status launch_pass_lines(glu_radix_sort_s* s, const KeyT* src_k, const uint3
                 HIP_TRY(count2_opt_in_result);
                 hipLaunchKernelGGL(count2, dim3(nb), dim3(1024), sizeof(PairCountSmem), stream, src_k, table, (uint32_t*) s->pair_t2.ptr,
                                    (uint32_t) count, shift, mask, pa.shift2, (1u << pa.bits2) - 1, tiles, xform, (const KeyT*) dst_k,
-                                   pa.plan, pa.pass);
+                                   pa.plan, pa.pass, pa.flags);
             }
             else
                 hipLaunchKernelGGL((radix_pair4_count_kernel<KeyT, G::TILE, false>), dim3(nb * kPairSub), dim3(256), 0, stream, src_k,
                                    sub_table, (uint32_t*) s->pair_t2.ptr, (uint32_t) count, shift, mask, pa.shift2,
-                                   (1u << pa.bits2) - 1, tiles, xform, (const KeyT*) dst_k, pa.plan, pa.pass);
+                                   (1u << pa.bits2) - 1, tiles, xform, (const KeyT*) dst_k, pa.plan, pa.pass, pa.flags);
             HIP_TRY(hipGetLastError());
         }
     }
@@ -636,17 +639,18 @@ glu_status launch_pass_lines(glu_radix_sort_s* s, const KeyT* src_k, const uint3
         if constexpr (BITS == 8)
             hipLaunchKernelGGL(radix_pair_unitsum_kernel, dim3(nb), dim3(1024), 0, stream, (const uint32_t*) s->pair_t2.ptr,
                                (const uint32_t*) leader_table, (const uint32_t*) (leader_table + (size_t) RADIX * nb), table,
-                               (uint2*) s->pair_ranges.ptr, (uint32_t) count, pa.plan, pa.pass);
+                               (uint2*) s->pair_ranges.ptr, (uint32_t) count, pa.plan, pa.pass, shift, mask, pa.flags);
         else
             hipLaunchKernelGGL(radix_pair4_unitsum_kernel, dim3(nb), dim3(1024), 0, stream, (const uint32_t*) s->pair_t2.ptr,
                                (const uint32_t*) sub_table, (const uint32_t*) (leader_table + (size_t) RADIX * nb), table,
-                               (uint2*) s->pair_ranges.ptr, (uint32_t) count, pa.plan, pa.pass);
+                               (uint2*) s->pair_ranges.ptr, (uint32_t) count, pa.plan, pa.pass, shift, mask, pa.flags);
         HIP_TRY(hipGetLastError());
     }
     if (pa.pair_role != 1)
     {
         hipLaunchKernelGGL((radix_count_kernel<KeyT, BITS, 1024, G::TILE, XF>), dim3(nb), dim3(1024), 0, stream, src_k, table,
-                           (uint32_t) count, shift, mask, tiles, xform, (const KeyT*) dst_k, pa.plan, pa.pass, pa.pair_role == 2);
+                           (uint32_t) count, shift, mask, tiles, xform, (const KeyT*) dst_k, pa.plan, pa.pass, pa.pair_role == 2,
+                           pa.flags);
         HIP_TRY(hipGetLastError());
     }
     s->mark(stream);
@@ -854,8 +858,13 @@ glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t cou
             else
                 i += 1;
         }
+    }
+    if (planned)
+    {
+        // per sort: no follower counts for itself yet, nothing is known about the key bits
         PassPlan* plan = (PassPlan*) s->plan.ptr;
-        HIP_TRY(hipMemsetAsync(plan->pair_fallback, 0, sizeof(plan->pair_fallback), stream));
+        static_assert(offsetof(PassPlan, bits_nor) + sizeof(plan->bits_nor) == sizeof(PassPlan), "the zeroed tail of the plan");
+        HIP_TRY(hipMemsetAsync(plan->pair_fallback, 0, sizeof(PassPlan) - offsetof(PassPlan, pair_fallback), stream));
     }
     if (planned)
         for (uint32_t i = 0; i < (uint32_t) kPlanMaxPasses; i++) s->last_pair_roles[i] = i < num_passes ? (uint32_t) passes[i].pair_role : 0u;
@@ -869,6 +878,9 @@ glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t cou
             pa.plan = (PassPlan*) s->plan.ptr;
             pa.pass = pass;
             pa.may_skip = xform == 0; // encode / decode passes run whatever the data looks like
+            // the first pass's count kernel notes which key bits vary at all (untyped keys: what is sorted is the raw
+            // bit pattern); a later pass whose digit cannot vary then knows that it is an identity before it counts
+            if (key_xf == KEY_XF_NONE && !s->no_bit_shortcut) pa.flags = pass == 0 ? kPlanCollectBits : (pa.may_skip ? kPlanShortcut : 0u);
             pa.pair_role = passes[pass].pair_role;
             if (pa.pair_role == 1)
             {
@@ -942,6 +954,7 @@ glu_status glu_radix_sort_create(glu_radix_sort* out)
     if (const char* e = getenv("GLU_HIP_SORT_NO_PLAN")) s->no_plan = atoi(e) != 0;
     if (const char* e = getenv("GLU_HIP_SORT_NO_LINES")) s->no_lines = atoi(e) != 0;
     if (const char* e = getenv("GLU_HIP_SORT_PAIRS")) s->pairs = atoi(e) != 0;
+    if (const char* e = getenv("GLU_HIP_SORT_NO_BIT_SHORTCUT")) s->no_bit_shortcut = atoi(e) != 0;
     if (const char* e = getenv("GLU_HIP_SORT_PAIR_MIN")) s->pair_min = (size_t) atoll(e);
     if (const char* e = getenv("GLU_HIP_SORT_PAIR_UNIT_DIV"))
     {

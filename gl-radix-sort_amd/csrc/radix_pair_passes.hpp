@@ -51,7 +51,7 @@ __global__ __launch_bounds__(1024) void radix_pair_count_kernel(const KeyT* __re
                                                                 uint32_t* __restrict__ t2, uint32_t n, uint32_t shift,
                                                                 uint32_t mask, uint32_t shift2, uint32_t mask2,
                                                                 uint32_t tiles_total, uint32_t xform, const KeyT* keys_b,
-                                                                PassPlan* plan, uint32_t pass)
+                                                                PassPlan* plan, uint32_t pass, uint32_t plan_flags = 0)
 {
     constexpr int THREADS = 1024;
     constexpr int WAVES = PairCountSmem::WAVES;
@@ -61,9 +61,25 @@ __global__ __launch_bounds__(1024) void radix_pair_count_kernel(const KeyT* __re
     const KeyT* __restrict__ keys = keys_a;
     if (plan)
     {
+        // this pass's digit lies in key bits that do not vary: an identity, known without counting -- no tables either, so
+        // the follower counts for itself (or finds its own digit constant)
+        if ((plan_flags & kPlanShortcut) && plan_digit_is_constant(plan, shift, mask)) // (kernel-uniform)
+        {
+            if (blockIdx.x == 0 && tid == 0)
+            {
+                plan->skip[pass] = kSkipWithoutCounting;
+                plan->pair_fallback[pass + 1] = 1;
+            }
+            return;
+        }
         if (pass > 0 && plan->flip[pass]) keys = keys_b;
-        if (blockIdx.x == 0 && tid == 0) plan->skip[pass] = 0;
+        if (blockIdx.x == 0 && tid == 0)
+        {
+            plan->skip[pass] = 0;
+            if (plan_flags & kPlanCollectBits) plan->bits_valid = 1;
+        }
     }
+    KeyT acc_or = 0, acc_and = (KeyT) ~(KeyT) 0; // of the raw keys this thread reads
     for (uint32_t i = tid; i < sizeof(PairCountSmem) / 4; i += THREADS) reinterpret_cast<uint32_t*>(&s)[i] = 0;
     __syncthreads();
 
@@ -77,6 +93,8 @@ __global__ __launch_bounds__(1024) void radix_pair_count_kernel(const KeyT* __re
 
     // every lane of the wave is active when this runs
     auto tally = [&](KeyT raw) {
+        acc_or |= raw;
+        acc_and &= raw;
         const KeyT k = codec_in.encode(raw);
         const uint32_t d = digit_of<KeyT>(k, shift, mask), e = digit_of<KeyT>(k, shift2, mask2);
         const uint32_t de = d | (e << 8);
@@ -96,6 +114,8 @@ __global__ __launch_bounds__(1024) void radix_pair_count_kernel(const KeyT* __re
         }
     };
     auto tally_one = [&](KeyT raw) { // lanes may be inactive
+        acc_or |= raw;
+        acc_and &= raw;
         const KeyT k = codec_in.encode(raw);
         const uint32_t d = digit_of<KeyT>(k, shift, mask), e = digit_of<KeyT>(k, shift2, mask2);
         atomicAdd(&my_hist[d], 1u);
@@ -140,6 +160,7 @@ __global__ __launch_bounds__(1024) void radix_pair_count_kernel(const KeyT* __re
     }
     for (; i < end; i += THREADS) tally_one(keys[i]);
     __syncthreads();
+    if (plan_flags & kPlanCollectBits) plan_publish_bits<KeyT>(plan, acc_or, acc_and, lane);
 
     // T1: the usual table entry; kept in hist1[0] for the row check below
     const uint32_t nb = gridDim.x, b = blockIdx.x;
@@ -241,9 +262,15 @@ __global__ __launch_bounds__(1024) void radix_pair_unitsum_kernel(const uint32_t
                                                                   const uint32_t* __restrict__ table_l,
                                                                   const uint32_t* __restrict__ totals_l,
                                                                   uint32_t* __restrict__ table_f, uint2* __restrict__ ranges,
-                                                                  uint32_t n, PassPlan* plan, uint32_t pass)
+                                                                  uint32_t n, PassPlan* plan, uint32_t pass,
+                                                                  uint32_t shift = 0, uint32_t mask = 0, uint32_t plan_flags = 0)
 {
     if (plan->pair_fallback[pass]) return; // (kernel-uniform)
+    if ((plan_flags & kPlanShortcut) && plan_digit_is_constant(plan, shift, mask)) // an identity, known without any table
+    {
+        if (blockIdx.x == 0 && threadIdx.x == 0) plan->skip[pass] = kSkipWithoutCounting;
+        return;
+    }
     __shared__ uint32_t base[kPairRadix + 1];
     __shared__ uint32_t tmp[16];
     __shared__ uint32_t found[2];
@@ -304,7 +331,7 @@ __global__ __launch_bounds__(256) void radix_pair4_count_kernel(const KeyT* __re
                                                                 uint32_t* __restrict__ t2, uint32_t n, uint32_t shift,
                                                                 uint32_t mask, uint32_t shift2, uint32_t mask2,
                                                                 uint32_t tiles_total, uint32_t xform, const KeyT* keys_b,
-                                                                PassPlan* plan, uint32_t pass)
+                                                                PassPlan* plan, uint32_t pass, uint32_t plan_flags = 0)
 {
     constexpr int THREADS = 256;
     constexpr int WAVES = THREADS / kWave;
@@ -314,9 +341,23 @@ __global__ __launch_bounds__(256) void radix_pair4_count_kernel(const KeyT* __re
     const KeyT* __restrict__ keys = keys_a;
     if (plan)
     {
+        if ((plan_flags & kPlanShortcut) && plan_digit_is_constant(plan, shift, mask)) // (as in radix_pair_count_kernel)
+        {
+            if (blockIdx.x == 0 && tid == 0)
+            {
+                plan->skip[pass] = kSkipWithoutCounting;
+                plan->pair_fallback[pass + 1] = 1;
+            }
+            return;
+        }
         if (pass > 0 && plan->flip[pass]) keys = keys_b;
-        if (blockIdx.x == 0 && tid == 0) plan->skip[pass] = 0;
+        if (blockIdx.x == 0 && tid == 0)
+        {
+            plan->skip[pass] = 0;
+            if (plan_flags & kPlanCollectBits) plan->bits_valid = 1;
+        }
     }
+    KeyT acc_or = 0, acc_and = (KeyT) ~(KeyT) 0; // of the raw keys this thread reads
     for (int i = tid; i < WAVES * 256; i += THREADS) (&hist[0][0])[i] = 0;
     __syncthreads();
     uint32_t first, last, sf, sl;
@@ -328,6 +369,8 @@ __global__ __launch_bounds__(256) void radix_pair4_count_kernel(const KeyT* __re
     uint32_t* my_hist = hist[wave];
     const KeyCodec<KeyT, XF> codec_in(xform & 3u);
     auto combined = [&](KeyT raw) {
+        acc_or |= raw;
+        acc_and &= raw;
         const KeyT k = codec_in.encode(raw);
         return digit_of<KeyT>(k, shift, mask) | (digit_of<KeyT>(k, shift2, mask2) << 4);
     };
@@ -374,6 +417,7 @@ __global__ __launch_bounds__(256) void radix_pair4_count_kernel(const KeyT* __re
         for (uint64_t i = begin + vbase * VEC + tid; i < end; i += THREADS) atomicAdd(&my_hist[combined(keys[i])], 1u);
     }
     __syncthreads();
+    if (plan_flags & kPlanCollectBits) plan_publish_bits<KeyT>(plan, acc_or, acc_and, lane);
     // thread = combined value: d = tid & 15, e = tid >> 4
     uint32_t c = 0;
 #pragma unroll
@@ -396,9 +440,15 @@ __global__ __launch_bounds__(1024) void radix_pair4_unitsum_kernel(const uint32_
                                                                    const uint32_t* __restrict__ sub_scanned,
                                                                    const uint32_t* __restrict__ totals_l,
                                                                    uint32_t* __restrict__ table_f, uint2* __restrict__ ranges,
-                                                                   uint32_t n, PassPlan* plan, uint32_t pass)
+                                                                   uint32_t n, PassPlan* plan, uint32_t pass,
+                                                                   uint32_t shift = 0, uint32_t mask = 0, uint32_t plan_flags = 0)
 {
     if (plan->pair_fallback[pass]) return; // (kernel-uniform)
+    if ((plan_flags & kPlanShortcut) && plan_digit_is_constant(plan, shift, mask)) // an identity, known without any table
+    {
+        if (blockIdx.x == 0 && threadIdx.x == 0) plan->skip[pass] = kSkipWithoutCounting;
+        return;
+    }
     __shared__ uint32_t base[kPair4Radix + 1];
     __shared__ uint32_t tmp[16];
     __shared__ uint32_t found[2];

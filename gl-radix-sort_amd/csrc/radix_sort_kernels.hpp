@@ -136,7 +136,57 @@ struct PassPlan
     // paired passes (radix_pair_passes.hpp): 1 = pass p counts for itself although its table was to come from the
     // two-digit histogram of pass p - 1; zeroed at the start of every sort, set by kernels that run before pass p
     uint32_t pair_fallback[kPlanMaxPasses + 1];
+    // Which key bits vary over the input: collected by the count kernel of the first pass of an untyped sort (the OR of
+    // all keys and the OR of all complemented keys, low / high word).  A later pass whose digit lies in bits that do not
+    // vary is an identity: its count kernel says so (skip[p] = 1) without reading the keys.  Zeroed with pair_fallback.
+    uint32_t bits_valid;
+    uint32_t bits_or[2], bits_nor[2];
 };
+
+// PassPlan::skip values: 0 = the pass runs, 1 = an identity found by the row scan (one digit value holds every key; the
+// tables of the pass are complete), kSkipWithoutCounting = an identity known before counting (no tables)
+constexpr uint32_t kSkipWithoutCounting = 2;
+
+// flags of the count kernels of planned sorts
+constexpr uint32_t kPlanCollectBits = 1; // first pass of an untyped sort: collect which key bits vary
+constexpr uint32_t kPlanShortcut = 2;    // a later pass that may be skipped: return at once if its digit cannot vary
+
+__device__ __forceinline__ bool plan_digit_is_constant(const PassPlan* plan, uint32_t shift, uint32_t mask)
+{
+    if (!plan->bits_valid) return false;
+    const uint32_t w = shift >> 5; // a digit never straddles the two words of a 64-bit key
+    return (((plan->bits_or[w] & plan->bits_nor[w]) >> (shift & 31u)) & mask) == 0;
+}
+
+// OR / AND of the keys a thread has seen -> the plan (once per wave)
+template<typename KeyT>
+__device__ __forceinline__ void plan_publish_bits(PassPlan* plan, KeyT acc_or, KeyT acc_and, uint32_t lane)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+    {
+        if constexpr (sizeof(KeyT) == 4)
+        {
+            acc_or |= (KeyT) __shfl_xor((uint32_t) acc_or, o);
+            acc_and &= (KeyT) __shfl_xor((uint32_t) acc_and, o);
+        }
+        else
+        {
+            acc_or |= (KeyT) __shfl_xor((unsigned long long) acc_or, o);
+            acc_and &= (KeyT) __shfl_xor((unsigned long long) acc_and, o);
+        }
+    }
+    if (lane == 0)
+    {
+        atomicOr(&plan->bits_or[0], (uint32_t) acc_or);
+        atomicOr(&plan->bits_nor[0], ~(uint32_t) acc_and);
+        if constexpr (sizeof(KeyT) == 8)
+        {
+            atomicOr(&plan->bits_or[1], (uint32_t) ((uint64_t) acc_or >> 32));
+            atomicOr(&plan->bits_nor[1], ~(uint32_t) ((uint64_t) acc_and >> 32));
+        }
+    }
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // K1: per-workgroup digit histogram.  table[d * num_blocks + b] = #keys of block b's range with digit d.
@@ -148,7 +198,7 @@ __global__ __launch_bounds__(THREADS) void radix_count_kernel(const KeyT* __rest
                                                               uint32_t shift, uint32_t mask, uint32_t tiles_total,
                                                               uint32_t xform = 0, const KeyT* keys_b = nullptr,
                                                               PassPlan* plan = nullptr, uint32_t pass = 0,
-                                                              bool pair_follower = false)
+                                                              bool pair_follower = false, uint32_t plan_flags = 0)
 {
     constexpr int RADIX = 1 << BITS;
     constexpr int WAVES = THREADS / kWave;
@@ -163,8 +213,18 @@ __global__ __launch_bounds__(THREADS) void radix_count_kernel(const KeyT* __rest
     const KeyT* __restrict__ keys = keys_a;
     if (plan)
     {
+        // a digit in key bits that do not vary (the first pass's count kernel collected them): an identity pass
+        if ((plan_flags & kPlanShortcut) && plan_digit_is_constant(plan, shift, MASK)) // (kernel-uniform)
+        {
+            if (blockIdx.x == 0 && tid == 0) plan->skip[pass] = kSkipWithoutCounting;
+            return;
+        }
         if (pass > 0 && plan->flip[pass]) keys = keys_b;
-        if (blockIdx.x == 0 && tid == 0) plan->skip[pass] = 0;
+        if (blockIdx.x == 0 && tid == 0)
+        {
+            plan->skip[pass] = 0;
+            if (plan_flags & kPlanCollectBits) plan->bits_valid = 1;
+        }
     }
     for (int i = tid; i < WAVES * RADIX; i += THREADS) (&hist[0][0])[i] = 0;
     __syncthreads();
@@ -176,6 +236,7 @@ __global__ __launch_bounds__(THREADS) void radix_count_kernel(const KeyT* __rest
     if (end > n) end = n;
 
     uint32_t* my_hist = hist[wave];
+    KeyT acc_or = 0, acc_and = (KeyT) ~(KeyT) 0; // of the raw keys this thread reads
 
     // every lane of the wave is active when this runs (wave-uniform trip counts below)
     auto tally = [&](uint32_t d) {
@@ -204,10 +265,14 @@ __global__ __launch_bounds__(THREADS) void radix_count_kernel(const KeyT* __rest
     auto tally_vec = [&](const VecT& a) {
         if constexpr (sizeof(KeyT) == 4)
         {
+            acc_or |= a.x | a.y | a.z | a.w;
+            acc_and &= a.x & a.y & a.z & a.w;
             tally(dig(a.x)); tally(dig(a.y)); tally(dig(a.z)); tally(dig(a.w));
         }
         else
         {
+            acc_or |= a.x | a.y;
+            acc_and &= a.x & a.y;
             tally(dig(a.x)); tally(dig(a.y));
         }
     };
@@ -234,10 +299,22 @@ __global__ __launch_bounds__(THREADS) void radix_count_kernel(const KeyT* __rest
 #pragma unroll
         for (int j = 0; j < 8; j++) k[j] = keys[i + (uint64_t) j * THREADS];
 #pragma unroll
-        for (int j = 0; j < 8; j++) atomicAdd(&my_hist[dig(k[j])], 1u);
+        for (int j = 0; j < 8; j++)
+        {
+            acc_or |= k[j];
+            acc_and &= k[j];
+            atomicAdd(&my_hist[dig(k[j])], 1u);
+        }
     }
-    for (; i < end; i += THREADS) atomicAdd(&my_hist[dig(keys[i])], 1u);
+    for (; i < end; i += THREADS)
+    {
+        const KeyT k = keys[i];
+        acc_or |= k;
+        acc_and &= k;
+        atomicAdd(&my_hist[dig(k)], 1u);
+    }
     __syncthreads();
+    if (plan_flags & kPlanCollectBits) plan_publish_bits<KeyT>(plan, acc_or, acc_and, lane);
 
     for (int d = tid; d < RADIX; d += THREADS)
     {
@@ -266,6 +343,8 @@ __global__ __launch_bounds__(THREADS) void radix_row_scan_kernel(uint32_t* __res
     constexpr int WAVES = THREADS / kWave;
     __shared__ uint32_t wave_sums[WAVES];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // the count kernel before this one found the pass an identity without counting (plan_digit_is_constant): no table
+    if (plan && plan->skip[pass] == kSkipWithoutCounting) return;
     uint32_t* row = table + (size_t) blockIdx.x * num_blocks;
     uint32_t carry = 0;
     for (uint32_t base = 0; base < num_blocks; base += THREADS)

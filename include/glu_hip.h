@@ -208,8 +208,10 @@ GLU_API glu_status glu_radix_sort_set_profiling(glu_radix_sort sort, int enable)
 GLU_API glu_status glu_radix_sort_read_profile(glu_radix_sort sort, double* count_ms, double* scan_ms,
                                                double* scatter_ms, uint64_t* passes);
 /* Diagnostics of the last sort of >= 2^22 elements on this object, whose passes are planned on the device (the caller has
- * synchronised the sort's stream): for pass p < passes, skipped[p] = 1 if the pass was an identity (every key had the same
- * digit value: its scatter did not run); pair_role[p] = 1 / 2 if the pass was the first / second of a pair of passes that
+ * synchronised the sort's stream): for pass p < passes, skipped[p] != 0 if the pass was an identity (every key had the same
+ * digit value: its scatter did not run) -- 1 if its count kernel found that out, 2 if it was known before counting (the
+ * first pass of a sort of unsigned keys notes which key bits vary at all; a later pass on bits that do not vary reads
+ * nothing); pair_role[p] = 1 / 2 if the pass was the first / second of a pair of passes that
  * share one read of the keys (large sorts with 8-bit digits: the first pass's count kernel also builds a two-digit
  * histogram, the second pass takes its count table from it), 0 if it stood alone; counted_alone[p] = 1 if a second pass
  * of a pair counted for itself after all (skewed digit values, a 16-bit counter overflow).  Any array may be NULL;

@@ -904,6 +904,8 @@ def _sort_and_plan(G, keys, vals, passes, key_bytes=4, env=None, run=None, bits=
     G.synchronize()
     skipped, alone, roles = sorter.read_plan(passes, roles=True)
     _sort_and_plan.last_roles = roles
+    _sort_and_plan.last_skip_raw = skipped  # 1 = identity found by counting, 2 = known before counting
+    skipped = [1 if x else 0 for x in skipped]
     return kb.get_data(keys.dtype), (vb.get_data(np.uint32) if vb is not None else None), skipped, alone
 
 
@@ -1174,3 +1176,44 @@ def test_paired_passes_4bit_u64_typed_keys_only_bit_ranges_and_capped_grid(G):
         gk, gv, _, _ = _sort_and_plan(G, k32, vals, 8, bits=4, env={"GLU_HIP_SORT_BLOCKS": blocks})
         _check_against_oracle(k32, vals, gk, gv)
         assert _sort_and_plan.last_roles == [1, 2] * 4
+
+
+@pytest.mark.parametrize("bits", DIGIT_BITS)
+def test_passes_on_key_bits_that_do_not_vary_are_identities_without_counting(G, bits):
+    """The count kernel of the first pass of an unsigned-key sort notes which key bits vary over the input; a later pass
+    whose digit lies in constant bits is skipped without reading the keys (skip value 2), also inside pairs of passes
+    and for 64-bit keys that hold 32-bit numbers."""
+    n = (1 << 23) + 321
+    rng = np.random.default_rng(51 + bits)
+    vals = np.arange(n, dtype=np.uint32)
+    per = 8 // bits  # passes per key byte
+    # bytes 1 and 3 of the key constant (non-zero), bytes 0 and 2 random
+    keys = (rng.integers(0, 2**32, n, dtype=np.uint32) & np.uint32(0x00FF00FF)) | np.uint32(0x5A00C300)
+    gk, gv, skipped, alone = _sort_and_plan(G, keys, vals, 4 * per, bits=bits)
+    _check_against_oracle(keys, vals, gk, gv)
+    assert _sort_and_plan.last_skip_raw == [0] * per + [2] * per + [0] * per + [2] * per
+    # the switch: the same passes are found to be identities by counting
+    gk2, gv2, skipped2, _ = _sort_and_plan(G, keys, vals, 4 * per, bits=bits, env={"GLU_HIP_SORT_NO_BIT_SHORTCUT": "1"})
+    assert (gk2 == gk).all() and (gv2 == gv).all() and _sort_and_plan.last_skip_raw == [0] * per + [1] * per + [0] * per + [1] * per
+    # a constant FIRST digit is found by counting (nothing is known before the first pass)
+    keys0 = (keys & np.uint32(0xFFFFFF00)) | np.uint32(0x11)
+    gk, gv, skipped, alone = _sort_and_plan(G, keys0, vals, 4 * per, bits=bits)
+    _check_against_oracle(keys0, vals, gk, gv)
+    assert _sort_and_plan.last_skip_raw == [1] + [2] * (per - 1) + [2] * per + [0] * per + [2] * per
+    # all keys equal: one read of the keys
+    same = np.full(n, 0xDEADBEEF, dtype=np.uint32)
+    gk, gv, skipped, alone = _sort_and_plan(G, same, vals, 4 * per, bits=bits)
+    assert (gk == same).all() and (gv == vals).all()
+    assert _sort_and_plan.last_skip_raw == [1] + [2] * (4 * per - 1)
+    # 64-bit keys holding 32-bit numbers, keys only
+    k64 = rng.integers(0, 2**32, n, dtype=np.uint64)
+    gk, _, skipped, alone = _sort_and_plan(G, k64, None, 8 * per, key_bytes=8, bits=bits)
+    assert (gk == np.sort(k64)).all()
+    assert _sort_and_plan.last_skip_raw == [0] * (4 * per) + [2] * (4 * per)
+    # signed keys: the sort is on encoded bit patterns, nothing is noted, constant bytes are found by counting
+    i32 = (keys & np.uint32(0x7FFFFFFF)).view(np.int32)
+    gk, gv, skipped, alone = _sort_and_plan(
+        G, i32, vals, 4 * per, bits=bits, run=lambda s, kb, vb: s.sort_typed_ptr(kb.device_ptr(), vb.device_ptr(), n, "int32"))
+    order = np.argsort(i32, kind="stable")
+    assert (gk == i32[order]).all() and (gv == vals[order]).all()
+    assert 2 not in _sort_and_plan.last_skip_raw

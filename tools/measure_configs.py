@@ -24,10 +24,13 @@ def time_sort(keys, vals, bits, key_bytes=4, reps=5):
     # bytes really moved per pair: a pass whose count table came from its leader's two-digit histogram did not read the keys
     # a second time (the pair moved 64 MiB of tables instead)
     moved = None
+    time_sort.key_reads = None
     if n >= 1 << 22:
         passes = (8 * key_bytes) // bits
         skipped, alone, roles = s.read_plan(passes, roles=True)
-        from_table = sum(1 for p in range(passes) if roles[p] == 2 and not alone[p])
+        from_table = sum(1 for p in range(passes) if roles[p] == 2 and not alone[p] and skipped[p] != 2)
+        # count kernels that read the keys: not those of passes known to be identities before counting (skip value 2)
+        time_sort.key_reads = sum(1 for p in range(passes) if skipped[p] != 2 and not (roles[p] == 2 and not alone[p]))
         leaders = sum(1 for p in range(passes) if roles[p] == 1)
         tables = 2 * 256 * 256 * 512 if bits == 8 else 2 * (256 * 16 * 1024 + 16 * 256 * 16 * 4)  # written and read once
         moved = passes * 2 * (key_bytes + 4) + (passes - from_table) * key_bytes + leaders * tables / n
@@ -50,9 +53,9 @@ for name, log2n, kind, key_bytes in (("C2 2^20 u32+u32 uniform", 20, "uniform", 
         bpp = passes * (3 * key_bytes + 8)
         if kind == "zero":
             # every pass has a constant digit and is skipped on the device: only the count kernels read the keys
-            rd = passes * key_bytes
-            print("%-46s digits %d-bit: %8.3f ms  %9.1f Mkeys/s  (all passes skipped: %d B/pair read, %.0f GB/s)" % (
-                name, bits, t * 1e3, n / t / 1e6, rd, n * rd / t / 1e9), flush=True)
+            rd = time_sort.key_reads * key_bytes
+            print("%-46s digits %d-bit: %8.3f ms  %9.1f Mkeys/s  (all passes skipped, %d of them known to be identities before counting: %d B/pair read, %.0f GB/s)" % (
+                name, bits, t * 1e3, n / t / 1e6, passes - time_sort.key_reads, rd, n * rd / t / 1e9), flush=True)
             continue
         own = "" if moved is None or abs(moved - bpp) < 0.01 else "; moved %.1f B/pair: %.1f %%" % (moved, n * moved / t / 8e12 * 100)
         print("%-46s digits %d-bit: %8.3f ms  %9.1f Mkeys/s  %6.0f GB/s at %d B/pair (%.1f %% of 8 TB/s%s)" % (
