@@ -195,7 +195,7 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
 #pragma unroll
         for (int i = decltype(i0)::value; i < decltype(i1)::value; i++)
         {
-            nkey[i] = src_keys[pf_base + i * kWave];
+            nkey[i] = src_keys[pf_base + i * kWave]; // (non-temporal loads here: 2 % slower inside the sort, same-box A/B)
             const uint32_t d = digit_of<KeyT>(key[i], shift, MASK);
             uint16_t* const cnt = my_cnt + d;
             const uint32_t prev = *cnt; // issued first: its LDS latency hides under the ballots below
