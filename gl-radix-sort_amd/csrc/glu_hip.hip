@@ -540,7 +540,10 @@ glu_status launch_pass(glu_radix_sort_s* s, const KeyT* src_k, const uint32_t* s
     // the count kernel only shares TILE and the grid with the scatter kernel; 1024 threads keep enough loads in flight
     // when there is one workgroup per CU
     constexpr int COUNT_THREADS = LARGE ? 1024 : G::THREADS;
-    hipLaunchKernelGGL((radix_count_kernel<KeyT, BITS, COUNT_THREADS, G::TILE, XF>), dim3(nb), dim3(COUNT_THREADS), 0, stream,
+    // (the first pass of a planned sort of unsigned keys runs the instantiation that also notes which key bits vary)
+    auto count_plain = radix_count_kernel<KeyT, BITS, COUNT_THREADS, G::TILE, XF, false>;
+    auto count_collect = radix_count_kernel<KeyT, BITS, COUNT_THREADS, G::TILE, XF, !XF>;
+    hipLaunchKernelGGL((pa.flags & kPlanCollectBits) ? count_collect : count_plain, dim3(nb), dim3(COUNT_THREADS), 0, stream,
                        src_k, table, (uint32_t) count, shift, mask, tiles, xform, (const KeyT*) dst_k, pa.plan, pa.pass, false,
                        pa.flags);
     HIP_TRY(hipGetLastError()); // every launch is checked where it happens: a failed count launch is reported as such
@@ -610,21 +613,29 @@ glu_status launch_pass_lines(glu_radix_sort_s* s, const KeyT* src_k, const uint3
             // leader: one read of the keys for this pass's table and the two-digit table the follower's comes from
             if constexpr (BITS == 8)
             {
-                auto count2 = radix_pair_count_kernel<KeyT, G::TILE, false>;
+                auto count2_plain = radix_pair_count_kernel<KeyT, G::TILE, false, false>;
+                auto count2_collect = radix_pair_count_kernel<KeyT, G::TILE, false, true>; // first pass: also notes which key bits vary
                 static std::once_flag count2_opt_in;
                 static hipError_t count2_opt_in_result = hipSuccess;
                 std::call_once(count2_opt_in, [&] {
-                    count2_opt_in_result = hipFuncSetAttribute((const void*) count2, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sizeof(PairCountSmem));
+                    count2_opt_in_result = hipFuncSetAttribute((const void*) count2_plain, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sizeof(PairCountSmem));
+                    if (count2_opt_in_result == hipSuccess)
+                        count2_opt_in_result = hipFuncSetAttribute((const void*) count2_collect, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sizeof(PairCountSmem));
                 });
                 HIP_TRY(count2_opt_in_result);
+                auto count2 = (pa.flags & kPlanCollectBits) ? count2_collect : count2_plain;
                 hipLaunchKernelGGL(count2, dim3(nb), dim3(1024), sizeof(PairCountSmem), stream, src_k, table, (uint32_t*) s->pair_t2.ptr,
                                    (uint32_t) count, shift, mask, pa.shift2, (1u << pa.bits2) - 1, tiles, xform, (const KeyT*) dst_k,
                                    pa.plan, pa.pass, pa.flags);
             }
             else
-                hipLaunchKernelGGL((radix_pair4_count_kernel<KeyT, G::TILE, false>), dim3(nb * kPairSub), dim3(256), 0, stream, src_k,
-                                   sub_table, (uint32_t*) s->pair_t2.ptr, (uint32_t) count, shift, mask, pa.shift2,
+            {
+                auto count4_plain = radix_pair4_count_kernel<KeyT, G::TILE, false, false>;
+                auto count4_collect = radix_pair4_count_kernel<KeyT, G::TILE, false, true>;
+                hipLaunchKernelGGL((pa.flags & kPlanCollectBits) ? count4_collect : count4_plain,
+                                   dim3(nb * kPairSub), dim3(256), 0, stream, src_k, sub_table, (uint32_t*) s->pair_t2.ptr, (uint32_t) count, shift, mask, pa.shift2,
                                    (1u << pa.bits2) - 1, tiles, xform, (const KeyT*) dst_k, pa.plan, pa.pass, pa.flags);
+            }
             HIP_TRY(hipGetLastError());
         }
     }
@@ -648,7 +659,9 @@ glu_status launch_pass_lines(glu_radix_sort_s* s, const KeyT* src_k, const uint3
     }
     if (pa.pair_role != 1)
     {
-        hipLaunchKernelGGL((radix_count_kernel<KeyT, BITS, 1024, G::TILE, XF>), dim3(nb), dim3(1024), 0, stream, src_k, table,
+        auto count_plain = radix_count_kernel<KeyT, BITS, 1024, G::TILE, XF, false>;
+        auto count_collect = radix_count_kernel<KeyT, BITS, 1024, G::TILE, XF, !XF>;
+        hipLaunchKernelGGL((pa.flags & kPlanCollectBits) ? count_collect : count_plain, dim3(nb), dim3(1024), 0, stream, src_k, table,
                            (uint32_t) count, shift, mask, tiles, xform, (const KeyT*) dst_k, pa.plan, pa.pass, pa.pair_role == 2,
                            pa.flags);
         HIP_TRY(hipGetLastError());

@@ -46,7 +46,7 @@ struct PairCountSmem
 };
 
 // t2 row of unit (d, b): words [(d * nb + b) * 128, + 128), counter e in the low (e even) / high (e odd) half of word e / 2
-template<typename KeyT, int TILE, bool XF = false>
+template<typename KeyT, int TILE, bool XF = false, bool COLLECT = false>
 __global__ __launch_bounds__(1024) void radix_pair_count_kernel(const KeyT* __restrict__ keys_a, uint32_t* __restrict__ table,
                                                                 uint32_t* __restrict__ t2, uint32_t n, uint32_t shift,
                                                                 uint32_t mask, uint32_t shift2, uint32_t mask2,
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(1024) void radix_pair_count_kernel(const KeyT* __re
         if (blockIdx.x == 0 && tid == 0)
         {
             plan->skip[pass] = 0;
-            if (plan_flags & kPlanCollectBits) plan->bits_valid = 1;
+            if (COLLECT && (plan_flags & kPlanCollectBits)) plan->bits_valid = 1;
         }
     }
     KeyT acc_or = 0, acc_and = (KeyT) ~(KeyT) 0; // of the raw keys this thread reads
@@ -93,8 +93,6 @@ __global__ __launch_bounds__(1024) void radix_pair_count_kernel(const KeyT* __re
 
     // every lane of the wave is active when this runs
     auto tally = [&](KeyT raw) {
-        acc_or |= raw;
-        acc_and &= raw;
         const KeyT k = codec_in.encode(raw);
         const uint32_t d = digit_of<KeyT>(k, shift, mask), e = digit_of<KeyT>(k, shift2, mask2);
         const uint32_t de = d | (e << 8);
@@ -114,8 +112,7 @@ __global__ __launch_bounds__(1024) void radix_pair_count_kernel(const KeyT* __re
         }
     };
     auto tally_one = [&](KeyT raw) { // lanes may be inactive
-        acc_or |= raw;
-        acc_and &= raw;
+        if (COLLECT) acc_or |= raw, acc_and &= raw;
         const KeyT k = codec_in.encode(raw);
         const uint32_t d = digit_of<KeyT>(k, shift, mask), e = digit_of<KeyT>(k, shift2, mask2);
         atomicAdd(&my_hist[d], 1u);
@@ -130,10 +127,12 @@ __global__ __launch_bounds__(1024) void radix_pair_count_kernel(const KeyT* __re
     auto tally_vec = [&](const VecT& a) {
         if constexpr (sizeof(KeyT) == 4)
         {
+            if (COLLECT) acc_or |= a.x | a.y | a.z | a.w, acc_and &= a.x & a.y & a.z & a.w;
             tally(a.x); tally(a.y); tally(a.z); tally(a.w);
         }
         else
         {
+            if (COLLECT) acc_or |= a.x | a.y, acc_and &= a.x & a.y;
             tally(a.x); tally(a.y);
         }
     };
@@ -160,7 +159,7 @@ __global__ __launch_bounds__(1024) void radix_pair_count_kernel(const KeyT* __re
     }
     for (; i < end; i += THREADS) tally_one(keys[i]);
     __syncthreads();
-    if (plan_flags & kPlanCollectBits) plan_publish_bits<KeyT>(plan, acc_or, acc_and, lane);
+    if (COLLECT && (plan_flags & kPlanCollectBits)) plan_publish_bits<KeyT>(plan, acc_or, acc_and, lane);
 
     // T1: the usual table entry; kept in hist1[0] for the row check below
     const uint32_t nb = gridDim.x, b = blockIdx.x;
@@ -326,7 +325,7 @@ constexpr uint32_t kPair4Radix = 16;
 // kPairSub] counts per (digit value, sub-block); the row-scan kernel behind this one scans it and copies every kPairSub-th
 // entry into the leader's usual [16][nb] table (the scanned count of a block = that of its first sub-block).  t2: per
 // sub-block 256 words, word d * 16 + e = #keys with digit p = d and digit p + 1 = e.
-template<typename KeyT, int TILE, bool XF = false>
+template<typename KeyT, int TILE, bool XF = false, bool COLLECT = false>
 __global__ __launch_bounds__(256) void radix_pair4_count_kernel(const KeyT* __restrict__ keys_a, uint32_t* __restrict__ table_sub,
                                                                 uint32_t* __restrict__ t2, uint32_t n, uint32_t shift,
                                                                 uint32_t mask, uint32_t shift2, uint32_t mask2,
@@ -354,7 +353,7 @@ __global__ __launch_bounds__(256) void radix_pair4_count_kernel(const KeyT* __re
         if (blockIdx.x == 0 && tid == 0)
         {
             plan->skip[pass] = 0;
-            if (plan_flags & kPlanCollectBits) plan->bits_valid = 1;
+            if (COLLECT && (plan_flags & kPlanCollectBits)) plan->bits_valid = 1;
         }
     }
     KeyT acc_or = 0, acc_and = (KeyT) ~(KeyT) 0; // of the raw keys this thread reads
@@ -369,8 +368,6 @@ __global__ __launch_bounds__(256) void radix_pair4_count_kernel(const KeyT* __re
     uint32_t* my_hist = hist[wave];
     const KeyCodec<KeyT, XF> codec_in(xform & 3u);
     auto combined = [&](KeyT raw) {
-        acc_or |= raw;
-        acc_and &= raw;
         const KeyT k = codec_in.encode(raw);
         return digit_of<KeyT>(k, shift, mask) | (digit_of<KeyT>(k, shift2, mask2) << 4);
     };
@@ -391,10 +388,12 @@ __global__ __launch_bounds__(256) void radix_pair4_count_kernel(const KeyT* __re
     auto tally_vec = [&](const VecT& a) {
         if constexpr (sizeof(KeyT) == 4)
         {
+            if (COLLECT) acc_or |= a.x | a.y | a.z | a.w, acc_and &= a.x & a.y & a.z & a.w;
             tally(a.x); tally(a.y); tally(a.z); tally(a.w);
         }
         else
         {
+            if (COLLECT) acc_or |= a.x | a.y, acc_and &= a.x & a.y;
             tally(a.x); tally(a.y);
         }
     };
@@ -414,10 +413,15 @@ __global__ __launch_bounds__(256) void radix_pair4_count_kernel(const KeyT* __re
             tally_vec(c);
             tally_vec(d);
         }
-        for (uint64_t i = begin + vbase * VEC + tid; i < end; i += THREADS) atomicAdd(&my_hist[combined(keys[i])], 1u);
+        for (uint64_t i = begin + vbase * VEC + tid; i < end; i += THREADS)
+        {
+            const KeyT raw = keys[i];
+            if (COLLECT) acc_or |= raw, acc_and &= raw;
+            atomicAdd(&my_hist[combined(raw)], 1u);
+        }
     }
     __syncthreads();
-    if (plan_flags & kPlanCollectBits) plan_publish_bits<KeyT>(plan, acc_or, acc_and, lane);
+    if (COLLECT && (plan_flags & kPlanCollectBits)) plan_publish_bits<KeyT>(plan, acc_or, acc_and, lane);
     // thread = combined value: d = tid & 15, e = tid >> 4
     uint32_t c = 0;
 #pragma unroll

@@ -178,12 +178,18 @@ __device__ __forceinline__ void plan_publish_bits(PassPlan* plan, KeyT acc_or, K
     }
     if (lane == 0)
     {
-        atomicOr(&plan->bits_or[0], (uint32_t) acc_or);
-        atomicOr(&plan->bits_nor[0], ~(uint32_t) acc_and);
+        // Thousands of waves OR into the same four words, and same-address atomics take ~10 ns each one after the other
+        // (75 us per launch when every wave did them): a wave that has nothing to add -- nearly all of them, the words fill
+        // up with the first few -- only reads.  (A stale read can only show fewer bits than there are: one atomic too many.)
+        auto add = [](uint32_t* word, uint32_t bits) {
+            if ((*reinterpret_cast<volatile uint32_t*>(word) | bits) != *reinterpret_cast<volatile uint32_t*>(word)) atomicOr(word, bits);
+        };
+        add(&plan->bits_or[0], (uint32_t) acc_or);
+        add(&plan->bits_nor[0], ~(uint32_t) acc_and);
         if constexpr (sizeof(KeyT) == 8)
         {
-            atomicOr(&plan->bits_or[1], (uint32_t) ((uint64_t) acc_or >> 32));
-            atomicOr(&plan->bits_nor[1], ~(uint32_t) ((uint64_t) acc_and >> 32));
+            add(&plan->bits_or[1], (uint32_t) ((uint64_t) acc_or >> 32));
+            add(&plan->bits_nor[1], ~(uint32_t) ((uint64_t) acc_and >> 32));
         }
     }
 }
@@ -192,7 +198,7 @@ __device__ __forceinline__ void plan_publish_bits(PassPlan* plan, KeyT acc_or, K
 // K1: per-workgroup digit histogram.  table[d * num_blocks + b] = #keys of block b's range with digit d.
 // Reads 1 key per pair (sizeof(KeyT) bytes), writes RADIX counters per workgroup.
 // ---------------------------------------------------------------------------------------------------------
-template<typename KeyT, int BITS, int THREADS, int TILE, bool XF = false>
+template<typename KeyT, int BITS, int THREADS, int TILE, bool XF = false, bool COLLECT = false>
 __global__ __launch_bounds__(THREADS) void radix_count_kernel(const KeyT* __restrict__ keys_a,
                                                               uint32_t* __restrict__ table, uint32_t n,
                                                               uint32_t shift, uint32_t mask, uint32_t tiles_total,
@@ -223,7 +229,7 @@ __global__ __launch_bounds__(THREADS) void radix_count_kernel(const KeyT* __rest
         if (blockIdx.x == 0 && tid == 0)
         {
             plan->skip[pass] = 0;
-            if (plan_flags & kPlanCollectBits) plan->bits_valid = 1;
+            if (COLLECT && (plan_flags & kPlanCollectBits)) plan->bits_valid = 1;
         }
     }
     for (int i = tid; i < WAVES * RADIX; i += THREADS) (&hist[0][0])[i] = 0;
@@ -265,14 +271,12 @@ __global__ __launch_bounds__(THREADS) void radix_count_kernel(const KeyT* __rest
     auto tally_vec = [&](const VecT& a) {
         if constexpr (sizeof(KeyT) == 4)
         {
-            acc_or |= a.x | a.y | a.z | a.w;
-            acc_and &= a.x & a.y & a.z & a.w;
+            if (COLLECT) acc_or |= a.x | a.y | a.z | a.w, acc_and &= a.x & a.y & a.z & a.w;
             tally(dig(a.x)); tally(dig(a.y)); tally(dig(a.z)); tally(dig(a.w));
         }
         else
         {
-            acc_or |= a.x | a.y;
-            acc_and &= a.x & a.y;
+            if (COLLECT) acc_or |= a.x | a.y, acc_and &= a.x & a.y;
             tally(dig(a.x)); tally(dig(a.y));
         }
     };
@@ -301,20 +305,18 @@ __global__ __launch_bounds__(THREADS) void radix_count_kernel(const KeyT* __rest
 #pragma unroll
         for (int j = 0; j < 8; j++)
         {
-            acc_or |= k[j];
-            acc_and &= k[j];
+            if (COLLECT) acc_or |= k[j], acc_and &= k[j];
             atomicAdd(&my_hist[dig(k[j])], 1u);
         }
     }
     for (; i < end; i += THREADS)
     {
         const KeyT k = keys[i];
-        acc_or |= k;
-        acc_and &= k;
+        if (COLLECT) acc_or |= k, acc_and &= k;
         atomicAdd(&my_hist[dig(k)], 1u);
     }
     __syncthreads();
-    if (plan_flags & kPlanCollectBits) plan_publish_bits<KeyT>(plan, acc_or, acc_and, lane);
+    if (COLLECT && (plan_flags & kPlanCollectBits)) plan_publish_bits<KeyT>(plan, acc_or, acc_and, lane);
 
     for (int d = tid; d < RADIX; d += THREADS)
     {
