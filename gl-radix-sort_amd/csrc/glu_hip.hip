@@ -380,8 +380,17 @@ template<typename KeyT, int BITS, bool LARGE>
 struct PairGeometry;
 template<> struct PairGeometry<uint32_t, 8, true> : Geometry<1024, 12, 1, true> {};
 template<> struct PairGeometry<uint32_t, 4, true> : Geometry<1024, 12, 1, true> {};
-template<> struct PairGeometry<uint32_t, 8, false> : Geometry<256, 16, 3, false> {};
-template<> struct PairGeometry<uint32_t, 4, false> : Geometry<256, 16, 3, false> {};
+// Small geometry of 32-bit keys (tuning builds override these three; tools/small_geometry_sweep.py).  512 x 8 instead of
+// round 1's 256 x 16: the same 4096-pair tile ranked, staged and written by twice the lanes -- a pass of a launch-bound sort
+// is one tile's latency chain per workgroup: 2^16 pairs 48 -> 43 us, 2^20: 72 -> 66 us, 3 M: 105 -> 97 us (1024 x 4 and
+// 2048-pair tiles lose again from 2^20 up; three workgroups per CU beat two and four).
+#ifndef GLU_SMALL_THREADS
+#define GLU_SMALL_THREADS 512
+#define GLU_SMALL_KPT 8
+#define GLU_SMALL_BLOCKS_PER_CU 3
+#endif
+template<> struct PairGeometry<uint32_t, 8, false> : Geometry<GLU_SMALL_THREADS, GLU_SMALL_KPT, GLU_SMALL_BLOCKS_PER_CU, false> {};
+template<> struct PairGeometry<uint32_t, 4, false> : Geometry<GLU_SMALL_THREADS, GLU_SMALL_KPT, GLU_SMALL_BLOCKS_PER_CU, false> {};
 template<> struct PairGeometry<uint64_t, 8, true> : Geometry<512, 16, 1, true> {};
 template<> struct PairGeometry<uint64_t, 4, true> : Geometry<1024, 8, 1, true> {};
 template<> struct PairGeometry<uint64_t, 8, false> : Geometry<256, 8, 4, false> {};
