@@ -442,6 +442,7 @@ struct glu_radix_sort_s
     bool no_lines = false;        // GLU_HIP_SORT_NO_LINES=1: never use the 128-byte-line scatter kernel (tests / tuning)
     bool nt_stores = true;        // GLU_HIP_SORT_NT_STORES=0: plain instead of non-temporal line stores in the line scatter (tuning)
     bool no_bit_shortcut = false; // GLU_HIP_SORT_NO_BIT_SHORTCUT=1: passes on key bits that do not vary still count (tests / tuning)
+    bool equal_shares = false;    // GLU_HIP_SORT_EQUAL_SHARES=1: line path: equal element shares per workgroup instead of whole tiles (tuning)
     bool pairs = true;            // GLU_HIP_SORT_PAIRS=0: every pass of a large sort counts for itself (tests / tuning)
     uint32_t last_pair_roles[kPlanMaxPasses] = {}; // host-side record of the last planned sort (glu_radix_sort_read_plan)
     size_t pair_min = 0;          // GLU_HIP_SORT_PAIR_MIN=N: element count from which passes are paired (tests / tuning)
@@ -554,7 +555,7 @@ glu_status launch_pass(glu_radix_sort_s* s, const KeyT* src_k, const uint32_t* s
     auto count_collect = radix_count_kernel<KeyT, BITS, COUNT_THREADS, G::TILE, XF, !XF>;
     hipLaunchKernelGGL((pa.flags & kPlanCollectBits) ? count_collect : count_plain, dim3(nb), dim3(COUNT_THREADS), 0, stream,
                        src_k, table, (uint32_t) count, shift, mask, tiles, xform, (const KeyT*) dst_k, pa.plan, pa.pass, false,
-                       pa.flags);
+                       pa.flags, 0u);
     HIP_TRY(hipGetLastError()); // every launch is checked where it happens: a failed count launch is reported as such
     s->mark(stream);
     if (!fused)
@@ -595,6 +596,12 @@ glu_status launch_pass_lines(glu_radix_sort_s* s, const KeyT* src_k, const uint3
     uint32_t* table = (uint32_t*) s->table.ptr;
     uint32_t* totals = table + (size_t) RADIX * nb;
 
+    // Whole tiles per workgroup (share = 0).  GLU_HIP_SORT_EQUAL_SHARES=1 (tuning) gives every workgroup the same number of
+    // elements instead (a multiple of 64): it takes the sawtooth out of sort time over n (with 2.3 tiles per workgroup a
+    // whole-tile split has some do 3 and the rest wait: 6 M pairs 237 -> 199 us, 8 M: 283 -> 241 us), but then every
+    // workgroup ends on a partial tile, whose guarded, un-prefetched loads cost as much as a whole tile: 5 M 174 -> 188 us,
+    // 13 M 290 -> 327 us, 2^28 level.  Not the default.
+    const uint32_t share = s->equal_shares ? (uint32_t) ((((uint64_t) count + nb - 1) / nb + 63u) & ~(uint64_t) 63u) : 0u;
     using Smem = LineSmem<KeyT, BITS, G::THREADS, G::KPT, VALS>;
     // the line stores are non-temporal: what a pass writes is next read by the count kernel of the following pass, a
     // once-through stream that runs at full speed only if the lines are not sitting dirty in L2 / Infinity Cache
@@ -635,7 +642,7 @@ glu_status launch_pass_lines(glu_radix_sort_s* s, const KeyT* src_k, const uint3
                 auto count2 = (pa.flags & kPlanCollectBits) ? count2_collect : count2_plain;
                 hipLaunchKernelGGL(count2, dim3(nb), dim3(1024), sizeof(PairCountSmem), stream, src_k, table, (uint32_t*) s->pair_t2.ptr,
                                    (uint32_t) count, shift, mask, pa.shift2, (1u << pa.bits2) - 1, tiles, xform, (const KeyT*) dst_k,
-                                   pa.plan, pa.pass, pa.flags);
+                                   pa.plan, pa.pass, pa.flags, share);
             }
             else
             {
@@ -643,7 +650,7 @@ glu_status launch_pass_lines(glu_radix_sort_s* s, const KeyT* src_k, const uint3
                 auto count4_collect = radix_pair4_count_kernel<KeyT, G::TILE, false, true>;
                 hipLaunchKernelGGL((pa.flags & kPlanCollectBits) ? count4_collect : count4_plain,
                                    dim3(nb * kPairSub), dim3(256), 0, stream, src_k, sub_table, (uint32_t*) s->pair_t2.ptr, (uint32_t) count, shift, mask, pa.shift2,
-                                   (1u << pa.bits2) - 1, tiles, xform, (const KeyT*) dst_k, pa.plan, pa.pass, pa.flags);
+                                   (1u << pa.bits2) - 1, tiles, xform, (const KeyT*) dst_k, pa.plan, pa.pass, pa.flags, share);
             }
             HIP_TRY(hipGetLastError());
         }
@@ -672,7 +679,7 @@ glu_status launch_pass_lines(glu_radix_sort_s* s, const KeyT* src_k, const uint3
         auto count_collect = radix_count_kernel<KeyT, BITS, 1024, G::TILE, XF, !XF>;
         hipLaunchKernelGGL((pa.flags & kPlanCollectBits) ? count_collect : count_plain, dim3(nb), dim3(1024), 0, stream, src_k, table,
                            (uint32_t) count, shift, mask, tiles, xform, (const KeyT*) dst_k, pa.plan, pa.pass, pa.pair_role == 2,
-                           pa.flags);
+                           pa.flags, share);
         HIP_TRY(hipGetLastError());
     }
     s->mark(stream);
@@ -705,7 +712,7 @@ glu_status launch_pass_lines(glu_radix_sort_s* s, const KeyT* src_k, const uint3
     }
     hipLaunchKernelGGL(scatter, dim3(nb), dim3(G::THREADS), sizeof(Smem), stream, src_k, src_v, dst_k, dst_v,
                        (const uint32_t*) table, (const uint32_t*) totals, (uint32_t) count, shift, mask, tiles,
-                       (unsigned long long*) nullptr, xform, pa.plan, pa.pass, ranges);
+                       (unsigned long long*) nullptr, xform, pa.plan, pa.pass, ranges, share);
     s->mark(stream);
     HIP_TRY(hipGetLastError());
     return GLU_OK;
@@ -976,6 +983,7 @@ glu_status glu_radix_sort_create(glu_radix_sort* out)
     if (const char* e = getenv("GLU_HIP_SORT_NO_PLAN")) s->no_plan = atoi(e) != 0;
     if (const char* e = getenv("GLU_HIP_SORT_NO_LINES")) s->no_lines = atoi(e) != 0;
     if (const char* e = getenv("GLU_HIP_SORT_PAIRS")) s->pairs = atoi(e) != 0;
+    if (const char* e = getenv("GLU_HIP_SORT_EQUAL_SHARES")) s->equal_shares = atoi(e) != 0;
     if (const char* e = getenv("GLU_HIP_SORT_NO_BIT_SHORTCUT")) s->no_bit_shortcut = atoi(e) != 0;
     if (const char* e = getenv("GLU_HIP_SORT_PAIR_MIN")) s->pair_min = (size_t) atoll(e);
     if (const char* e = getenv("GLU_HIP_SORT_PAIR_UNIT_DIV"))

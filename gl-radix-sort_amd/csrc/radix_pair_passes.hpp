@@ -51,7 +51,8 @@ __global__ __launch_bounds__(1024) void radix_pair_count_kernel(const KeyT* __re
                                                                 uint32_t* __restrict__ t2, uint32_t n, uint32_t shift,
                                                                 uint32_t mask, uint32_t shift2, uint32_t mask2,
                                                                 uint32_t tiles_total, uint32_t xform, const KeyT* keys_b,
-                                                                PassPlan* plan, uint32_t pass, uint32_t plan_flags = 0)
+                                                                PassPlan* plan, uint32_t pass, uint32_t plan_flags = 0,
+                                                                uint32_t share = 0)
 {
     constexpr int THREADS = 1024;
     constexpr int WAVES = PairCountSmem::WAVES;
@@ -83,11 +84,8 @@ __global__ __launch_bounds__(1024) void radix_pair_count_kernel(const KeyT* __re
     for (uint32_t i = tid; i < sizeof(PairCountSmem) / 4; i += THREADS) reinterpret_cast<uint32_t*>(&s)[i] = 0;
     __syncthreads();
 
-    uint32_t first, last;
-    block_tile_range(blockIdx.x, gridDim.x, tiles_total, first, last);
-    const uint64_t begin = (uint64_t) first * TILE;
-    uint64_t end = (uint64_t) last * TILE;
-    if (end > n) end = n;
+    uint64_t begin, end;
+    block_range(blockIdx.x, gridDim.x, tiles_total, TILE, n, share, begin, end);
     uint32_t* my_hist = s.hist1[wave];
     const KeyCodec<KeyT, XF> codec_in(xform & 3u);
 
@@ -330,7 +328,8 @@ __global__ __launch_bounds__(256) void radix_pair4_count_kernel(const KeyT* __re
                                                                 uint32_t* __restrict__ t2, uint32_t n, uint32_t shift,
                                                                 uint32_t mask, uint32_t shift2, uint32_t mask2,
                                                                 uint32_t tiles_total, uint32_t xform, const KeyT* keys_b,
-                                                                PassPlan* plan, uint32_t pass, uint32_t plan_flags = 0)
+                                                                PassPlan* plan, uint32_t pass, uint32_t plan_flags = 0,
+                                                                uint32_t share = 0)
 {
     constexpr int THREADS = 256;
     constexpr int WAVES = THREADS / kWave;
@@ -359,12 +358,28 @@ __global__ __launch_bounds__(256) void radix_pair4_count_kernel(const KeyT* __re
     KeyT acc_or = 0, acc_and = (KeyT) ~(KeyT) 0; // of the raw keys this thread reads
     for (int i = tid; i < WAVES * 256; i += THREADS) (&hist[0][0])[i] = 0;
     __syncthreads();
-    uint32_t first, last, sf, sl;
-    block_tile_range(b, nb, tiles_total, first, last);
-    block_tile_range(j, kPairSub, last - first, sf, sl);
-    const uint64_t begin = (uint64_t) (first + sf) * TILE;
-    uint64_t end = (uint64_t) (first + sl) * TILE;
-    if (end > n) end = n;
+    // sub-block j of block b: the j-th sixteenth of the block's tiles, or (share > 0: blocks are equal shares of the
+    // elements) the j-th piece of ceil(share / 16) elements rounded up to 64
+    uint64_t begin, end;
+    if (share)
+    {
+        uint64_t b0, b1;
+        block_range(b, nb, tiles_total, TILE, n, share, b0, b1);
+        const uint32_t sub = ((share + kPairSub - 1) / kPairSub + 63u) & ~63u;
+        begin = b0 + (uint64_t) j * sub;
+        if (begin > b1) begin = b1;
+        end = begin + sub;
+        if (end > b1) end = b1;
+    }
+    else
+    {
+        uint32_t first, last, sf, sl;
+        block_tile_range(b, nb, tiles_total, first, last);
+        block_tile_range(j, kPairSub, last - first, sf, sl);
+        begin = (uint64_t) (first + sf) * TILE;
+        end = (uint64_t) (first + sl) * TILE;
+        if (end > n) end = n;
+    }
     uint32_t* my_hist = hist[wave];
     const KeyCodec<KeyT, XF> codec_in(xform & 3u);
     auto combined = [&](KeyT raw) {

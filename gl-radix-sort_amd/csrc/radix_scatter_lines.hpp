@@ -66,7 +66,7 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
     const KeyT* __restrict__ keys_a, const uint32_t* __restrict__ vals_a, KeyT* __restrict__ keys_b,
     uint32_t* __restrict__ vals_b, const uint32_t* __restrict__ table, const uint32_t* __restrict__ totals, uint32_t n,
     uint32_t shift, uint32_t mask, uint32_t tiles_total, unsigned long long* stamps = nullptr, uint32_t xform = 0,
-    PassPlan* plan = nullptr, uint32_t pass = 0, const uint2* __restrict__ ranges = nullptr)
+    PassPlan* plan = nullptr, uint32_t pass = 0, const uint2* __restrict__ ranges = nullptr, uint32_t share = 0)
 {
     const KeyT* __restrict__ src_keys = keys_a;
     const uint32_t* __restrict__ src_vals = vals_a;
@@ -129,9 +129,9 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
     for (int i = tid; i < WAVES * Smem::WCNT_STRIDE / 2; i += THREADS) reinterpret_cast<uint32_t*>(&s.wcnt[0][0])[i] = 0;
     __syncthreads();
 
-    // The workgroup's element range [r0, r1), cut into tiles from r0: a run of whole tiles of the array, or -- the
-    // follower of a pair of passes (radix_pair_passes.hpp) -- a run of whole units of the pass before, which starts and
-    // ends at any element.  Only the last tile of a range can be partial.
+    // The workgroup's element range [r0, r1), cut into tiles from r0: an equal share of the elements (or whole tiles of
+    // the array: tuning harness), or -- the follower of a pair of passes (radix_pair_passes.hpp) -- a run of whole units of
+    // the pass before, which starts and ends at any element.  Only the last tile of a range can be partial.
     uint64_t r0, r1;
     if (ranges && !plan->pair_fallback[pass])
     {
@@ -140,13 +140,7 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
         r1 = r.y;
     }
     else
-    {
-        uint32_t first_tile, end_tile;
-        block_tile_range(b, nb, tiles_total, first_tile, end_tile);
-        r0 = (uint64_t) first_tile * TILE;
-        r1 = (uint64_t) end_tile * TILE;
-        if (r1 > n) r1 = n;
-    }
+        block_range(b, nb, tiles_total, TILE, n, share, r0, r1); // whole tiles (share == 0) or an equal share of the elements
     const uint32_t first = 0, last = (uint32_t) ((r1 - r0 + (uint64_t) TILE - 1) / (uint64_t) TILE);
     const uint32_t last_tile_of_range = last;
     const uint32_t wave_off = wave * WAVE_TILE + lane; // wave-striped: item i of lane l of wave w = element w*64*KPT + i*64 + l

@@ -110,6 +110,29 @@ __device__ __forceinline__ uint32_t wave_exclusive_sum(uint32_t v, uint32_t lane
     return (uint32_t) incl - v;
 }
 
+// Element range [begin, end) of workgroup b.  share == 0: its whole tiles (block_tile_range; the kernels of the small
+// geometry, whose scatter works on whole tiles).  share > 0 (the line kernel and the count kernels in front of it): an
+// equal share of the elements, a multiple of 64 -- no workgroup gets a whole tile more than another, which is what made
+// sort time a sawtooth over n between 4 M and 60 M elements (2.3 tiles per workgroup = some with 3, the rest waiting).
+__device__ __forceinline__ void block_range(uint32_t b, uint32_t nb, uint32_t tiles_total, uint32_t tile, uint32_t n,
+                                            uint32_t share, uint64_t& begin, uint64_t& end)
+{
+    if (share)
+    {
+        begin = (uint64_t) b * share;
+        if (begin > n) begin = n;
+        end = begin + share;
+    }
+    else
+    {
+        uint32_t first, last;
+        block_tile_range(b, nb, tiles_total, first, last);
+        begin = (uint64_t) first * tile;
+        end = (uint64_t) last * tile;
+    }
+    if (end > n) end = n;
+}
+
 // Sum of the first `wave` entries of an LDS array of per-wave totals (count <= 64), without a branch per entry: lane l
 // reads entry l, the wave scans them, and the (wave-uniform) result is read from lane `wave`.
 __device__ __forceinline__ uint32_t sum_of_preceding_waves(const uint32_t* totals, int count, uint32_t wave, uint32_t lane)
@@ -204,7 +227,8 @@ __global__ __launch_bounds__(THREADS) void radix_count_kernel(const KeyT* __rest
                                                               uint32_t shift, uint32_t mask, uint32_t tiles_total,
                                                               uint32_t xform = 0, const KeyT* keys_b = nullptr,
                                                               PassPlan* plan = nullptr, uint32_t pass = 0,
-                                                              bool pair_follower = false, uint32_t plan_flags = 0)
+                                                              bool pair_follower = false, uint32_t plan_flags = 0,
+                                                              uint32_t share = 0)
 {
     constexpr int RADIX = 1 << BITS;
     constexpr int WAVES = THREADS / kWave;
@@ -235,11 +259,8 @@ __global__ __launch_bounds__(THREADS) void radix_count_kernel(const KeyT* __rest
     for (int i = tid; i < WAVES * RADIX; i += THREADS) (&hist[0][0])[i] = 0;
     __syncthreads();
 
-    uint32_t first, last;
-    block_tile_range(blockIdx.x, gridDim.x, tiles_total, first, last);
-    const uint64_t begin = (uint64_t) first * TILE;
-    uint64_t end = (uint64_t) last * TILE;
-    if (end > n) end = n;
+    uint64_t begin, end;
+    block_range(blockIdx.x, gridDim.x, tiles_total, TILE, n, share, begin, end);
 
     uint32_t* my_hist = hist[wave];
     KeyT acc_or = 0, acc_and = (KeyT) ~(KeyT) 0; // of the raw keys this thread reads

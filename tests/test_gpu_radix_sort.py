@@ -1217,3 +1217,24 @@ def test_passes_on_key_bits_that_do_not_vary_are_identities_without_counting(G, 
     order = np.argsort(i32, kind="stable")
     assert (gk == i32[order]).all() and (gv == vals[order]).all()
     assert 2 not in _sort_and_plan.last_skip_raw
+
+
+@pytest.mark.parametrize("bits", DIGIT_BITS)
+def test_equal_element_shares_per_workgroup(G, bits):
+    """GLU_HIP_SORT_EQUAL_SHARES=1 (a tuning switch): the line path cuts the input into equal element shares instead of whole
+    tiles, every workgroup ends on a partial tile; with and without paired passes, 32- and 64-bit keys."""
+    rng = np.random.default_rng(61 + bits)
+    for n, pair_min in ((4_100_000, "0"), ((1 << 23) + 4321, "1"), (6_000_001, "1")):
+        keys = rng.integers(0, 2**32, n, dtype=np.uint32)
+        keys[::9] = keys[3]
+        vals = np.arange(n, dtype=np.uint32)
+        gk, gv, _, _ = _sort_and_plan(G, keys, vals, 32 // bits, bits=bits,
+                                      env={"GLU_HIP_SORT_EQUAL_SHARES": "1", "GLU_HIP_SORT_PAIR_MIN": pair_min})
+        _check_against_oracle(keys, vals, gk, gv)
+    n = 5_000_003
+    k64 = rng.integers(0, 2**64, n, dtype=np.uint64)
+    vals = np.arange(n, dtype=np.uint32)
+    gk, gv, _, _ = _sort_and_plan(G, k64, vals, 64 // bits, key_bytes=8, bits=bits,
+                                  env={"GLU_HIP_SORT_EQUAL_SHARES": "1", "GLU_HIP_SORT_PAIR_MIN": "1"})
+    order = np.argsort(k64, kind="stable")
+    assert (gk == k64[order]).all() and (gv == vals[order]).all()

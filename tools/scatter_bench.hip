@@ -279,7 +279,7 @@ void run_lines(Ctx& c, uint32_t shift, uint32_t mask_override = 0)
     CK(hipMemset(c.vals2, 0xff, c.n * 4));
     float t_scatter = time_min(c, 5, [&] {
         hipLaunchKernelGGL(scatter, dim3(nb), dim3(THREADS), sizeof(Smem), 0, skeys, VALS ? svals : nullptr, c.keys2, VALS ? c.vals2 : nullptr,
-                           c.table, totals, (uint32_t) n_eff, shift, mask, tiles, (unsigned long long*) nullptr, 0u, (PassPlan*) nullptr, 0u, (const uint2*) nullptr);
+                           c.table, totals, (uint32_t) n_eff, shift, mask, tiles, (unsigned long long*) nullptr, 0u, (PassPlan*) nullptr, 0u, (const uint2*) nullptr, 0u);
     });
     CK(hipGetLastError());
     CK(hipDeviceSynchronize());
@@ -292,7 +292,7 @@ void run_lines(Ctx& c, uint32_t shift, uint32_t mask_override = 0)
     CK(hipMalloc(&st, 128));
     CK(hipMemset(st, 0, 128));
     hipLaunchKernelGGL(scatter_st, dim3(nb), dim3(THREADS), sizeof(Smem), 0, skeys, VALS ? svals : nullptr, c.keys2, VALS ? c.vals2 : nullptr, c.table,
-                       totals, (uint32_t) n_eff, shift, mask, tiles, st, 0u, (PassPlan*) nullptr, 0u, (const uint2*) nullptr);
+                       totals, (uint32_t) n_eff, shift, mask, tiles, st, 0u, (PassPlan*) nullptr, 0u, (const uint2*) nullptr, 0u);
     unsigned long long hst[16];
     CK(hipMemcpy(hst, st, 128, hipMemcpyDeviceToHost));
     CK(hipFree(st));
@@ -303,7 +303,7 @@ void run_lines(Ctx& c, uint32_t shift, uint32_t mask_override = 0)
         for (int r = 0; r < 5; r++)
         {
             hipLaunchKernelGGL(scatter, dim3(nb), dim3(THREADS), sizeof(Smem), 0, skeys, VALS ? svals : nullptr, c.keys2, VALS ? c.vals2 : nullptr,
-                               c.table, totals, (uint32_t) n_eff, shift, mask, tiles, (unsigned long long*) nullptr, 0u, (PassPlan*) nullptr, 0u, (const uint2*) nullptr);
+                               c.table, totals, (uint32_t) n_eff, shift, mask, tiles, (unsigned long long*) nullptr, 0u, (PassPlan*) nullptr, 0u, (const uint2*) nullptr, 0u);
             CK(hipEventRecord(c.ev[0]));
             hipLaunchKernelGGL((radix_count_kernel<uint32_t, BITS, THREADS, TILE>), dim3(nb), dim3(THREADS), 0, 0, c.keys2, c.table + (1 << 20), (uint32_t) n_eff,
                                shift + BITS, mask, tiles, 0u);
@@ -713,7 +713,7 @@ int main(int argc, char** argv)
     {   // count kernel alone: threads per workgroup at one workgroup per CU
         const uint32_t tiles = (uint32_t) ((c.n + 12288 - 1) / 12288), nb = std::min<uint32_t>(tiles, (uint32_t) c.cus);
         auto cnt = [&](auto kern, int threads, const char* name) {
-            float t = time_min(c, 7, [&] { hipLaunchKernelGGL(kern, dim3(nb), dim3(threads), 0, 0, c.keys, c.table, (uint32_t) c.n, shift, 255u, tiles, 0u, (const uint32_t*) nullptr, (PassPlan*) nullptr, 0u, false, 0u); });
+            float t = time_min(c, 7, [&] { hipLaunchKernelGGL(kern, dim3(nb), dim3(threads), 0, 0, c.keys, c.table, (uint32_t) c.n, shift, 255u, tiles, 0u, (const uint32_t*) nullptr, (PassPlan*) nullptr, 0u, false, 0u, 0u); });
             printf("count %s: %.3f ms (%.0f GB/s)\n", name, t, c.n * 4.0 / t / 1e6);
         };
         cnt(radix_count_kernel<uint32_t, 8, 256, 12288>, 256, "8-bit  256 thr");
