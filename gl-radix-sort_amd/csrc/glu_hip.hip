@@ -536,7 +536,12 @@ glu_status launch_pass(glu_radix_sort_s* s, const KeyT* src_k, const uint32_t* s
     auto scatter = radix_scatter_kernel<KeyT, BITS, G::THREADS, G::KPT, G::CARRY, 0, false, G::BLOCKS_PER_CU * G::THREADS / 256, 1, false, false, XF, VALS>;
     // launch-bound sizes (small geometry, few workgroups): the scatter sums the counts itself, no row-scan launch
     auto scatter_fused = radix_scatter_kernel<KeyT, BITS, G::THREADS, G::KPT, G::CARRY, 0, false, G::BLOCKS_PER_CU * G::THREADS / 256, 1, false, false, XF, VALS, !LARGE>;
-    const bool fused = !LARGE && nb <= kFusedScanMaxBlocks && !histogram_out && !s->no_fused_scan && !pa.plan;
+    // (THREADS / RADIX threads share a digit's row in that prologue.  8-bit digits, 2 sharers: up to 32 workgroups -- with 64 the
+    // prologue costs more than the launch, 2^18 pairs 54 -> 60 us.  4-bit digits, 32 sharers: up to 256 workgroups, 2^18 pairs 88
+    // -> 75 us, 2^20: 114 -> 106 us; with 512 every workgroup reads 32 KiB of table and the pass loses again.)
+    constexpr uint32_t kRowSharers = G::THREADS / RADIX >= 1 ? G::THREADS / RADIX : 1;
+    constexpr uint32_t kFusedLimit = kFusedScanMaxBlocks * (kRowSharers / 4 >= 1 ? kRowSharers / 4 : 1);
+    const bool fused = !LARGE && nb <= kFusedLimit && !histogram_out && !s->no_fused_scan && !pa.plan;
     static std::once_flag lds_opt_in; // per instantiation: allow > 64 KiB of dynamic LDS (handles may live on several threads)
     static hipError_t lds_opt_in_result = hipSuccess;
     std::call_once(lds_opt_in, [&] {

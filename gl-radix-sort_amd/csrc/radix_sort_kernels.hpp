@@ -404,7 +404,8 @@ __global__ __launch_bounds__(THREADS) void radix_row_scan_kernel(uint32_t* __res
     }
 }
 
-constexpr uint32_t kFusedScanMaxBlocks = 32; // FUSED_SCAN scatter: every workgroup reads RADIX x nb counts itself
+constexpr uint32_t kFusedScanMaxBlocks = 32; // FUSED_SCAN scatter: every workgroup reads RADIX x nb counts itself, at most this many per thread
+                                             // (THREADS / RADIX threads share a row; the host raises the limit for 4-bit digits: launch_pass)
 
 // ---------------------------------------------------------------------------------------------------------
 // K4: stable scatter of (key, val) by one digit.
@@ -568,18 +569,41 @@ __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_ker
         uint32_t t = 0, before = 0;
         if (FUSED_SCAN)
         {
-            if (tid < RADIX)
+            // THREADS / RADIX threads share a digit's row: thread (part, d) sums the entries [part * chunk, + chunk) -- at most
+            // kFusedScanMaxBlocks independent loads per thread (measured against 16 guarded loads in flight and against a
+            // block-major table: this plain loop wins; twice as many loads per thread cost more than the row-scan launch
+            // they save) -- and thread d adds the parts up.  With 4-bit digits 32 threads share a row, and sorts of up to 256
+            // workgroups run without the row-scan kernel (the host decides: launch_pass).
+            constexpr uint32_t PARTS = THREADS / RADIX >= 1 ? THREADS / RADIX : 1;
+            uint32_t* scratch = reinterpret_cast<uint32_t*>(&s.stage); // (the staging area is not in use yet)
+            static_assert(sizeof(s.stage) >= 2 * THREADS * sizeof(uint32_t), "prologue scratch");
+            const uint32_t part = tid / RADIX, d = tid % RADIX;
+            if (part < PARTS)
             {
-                // nb <= kFusedScanMaxBlocks, uniform trip count, independent loads of one contiguous row per thread
-                // (measured against 16 guarded loads in flight and against a block-major table: this plain loop wins)
-                const uint32_t* row = table + (size_t) tid * nb;
-                for (uint32_t j = 0; j < nb; j++)
+                const uint32_t chunk = (nb + PARTS - 1) / PARTS;
+                const uint32_t j0 = part * chunk, j1 = j0 + chunk < nb ? j0 + chunk : nb;
+                const uint32_t* row = table + (size_t) d * nb;
+                uint32_t tp = 0, bp = 0;
+                for (uint32_t j = j0; j < j1; j++)
                 {
                     const uint32_t c = row[j];
-                    t += c;
-                    before += j < b ? c : 0u;
+                    tp += c;
+                    bp += j < b ? c : 0u;
+                }
+                scratch[tid] = tp;
+                scratch[THREADS + tid] = bp;
+            }
+            __syncthreads();
+            if (tid < RADIX)
+            {
+#pragma unroll
+                for (uint32_t k = 0; k < PARTS; k++)
+                {
+                    t += scratch[k * RADIX + tid];
+                    before += scratch[THREADS + k * RADIX + tid];
                 }
             }
+            __syncthreads(); // the staging area is free again
         }
         else
             t = tid < RADIX ? totals[tid] : 0;
