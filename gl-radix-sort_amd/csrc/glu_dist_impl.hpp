@@ -11,7 +11,15 @@
 //   3. every rank derives the same contiguous bucket -> rank map (a bucket is never split) and its send / receive counts;
 //   4. ONE grouped exchange (ncclGroupStart .. ncclGroupEnd) carries keys and values to and from every peer, receive
 //      segments in source-rank order; the part that stays on the rank is a device copy;
-//   5. local stable sort of what was received.
+//   5. local stable sort of what was received: the shard arrives as one message per source rank, each grouped by bucket,
+//      and is sorted by its low 24 bits per bucket with three SEGMENTED passes (radix_seg_passes.hpp; the first one reads
+//      the messages where they lie, so regrouping them by bucket costs no pass).  Shards that are small, made of very many
+//      tiny pieces, or partitioned on a lower byte take the ordinary sort of all 32 bits instead.
+// Errors are collective: what a rank finds wrong before a collective (arguments, sizes, allocations) travels with the data of
+// that collective -- a status word in the histogram rows of glu_dist_sort_begin, a one-word all-gather in front of the exchange
+// of glu_dist_sort_finish -- and every rank returns the failure before anything is sent or received.  What all ranks can
+// compute alike (every rank's shard size) is checked by all of them.  A failing RCCL or HIP call after that point is not
+// recoverable (the communicator is broken); it is reported by the rank that sees it.
 // Concatenating the ranks' outputs in rank order equals the single-device stable sort: equal keys share a bucket, a
 // bucket has one owner, the partition and the local sort are stable, and receive segments keep (source rank, source
 // index) order.  RCCL is bound with dlopen at first use, so the library has no link-time dependency on it and a process
@@ -25,6 +33,12 @@ namespace
 {
 constexpr int kDistBuckets = 256;
 constexpr uint32_t kDistTopBits = 8;
+// words per rank in the histogram all-gather: the 256 bucket counts, then the slice's element count (low, high word) and the
+// rank's status so far (0 = fine): every rank sees every rank's row and takes the same decisions
+constexpr int kDistRow = 264;
+constexpr int kDistRowCountLo = 256, kDistRowCountHi = 257, kDistRowStatus = 258;
+constexpr uint64_t kDistShardLimit = 0xFFFF0000ull; // pairs one device sorts (32-bit indexing)
+constexpr size_t kDistSegMinDefault = (size_t) 1 << 24; // shards below this take the ordinary local sort
 
 struct RcclApi
 {
@@ -172,8 +186,15 @@ struct glu_dist_s
     size_t marks_used = 0;
     Scratch part_k, part_v;             // the local slice grouped by bucket (send side)
     Scratch recv_k, recv_v;             // receive side of glu_dist_sort_ptr (glu_dist_sort_finish takes the caller's)
-    Scratch hist;                       // [256] local bucket histogram, [world * 256] gathered
-    uint32_t* all_hist_host = nullptr;  // pinned
+    Scratch hist;                       // [kDistRow] local row, [world * kDistRow] gathered rows, [4 + world] status words
+    uint32_t* all_hist_host = nullptr;  // pinned: the gathered rows; behind them 8 words of trailer staging, 4 + world of status
+    std::vector<uint32_t> hist_dense;   // [world][256] the bucket counts of the gathered rows
+    uint64_t shard_limit = kDistShardLimit; // GLU_HIP_DIST_TEST_SHARD_LIMIT lowers it (tests of the collective error path)
+    size_t seg_min = kDistSegMinDefault;    // GLU_HIP_DIST_SEG_MIN: shard size from which the local sort is segmented
+    bool seg_enabled = true;                // GLU_HIP_DIST_SEG=0: always the ordinary local sort
+    bool seg_forced = false;                // GLU_HIP_DIST_SEG=2: segmented whenever the shard has 2^16 pairs, however fragmented (tests)
+    int test_fail_begin = -1, test_fail_finish = -1; // GLU_HIP_DIST_TEST_FAIL=begin:<rank> / finish:<rank>: that rank reports a failure
+    uint32_t last_local_sort = 0;           // 1 = the last sort's local sort was segmented, 0 = ordinary (glu_dist_last_local_sort)
     std::vector<int> owner;
     std::vector<uint64_t> send_counts, recv_counts;
     size_t local_count = 0;
@@ -233,6 +254,16 @@ glu_status glu_dist_create(const void* unique_id, size_t id_bytes, int world_siz
     d->rank = rank;
     d->owner.assign(kDistBuckets, 0);
     if (const char* e = getenv("GLU_HIP_DIST_TEST_REPARTITION")) d->repartition_at_world_1 = atoi(e) != 0;
+    if (const char* e = getenv("GLU_HIP_DIST_TEST_SHARD_LIMIT"))
+        if (atoll(e) > 0) d->shard_limit = (uint64_t) atoll(e);
+    if (const char* e = getenv("GLU_HIP_DIST_SEG_MIN")) d->seg_min = (size_t) atoll(e);
+    if (const char* e = getenv("GLU_HIP_DIST_SEG")) d->seg_enabled = atoi(e) != 0, d->seg_forced = atoi(e) == 2;
+    if (const char* e = getenv("GLU_HIP_DIST_TEST_FAIL"))
+    {
+        if (strncmp(e, "begin:", 6) == 0) d->test_fail_begin = atoi(e + 6);
+        if (strncmp(e, "finish:", 7) == 0) d->test_fail_finish = atoi(e + 7);
+    }
+    d->hist_dense.assign((size_t) world_size * kDistBuckets, 0);
     d->send_counts.assign(world_size, 0);
     d->recv_counts.assign(world_size, 0);
     auto cleanup = [&](glu_status st) {
@@ -250,9 +281,9 @@ glu_status glu_dist_create(const void* unique_id, size_t id_bytes, int world_siz
     hipError_t e = hipStreamCreateWithFlags(&d->aux, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&d->ev_hist, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&d->ev_plan, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipHostMalloc((void**) &d->all_hist_host, (size_t) world_size * kDistBuckets * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipHostMalloc((void**) &d->all_hist_host, ((size_t) world_size * kDistRow + 8 + 4 + world_size) * sizeof(uint32_t));
     if (e != hipSuccess) return cleanup(fail(GLU_ERROR_DEVICE, "glu_dist_create: %s", hipGetErrorString(e)));
-    if (glu_status st = d->hist.reserve((size_t) (world_size + 1) * kDistBuckets * sizeof(uint32_t)); st != GLU_OK) return cleanup(st);
+    if (glu_status st = d->hist.reserve(((size_t) (world_size + 1) * kDistRow + 4 + world_size) * sizeof(uint32_t)); st != GLU_OK) return cleanup(st);
     *out = d;
     return GLU_OK;
 }
@@ -260,6 +291,7 @@ glu_status glu_dist_create(const void* unique_id, size_t id_bytes, int world_siz
 glu_status glu_dist_destroy(glu_dist d)
 {
     if (!d) return GLU_OK;
+    GLU_TRY(enter());
     (void) hipDeviceSynchronize();
     if (d->comm) (void) rccl().CommDestroy(d->comm);
     if (d->sorter) (void) glu_radix_sort_destroy(d->sorter);
@@ -319,10 +351,11 @@ glu_status glu_dist_prepare(glu_dist d, size_t local_count, size_t recv_capacity
 
 glu_status glu_dist_set_reserved_cus(glu_dist d, int cus)
 {
+    GLU_TRY(enter());
     if (!d) return fail(GLU_ERROR_INVALID_ARGUMENT, "dist is NULL");
     if (cus < 0 || cus * 4 >= g_dev.num_cus) return fail(GLU_ERROR_INVALID_ARGUMENT, "cannot reserve %d of %d CUs", cus, g_dev.num_cus);
     d->reserved_cus = cus;
-    d->sorter->max_blocks = cus ? (uint32_t) (g_dev.num_cus - cus) : 0u;
+    d->sorter->reserved_cus = (uint32_t) cus; // every pass: (CUs - reserved) x workgroups per CU of its geometry
     return GLU_OK;
 }
 
@@ -378,19 +411,38 @@ glu_status glu_dist_plan_counts(const uint32_t* all_hist, int world_size, int ra
 // Steps 1-3: partition the local slice, exchange the histograms, plan.  The partition is enqueued on `stream`; the call
 // returns when the host has the plan (it waited for the histogram exchange on the side stream, not for the partition's
 // scatter kernel).  *recv_count = number of pairs this rank will receive: the caller sizes its receive arrays with it.
+// Collective: what this rank finds wrong with its own arguments or allocations travels in its histogram row, and every
+// rank returns a failure (none is left waiting in a collective).
 glu_status glu_dist_sort_begin(glu_dist d, const uint32_t* keys, const uint32_t* vals, size_t local_count, void* stream,
                                size_t* recv_count)
 {
     GLU_TRY(enter());
     if (!d) return fail(GLU_ERROR_INVALID_ARGUMENT, "dist is NULL");
-    if (local_count > 0 && (!keys || !vals)) return fail(GLU_ERROR_INVALID_ARGUMENT, "NULL array");
-    if (local_count > 0xFFFF0000ull) return fail(GLU_ERROR_INVALID_ARGUMENT, "count %zu does not fit 32-bit indexing", local_count);
     hipStream_t st = pick_stream(stream);
+    d->began = false;
+    // rank-local findings: remembered, not returned -- the rank still takes part in the histogram exchange
+    glu_status local = GLU_OK;
+    std::string local_message;
+    auto note = [&](glu_status status) {
+        if (local == GLU_OK && status != GLU_OK)
+        {
+            local = status;
+            local_message = g_last_error;
+        }
+    };
+    if (local_count > 0 && (!keys || !vals)) note(fail(GLU_ERROR_INVALID_ARGUMENT, "NULL array"));
+    if (local_count > kDistShardLimit) note(fail(GLU_ERROR_INVALID_ARGUMENT, "count %zu does not fit 32-bit indexing", local_count));
+    note(d->part_k.reserve(std::max<size_t>(local_count, 1) * sizeof(uint32_t)));
+    note(d->part_v.reserve(std::max<size_t>(local_count, 1) * sizeof(uint32_t)));
+    {
+        uint64_t cap = (uint64_t) g_dev.num_cus * kMaxBlocksPerCu;
+        note(d->sorter->table.reserve((kMaxRadix * cap + kMaxRadix) * sizeof(uint32_t)));
+    }
+    if (d->test_fail_begin == d->rank) note(fail(GLU_ERROR_OUT_OF_MEMORY, "injected failure of rank %d (GLU_HIP_DIST_TEST_FAIL)", d->rank));
     glu_dist_s::Marks* marks = dist_marks(d, true);
-    GLU_TRY(d->part_k.reserve(std::max<size_t>(local_count, 1) * sizeof(uint32_t)));
-    GLU_TRY(d->part_v.reserve(std::max<size_t>(local_count, 1) * sizeof(uint32_t)));
     uint32_t* hist = (uint32_t*) d->hist.ptr;
-    uint32_t* all_hist = hist + kDistBuckets;
+    uint32_t* all_hist = hist + kDistRow;
+    uint32_t* trailer_host = d->all_hist_host + (size_t) d->world * kDistRow;
     if (marks) HIP_TRY(hipEventRecord(marks->e[0], st));
 
     // 1 + 2, on the top key byte first.  If every key of every rank shares that byte (24-bit keys, small integers ...) all
@@ -400,56 +452,93 @@ glu_status glu_dist_sort_begin(glu_dist d, const uint32_t* keys, const uint32_t*
     // inputs.)  Every rank sees the same gathered histograms and takes the same decision.
     for (uint32_t shift = 32 - kDistTopBits;; shift -= kDistTopBits)
     {
+        // the row's trailer (the host's copy of the previous one has been consumed: the call waited for its all-gather)
+        trailer_host[0] = (uint32_t) ((uint64_t) local_count & 0xFFFFFFFFu);
+        trailer_host[1] = (uint32_t) ((uint64_t) local_count >> 32);
+        trailer_host[2] = (uint32_t) local;
+        trailer_host[3] = 0;
+        HIP_TRY(hipMemcpyAsync(hist + kDistRowCountLo, trailer_host, 4 * sizeof(uint32_t), hipMemcpyHostToDevice, st));
         // 1. stable partition by the bucket (key >> shift) & 255; the histogram is ready (and ev_hist recorded) after the
         //    row scan, before the scatter
-        if (local_count == 0)
+        if (local_count == 0 || local != GLU_OK)
         {
             HIP_TRY(hipMemsetAsync(hist, 0, kDistBuckets * sizeof(uint32_t), st));
             HIP_TRY(hipEventRecord(d->ev_hist, st));
         }
         else
         {
-            uint64_t cap = (uint64_t) g_dev.num_cus * kMaxBlocksPerCu;
-            GLU_TRY(d->sorter->table.reserve((kMaxRadix * cap + kMaxRadix) * sizeof(uint32_t)));
-            const uint32_t saved_blocks = d->sorter->max_blocks;
+            const uint32_t saved_reserved = d->sorter->reserved_cus;
             // The histogram exchange of step 2 needs a CU beside the scatter, and workgroups are dealt round-robin to the 8
             // XCDs: with 254 workgroups six XCDs are full and a one-workgroup kernel bound for one of them waits for the
             // scatter to end (measured: 0.40 ms for the exchange with 2 CUs left, 0.016 ms with 8 = one per XCD).
             const int leave = std::max(d->reserved_cus, 8);
-            if (leave > 0 && g_dev.num_cus > 4 * leave && (saved_blocks == 0 || saved_blocks > (uint32_t) (g_dev.num_cus - leave)))
-                d->sorter->max_blocks = (uint32_t) (g_dev.num_cus - leave);
+            if (g_dev.num_cus > 4 * leave) d->sorter->reserved_cus = (uint32_t) leave;
             d->sorter->after_histogram_event = d->ev_hist;
             glu_status ps = dispatch_pass<uint32_t>(d->sorter, keys, vals, (uint32_t*) d->part_k.ptr, (uint32_t*) d->part_v.ptr,
                                                     local_count, shift, kDistTopBits, hist, st);
             d->sorter->after_histogram_event = nullptr;
-            d->sorter->max_blocks = saved_blocks;
-            GLU_TRY(ps);
+            d->sorter->reserved_cus = saved_reserved;
+            GLU_TRY(ps); // (a launch failure: not recoverable, see the head of this file)
         }
         if (marks && shift == 32 - kDistTopBits) HIP_TRY(hipEventRecord(marks->e[1], st));
 
-        // 2. every rank learns every rank's histogram (R x 256 words): side stream, beside the scatter kernel
+        // 2. every rank learns every rank's row (R x 264 words): side stream, beside the scatter kernel
         HIP_TRY(hipStreamWaitEvent(d->aux, d->ev_hist, 0));
         if (marks && shift == 32 - kDistTopBits) HIP_TRY(hipEventRecord(marks->e[4], d->aux));
-        NCCL_TRY(rccl().AllGather(hist, all_hist, kDistBuckets, ncclUint32, d->comm, d->aux));
-        HIP_TRY(hipMemcpyAsync(d->all_hist_host, all_hist, (size_t) d->world * kDistBuckets * sizeof(uint32_t), hipMemcpyDeviceToHost, d->aux));
+        NCCL_TRY(rccl().AllGather(hist, all_hist, kDistRow, ncclUint32, d->comm, d->aux));
+        HIP_TRY(hipMemcpyAsync(d->all_hist_host, all_hist, (size_t) d->world * kDistRow * sizeof(uint32_t), hipMemcpyDeviceToHost, d->aux));
         if (marks) HIP_TRY(hipEventRecord(marks->e[5], d->aux));
         HIP_TRY(hipEventRecord(d->ev_plan, d->aux));
         HIP_TRY(hipEventSynchronize(d->ev_plan));
+
+        // every rank reads every row: the same verdict everywhere
+        for (int r = 0; r < d->world; r++)
+        {
+            const uint32_t* row = d->all_hist_host + (size_t) r * kDistRow;
+            if (row[kDistRowStatus] != 0)
+            {
+                if (r == d->rank)
+                {
+                    g_last_error = local_message;
+                    return local;
+                }
+                return fail((glu_status) row[kDistRowStatus], "rank %d reported a failure in glu_dist_sort_begin (status %u): no rank sorts", r,
+                            row[kDistRowStatus]);
+            }
+        }
+        for (int r = 0; r < d->world; r++)
+        {
+            const uint32_t* row = d->all_hist_host + (size_t) r * kDistRow;
+            uint64_t sum = 0;
+            for (int b = 0; b < kDistBuckets; b++) sum += row[b];
+            const uint64_t count_r = (uint64_t) row[kDistRowCountLo] | ((uint64_t) row[kDistRowCountHi] << 32);
+            if (sum != count_r)
+                return fail(GLU_ERROR_INVALID_STATE, "rank %d: bucket histogram sums to %llu, its slice holds %llu", r, (unsigned long long) sum,
+                            (unsigned long long) count_r);
+            memcpy(&d->hist_dense[(size_t) r * kDistBuckets], row, kDistBuckets * sizeof(uint32_t));
+        }
         d->partition_shift = shift;
-        if (shift == 0 || (d->world == 1 && !d->repartition_at_world_1) || !dist_single_bucket(d->all_hist_host, d->world)) break;
+        if (shift == 0 || (d->world == 1 && !d->repartition_at_world_1) || !dist_single_bucket(d->hist_dense.data(), d->world)) break;
         if (marks) HIP_TRY(hipEventRecord(marks->e[1], st)); // the repeated partition counts as partition time
     }
 
-    // 3. identical plan on every rank
-    dist_plan_buckets(d->all_hist_host, d->world, d->owner.data());
-    dist_plan_counts(d->all_hist_host, d->world, d->rank, d->owner.data(), d->send_counts.data(), d->recv_counts.data());
-    uint64_t total = 0, sent = 0;
-    for (int r = 0; r < d->world; r++) total += d->recv_counts[r], sent += d->send_counts[r];
-    if (sent != local_count) return fail(GLU_ERROR_INVALID_STATE, "bucket histogram sums to %llu, expected %zu", (unsigned long long) sent, local_count);
-    if (total > 0xFFFF0000ull)
-        return fail(GLU_ERROR_INVALID_ARGUMENT,
-                    "this rank would receive %llu pairs (buckets are never split: a hot bucket bounds the balance), more than one device sorts",
-                    (unsigned long long) total);
+    // 3. identical plan on every rank; every rank checks every rank's shard size
+    dist_plan_buckets(d->hist_dense.data(), d->world, d->owner.data());
+    for (int r = 0; r < d->world; r++)
+    {
+        uint64_t shard = 0;
+        for (int b = 0; b < kDistBuckets; b++)
+            if (d->owner[b] == r)
+                for (int q = 0; q < d->world; q++) shard += d->hist_dense[(size_t) q * kDistBuckets + b];
+        if (shard > d->shard_limit)
+            return fail(GLU_ERROR_INVALID_ARGUMENT,
+                        "rank %d would receive %llu pairs (buckets are never split: a hot bucket bounds the balance), more than one device "
+                        "sorts (%llu): no rank sorts",
+                        r, (unsigned long long) shard, (unsigned long long) d->shard_limit);
+    }
+    dist_plan_counts(d->hist_dense.data(), d->world, d->rank, d->owner.data(), d->send_counts.data(), d->recv_counts.data());
+    uint64_t total = 0;
+    for (int r = 0; r < d->world; r++) total += d->recv_counts[r];
     d->local_count = local_count;
     d->recv_total = total;
     d->began = true;
@@ -457,19 +546,97 @@ glu_status glu_dist_sort_begin(glu_dist d, const uint32_t* keys, const uint32_t*
     return GLU_OK;
 }
 
-// Steps 4-5 into the caller's receive arrays (capacity in pairs, at least the count glu_dist_sort_begin returned).
-glu_status glu_dist_sort_finish(glu_dist d, uint32_t* recv_keys, uint32_t* recv_vals, size_t capacity, void* stream)
+} // extern "C"
+
+namespace
 {
-    GLU_TRY(enter());
-    if (!d) return fail(GLU_ERROR_INVALID_ARGUMENT, "dist is NULL");
+// The pieces of the shard as it arrives (source-major: the message of source s holds this rank's buckets in ascending
+// order), as segments = buckets, in the order (source, bucket): a bucket's pieces are in source order, which is the
+// stable order of its elements.
+void dist_shard_pieces(const glu_dist_s* d, std::vector<SegPiece>& pieces, uint32_t& nseg)
+{
+    int g0 = kDistBuckets, g1 = 0;
+    for (int b = 0; b < kDistBuckets; b++)
+        if (d->owner[b] == d->rank) g0 = std::min(g0, b), g1 = std::max(g1, b + 1);
+    nseg = g1 > g0 ? (uint32_t) (g1 - g0) : 0u;
+    pieces.clear();
+    uint64_t at = 0;
+    for (int s = 0; s < d->world; s++)
+        for (int b = g0; b < g1; b++)
+        {
+            const uint64_t len = d->hist_dense[(size_t) s * kDistBuckets + b];
+            if (len) pieces.push_back(SegPiece{at, len, (uint32_t) (b - g0)});
+            at += len;
+        }
+}
+
+// Steps 4-5.  `pre_status`: what the caller (glu_dist_sort_ptr) found wrong on this rank before the call.
+glu_status dist_sort_finish(glu_dist_s* d, uint32_t* recv_keys, uint32_t* recv_vals, size_t capacity, hipStream_t st, glu_status pre_status)
+{
     if (!d->began) return fail(GLU_ERROR_INVALID_STATE, "glu_dist_sort_finish without glu_dist_sort_begin");
     d->began = false;
     const size_t n_recv = (size_t) d->recv_total;
-    if (n_recv > capacity) return fail(GLU_ERROR_INVALID_ARGUMENT, "receive arrays hold %zu pairs, %zu arrive", capacity, n_recv);
-    if (n_recv > 0 && (!recv_keys || !recv_vals)) return fail(GLU_ERROR_INVALID_ARGUMENT, "NULL receive array");
-    hipStream_t st = pick_stream(stream);
+    // rank-local findings first, none returned yet: the ranks agree on them before anything is sent
+    glu_status local = pre_status;
+    std::string local_message = g_last_error;
+    auto note = [&](glu_status status) {
+        if (local == GLU_OK && status != GLU_OK)
+        {
+            local = status;
+            local_message = g_last_error;
+        }
+    };
+    if (n_recv > capacity) note(fail(GLU_ERROR_INVALID_ARGUMENT, "receive arrays hold %zu pairs, %zu arrive", capacity, n_recv));
+    if (n_recv > 0 && (!recv_keys || !recv_vals)) note(fail(GLU_ERROR_INVALID_ARGUMENT, "NULL receive array"));
+    if (d->test_fail_finish == d->rank) note(fail(GLU_ERROR_OUT_OF_MEMORY, "injected failure of rank %d (GLU_HIP_DIST_TEST_FAIL)", d->rank));
+    if (local == GLU_OK && n_recv > 1) note(sort_prepare(d->sorter, n_recv, sizeof(uint32_t), true));
+
+    // the local sort: three segmented passes on the low 24 bits (the shard arrives grouped by source rank, then bucket),
+    // unless the shard is small, was partitioned on a lower byte, or falls into so many tiny pieces that a workgroup would
+    // spend its time on sub-block prologues (about two tiles' time each, whatever the size)
+    SegPlan plan;
+    bool segmented = false;
+    if (local == GLU_OK && d->seg_enabled && d->partition_shift == 32 - kDistTopBits &&
+        n_recv >= std::max(d->seg_forced ? (size_t) 0 : d->seg_min, kSegMinCount) &&
+        d->sorter->digit_bits == 8 && !d->sorter->no_lines && (((uintptr_t) recv_keys | (uintptr_t) recv_vals) & 15u) == 0)
+    {
+        std::vector<SegPiece> pieces;
+        uint32_t nseg = 0;
+        dist_shard_pieces(d, pieces, nseg);
+        seg_make_plan(d->sorter, std::move(pieces), nseg, n_recv, 32 - kDistTopBits, true, plan);
+        const uint64_t tiles_per_wg = n_recv / LinesGeometry<uint32_t, 8, true>::TILE / usable_cus(d->sorter);
+        segmented = !plan.by_copies && (d->seg_forced || plan.max_subs_per_wg() <= 2 + tiles_per_wg / 6);
+    }
+    d->last_local_sort = segmented ? 1u : 0u;
+
+    if (d->world > 1)
+    {
+        // one word per rank: is everybody ready to exchange?  (side stream; the partition may still be running on `st`)
+        uint32_t* status_dev = (uint32_t*) d->hist.ptr + (size_t) (d->world + 1) * kDistRow;
+        uint32_t* status_host = d->all_hist_host + (size_t) d->world * kDistRow + 8;
+        status_host[0] = (uint32_t) local;
+        HIP_TRY(hipMemcpyAsync(status_dev, status_host, sizeof(uint32_t), hipMemcpyHostToDevice, d->aux));
+        NCCL_TRY(rccl().AllGather(status_dev, status_dev + 4, 1, ncclUint32, d->comm, d->aux));
+        HIP_TRY(hipMemcpyAsync(status_host + 4, status_dev + 4, (size_t) d->world * sizeof(uint32_t), hipMemcpyDeviceToHost, d->aux));
+        HIP_TRY(hipEventRecord(d->ev_plan, d->aux));
+        HIP_TRY(hipEventSynchronize(d->ev_plan));
+        for (int r = 0; r < d->world; r++)
+            if (status_host[4 + r] != 0 && r != d->rank && local == GLU_OK)
+                return fail((glu_status) status_host[4 + r], "rank %d reported a failure in glu_dist_sort_finish (status %u): nothing was exchanged", r,
+                            status_host[4 + r]);
+    }
+    if (local != GLU_OK)
+    {
+        g_last_error = local_message;
+        return local;
+    }
+
     const uint32_t* part_k = (const uint32_t*) d->part_k.ptr;
     const uint32_t* part_v = (const uint32_t*) d->part_v.ptr;
+    // where the exchange delivers: the segmented sort reads the shard from the sorter's scratch arrays and leaves its
+    // result (after an odd number of passes) in the caller's; the ordinary sort works in place in the caller's
+    uint32_t* land_k = segmented ? (uint32_t*) d->sorter->keys.ptr : recv_keys;
+    uint32_t* land_v = segmented ? (uint32_t*) d->sorter->vals.ptr : recv_vals;
 
     // 4. one grouped exchange: keys and values to and from every peer; receive segments in source-rank order
     std::vector<uint64_t> soff(d->world + 1, 0), roff(d->world + 1, 0);
@@ -490,8 +657,8 @@ glu_status glu_dist_sort_finish(glu_dist d, uint32_t* recv_keys, uint32_t* recv_
             }
             if (d->recv_counts[peer] && res == ncclSuccess)
             {
-                res = rccl().Recv(recv_keys + roff[peer], (size_t) d->recv_counts[peer], ncclUint32, peer, d->comm, st);
-                if (res == ncclSuccess) res = rccl().Recv(recv_vals + roff[peer], (size_t) d->recv_counts[peer], ncclUint32, peer, d->comm, st);
+                res = rccl().Recv(land_k + roff[peer], (size_t) d->recv_counts[peer], ncclUint32, peer, d->comm, st);
+                if (res == ncclSuccess) res = rccl().Recv(land_v + roff[peer], (size_t) d->recv_counts[peer], ncclUint32, peer, d->comm, st);
             }
         }
         ncclResult_t end = rccl().GroupEnd();
@@ -501,16 +668,30 @@ glu_status glu_dist_sort_finish(glu_dist d, uint32_t* recv_keys, uint32_t* recv_
     if (d->send_counts[d->rank])
     {
         const size_t bytes = (size_t) d->send_counts[d->rank] * sizeof(uint32_t);
-        HIP_TRY(hipMemcpyAsync(recv_keys + roff[d->rank], part_k + soff[d->rank], bytes, hipMemcpyDeviceToDevice, st));
-        HIP_TRY(hipMemcpyAsync(recv_vals + roff[d->rank], part_v + soff[d->rank], bytes, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(land_k + roff[d->rank], part_k + soff[d->rank], bytes, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(land_v + roff[d->rank], part_v + soff[d->rank], bytes, hipMemcpyDeviceToDevice, st));
     }
     glu_dist_s::Marks* marks = dist_marks(d, false);
     if (marks) HIP_TRY(hipEventRecord(marks->e[2], st));
 
     // 5. local stable sort of the received pairs
-    if (n_recv > 1) GLU_TRY(sort_run<uint32_t>(d->sorter, recv_keys, recv_vals, n_recv, 0, st));
+    if (segmented)
+        GLU_TRY(seg_run_plan(d->sorter, plan, land_k, land_v, recv_keys, recv_vals, st));
+    else if (n_recv > 1)
+        GLU_TRY(sort_run<uint32_t>(d->sorter, recv_keys, recv_vals, n_recv, 0, st));
     if (marks) HIP_TRY(hipEventRecord(marks->e[3], st));
     return GLU_OK;
+}
+} // namespace
+
+extern "C" {
+
+// Steps 4-5 into the caller's receive arrays (capacity in pairs, at least the count glu_dist_sort_begin returned).
+glu_status glu_dist_sort_finish(glu_dist d, uint32_t* recv_keys, uint32_t* recv_vals, size_t capacity, void* stream)
+{
+    GLU_TRY(enter());
+    if (!d) return fail(GLU_ERROR_INVALID_ARGUMENT, "dist is NULL");
+    return dist_sort_finish(d, recv_keys, recv_vals, capacity, pick_stream(stream), GLU_OK);
 }
 
 // Both halves with the object's own receive arrays (grown when the shard does not fit: an allocation, so callers that
@@ -520,19 +701,28 @@ glu_status glu_dist_sort_ptr(glu_dist d, const uint32_t* keys, const uint32_t* v
 {
     size_t n_recv = 0;
     GLU_TRY(glu_dist_sort_begin(d, keys, vals, local_count, stream, &n_recv));
+    // from here to the exchange a failure of this rank alone must not return: the ranks agree on it in dist_sort_finish
+    glu_status grown = GLU_OK;
     const size_t have = d->recv_k.size / sizeof(uint32_t);
-    if (have < n_recv)
+    if (have < std::max<size_t>(n_recv, 1))
     {
         // the exchange has not been posted yet: the partition may still be running on `stream`, the old arrays are idle
         const size_t want = n_recv + n_recv / 8 + 4096;
-        GLU_TRY(d->recv_k.reserve(want * sizeof(uint32_t)));
-        GLU_TRY(d->recv_v.reserve(want * sizeof(uint32_t)));
+        grown = d->recv_k.reserve(want * sizeof(uint32_t));
+        if (grown == GLU_OK) grown = d->recv_v.reserve(want * sizeof(uint32_t));
     }
-    GLU_TRY(sort_prepare(d->sorter, n_recv, sizeof(uint32_t), true));
-    GLU_TRY(glu_dist_sort_finish(d, (uint32_t*) d->recv_k.ptr, (uint32_t*) d->recv_v.ptr, d->recv_k.size / sizeof(uint32_t), stream));
+    const size_t capacity = grown == GLU_OK ? std::min(d->recv_k.size, d->recv_v.size) / sizeof(uint32_t) : 0;
+    GLU_TRY(dist_sort_finish(d, (uint32_t*) d->recv_k.ptr, (uint32_t*) d->recv_v.ptr, capacity, pick_stream(stream), grown));
     if (out_keys) *out_keys = (uint32_t*) d->recv_k.ptr;
     if (out_vals) *out_vals = (uint32_t*) d->recv_v.ptr;
     if (out_count) *out_count = n_recv;
+    return GLU_OK;
+}
+
+glu_status glu_dist_last_local_sort(glu_dist d, uint32_t* segmented)
+{
+    if (!d || !segmented) return fail(GLU_ERROR_INVALID_ARGUMENT, "NULL argument");
+    *segmented = d->last_local_sort;
     return GLU_OK;
 }
 

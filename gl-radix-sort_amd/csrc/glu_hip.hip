@@ -16,6 +16,7 @@
 #include "radix_sort_kernels.hpp"
 #include "radix_scatter_lines.hpp"
 #include "radix_pair_passes.hpp"
+#include "radix_seg_passes.hpp"
 #include "scan_reduce_kernels.hpp"
 
 using namespace glu_hip;
@@ -97,18 +98,16 @@ glu_status ensure_device()
     return GLU_OK;
 }
 
-// Every public entry point runs this first: the device is initialised once per process, and every host thread that
-// calls into the library gets that device as its current HIP device (a new thread's current device is 0, so without
-// this a second thread would allocate scratch on device 0 and launch on a stream of device k).
-thread_local int t_bound_device = -1;
+// Every public entry point runs this first: the device is initialised once per process, and the calling thread's
+// current HIP device is made the library's device (a new thread's current device is 0, and an application may switch
+// devices between two library calls -- torch.cuda.device(k), hipSetDevice -- so the current device is asked for every
+// time instead of being remembered per thread: without this, scratch would be allocated on one device and the kernels
+// launched on a stream of another).
 glu_status enter()
 {
     GLU_TRY(ensure_device());
-    if (t_bound_device != g_dev.id)
-    {
-        HIP_TRY(hipSetDevice(g_dev.id));
-        t_bound_device = g_dev.id;
-    }
+    int current = -1;
+    if (hipGetDevice(&current) != hipSuccess || current != g_dev.id) HIP_TRY(hipSetDevice(g_dev.id));
     return GLU_OK;
 }
 
@@ -433,8 +432,24 @@ struct glu_radix_sort_s
     Scratch pair_table;  // the follower's count table + digit totals,
     Scratch pair_ranges; // the element range of every follower workgroup,
     Scratch pair_sub;    // and (4-bit digits) the leader's table per sub-block: [16][num_blocks * 16]
+    Scratch seg_desc;    // segmented passes (glu_dist's local sort): sub-block descriptors of the pass being enqueued
+    Scratch seg_zero;    // and RADIX zero words (the digit totals a segmented scatter adds to its absolute table entries)
+    bool last_planned = false; // the last sort on this object ran with a device-side plan (glu_radix_sort_read_plan)
+    // pinned host images of the descriptors, a ring: a call fills the next one and enqueues its copy; an image is reused
+    // only after the copy enqueued from it has run (its event)
+    struct SegStage
+    {
+        void* host = nullptr;
+        size_t size = 0;
+        hipEvent_t copied = nullptr;
+        bool in_flight = false;
+    };
+    SegStage seg_stage[4];
+    uint32_t seg_stage_next = 0;
     uint32_t digit_bits = 8;
     uint32_t max_blocks = 0;   // GLU_HIP_SORT_BLOCKS: cap on the number of workgroups (tuning)
+    uint32_t reserved_cus = 0; // CUs the pass kernels leave free (glu_dist: RCCL kernels run beside them); the grid of a pass
+                               // is (CUs - reserved) x workgroups per CU of its geometry
     bool force_small = false;  // GLU_HIP_SORT_SMALL=1: always use the small-tile geometry (tests / tuning)
     bool no_single_block = false; // GLU_HIP_SORT_NO_SINGLE_BLOCK=1: never take the one-workgroup path (tests / tuning)
     bool no_fused_scan = false;   // GLU_HIP_SORT_NO_FUSED_SCAN=1: always launch the row-scan kernel (tests / tuning)
@@ -480,6 +495,12 @@ namespace
 constexpr size_t kPairMinKeyBytes = (size_t) 1 << 28;
 constexpr size_t kPlanMinCount = (size_t) 1 << 22; // planned sorts: see PlanArgs below
 
+// CUs the pass kernels of `s` may fill (glu_dist reserves some for RCCL kernels that run beside them)
+inline uint32_t usable_cus(const glu_radix_sort_s* s)
+{
+    return (uint32_t) std::max<int>(1, g_dev.num_cus - (int) s->reserved_cus);
+}
+
 glu_status sort_prepare(glu_radix_sort_s* s, size_t count, size_t key_size, bool with_vals = true)
 {
     if (count <= 1) return GLU_OK;
@@ -487,7 +508,12 @@ glu_status sort_prepare(glu_radix_sort_s* s, size_t count, size_t key_size, bool
     if (with_vals) GLU_TRY(s->vals.reserve(count * sizeof(uint32_t)));
     uint64_t cap = (uint64_t) g_dev.num_cus * kMaxBlocksPerCu;
     GLU_TRY(s->table.reserve((kMaxRadix * cap + kMaxRadix) * sizeof(uint32_t)));
-    GLU_TRY(s->plan.reserve(sizeof(PassPlan)));
+    if (s->plan.size < sizeof(PassPlan))
+    {
+        GLU_TRY(s->plan.reserve(sizeof(PassPlan)));
+        HIP_TRY(hipMemset(s->plan.ptr, 0, sizeof(PassPlan))); // never read uninitialised (glu_radix_sort_read_plan)
+        HIP_TRY(hipDeviceSynchronize());                       // (the sort's stream does not wait for the null stream)
+    }
     if (count >= kPlanMinCount && count >= (s->pair_min ? s->pair_min : kPairMinKeyBytes / key_size) && s->pairs && !s->no_plan &&
         !s->no_lines && !s->force_small)
     {
@@ -525,7 +551,7 @@ glu_status launch_pass(glu_radix_sort_s* s, const KeyT* src_k, const uint32_t* s
     using G = GeometryFor<KeyT, BITS, LARGE, VALS>;
     constexpr int RADIX = 1 << BITS;
     const uint32_t tiles = (uint32_t) ((count + G::TILE - 1) / G::TILE);
-    uint64_t cap = (uint64_t) g_dev.num_cus * G::BLOCKS_PER_CU;
+    uint64_t cap = (uint64_t) usable_cus(s) * G::BLOCKS_PER_CU;
     if (s->max_blocks) cap = std::min<uint64_t>(cap, s->max_blocks);
     const uint32_t nb = (uint32_t) std::max<uint64_t>(1, std::min<uint64_t>(tiles, cap));
     const uint32_t mask = (1u << bits) - 1;
@@ -594,7 +620,7 @@ glu_status launch_pass_lines(glu_radix_sort_s* s, const KeyT* src_k, const uint3
     using G = LinesGeometry<KeyT, BITS, VALS>;
     constexpr int RADIX = 1 << BITS;
     const uint32_t tiles = (uint32_t) ((count + G::TILE - 1) / G::TILE);
-    uint64_t cap = (uint64_t) g_dev.num_cus;
+    uint64_t cap = (uint64_t) usable_cus(s);
     if (s->max_blocks) cap = std::min<uint64_t>(cap, s->max_blocks);
     const uint32_t nb = (uint32_t) std::max<uint64_t>(1, std::min<uint64_t>(tiles, cap));
     const uint32_t mask = (1u << bits) - 1;
@@ -717,7 +743,7 @@ glu_status launch_pass_lines(glu_radix_sort_s* s, const KeyT* src_k, const uint3
     }
     hipLaunchKernelGGL(scatter, dim3(nb), dim3(G::THREADS), sizeof(Smem), stream, src_k, src_v, dst_k, dst_v,
                        (const uint32_t*) table, (const uint32_t*) totals, (uint32_t) count, shift, mask, tiles,
-                       (unsigned long long*) nullptr, xform, pa.plan, pa.pass, ranges, share);
+                       (unsigned long long*) nullptr, xform, pa.plan, pa.pass, ranges, share, (const uint32_t*) nullptr);
     s->mark(stream);
     HIP_TRY(hipGetLastError());
     return GLU_OK;
@@ -854,6 +880,7 @@ glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t cou
     int cur = 0;
     // large sorts: device-side pass plan (constant-digit passes are skipped, the arrays' roles follow on the device)
     const bool planned = count >= kPlanMinCount && !s->no_plan;
+    s->last_planned = planned;
     // the passes: digit positions, key transforms (typed keys: encode on the first pass's loads, decode on the last
     // pass's stores), and which passes share one count kernel (radix_pair_passes.hpp)
     struct PassDesc
@@ -963,6 +990,223 @@ glu_status sort_run(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t coun
     const size_t steps = (num_steps == 0 || num_steps > kMaxSteps) ? kMaxSteps : num_steps;
     return sort_bits<KeyT>(s, keys, vals, count, 0u, (uint32_t) steps * 4, stream, key_xf);
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// segmented sort (radix_seg_passes.hpp): glu_radix_sort_run_segments_ptr
+// ------------------------------------------------------------------------------------------------------------
+struct SegPiece
+{
+    uint64_t begin, len;
+    uint32_t seg;
+};
+
+// Device image of one segmented pass's descriptors (uint32 words): subs[nsb] as (begin, end) pairs, wg_first[nwg + 1],
+// seg_list[nseg + 1], seg_start[nseg].
+struct SegImage
+{
+    std::vector<uint32_t> words;
+    uint32_t nsb = 0, nwg = 0, nseg = 0, max_subs_per_wg = 0;
+    size_t off_first = 0, off_list = 0, off_start = 0;
+};
+
+// Cuts the pieces (sorted by segment, in the stable order of each segment's elements) into sub-blocks: workgroup w of
+// `nwg` takes the elements [w * share, (w + 1) * share) of the pieces laid end to end, a sub-block is the part of one
+// piece inside one workgroup's share.  Pure host function of its arguments.
+void seg_build_image(const SegPiece* pieces, size_t npieces, uint32_t nseg, const uint64_t* seg_start, uint64_t total,
+                     uint32_t nwg, SegImage& img)
+{
+    img.nwg = nwg;
+    img.nseg = nseg;
+    const uint64_t share = std::max<uint64_t>(1, (total + nwg - 1) / nwg);
+    std::vector<uint32_t> subs, first(nwg + 1, 0), list(nseg + 1, 0);
+    subs.reserve(2 * (npieces + nwg));
+    uint64_t pos = 0; // position in the pieces laid end to end
+    uint32_t seg_seen = 0;
+    for (size_t p = 0; p < npieces; p++)
+    {
+        const SegPiece& pc = pieces[p];
+        if (pc.len == 0) continue;
+        while (seg_seen <= pc.seg) list[seg_seen++] = (uint32_t) (subs.size() / 2); // segments [.., pc.seg] start here
+        uint64_t done = 0;
+        while (done < pc.len)
+        {
+            const uint64_t w = (pos + done) / share;
+            const uint64_t room = (w + 1) * share - (pos + done);
+            const uint64_t take = std::min<uint64_t>(room, pc.len - done);
+            subs.push_back((uint32_t) (pc.begin + done));
+            subs.push_back((uint32_t) (pc.begin + done + take));
+            first[std::min<uint64_t>(w, nwg - 1) + 1]++; // (counts; turned into offsets below)
+            done += take;
+        }
+        pos += pc.len;
+    }
+    img.nsb = (uint32_t) (subs.size() / 2);
+    while (seg_seen <= nseg) list[seg_seen++] = img.nsb;
+    img.max_subs_per_wg = 0;
+    for (uint32_t w = 0; w < nwg; w++)
+    {
+        img.max_subs_per_wg = std::max(img.max_subs_per_wg, first[w + 1]);
+        first[w + 1] += first[w];
+    }
+    img.words.clear();
+    img.words.insert(img.words.end(), subs.begin(), subs.end());
+    img.off_first = img.words.size();
+    img.words.insert(img.words.end(), first.begin(), first.end());
+    img.off_list = img.words.size();
+    img.words.insert(img.words.end(), list.begin(), list.end());
+    img.off_start = img.words.size();
+    for (uint32_t g = 0; g < nseg; g++) img.words.push_back((uint32_t) seg_start[g]);
+    if (img.words.size() % 2) img.words.push_back(0); // the next image's (begin, end) pairs stay 8-byte aligned
+}
+
+constexpr size_t kSegMinCount = 1 << 16; // below: gather + one sort per segment (the line kernel wants whole tiles to prefetch)
+
+// One segmented pass on the 8-bit digit at `shift`: count per sub-block, scan per segment, line scatter over sub-blocks.
+glu_status launch_seg_pass(glu_radix_sort_s* s, const uint32_t* src_k, const uint32_t* src_v, uint32_t* dst_k, uint32_t* dst_v,
+                           size_t count, uint32_t shift, const uint32_t* image, const SegImage& img, hipStream_t stream)
+{
+    using G = LinesGeometry<uint32_t, 8, true>;
+    constexpr int RADIX = 256;
+    constexpr int RS = (G::KPT + 2) / 3;
+    using Smem = LineSmem<uint32_t, 8, G::THREADS, G::KPT, true>;
+    auto scatter_nt = radix_scatter_lines_kernel<uint32_t, 8, G::THREADS, G::KPT, false, true, 0, false, RS, true, true, 0, true>;
+    auto scatter_plain = radix_scatter_lines_kernel<uint32_t, 8, G::THREADS, G::KPT, false, true, 0, false, RS, true, false, 0, true>;
+    static std::once_flag lds_opt_in;
+    static hipError_t lds_opt_in_result = hipSuccess;
+    std::call_once(lds_opt_in, [&] {
+        lds_opt_in_result = hipFuncSetAttribute((const void*) scatter_nt, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sizeof(Smem));
+        if (lds_opt_in_result == hipSuccess)
+            lds_opt_in_result = hipFuncSetAttribute((const void*) scatter_plain, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sizeof(Smem));
+    });
+    HIP_TRY(lds_opt_in_result);
+    uint32_t* table = (uint32_t*) s->table.ptr;
+    const uint2* subs = (const uint2*) image;
+    s->mark(stream);
+    hipLaunchKernelGGL((radix_seg_count_kernel<8, 1024>), dim3(img.nwg), dim3(1024), 0, stream, src_k, subs, image + img.off_first, table,
+                       shift, 255u);
+    HIP_TRY(hipGetLastError());
+    s->mark(stream);
+    hipLaunchKernelGGL((radix_seg_scan_kernel<RADIX>), dim3(img.nseg), dim3(RADIX), 0, stream, table, image + img.off_list,
+                       image + img.off_start);
+    HIP_TRY(hipGetLastError());
+    s->mark(stream);
+    hipLaunchKernelGGL(s->nt_stores ? scatter_nt : scatter_plain, dim3(img.nwg), dim3(G::THREADS), sizeof(Smem), stream, src_k, src_v,
+                       dst_k, dst_v, (const uint32_t*) table, (const uint32_t*) nullptr, (uint32_t) count, shift, 255u, 0u,
+                       (unsigned long long*) nullptr, 0u, (PassPlan*) nullptr, 0u, subs, 0u, image + img.off_first);
+    HIP_TRY(hipGetLastError());
+    s->mark(stream);
+    return GLU_OK;
+}
+
+// Host half of a segmented sort: the pieces sorted by segment (stably: the caller's order of a segment's pieces is the
+// order of its elements), where every segment starts in the output, and the descriptor images of the passes.  Nothing is
+// enqueued, so a caller (glu_dist) can look at `max_subs_per_wg` -- a workgroup pays about two tiles' time per sub-block,
+// whatever its size -- and decide for another way before anything runs.
+struct SegPlan
+{
+    std::vector<SegPiece> pieces;
+    std::vector<uint64_t> seg_start; // [nseg + 1]
+    uint32_t nseg = 0, passes = 0, bits = 0;
+    size_t count = 0;
+    bool by_copies = false; // small or unaligned inputs: gather with copies + one ordinary sort per segment
+    SegImage first, later;
+    uint32_t max_subs_per_wg() const { return std::max(first.max_subs_per_wg, later.max_subs_per_wg); }
+};
+
+void seg_make_plan(glu_radix_sort_s* s, std::vector<SegPiece>&& pieces, uint32_t nseg, size_t count, uint32_t bits, bool aligned,
+                   SegPlan& plan)
+{
+    plan.pieces = std::move(pieces);
+    std::stable_sort(plan.pieces.begin(), plan.pieces.end(), [](const SegPiece& a, const SegPiece& b) { return a.seg < b.seg; });
+    plan.nseg = nseg;
+    plan.count = count;
+    plan.bits = bits;
+    plan.passes = bits / 8;
+    plan.seg_start.assign(nseg + 1, 0);
+    for (const SegPiece& pc : plan.pieces) plan.seg_start[pc.seg + 1] += pc.len;
+    for (uint32_t g = 0; g < nseg; g++) plan.seg_start[g + 1] += plan.seg_start[g];
+    plan.by_copies = count < kSegMinCount || !aligned || plan.passes == 0;
+    if (plan.by_copies) return;
+    // descriptors of the first pass (the caller's pieces) and of the later ones (whole segments of the pass before)
+    const uint32_t nwg = usable_cus(s);
+    seg_build_image(plan.pieces.data(), plan.pieces.size(), nseg, plan.seg_start.data(), count, nwg, plan.first);
+    if (plan.passes > 1)
+    {
+        std::vector<SegPiece> whole(nseg);
+        for (uint32_t g = 0; g < nseg; g++) whole[g] = SegPiece{plan.seg_start[g], plan.seg_start[g + 1] - plan.seg_start[g], g};
+        seg_build_image(whole.data(), whole.size(), nseg, plan.seg_start.data(), count, nwg, plan.later);
+    }
+}
+
+// Device half: enqueues the passes of `plan` on `stream`.
+glu_status seg_run_plan(glu_radix_sort_s* s, const SegPlan& plan, uint32_t* in_k, uint32_t* in_v, uint32_t* out_k, uint32_t* out_v,
+                        hipStream_t stream)
+{
+    const size_t count = plan.count;
+    const uint32_t passes = plan.passes, nseg = plan.nseg;
+    GLU_TRY(sort_prepare(s, count, sizeof(uint32_t), true));
+    if (plan.by_copies)
+    {
+        // small (or unaligned, or nothing to sort by): lay the segments out with copies, then one sort per segment
+        uint64_t at = 0;
+        for (const SegPiece& pc : plan.pieces)
+        {
+            if (pc.len == 0) continue;
+            HIP_TRY(hipMemcpyAsync(out_k + at, in_k + pc.begin, pc.len * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
+            HIP_TRY(hipMemcpyAsync(out_v + at, in_v + pc.begin, pc.len * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
+            at += pc.len;
+        }
+        if (passes)
+            for (uint32_t g = 0; g < nseg; g++)
+            {
+                const uint64_t len = plan.seg_start[g + 1] - plan.seg_start[g];
+                if (len > 1)
+                    GLU_TRY(sort_bits<uint32_t>(s, out_k + plan.seg_start[g], out_v + plan.seg_start[g], (size_t) len, 0u, plan.bits, stream));
+            }
+        return GLU_OK;
+    }
+    uint32_t* tmp_k = (uint32_t*) s->keys.ptr;
+    uint32_t* tmp_v = (uint32_t*) s->vals.ptr;
+    const SegImage &first = plan.first, &later = plan.later;
+    const size_t bytes = (first.words.size() + later.words.size()) * sizeof(uint32_t);
+    GLU_TRY(s->seg_desc.reserve(std::max<size_t>(bytes, 1 << 16)));
+    GLU_TRY(s->table.reserve((size_t) std::max(first.nsb, later.nsb) * 256 * sizeof(uint32_t)));
+    glu_radix_sort_s::SegStage& st = s->seg_stage[s->seg_stage_next++ % 4];
+    if (st.in_flight) HIP_TRY(hipEventSynchronize(st.copied)); // (four calls ago: long done)
+    if (st.size < bytes)
+    {
+        if (st.host) HIP_TRY(hipHostFree(st.host));
+        st.host = nullptr;
+        st.size = 0;
+        HIP_TRY(hipHostMalloc(&st.host, std::max<size_t>(bytes, 1 << 16)));
+        st.size = std::max<size_t>(bytes, 1 << 16);
+    }
+    if (!st.copied) HIP_TRY(hipEventCreateWithFlags(&st.copied, hipEventDisableTiming));
+    memcpy(st.host, first.words.data(), first.words.size() * sizeof(uint32_t));
+    if (!later.words.empty())
+        memcpy((uint32_t*) st.host + first.words.size(), later.words.data(), later.words.size() * sizeof(uint32_t));
+    HIP_TRY(hipMemcpyAsync(s->seg_desc.ptr, st.host, bytes, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipEventRecord(st.copied, stream));
+    st.in_flight = true;
+    const uint32_t* image_first = (const uint32_t*) s->seg_desc.ptr;
+    const uint32_t* image_later = image_first + first.words.size();
+
+    // the arrays of every pass: the last one writes `out`; with an odd number of passes they alternate in -> out -> in -> out,
+    // with an even number the sort's own scratch stands in for `out` until the last pass (in -> tmp -> in -> tmp -> out)
+    const uint32_t* src_k = in_k;
+    const uint32_t* src_v = in_v;
+    for (uint32_t p = 0; p < passes; p++)
+    {
+        const bool last = p + 1 == passes;
+        uint32_t* dst_k = last ? out_k : (src_k == in_k ? ((passes & 1u) ? out_k : tmp_k) : in_k);
+        uint32_t* dst_v = last ? out_v : (src_v == in_v ? ((passes & 1u) ? out_v : tmp_v) : in_v);
+        GLU_TRY(launch_seg_pass(s, src_k, src_v, dst_k, dst_v, count, p * 8, p == 0 ? image_first : image_later,
+                                p == 0 ? first : later, stream));
+        src_k = dst_k;
+        src_v = dst_v;
+    }
+    return GLU_OK;
+}
 } // namespace
 
 extern "C" {
@@ -1006,12 +1250,18 @@ glu_status glu_radix_sort_destroy(glu_radix_sort sort)
 {
     GLU_TRY(enter());
     if (!sort) return GLU_OK;
-    (void) hipStreamSynchronize(g_dev.queue);
-    sort->keys.release();
-    sort->vals.release();
-    sort->table.release();
-    sort->plan.release();
+    // the object may last have been used on a caller's stream (the *_ptr entry points): drain the device, not only the
+    // library queue, before its scratch goes away (RAII of the reference: RadixSort.hpp:194-200, gl_utils.hpp:184-188)
+    (void) hipDeviceSynchronize();
+    for (Scratch* sc : {&sort->keys, &sort->vals, &sort->table, &sort->plan, &sort->pair_t2, &sort->pair_table, &sort->pair_ranges,
+                        &sort->pair_sub, &sort->seg_desc, &sort->seg_zero})
+        sc->release();
     for (hipEvent_t e : sort->events) (void) hipEventDestroy(e);
+    for (glu_radix_sort_s::SegStage& st : sort->seg_stage)
+    {
+        if (st.host) (void) hipHostFree(st.host);
+        if (st.copied) (void) hipEventDestroy(st.copied);
+    }
     delete sort;
     return GLU_OK;
 }
@@ -1090,6 +1340,7 @@ glu_status glu_radix_sort_run_keys_ptr(glu_radix_sort sort, uint32_t* keys, size
 {
     GLU_TRY(enter());
     if (!sort) return fail(GLU_ERROR_INVALID_ARGUMENT, "sort is NULL");
+    if (count == 0) return GLU_OK; // an empty shard: NULL arrays are fine
     if (!keys) return fail(GLU_ERROR_INVALID_ARGUMENT, "Invalid key buffer");
     return sort_run<uint32_t>(sort, keys, nullptr, count, num_steps, pick_stream(stream));
 }
@@ -1098,6 +1349,7 @@ glu_status glu_radix_sort_run_keys_u64_ptr(glu_radix_sort sort, uint64_t* keys, 
 {
     GLU_TRY(enter());
     if (!sort) return fail(GLU_ERROR_INVALID_ARGUMENT, "sort is NULL");
+    if (count == 0) return GLU_OK;
     if (!keys) return fail(GLU_ERROR_INVALID_ARGUMENT, "Invalid key buffer");
     return sort_run<uint64_t>(sort, keys, nullptr, count, num_steps, pick_stream(stream));
 }
@@ -1107,6 +1359,9 @@ glu_status glu_radix_sort_run_typed_ptr(glu_radix_sort sort, void* keys, uint32_
 {
     GLU_TRY(enter());
     if (!sort) return fail(GLU_ERROR_INVALID_ARGUMENT, "sort is NULL");
+    if ((int) key_type < (int) GLU_KEY_UINT32 || (int) key_type > (int) GLU_KEY_FLOAT64)
+        return fail(GLU_ERROR_INVALID_ARGUMENT, "Invalid key type: %d", (int) key_type);
+    if (count == 0) return GLU_OK;
     if (!keys) return fail(GLU_ERROR_INVALID_ARGUMENT, "Invalid key buffer");
     hipStream_t st = pick_stream(stream);
     switch (key_type)
@@ -1126,10 +1381,11 @@ glu_status glu_radix_sort_run_bit_range_ptr(glu_radix_sort sort, void* keys, uin
 {
     GLU_TRY(enter());
     if (!sort) return fail(GLU_ERROR_INVALID_ARGUMENT, "sort is NULL");
-    if (!keys) return fail(GLU_ERROR_INVALID_ARGUMENT, "Invalid key buffer");
     if (key_bits != 32 && key_bits != 64) return fail(GLU_ERROR_INVALID_ARGUMENT, "key_bits must be 32 or 64 (got %u)", key_bits);
     if (begin_bit > end_bit || end_bit > key_bits)
         return fail(GLU_ERROR_INVALID_ARGUMENT, "bad bit range [%u, %u) for %u-bit keys", begin_bit, end_bit, key_bits);
+    if (count == 0) return GLU_OK;
+    if (!keys) return fail(GLU_ERROR_INVALID_ARGUMENT, "Invalid key buffer");
     hipStream_t st = pick_stream(stream);
     if (key_bits == 32) return sort_bits<uint32_t>(sort, (uint32_t*) keys, vals, count, begin_bit, end_bit, st);
     return sort_bits<uint64_t>(sort, (uint64_t*) keys, vals, count, begin_bit, end_bit, st);
@@ -1172,6 +1428,38 @@ glu_status glu_radix_sort_partition_ptr(glu_radix_sort sort, const uint32_t* src
     return dispatch_pass<uint32_t>(sort, src_keys, src_vals, dst_keys, dst_vals, count, shift, bits, digit_histogram, st);
 }
 
+glu_status glu_radix_sort_run_segments_ptr(glu_radix_sort sort, uint32_t* in_keys, uint32_t* in_vals, uint32_t* out_keys,
+                                           uint32_t* out_vals, size_t count, const uint64_t* piece_begin,
+                                           const uint64_t* piece_len, const uint32_t* piece_segment, size_t num_pieces,
+                                           uint32_t num_segments, uint32_t key_bits, void* stream)
+{
+    GLU_TRY(enter());
+    if (!sort) return fail(GLU_ERROR_INVALID_ARGUMENT, "sort is NULL");
+    if (key_bits > 32 || key_bits % 8 != 0) return fail(GLU_ERROR_INVALID_ARGUMENT, "key_bits must be 0, 8, 16, 24 or 32 (got %u)", key_bits);
+    if (count > 0xFFFF0000ull) return fail(GLU_ERROR_INVALID_ARGUMENT, "count %zu does not fit 32-bit indexing", count);
+    if (num_pieces > 0 && (!piece_begin || !piece_len || !piece_segment)) return fail(GLU_ERROR_INVALID_ARGUMENT, "NULL piece array");
+    if (num_segments == 0 && num_pieces > 0) return fail(GLU_ERROR_INVALID_ARGUMENT, "pieces but no segments");
+    std::vector<SegPiece> pieces(num_pieces);
+    uint64_t total = 0;
+    for (size_t i = 0; i < num_pieces; i++)
+    {
+        if (piece_segment[i] >= num_segments) return fail(GLU_ERROR_INVALID_ARGUMENT, "piece %zu names segment %u of %u", i, piece_segment[i], num_segments);
+        if (piece_begin[i] > count || piece_len[i] > count - piece_begin[i])
+            return fail(GLU_ERROR_INVALID_ARGUMENT, "piece %zu [%llu, +%llu) exceeds count %zu", i, (unsigned long long) piece_begin[i],
+                        (unsigned long long) piece_len[i], count);
+        pieces[i] = SegPiece{piece_begin[i], piece_len[i], piece_segment[i]};
+        total += piece_len[i];
+    }
+    if (total != count) return fail(GLU_ERROR_INVALID_ARGUMENT, "the pieces hold %llu elements, count is %zu", (unsigned long long) total, count);
+    if (count == 0) return GLU_OK;
+    if (!in_keys || !in_vals || !out_keys || !out_vals) return fail(GLU_ERROR_INVALID_ARGUMENT, "NULL array");
+    if (in_keys == out_keys || in_vals == out_vals) return fail(GLU_ERROR_INVALID_ARGUMENT, "the segmented sort needs distinct input and output arrays");
+    const bool aligned = (((uintptr_t) in_keys | (uintptr_t) in_vals | (uintptr_t) out_keys | (uintptr_t) out_vals) & 15u) == 0;
+    SegPlan plan;
+    seg_make_plan(sort, std::move(pieces), num_segments, count, key_bits, aligned, plan);
+    return seg_run_plan(sort, plan, in_keys, in_vals, out_keys, out_vals, pick_stream(stream));
+}
+
 glu_status glu_radix_sort_set_digit_bits(glu_radix_sort sort, uint32_t bits)
 {
     GLU_TRY(enter());
@@ -1203,14 +1491,16 @@ glu_status glu_radix_sort_read_plan(glu_radix_sort sort, uint32_t* skipped, uint
     GLU_TRY(enter());
     if (!sort) return fail(GLU_ERROR_INVALID_ARGUMENT, "sort is NULL");
     if (passes > (size_t) kPlanMaxPasses) return fail(GLU_ERROR_INVALID_ARGUMENT, "at most %d passes", kPlanMaxPasses);
-    if (!sort->plan.ptr) return fail(GLU_ERROR_INVALID_STATE, "no planned sort has run on this object");
+    if (!sort->plan.ptr) return fail(GLU_ERROR_INVALID_STATE, "no sort has run on this object");
     PassPlan host;
-    HIP_TRY(hipMemcpy(&host, sort->plan.ptr, sizeof(host), hipMemcpyDeviceToHost));
+    memset(&host, 0, sizeof(host));
+    // a sort below 2^22 elements runs without a device-side plan: every pass ran, none was paired
+    if (sort->last_planned) HIP_TRY(hipMemcpy(&host, sort->plan.ptr, sizeof(host), hipMemcpyDeviceToHost));
     for (size_t p = 0; p < passes; p++)
     {
         if (skipped) skipped[p] = host.skip[p];
         if (counted_alone) counted_alone[p] = host.pair_fallback[p];
-        if (pair_role) pair_role[p] = sort->last_pair_roles[p];
+        if (pair_role) pair_role[p] = sort->last_planned ? sort->last_pair_roles[p] : 0u;
     }
     return GLU_OK;
 }
@@ -1386,6 +1676,7 @@ glu_status scan_level(Elem<S, N>* data, size_t count, size_t partitions, Elem<S,
         hipLaunchKernelGGL((scan_chunk_sums_kernel<S, N, true>), grid, dim3(C::THREADS), 0, stream, (const T*) data, sums, (uint64_t) count, (uint32_t) chunks);
     else
         hipLaunchKernelGGL((scan_chunk_sums_kernel<S, N, false>), grid, dim3(C::THREADS), 0, stream, (const T*) data, sums, (uint64_t) count, (uint32_t) chunks);
+    HIP_TRY(hipGetLastError()); // every launch is checked where it happens
     GLU_TRY((scan_level<S, N>(sums, chunks, partitions, scratch + chunks * partitions, stream)));
     if (aligned)
         hipLaunchKernelGGL((scan_chunks_kernel<S, N, true>), grid, dim3(C::THREADS), 0, stream, data, (const T*) sums, (uint64_t) count, (uint32_t) chunks);
@@ -1514,7 +1805,7 @@ glu_status glu_scan_destroy(glu_scan scan)
 {
     GLU_TRY(enter());
     if (!scan) return GLU_OK;
-    (void) hipStreamSynchronize(g_dev.queue);
+    (void) hipDeviceSynchronize(); // (a caller stream may still run its kernels)
     scan->sums.release();
     scan->chain.release();
     scan->ticket.release();
@@ -1584,7 +1875,7 @@ glu_status glu_reduce_destroy(glu_reduce reduce)
 {
     GLU_TRY(enter());
     if (!reduce) return GLU_OK;
-    (void) hipStreamSynchronize(g_dev.queue);
+    (void) hipDeviceSynchronize();
     reduce->partials.release();
     delete reduce;
     return GLU_OK;

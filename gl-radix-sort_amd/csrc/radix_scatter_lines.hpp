@@ -60,19 +60,27 @@ struct LineSmem
 // take tail copy and ranking in opposite order.  NT_STORES: non-temporal line stores (what the library runs).  PRIO:
 // tuning only (s_setprio around the LDS-bound phases: measured, no effect).  STAMPS: s_memtime per phase of the first and
 // the last wave into stamps[0..15] (tools/scatter_bench.hip).
+//
+// SEG (segmented passes: the local sort of the sharded sort, glu_dist_impl.hpp): the workgroup runs the whole pass body once
+// per SUB-BLOCK of its list [seg_first[b], seg_first[b + 1]): element range `ranges[i]` of the source arrays, counted on its
+// own (radix_seg_count_kernel), with `table[i * RADIX + d]` = the ABSOLUTE destination index of the sub-block's first
+// element with digit d (radix_seg_scan_kernel: segment start + digits below d in the segment + the segment's earlier
+// sub-blocks).  Everything else -- ranking, line carry, whole-line stores, element-wise stores at the two ends of a
+// (sub-block, digit) range -- is the pass as above; `totals`, `plan`, `share` are not used.
 template<typename KeyT, int BITS, int THREADS, int KPT, bool XF = false, bool VALS = true, int ABLATE = 0, bool STAMPS = false,
-         int RANK_SPLIT = (KPT + 2) / 3, bool STAGGER = true, bool NT_STORES = false, int PRIO = 0>
+         int RANK_SPLIT = (KPT + 2) / 3, bool STAGGER = true, bool NT_STORES = false, int PRIO = 0, bool SEG = false>
 __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
     const KeyT* __restrict__ keys_a, const uint32_t* __restrict__ vals_a, KeyT* __restrict__ keys_b,
     uint32_t* __restrict__ vals_b, const uint32_t* __restrict__ table, const uint32_t* __restrict__ totals, uint32_t n,
     uint32_t shift, uint32_t mask, uint32_t tiles_total, unsigned long long* stamps = nullptr, uint32_t xform = 0,
-    PassPlan* plan = nullptr, uint32_t pass = 0, const uint2* __restrict__ ranges = nullptr, uint32_t share = 0)
+    PassPlan* plan = nullptr, uint32_t pass = 0, const uint2* __restrict__ ranges = nullptr, uint32_t share = 0,
+    const uint32_t* __restrict__ seg_first = nullptr)
 {
     const KeyT* __restrict__ src_keys = keys_a;
     const uint32_t* __restrict__ src_vals = vals_a;
     KeyT* __restrict__ dst_keys = keys_b;
     uint32_t* __restrict__ dst_vals = vals_b;
-    if (plan)
+    if (!SEG && plan)
     {
         const uint32_t flip = pass > 0 ? plan->flip[pass] : 0u;
         const uint32_t skip = plan->skip[pass];
@@ -110,7 +118,34 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
     uint32_t carry_start = 0; // 32-aligned global index of the digit's first carried element; carried = digit_base - carry_start
     uint32_t owned_from = 0;  // first global index of the digit inside this workgroup's range
 
+    unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = 0;
+    auto stamp = [&](int slot) {
+        if (STAMPS)
+        {
+            unsigned long long t = __builtin_amdgcn_s_memtime();
+            acc[slot] += t - tprev;
+            tprev = t;
+        }
+    };
+
+    const uint32_t wave_off = wave * WAVE_TILE + lane; // wave-striped: item i of lane l of wave w = element w*64*KPT + i*64 + l
+    // (readfirstlane: the values are workgroup-uniform; it keeps them and everything derived from them in scalar registers)
+    const uint32_t sb_first = SEG ? (uint32_t) __builtin_amdgcn_readfirstlane((int) seg_first[b]) : 0u;
+    const uint32_t sb_last = SEG ? (uint32_t) __builtin_amdgcn_readfirstlane((int) seg_first[b + 1]) : 1u;
+    for (uint32_t sb = sb_first; sb < sb_last; sb++)
+    {
     // ---- prologue: exclusive scan of the digit totals (RadixSort.hpp:148-152) + this block's scanned table entry (:176)
+    if (SEG)
+    {
+        if (digit_owner)
+        {
+            digit_base = table[(size_t) sb * RADIX + sd]; // absolute: the segmented scan has added everything
+            owned_from = digit_base;
+            carry_start = digit_base & ~(LINE - 1);
+        }
+    }
+    else
     {
         const uint32_t t = digit_owner ? totals[sd] : 0u;
         uint32_t wtotal;
@@ -131,9 +166,16 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
 
     // The workgroup's element range [r0, r1), cut into tiles from r0: an equal share of the elements (or whole tiles of
     // the array: tuning harness), or -- the follower of a pair of passes (radix_pair_passes.hpp) -- a run of whole units of
-    // the pass before, which starts and ends at any element.  Only the last tile of a range can be partial.
+    // the pass before, which starts and ends at any element, or -- SEG -- the sub-block's range.  Only the last tile of a
+    // range can be partial.
     uint64_t r0, r1;
-    if (ranges && !plan->pair_fallback[pass])
+    if (SEG)
+    {
+        const uint2 r = ranges[sb];
+        r0 = (uint32_t) __builtin_amdgcn_readfirstlane((int) r.x);
+        r1 = (uint32_t) __builtin_amdgcn_readfirstlane((int) r.y);
+    }
+    else if (ranges && !plan->pair_fallback[pass])
     {
         const uint2 r = ranges[b];
         r0 = r.x;
@@ -143,18 +185,6 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
         block_range(b, nb, tiles_total, TILE, n, share, r0, r1); // whole tiles (share == 0) or an equal share of the elements
     const uint32_t first = 0, last = (uint32_t) ((r1 - r0 + (uint64_t) TILE - 1) / (uint64_t) TILE);
     const uint32_t last_tile_of_range = last;
-    const uint32_t wave_off = wave * WAVE_TILE + lane; // wave-striped: item i of lane l of wave w = element w*64*KPT + i*64 + l
-
-    unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long tprev = 0;
-    auto stamp = [&](int slot) {
-        if (STAMPS)
-        {
-            unsigned long long t = __builtin_amdgcn_s_memtime();
-            acc[slot] += t - tprev;
-            tprev = t;
-        }
-    };
 
     KeyT key[KPT], nkey[KPT];
     uint32_t val[KPT];
@@ -511,6 +541,8 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
             }
         }
     }
+    if (SEG) __syncthreads(); // the carry slots and the per-digit records are rewritten by the next sub-block
+    } // sub-blocks
     if (STAMPS && lane == 0 && (wave == 0 || wave == WAVES - 1) && stamps)
     {
         // first and last wave of the workgroup: between them they show what a phase costs and what the barrier hides

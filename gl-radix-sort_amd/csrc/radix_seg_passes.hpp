@@ -1,0 +1,143 @@
+// radix_seg_passes.hpp -- count and scan kernels of SEGMENTED counting passes (glu_radix_sort_run_segments_ptr: the local
+// sort of the sharded sort after its exchange, glu_dist_impl.hpp).
+//
+// A segmented pass is the stable counting pass of the reference (k_radix_sort_counting_shader + BlellochScan +
+// k_radix_sort_reordering_shader, glu/RadixSort.hpp:11-183) applied to every SEGMENT of the array on its own, all segments
+// in one launch sequence: dst = segment start + (keys of the segment with a smaller digit) + (keys with this digit earlier
+// in the segment) -- RadixSort.hpp:174-177 with the "global offset" taken per segment.
+//
+// The input is cut into SUB-BLOCKS (host: seg_build_image in glu_hip.hip): element ranges that lie inside one piece of one
+// segment and inside one workgroup's share of the work.  Sub-blocks are numbered segment-major, in the stable order of the
+// segment's elements, so a segment's sub-blocks are the contiguous index range [seg_list[g], seg_list[g + 1]).
+//   radix_seg_count_kernel   a workgroup per share, sub-block by sub-block: table[i][d] = #keys of sub-block i with digit d   ([sub-block][digit])
+//   radix_seg_scan_kernel    one workgroup per segment:   table[i][d] = absolute destination of the first such key
+//   radix_scatter_lines_kernel<..., SEG = true> (radix_scatter_lines.hpp): a workgroup runs the pass body over its sub-blocks
+#pragma once
+
+#include "radix_sort_kernels.hpp"
+
+namespace glu_hip
+{
+// K1 per sub-block.  Reads 4 B per key; a range may start and end at any element of a 16-byte aligned array.  Workgroup w
+// counts the sub-blocks [seg_first[w], seg_first[w + 1]) one after the other -- the same equal share of the elements that
+// workgroup w of the scatter kernel moves.  (One workgroup per sub-block, the first version, ran 125 us where the plain
+// count kernel takes 86 us for the same 2^27 keys: sub-blocks come in all sizes, two share a CU, and the CU that draws two
+// large ones sets the kernel time.)
+template<int BITS, int THREADS>
+__global__ __launch_bounds__(THREADS) void radix_seg_count_kernel(const uint32_t* __restrict__ keys,
+                                                                  const uint2* __restrict__ subs,
+                                                                  const uint32_t* __restrict__ seg_first,
+                                                                  uint32_t* __restrict__ table, uint32_t shift, uint32_t mask)
+{
+    constexpr int RADIX = 1 << BITS;
+    constexpr int WAVES = THREADS / kWave;
+    __shared__ uint32_t hist[WAVES][RADIX];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t* my_hist = hist[wave];
+    auto dig = [&](uint32_t k) { return digit_of<uint32_t>(k, shift, mask); };
+    // every lane of the wave is active when this runs: a wave whose 64 digits are equal (constant / heavily duplicated
+    // keys) makes one add instead of a 64-way same-address LDS atomic
+    auto tally = [&](uint32_t d) {
+        const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
+        if (__ballot(d != d0) == 0)
+        {
+            if (lane == 0) atomicAdd(&my_hist[d0], 64u);
+        }
+        else
+            atomicAdd(&my_hist[d], 1u);
+    };
+    const uint32_t sb_first = seg_first[blockIdx.x], sb_last = seg_first[blockIdx.x + 1];
+    for (int i = tid; i < WAVES * RADIX; i += THREADS) (&hist[0][0])[i] = 0;
+    __syncthreads();
+    for (uint32_t sb = sb_first; sb < sb_last; sb++)
+    {
+        const uint2 r = subs[sb];
+        const uint64_t begin = r.x, end = r.y;
+        // head: the elements in front of the first 16-byte boundary
+        uint64_t vstart = (begin + 3ull) & ~3ull;
+        if (vstart > end) vstart = end;
+        if (begin + tid < vstart) atomicAdd(&my_hist[dig(keys[begin + tid])], 1u);
+        const uint64_t nvec = (end - vstart) / 4;
+        const uint4* vkeys = reinterpret_cast<const uint4*>(keys + vstart);
+        uint64_t vbase = 0;
+        for (; vbase + 4 * THREADS <= nvec; vbase += 4 * THREADS) // block-uniform trip count, 4 x 16 B in flight per lane
+        {
+            const uint4 a = load_streaming(&vkeys[vbase + tid]);
+            const uint4 b = load_streaming(&vkeys[vbase + tid + THREADS]);
+            const uint4 c = load_streaming(&vkeys[vbase + tid + 2 * THREADS]);
+            const uint4 d = load_streaming(&vkeys[vbase + tid + 3 * THREADS]);
+            tally(dig(a.x)); tally(dig(a.y)); tally(dig(a.z)); tally(dig(a.w));
+            tally(dig(b.x)); tally(dig(b.y)); tally(dig(b.z)); tally(dig(b.w));
+            tally(dig(c.x)); tally(dig(c.y)); tally(dig(c.z)); tally(dig(c.w));
+            tally(dig(d.x)); tally(dig(d.y)); tally(dig(d.z)); tally(dig(d.w));
+        }
+        for (uint64_t v = vbase + tid; v < nvec; v += THREADS) // lanes may be inactive: plain atomics
+        {
+            const uint4 a = vkeys[v];
+            atomicAdd(&my_hist[dig(a.x)], 1u);
+            atomicAdd(&my_hist[dig(a.y)], 1u);
+            atomicAdd(&my_hist[dig(a.z)], 1u);
+            atomicAdd(&my_hist[dig(a.w)], 1u);
+        }
+        const uint64_t tail = vstart + nvec * 4 + tid;
+        if (tail < end) atomicAdd(&my_hist[dig(keys[tail])], 1u);
+        __syncthreads();
+        // the sub-block's row, and the counters back to zero for the next one
+        for (int d = tid; d < RADIX; d += THREADS)
+        {
+            uint32_t c = 0;
+#pragma unroll
+            for (int w = 0; w < WAVES; w++)
+            {
+                c += hist[w][d];
+                hist[w][d] = 0;
+            }
+            table[(size_t) sb * RADIX + d] = c;
+        }
+        __syncthreads();
+    }
+}
+
+// K2 per segment: thread d walks the segment's sub-blocks (rows of the table, RADIX consecutive words each: coalesced),
+// turns the counts of digit d into running sums, scans the RADIX digit totals of the segment, and adds segment start +
+// digit offset to every entry.  (What BlellochScan + the reorder shader's 16-lane global scan do per pass in the
+// reference, BlellochScan.hpp:142-190, RadixSort.hpp:148-152 -- per segment.)
+template<int RADIX>
+__global__ __launch_bounds__(RADIX) void radix_seg_scan_kernel(uint32_t* __restrict__ table,
+                                                               const uint32_t* __restrict__ seg_list,
+                                                               const uint32_t* __restrict__ seg_start)
+{
+    constexpr int WAVES = (RADIX + kWave - 1) / kWave;
+    __shared__ uint32_t wave_sums[WAVES];
+    const uint32_t d = threadIdx.x, lane = d & 63, wave = d >> 6;
+    const uint32_t g = blockIdx.x;
+    const uint32_t i0 = seg_list[g], i1 = seg_list[g + 1];
+    uint32_t run = 0;
+    uint32_t i = i0;
+    for (; i + 4 <= i1; i += 4) // 4 independent loads in flight
+    {
+        uint32_t* row = table + (size_t) i * RADIX + d;
+        const uint32_t c0 = row[0], c1 = row[RADIX], c2 = row[2 * RADIX], c3 = row[3 * RADIX];
+        row[0] = run;
+        row[RADIX] = run + c0;
+        row[2 * RADIX] = run + c0 + c1;
+        row[3 * RADIX] = run + c0 + c1 + c2;
+        run += c0 + c1 + c2 + c3;
+    }
+    for (; i < i1; i++)
+    {
+        uint32_t* row = table + (size_t) i * RADIX + d;
+        const uint32_t c = row[0];
+        row[0] = run;
+        run += c;
+    }
+    uint32_t wtotal;
+    uint32_t excl = wave_exclusive_sum(run, lane, wtotal);
+    if (lane == 0) wave_sums[wave] = wtotal;
+    __syncthreads();
+    for (uint32_t w = 0; w < wave; w++) excl += wave_sums[w];
+    const uint32_t add = seg_start[g] + excl;
+    for (i = i0; i < i1; i++) table[(size_t) i * RADIX + d] += add;
+}
+
+} // namespace glu_hip

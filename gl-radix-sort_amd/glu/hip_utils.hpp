@@ -149,7 +149,7 @@ namespace glu
     template<typename IntegerT>
     IntegerT next_power_of_2(IntegerT n)
     {
-        if (n <= 1) return 1;
+        if (n == 0) return 0; // the reference's bit-smearing form wraps to 0 here (gl_utils.hpp:291-302)
         IntegerT p = 1;
         while (p < n) p <<= 1;
         return p;

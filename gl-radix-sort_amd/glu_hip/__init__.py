@@ -61,6 +61,7 @@ SYMBOLS = [
     ("glu_radix_sort_run_typed_ptr", _int, [_vp, _vp, _vp, _sz, _int, _vp]),
     ("glu_radix_sort_run_bit_range_ptr", _int, [_vp, _vp, _vp, _sz, _u32, _u32, _u32, _vp]),
     ("glu_radix_sort_partition_ptr", _int, [_vp, _vp, _vp, _vp, _vp, _sz, _u32, _u32, _vp, _vp]),
+    ("glu_radix_sort_run_segments_ptr", _int, [_vp, _vp, _vp, _vp, _vp, _sz, _P(_u64), _P(_u64), _P(_u32), _sz, _u32, _u32, _vp]),
     ("glu_radix_sort_set_digit_bits", _int, [_vp, _u32]),
     ("glu_radix_sort_get_digit_bits", _int, [_vp, _P(_u32)]),
     ("glu_radix_sort_scratch_size", _int, [_vp, _P(_sz)]),
@@ -86,6 +87,7 @@ SYMBOLS = [
     ("glu_dist_sort_begin", _int, [_vp, _vp, _vp, _sz, _vp, _P(_sz)]),
     ("glu_dist_sort_finish", _int, [_vp, _vp, _vp, _sz, _vp]),
     ("glu_dist_sort_ptr", _int, [_vp, _vp, _vp, _sz, _vp, _P(_vp), _P(_vp), _P(_sz)]),
+    ("glu_dist_last_local_sort", _int, [_vp, _P(_u32)]),
     ("glu_dist_set_reserved_cus", _int, [_vp, _int]),
     ("glu_dist_set_profiling", _int, [_vp, _int]),
     ("glu_dist_phase_times", _int, [_vp, _P(ctypes.c_double), _P(_u64)]),
@@ -302,6 +304,20 @@ class RadixSort:
         fn = lib().glu_radix_sort_run_ptr if key_bytes == 4 else lib().glu_radix_sort_run_u64_ptr
         check(fn(self._h, _vp(keys_ptr), _vp(vals_ptr), count, num_steps, _vp(stream)))
 
+    def run_segments_ptr(self, in_keys, in_vals, out_keys, out_vals, count, piece_begin, piece_len, piece_segment,
+                         num_segments, key_bits, stream=None):
+        """Segmented stable sort (glu_radix_sort_run_segments_ptr): the pieces [piece_begin[i], + piece_len[i]) of the
+        input arrays, grouped into segments piece_segment[i], leave as segments in ascending order, each stably sorted by
+        its low key_bits bits; the input arrays are clobbered."""
+        pb = np.ascontiguousarray(piece_begin, dtype=np.uint64)
+        pl = np.ascontiguousarray(piece_len, dtype=np.uint64)
+        ps = np.ascontiguousarray(piece_segment, dtype=np.uint32)
+        assert pb.shape == pl.shape == ps.shape and pb.ndim == 1
+        check(lib().glu_radix_sort_run_segments_ptr(
+            self._h, _vp(in_keys), _vp(in_vals), _vp(out_keys), _vp(out_vals), count,
+            pb.ctypes.data_as(_P(_u64)), pl.ctypes.data_as(_P(_u64)), ps.ctypes.data_as(_P(_u32)), pb.shape[0],
+            num_segments, key_bits, _vp(stream)))
+
     def partition_ptr(self, src_keys, src_vals, dst_keys, dst_vals, count, shift, bits, histogram_ptr=None,
                       stream=None):
         check(lib().glu_radix_sort_partition_ptr(self._h, _vp(src_keys), _vp(src_vals), _vp(dst_keys), _vp(dst_vals),
@@ -448,6 +464,12 @@ class Dist:
         sh = _u32(0)
         check(lib().glu_dist_partition_shift(self._h, ctypes.byref(sh)))
         return sh.value
+
+    def last_local_sort(self):
+        """'segmented' (three passes over the low 24 bits per bucket) or 'ordinary' (all 32 bits): the last sort's local sort."""
+        v = _u32(0)
+        check(lib().glu_dist_last_local_sort(self._h, ctypes.byref(v)))
+        return "segmented" if v.value else "ordinary"
 
     def set_reserved_cus(self, cus):
         check(lib().glu_dist_set_reserved_cus(self._h, cus))

@@ -8,13 +8,16 @@ for.  Rank r holds slice r of the global array.  Steps:
   2. all-gather of the R x 256 histogram -> every rank derives the same contiguous bucket -> rank assignment;
   3. ONE grouped exchange of keys and values (RCCL: ncclSend / ncclRecv to and from every peer inside one
      ncclGroupStart / ncclGroupEnd), receive segments ordered by source rank;
-  4. each rank: full local stable sort of what it received.
+  4. each rank: local stable sort of what it received -- three segmented passes over the low 24 bits per bucket
+     (glu_radix_sort_run_segments_ptr: the shard arrives as one message per source rank, each grouped by bucket, and the
+     first pass regroups it), or the ordinary sort of all 32 bits for small / fragmented shards.
 
-On the GPU (process group backend "nccl" = RCCL) all of it happens inside libglu_hip.so: this module is a binding of
-the glu_dist_* entry points of include/glu_hip.h (the library makes its own RCCL communicator from a unique id that is
-broadcast through the torch process group; torch only owns the tensors).  The pure-Python transport below survives for
-process groups without RCCL (gloo): the CPU tests with an oracle-backed stand-in for the device work, and the GPU tests
-that run several ranks on one GPU, which RCCL refuses.
+Two transports.  `native` = the whole sort inside libglu_hip.so (glu_dist_* of include/glu_hip.h: the library makes its
+own RCCL communicator from a unique id that is broadcast through the torch process group; torch only owns the tensors):
+what bench.py --gpus N runs, opted into with native=True or GLU_HIP_DIST_NATIVE=1 -- it has only ever met one-rank RCCL
+communicators and a file-based test double, never more than one real GPU.  Default = the torch.distributed transport below
+(all_gather + all_to_all_single under "nccl", point-to-point under gloo) around the same C-ABI device work; it is also what
+the CPU tests drive with an oracle-backed stand-in for the device work.
 
 The concatenation of the rank outputs in rank order equals the single-device stable sort: a bucket is never
 split across ranks, equal keys share a bucket, the local partition and the local sort are stable and receive
@@ -69,6 +72,23 @@ def split_counts(all_hist, bucket_to_rank, rank):
     return send, recv
 
 
+def shard_pieces(all_hist, bucket_to_rank, rank):
+    """The shard of `rank` as it arrives: one message per source rank, each holding the rank's buckets in ascending
+    order.  Returns (begin, length, segment) per piece in (source, bucket) order and the number of segments (= buckets
+    the rank owns): a segment's pieces are in source order, the stable order of its elements."""
+    all_hist = np.asarray(all_hist, dtype=np.int64)
+    mine = np.nonzero(np.asarray(bucket_to_rank) == rank)[0]
+    if mine.size == 0:
+        z = np.zeros(0, dtype=np.uint64)
+        return z, z, np.zeros(0, dtype=np.uint32), 0
+    g0, g1 = int(mine[0]), int(mine[-1]) + 1
+    lens = all_hist[:, g0:g1].reshape(-1)
+    begin = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    seg = np.tile(np.arange(g1 - g0, dtype=np.uint32), all_hist.shape[0])
+    keep = lens > 0
+    return begin[keep].astype(np.uint64), lens[keep].astype(np.uint64), seg[keep], g1 - g0
+
+
 class HipLocalOps:
     """Device work of one rank on torch tensors (int32 views of the uint32 data) through libglu_hip.so."""
 
@@ -106,6 +126,11 @@ class HipLocalOps:
             return
         self.sorter.run_ptr(keys.data_ptr(), vals.data_ptr(), count, 0, self._stream())
 
+    def sort_segments(self, in_keys, in_vals, out_keys, out_vals, count, begin, length, seg, nseg, key_bits):
+        """The shard's pieces (source-major, grouped by bucket) -> buckets in order, each sorted by its low key_bits bits."""
+        self.sorter.run_segments_ptr(in_keys.data_ptr(), in_vals.data_ptr(), out_keys.data_ptr(), out_vals.data_ptr(), count,
+                                     begin, length, seg, nseg, key_bits, self._stream())
+
 
 class SortHandle:
     """Result of DistributedRadixSort.sort_async: this rank's shard (views into the slot's receive buffers, valid until
@@ -142,22 +167,35 @@ class DistributedRadixSort:
         self.torch, self.dist, self.group = torch, dist, group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
-        # RCCL process group and no injected device ops: the whole sort runs inside the C library (glu_dist_*)
-        # (native=True asks for it under any backend: the rehearsal of bench.py, where the ranks share one GPU, the torch
-        # group is gloo and GLU_HIP_RCCL_LIB names the test transport)
-        self.native = (local_ops is None and local_ops_factory is None and torch.cuda.is_available()
-                       and (dist.get_backend(group) == "nccl" if native is None else bool(native)))
+        # native: the whole sort inside the C library (glu_dist_*).  Opt-in (argument or GLU_HIP_DIST_NATIVE=1): it has never
+        # run over more than one real GPU; bench.py opts in and verifies its output.  (native=True works under any backend:
+        # the rehearsal of bench.py, where the ranks share one GPU, the torch group is gloo and GLU_HIP_RCCL_LIB names the
+        # test transport.)
+        import os
+
+        if native is None:
+            native = os.environ.get("GLU_HIP_DIST_NATIVE", "0") not in ("", "0")
+        self.native = bool(native) and local_ops is None and local_ops_factory is None and torch.cuda.is_available()
         self.capacity_factor = capacity_factor
+        self.segmented_min = 1 << 24  # torch transport: shards from this size up take the segmented local sort
+        self.last_local_sort = None
         if self.native:
-            try:
-                self._slots = [{"ops": None, "native": self._make_native(profile), "bufs": None, "stream": None}
-                               for _ in range(max(1, slots))]
-            except Exception as e:  # e.g. no usable librccl for dlopen: every rank fails alike -> torch transport
+            made = []
+            for _ in range(max(1, slots)):
+                nd = self._make_native(profile)  # collective: every rank gets an object or every rank gets None
+                if nd is None:
+                    break
+                made.append(nd)
+            if len(made) == max(1, slots):
+                self._slots = [{"ops": None, "native": nd, "bufs": None, "stream": None} for nd in made]
+            else:
                 import warnings
 
-                warnings.warn("glu_dist is not available (%s): using the torch.distributed transport" % (e,))
+                for nd in made:
+                    nd.destroy()
+                warnings.warn("glu_dist is not available on every rank (%s): using the torch.distributed transport"
+                              % (self.native_error,))
                 self.native = False
-                self.native_error = str(e)
         if not self.native:
             if local_ops_factory is None:
                 local_ops_factory = (lambda: local_ops) if local_ops is not None else HipLocalOps
@@ -169,15 +207,49 @@ class DistributedRadixSort:
         self.profile = profile
         self._stamps = []
 
+    def _all_agree(self, ok):
+        """True iff `ok` holds on every rank (one all_gather_object: works under gloo and nccl alike)."""
+        flags = [None] * self.world
+        self.dist.all_gather_object(flags, bool(ok), group=self.group)
+        return all(flags)
+
     def _make_native(self, profile):
-        """One glu_dist per slot: rank 0 draws the RCCL unique id, the torch process group carries it to the others."""
+        """One glu_dist per slot: rank 0 draws the RCCL unique id, the torch process group carries it to the others.
+        Every step's outcome is agreed between the ranks before the next one, so that either every rank has an object or
+        every rank falls back to the torch transport (nobody is left inside ncclCommInitRank or a broadcast)."""
         from . import Dist, dist_unique_id
 
-        ids = [dist_unique_id() if self.rank == 0 else None]
+        self.native_error = None
+        uid, err = None, None
+        if self.rank == 0:
+            try:
+                uid = dist_unique_id()  # dlopens RCCL
+            except Exception as e:
+                err = str(e)
+        ids = [(uid, err)]
         src = self.dist.get_global_rank(self.group, 0) if self.group is not None else 0
-        self.dist.broadcast_object_list(ids, src=src, group=self.group)
-        d = Dist(ids[0], self.world, self.rank)
-        d.set_profiling(profile)
+        self.dist.broadcast_object_list(ids, src=src, group=self.group)  # rank 0 always broadcasts, success or not
+        uid, err = ids[0]
+        mine = err
+        if mine is None and self.rank != 0:
+            try:
+                dist_unique_id()  # can this rank load RCCL at all?  (the id itself is thrown away)
+            except Exception as e:
+                mine = str(e)
+        if not self._all_agree(mine is None):
+            self.native_error = mine or "another rank cannot load RCCL"
+            return None
+        d = None
+        try:
+            d = Dist(uid, self.world, self.rank)  # ncclCommInitRank: collective; every rank has RCCL by now
+            d.set_profiling(profile)
+        except Exception as e:
+            mine = str(e)
+        if not self._all_agree(d is not None):
+            self.native_error = mine or "glu_dist_create failed on another rank"
+            if d is not None:
+                d.destroy()
+            return None
         return d
 
     def local_sorters(self):
@@ -199,6 +271,7 @@ class DistributedRadixSort:
                 "part_v": t.empty(max(n_local, 1), dtype=t.int32, device=device),
                 "recv_k": t.empty(cap, dtype=t.int32, device=device),
                 "recv_v": t.empty(cap, dtype=t.int32, device=device),
+                "out_k": None, "out_v": None,  # output arrays of the segmented local sort (allocated on first use)
                 "hist": t.zeros(NUM_BUCKETS, dtype=t.int32, device=device),
                 "all_hist": t.zeros(self.world * NUM_BUCKETS, dtype=t.int32, device=device),
             }
@@ -335,8 +408,21 @@ class DistributedRadixSort:
         self._all_to_all(recv_v, b["part_v"][:n_local], recv_counts, send_counts)
         self._stamp(marks, keys.device)
 
-        # 5. local stable sort of the received pairs
-        ops.sort(recv_k, recv_v, n_recv)
+        # 5. local stable sort of the received pairs: segmented (three passes over the low 24 bits per bucket, the first one
+        #    regrouping the source-major shard) when the device ops offer it and the shard is large and not fragmented
+        self.last_local_sort = "ordinary"
+        if hasattr(ops, "sort_segments") and n_recv >= self.segmented_min:
+            begin, length, seg, nseg = shard_pieces(all_hist, owner, self.rank)
+            if 0 < begin.size <= 1024:
+                if b["out_k"] is None or b["out_k"].numel() < b["cap"]:
+                    b["out_k"] = t.empty(b["cap"], dtype=t.int32, device=b["device"])
+                    b["out_v"] = t.empty(b["cap"], dtype=t.int32, device=b["device"])
+                out_k, out_v = b["out_k"][:n_recv], b["out_v"][:n_recv]
+                ops.sort_segments(recv_k, recv_v, out_k, out_v, n_recv, begin, length, seg, nseg, 32 - TOP_BITS)
+                self.last_local_sort = "segmented"
+                recv_k, recv_v = out_k, out_v
+        if self.last_local_sort == "ordinary":
+            ops.sort(recv_k, recv_v, n_recv)
         self._stamp(marks, keys.device)
         if marks:
             self._stamps.append(marks)
@@ -347,6 +433,7 @@ class DistributedRadixSort:
         cap = int(n_recv * 1.1) + 4096
         b["recv_k"] = t.empty(cap, dtype=t.int32, device=b["device"])
         b["recv_v"] = t.empty(cap, dtype=t.int32, device=b["device"])
+        b["out_k"] = b["out_v"] = None
         b["cap"] = cap
         if hasattr(slot["ops"], "prepare"):
             slot["ops"].prepare(cap)

@@ -194,6 +194,21 @@ GLU_API glu_status glu_radix_sort_run_bit_range_ptr(glu_radix_sort sort, void* k
 GLU_API glu_status glu_radix_sort_partition_ptr(glu_radix_sort sort, const uint32_t* src_keys, const uint32_t* src_vals,
                                                 uint32_t* dst_keys, uint32_t* dst_vals, size_t count, uint32_t shift,
                                                 uint32_t bits, uint32_t* digit_histogram, void* stream);
+/* Segmented stable sort (not in the reference; it is the local sort of the sharded sort below, where a rank's shard
+ * arrives as one message per source rank, each grouped by top-byte bucket): the input arrays hold `num_pieces` pieces,
+ * piece i = elements [piece_begin[i], piece_begin[i] + piece_len[i]) of in_keys / in_vals, together exactly `count`
+ * elements; piece i belongs to segment piece_segment[i] < num_segments.  Segment g = its pieces laid end to end in the
+ * order they are listed.  The output arrays receive the segments in ascending order of g, each stably sorted by the low
+ * `key_bits` key bits (0, 8, 16, 24 or 32; 0 = only the regrouping).  Each pass is the reference's stable counting pass
+ * (RadixSort.hpp:142-182) applied per segment, all segments in one launch sequence of the sort's own kernels; the first
+ * pass reads the pieces where they lie, so the regrouping costs no pass of its own.  in != out; the input arrays are used
+ * as scratch (their contents are lost).  Enqueues on `stream` (the piece arrays are read before the call returns); after
+ * glu_radix_sort_prepare(sort, count) it allocates nothing on the device. */
+GLU_API glu_status glu_radix_sort_run_segments_ptr(glu_radix_sort sort, uint32_t* in_keys, uint32_t* in_vals,
+                                                   uint32_t* out_keys, uint32_t* out_vals, size_t count,
+                                                   const uint64_t* piece_begin, const uint64_t* piece_len,
+                                                   const uint32_t* piece_segment, size_t num_pieces, uint32_t num_segments,
+                                                   uint32_t key_bits, void* stream);
 /* Digit width (bits per counting pass) the sort uses internally: 4 (the reference's pass structure: 8 passes
  * for 32-bit keys) or 8 (4 passes).  The sorted result is identical; see DESIGN.md. */
 GLU_API glu_status glu_radix_sort_set_digit_bits(glu_radix_sort sort, uint32_t bits);
@@ -256,7 +271,13 @@ GLU_API glu_status glu_reduce_run_ptr(glu_reduce reduce, void* data, size_t coun
  * local stable sort.  The ranks' outputs concatenated in rank order equal the single-device stable sort; shard sizes
  * follow the data.  If all keys of all ranks share the top byte (24-bit keys ...), the partition falls back to the next lower
  * byte, so that small-range keys still spread over the ranks; one hot bucket still bounds the balance.  RCCL is loaded with dlopen at first use (GLU_HIP_RCCL_LIB overrides the name).
- * Every rank must issue the same sequence of glu_dist calls (they contain collectives). */
+ * Every rank must issue the same sequence of glu_dist calls (they contain collectives).
+ * Errors are collective: when one rank finds its arguments, sizes or allocations wrong in glu_dist_sort_begin /
+ * glu_dist_sort_finish / glu_dist_sort_ptr, EVERY rank returns a non-zero status from that call (the failing rank its own,
+ * the others the same code with a message naming the rank) before anything is sent or received, and the object can be used
+ * for the next sort; no rank is left waiting in a collective.  A rank that must give up between begin and finish (it
+ * cannot allocate its receive arrays) still calls glu_dist_sort_finish, with capacity 0.  A failing RCCL or HIP call
+ * after the ranks have agreed is not recoverable (it is reported by the rank that sees it; destroy the object). */
 
 #define GLU_DIST_UNIQUE_ID_BYTES 128
 /* Rank 0: ncclGetUniqueId; the caller carries the bytes to the other ranks (MPI, torch.distributed, a file ...). */
@@ -285,6 +306,10 @@ GLU_API glu_status glu_dist_sort_finish(glu_dist dist, uint32_t* recv_keys, uint
  * pointers valid until the next sort on `dist`. */
 GLU_API glu_status glu_dist_sort_ptr(glu_dist dist, const uint32_t* keys, const uint32_t* vals, size_t local_count,
                                      void* stream, uint32_t** out_keys, uint32_t** out_vals, size_t* out_count);
+/* 1 if the local sort of the last sort on `dist` ran as three segmented passes over the low 24 bits (the shard arrives as
+ * one message per source rank, each grouped by bucket; glu_radix_sort_run_segments_ptr), 0 if it was the ordinary sort of
+ * all 32 bits (small shards, shards made of very many tiny pieces, a partition on a lower byte). */
+GLU_API glu_status glu_dist_last_local_sort(glu_dist dist, uint32_t* segmented);
 /* CUs that the sort kernels of `dist` leave free (for RCCL kernels of another sort in flight; the partition pass always
  * leaves 8, one per XCD, for the histogram all-gather that runs beside its scatter kernel). */
 GLU_API glu_status glu_dist_set_reserved_cus(glu_dist dist, int cus);

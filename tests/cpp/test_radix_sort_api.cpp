@@ -85,6 +85,19 @@ namespace
     }
 } // namespace
 
+TEST_CASE("integer-helpers-like-the-reference")
+{
+    // glu/gl_utils.hpp:279-302 (values the reference's own arithmetic gives, including its edge cases at 0)
+    CHECK(glu::next_power_of_2<uint32_t>(0) == 0u);
+    CHECK(glu::next_power_of_2<uint32_t>(1) == 1u);
+    CHECK(glu::next_power_of_2<uint32_t>(3) == 4u);
+    CHECK(glu::next_power_of_2<uint32_t>(1024) == 1024u);
+    CHECK(glu::next_power_of_2<uint32_t>(1025) == 2048u);
+    CHECK(glu::is_power_of_2<uint32_t>(0));
+    CHECK(glu::is_power_of_2<uint32_t>(64) && !glu::is_power_of_2<uint32_t>(65));
+    CHECK(glu::div_ceil<size_t>(1025, 1024) == 2 && glu::div_ceil<size_t>(1024, 1024) == 1 && glu::div_ceil<size_t>(0, 1024) == 0);
+}
+
 TEST_CASE("RadixSort-reference-cases")
 {
     // RadixSort-128-256-512-1024, RadixSort-2048 and RadixSort-multiple-sizes of the reference

@@ -23,8 +23,9 @@ def test_single_rank_nccl_distributed_sort(built):
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
     try:
-        sorter = D.DistributedRadixSort(slots=2, profile=True)
-        assert sorter.native  # RCCL group: the C ABI does everything
+        assert not D.DistributedRadixSort().native  # the default is the torch transport; the C-ABI sort is opted into
+        sorter = D.DistributedRadixSort(slots=2, profile=True, native=True)
+        assert sorter.native  # the C ABI does everything
         for n, seed in ((1 << 20, 1), (300001, 2), (4097, 3), (0, 4), (1, 5), (5 * (1 << 20) + 3, 6)):
             rng = np.random.default_rng(seed)
             keys = rng.integers(0, 2**32, n, dtype=np.uint32)
@@ -331,12 +332,23 @@ def _mock_cases(world):
     build("only_last_rank_has_keys", 24, uniform, [0] * (world - 1) + [70001])
     build("two_keys", None, lambda r, n: np.array([5, 3][:n], dtype=np.uint32), [2] + [0] * (world - 1))
     build("line_kernel_sizes", 24, uniform, [3 * (1 << 20) + 17 + 4096 * r for r in range(world)])
+    # equal keys that straddle source ranks: five key values over all ranks (stability = source rank, then source index)
+    build("few_distinct_keys", 24,
+          lambda r, n: np.random.default_rng(500 + r).choice(np.array([7, 0x40000007, 0x40000008, 0xC0FFEE00, 0xFFFFFFFF], dtype=np.uint32), n),
+          sizes)
+    # a duplicate-heavy low half under a uniform top byte: long runs of equal keys inside every bucket, from every source
+    build("duplicates_in_every_bucket", 24,
+          lambda r, n: (np.random.default_rng(600 + r).integers(0, 256, n, dtype=np.uint32) << np.uint32(24)) | np.uint32(0x00ABCD00 + r % 2),
+          [400003 + 64 * r for r in range(world)])
     return cases
 
 
-def _mock_rank_worker(rank, world, unique_id, mock_lib, mock_dir, q):
+def _mock_rank_worker(rank, world, unique_id, mock_lib, mock_dir, q, seg_mode=None):
     import os
     import sys
+
+    if seg_mode is not None:
+        os.environ["GLU_HIP_DIST_SEG"] = seg_mode  # "2": segmented local sort for every shard of 2^16 pairs up; "0": never
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for p in (os.path.join(root, "gl-radix-sort_amd"), os.path.join(root, "oracle"), os.path.join(root, "tests")):
@@ -384,14 +396,18 @@ def _mock_rank_worker(rank, world, unique_id, mock_lib, mock_dir, q):
             same = same and bool((b.get_data(np.uint32)[:cnt] == ref).all())
         if keys.size:  # the input is untouched
             same = same and bool((kb.get_data(np.uint32) == keys).all()) and bool((vb.get_data(np.uint32) == vals).all())
-        out.append((name, first.partition_shift(), gk, gv, same))
+        out.append((name, first.partition_shift(), gk, gv, same, first.last_local_sort()))
     first.destroy()
     second.destroy()
     q.put((rank, out))
 
 
+@pytest.mark.parametrize("seg_mode", ["2", "0", None])
 @pytest.mark.parametrize("world", [2, 3, 8])
-def test_native_multi_rank_sort_over_mock_transport(built, world, tmp_path):
+def test_native_multi_rank_sort_over_mock_transport(built, world, seg_mode, tmp_path):
+    """seg_mode "2": every shard of 2^16 pairs or more takes the segmented local sort (the exchange then lands in the
+    sorter's scratch and the first pass regroups the source-major shard by bucket), "0": never, None: the library's rule
+    (these shards are below its 2^24 threshold)."""
     import torch.multiprocessing as mp
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -400,13 +416,13 @@ def test_native_multi_rank_sort_over_mock_transport(built, world, tmp_path):
     unique_id = os.urandom(128)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_mock_rank_worker, args=(r, world, unique_id, mock_lib, str(tmp_path), q)) for r in range(world)]
+    procs = [ctx.Process(target=_mock_rank_worker, args=(r, world, unique_id, mock_lib, str(tmp_path), q, seg_mode)) for r in range(world)]
     for p in procs:
         p.start()
     import queue
 
     try:
-        results = dict(q.get(timeout=600) for _ in range(world))
+        results = dict(q.get(timeout=900) for _ in range(world))
     except queue.Empty:
         for p in procs:
             p.join(timeout=5)
@@ -427,10 +443,121 @@ def test_native_multi_rank_sort_over_mock_transport(built, world, tmp_path):
         assert all(g[4] for g in got), name                 # begin / finish on two communicators gave the same shards
         if shift is not None:
             assert all(g[1] == shift for g in got), (name, [g[1] for g in got])
+        for g in got:  # which local sort ran: the segmented one exactly when forced and the shard is large enough for it
+            want = "segmented" if (seg_mode == "2" and g[2].size >= (1 << 16) and g[1] == 24) else "ordinary"
+            assert g[5] == want, (name, g[2].size, g[1], g[5])
         if name == "uniform":  # the plan balances: a shard exceeds its share by less than the hottest (unsplittable) bucket
             sizes = [g[2].size for g in got]
             hottest = int(np.bincount(all_keys >> 24, minlength=256).max())
             assert max(sizes) <= ek.size / world + hottest, (sizes, hottest)
+
+
+def _mock_failure_worker(rank, world, unique_id, mock_lib, mock_dir, q, env):
+    import os
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (os.path.join(root, "gl-radix-sort_amd"), os.path.join(root, "oracle"), os.path.join(root, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["GLU_HIP_RCCL_LIB"] = mock_lib
+    os.environ["GLU_MOCK_RCCL_DIR"] = mock_dir
+    os.environ.update(env)
+    import numpy as np
+    import glu_hip as G
+
+    G.set_device(0)
+    d = G.Dist(unique_id, world, rank)
+    n = 100000 + 10 * rank
+    rng = np.random.default_rng(900 + rank)
+    keys = rng.integers(0, 2**32, n, dtype=np.uint32)
+    if env.get("GLU_HIP_DIST_TEST_SHARD_LIMIT"):
+        keys[: n * 9 // 10] |= np.uint32(0xFF000000)  # nine tenths of every slice go to the last rank: over the lowered limit
+    vals = np.arange(n, dtype=np.uint32)
+    kb, vb = G.ShaderStorageBuffer(keys), G.ShaderStorageBuffer(vals)
+    outcomes = []
+    for attempt in range(2):
+        try:
+            d.sort_ptr(kb.device_ptr(), vb.device_ptr(), n)
+            G.synchronize()
+            outcomes.append(("ok", ""))
+        except G.GluError as e:
+            outcomes.append((e.status, str(e)))
+    # the same through begin / finish with a rank that gives up in between (capacity 0)
+    try:
+        cnt = d.sort_begin(kb.device_ptr(), vb.device_ptr(), n)
+        if rank == 1 and not env:
+            d.sort_finish(None, None, 0)
+        else:
+            rk, rv = G.ShaderStorageBuffer(size=max(cnt, 1) * 4), G.ShaderStorageBuffer(size=max(cnt, 1) * 4)
+            d.sort_finish(rk.device_ptr(), rv.device_ptr(), cnt)
+        G.synchronize()
+        outcomes.append(("ok", ""))
+    except G.GluError as e:
+        outcomes.append((e.status, str(e)))
+    # and the object still sorts afterwards when nothing is wrong any more
+    if not env:
+        try:
+            _, _, cnt = d.sort_ptr(kb.device_ptr(), vb.device_ptr(), n)
+            G.synchronize()
+            outcomes.append(("ok", cnt))
+        except G.GluError as e:
+            outcomes.append((e.status, str(e)))
+    d.destroy()
+    q.put((rank, outcomes))
+
+
+@pytest.mark.parametrize("env", [{"GLU_HIP_DIST_TEST_SHARD_LIMIT": "150000"}, {"GLU_HIP_DIST_TEST_FAIL": "begin:2"},
+                                 {"GLU_HIP_DIST_TEST_FAIL": "finish:0"}, {}])
+def test_native_failures_are_collective(built, env, tmp_path):
+    """One rank's shard over the (test-lowered) limit, a rank whose allocation fails before the histogram exchange or before
+    the data exchange, a rank that cannot provide receive arrays: EVERY rank returns a failure from that call and none
+    hangs in a collective; with nothing wrong any more the same objects sort."""
+    import torch.multiprocessing as mp
+    import queue
+
+    world = 3
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    mock_lib = os.path.join(root, "tests", "cpp", "bin", "libmock_rccl.so")
+    unique_id = os.urandom(128)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_mock_failure_worker, args=(r, world, unique_id, mock_lib, str(tmp_path), q, env)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        results = dict(q.get(timeout=300) for _ in range(world))
+    except queue.Empty:
+        for p in procs:
+            p.kill()
+        raise AssertionError("a rank hung or died (exit codes %s)" % [p.exitcode for p in procs])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    import glu_hip as G
+
+    for r in range(world):
+        out = results[r]
+        if env.get("GLU_HIP_DIST_TEST_SHARD_LIMIT"):
+            assert [o[0] for o in out] == [G.GLU_ERROR_INVALID_ARGUMENT] * 3, (r, out)
+            assert all("would receive" in o[1] and "no rank sorts" in o[1] for o in out), out
+            named = {o[1].split("rank ")[1].split(" ")[0] for o in out}
+            assert len(named) == 1, out  # every call names the same rank ...
+            all_named = globals().setdefault("_named_ranks", set())
+            all_named |= named
+        elif env:
+            assert [o[0] for o in out] == [G.GLU_ERROR_OUT_OF_MEMORY] * 3, (r, out)
+            failing = int(env["GLU_HIP_DIST_TEST_FAIL"].split(":")[1])
+            assert all(("injected failure" in o[1]) == (r == failing) for o in out), (r, out)
+        else:
+            assert out[0][0] == "ok" and out[1][0] == "ok", (r, out)
+            assert out[2][0] == G.GLU_ERROR_INVALID_ARGUMENT, (r, out)  # rank 1 gave up: nobody exchanged
+            assert ("receive arrays hold 0 pairs" in out[2][1]) == (r == 1), (r, out)
+            assert out[3][0] == "ok", (r, out)
+    if env.get("GLU_HIP_DIST_TEST_SHARD_LIMIT"):
+        assert len(globals().pop("_named_ranks")) == 1  # ... on every rank
+    if not env:
+        assert sum(results[r][3][1] for r in range(world)) == sum(100000 + 10 * r for r in range(world))
 
 
 def test_bench_multi_gpu_command_line_rehearsal(built):

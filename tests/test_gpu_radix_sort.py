@@ -276,8 +276,91 @@ def test_pointer_entry_points_accept_empty_inputs(G):
     s = G.RadixSort()
     s.run_ptr(0, 0, 0)
     s.run_ptr(0, 0, 0, key_bytes=8)
+    s.sort_keys_ptr(0, 0)
+    s.sort_keys_ptr(0, 0, key_bytes=8)
+    for key_type in G.RadixSort.KEY_TYPES:  # GLU_KEY_UINT32 .. GLU_KEY_FLOAT64
+        s.sort_typed_ptr(0, 0, 0, key_type)
+    s.sort_bit_range_ptr(0, 0, 0, 8, 24)
+    s.sort_bit_range_ptr(0, 0, 0, 8, 24, key_bytes=8)
     with pytest.raises(G.GluError):
         s.run_ptr(0, 0, 5)
+    with pytest.raises(G.GluError):
+        s.sort_keys_ptr(0, 5)
+    with pytest.raises(G.GluError):
+        s.sort_typed_ptr(0, 0, 5, "int32")
+    with pytest.raises(G.GluError):  # an invalid key type is an error whatever the count
+        G.check(G.lib().glu_radix_sort_run_typed_ptr(s._h, None, None, 0, 17, None))
+    with pytest.raises(G.GluError):
+        s.sort_bit_range_ptr(0, 0, 5, 8, 24)
+    with pytest.raises(G.GluError):
+        s.sort_bit_range_ptr(0, 0, 0, 24, 8)  # so is a bad bit range
+
+
+def test_destroy_releases_every_scratch_array(G):
+    """64 sort objects prepared for 2^26 pairs (which includes the tables of the paired passes, 33 MiB) come and go: the
+    device's free memory returns to where it was (RAII of the reference: RadixSort.hpp:194-200, gl_utils.hpp:184-188)."""
+    import torch
+
+    torch.cuda.synchronize()
+    G.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    low = free0
+    for i in range(64):
+        s = G.RadixSort()
+        s.prepare_internal_buffers(1 << 26)
+        assert s.scratch_size() > 2 * 4 * (1 << 26) + (32 << 20)  # key + value scratch + the two-digit tables
+        low = min(low, torch.cuda.mem_get_info()[0])
+        s.destroy()
+    G.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert low < free0 - (500 << 20)
+    assert abs(free1 - free0) <= (8 << 20), (free0, free1)  # (the allocator's own granularity; the leak was 33 MiB per object)
+
+
+def test_destroy_waits_for_work_on_a_caller_stream(G):
+    """A sort enqueued on the caller's stream and the object destroyed right away: the scratch outlives the kernels."""
+    import torch
+
+    n = 6 * (1 << 20) + 5
+    rng = np.random.default_rng(11)
+    keys = rng.integers(0, 2**32, n, dtype=np.uint32)
+    vals = np.arange(n, dtype=np.uint32)
+    ek, ev = O.stable_sort_pairs(keys, vals)
+    side = torch.cuda.Stream()
+    for _ in range(3):
+        kt = torch.from_numpy(keys.view(np.int32)).cuda()
+        vt = torch.from_numpy(vals.view(np.int32)).cuda()
+        torch.cuda.synchronize()
+        s = G.RadixSort()
+        s.run_ptr(kt.data_ptr(), vt.data_ptr(), n, 0, side.cuda_stream)
+        s.destroy()  # frees the scratch arrays: must not happen under the running passes
+        other = G.RadixSort()
+        other.prepare_internal_buffers(n)  # likely to get the freed addresses
+        side.synchronize()
+        assert (kt.cpu().numpy().view(np.uint32) == ek).all() and (vt.cpu().numpy().view(np.uint32) == ev).all()
+
+
+def test_read_plan_of_an_unplanned_sort_is_all_zero(G):
+    """Below 2^22 elements a sort has no device-side plan: read_plan reports every pass as run and alone (it used to
+    return whatever the plan buffer held)."""
+    big = 5 * (1 << 20)
+    rng = np.random.default_rng(5)
+    s = G.RadixSort()
+    k = rng.integers(0, 1 << 16, big, dtype=np.uint32)  # two constant digits: a planned sort that skips passes
+    kb, vb = G.ShaderStorageBuffer(k), G.ShaderStorageBuffer(np.arange(big, dtype=np.uint32))
+    s(kb, vb, big)
+    G.synchronize()
+    assert any(s.read_plan(4))
+    k2 = rng.integers(0, 2**32, 100000, dtype=np.uint32)
+    kb2, vb2 = G.ShaderStorageBuffer(k2), G.ShaderStorageBuffer(np.arange(100000, dtype=np.uint32))
+    s(kb2, vb2, 100000)
+    G.synchronize()
+    skipped, alone, roles = s.read_plan(4, roles=True)
+    assert not any(skipped) and not any(alone) and not any(roles)
+    fresh = G.RadixSort()
+    fresh(kb2, vb2, 100000)
+    G.synchronize()
+    assert fresh.read_plan(4, roles=True) == ([0] * 4, [0] * 4, [0] * 4)
 
 
 def test_small_geometry_forced_matches(G, monkeypatch):
