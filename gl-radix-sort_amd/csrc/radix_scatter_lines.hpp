@@ -38,10 +38,16 @@ struct LineSmem
     static constexpr int WAVES = THREADS / kWave;
     static constexpr int TILE = THREADS * KPT;
     static constexpr int LINE = line_elems<KeyT>();
-    static constexpr int CARRY = RADIX * LINE;
+    // A digit's carry row holds LINE slots.  Rows of 4-byte keys are LINE + 1 slots apart: with rows of exactly 32 x 8 B = 256 B
+    // every digit's slot s lies in the same LDS bank column, and the two phases whose lanes walk (digit, quad of slots) pairs
+    // -- the tail copy's writes (16 lanes = 2 digits x 8 quads onto 4 columns: 4-way on every store) and the first lines'
+    // reads -- serialise; one slot of padding rotates the columns by the digit.  (8-byte keys: no LDS left for it.)
+    static constexpr int CSTRIDE = LINE + (sizeof(KeyT) == 4 ? 1 : 0);
+    static constexpr int CARRY = RADIX * CSTRIDE;
     static constexpr int MAXLINES = (TILE + RADIX * (LINE - 1)) / LINE + 2;
     static_assert(TILE < 65536 && MAXLINES < 65536, "ranked positions and line numbers share one 32-bit scan word");
-    PairArray<KeyT, TILE + CARRY, VALS> buf; // [0, TILE): the tile in ranked order;  [TILE + d * LINE, + LINE): carry of digit d
+    static_assert(RADIX <= 256, "the line table holds digits as bytes");
+    PairArray<KeyT, TILE + CARRY, VALS> buf; // [0, TILE): the tile in ranked order;  [TILE + d * CSTRIDE, + LINE): carry of digit d
     // 16-bit counters (a wave ranks at most 64 * KPT elements of a tile, positions stay below TILE < 65536): half the LDS
     // of 32-bit ones, which the tile gets.  Rows of RADIX + 4 halfwords: the scan's four rows per thread land 8 banks apart.
     static constexpr int WCNT_STRIDE = RADIX + 4;
@@ -49,8 +55,8 @@ struct LineSmem
     uint4 dinfo[RADIX];  // .x global index of the digit's first line this tile (= of its carried elements), .y ranked position
                          // of combined element 0 (= first ranked position - carried count), .z first line | carried << 16,
                          // .w first global index of the digit that this workgroup owns
-    uint2 tail[RADIX];   // new carry: slot s in [.y & 0xff, .y >> 8) <- ranked position .x + s
-    uint16_t ltab[(MAXLINES + 1) & ~1]; // digit of every line written this tile
+    uint32_t tail[RADIX]; // new carry: slots [lo, hi) <- ranked positions (p + slot) mod 2^16; p | lo << 16 | hi << 24
+    uint8_t ltab[(MAXLINES + 3) & ~3]; // digit of every line written this tile
     uint32_t scan_tmp[WAVES];
     uint32_t total_lines;
 };
@@ -245,6 +251,35 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
     using I0 = std::integral_constant<int, 0>;
     using ISplit = std::integral_constant<int, RANK_SPLIT>;
     using IEnd = std::integral_constant<int, KPT>;
+    constexpr uint32_t CSTRIDE = Smem::CSTRIDE;
+    // ---- new carry: the elements of every digit past its last full line move to the digit's carry slots.  Work items are
+    //      (digit, quad of slots).
+    constexpr int TAIL_ITEMS = RADIX * (int) (LINE / 4);
+    auto copy_tails = [&]() {
+        if (PRIO & 2) __builtin_amdgcn_s_setprio(2);
+#pragma unroll
+        for (int it = 0; it < (TAIL_ITEMS + THREADS - 1) / THREADS; it++)
+        {
+            const uint32_t item = it * THREADS + tid;
+            if (TAIL_ITEMS % THREADS == 0 || item < (uint32_t) TAIL_ITEMS)
+            {
+                const uint32_t d = item / (LINE / 4), s0 = (item % (LINE / 4)) * 4;
+                const uint32_t t = s.tail[d];
+                const uint32_t from = t & 0xFFFFu, lo = (t >> 16) & 0xFFu, hi = t >> 24;
+                KeyT k[4];
+                uint32_t v[4];
+                // slots below lo read the element of slot lo (a valid position), slots from hi up read past the run
+                // (inside the buffer): neither is written.  (`from` is the ranked position of slot 0 modulo 2^16: it lies
+                // before the digit's run -- "negative" when the run is short -- and only from + slot, slot >= lo, is a position)
+#pragma unroll
+                for (int e = 0; e < 4; e++) s.buf.get((from + (s0 + e > lo ? s0 + e : lo)) & 0xFFFFu, k[e], v[e]);
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                    if (s0 + e >= lo && s0 + e < hi) s.buf.put((uint32_t) TILE + d * CSTRIDE + s0 + e, k[e], v[e]);
+            }
+        }
+        if (PRIO & 2) __builtin_amdgcn_s_setprio(0);
+    };
 
     // ---- prologue of the software pipeline: the first tile is loaded and ranked here; every later tile is loaded and
     //      ranked under the phases of the tile before it
@@ -318,7 +353,7 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
                     }
                     const uint32_t m = c_d + n_d, c_new = m & (LINE - 1), k = n_d < c_new ? n_d : c_new;
                     s.dinfo[sd] = make_uint4(carry_start, pos - c_d, line0 | (c_d << 16), owned_from);
-                    s.tail[sd] = make_uint2(pos + n_d - c_new, (c_new - k) | (c_new << 8));
+                    s.tail[sd] = ((pos + n_d - c_new) & 0xFFFFu) | ((c_new - k) << 16) | (c_new << 24);
                     digit_base += n_d;
                     carry_start += nl_d * LINE;
                     if (tid == (uint32_t) RADIX - 1) s.total_lines = line0 + nl_d;
@@ -328,7 +363,7 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
                 // that holds a large part of the tile: at most TILE / 32 / kOwnLines of them) the wave fills together.
                 constexpr uint32_t kOwnLines = 32;
                 if (digit_owner)
-                    for (uint32_t j = 0; j < (nl_d < kOwnLines ? nl_d : kOwnLines); j++) s.ltab[line0 + j] = (uint16_t) sd;
+                    for (uint32_t j = 0; j < (nl_d < kOwnLines ? nl_d : kOwnLines); j++) s.ltab[line0 + j] = (uint8_t) sd;
                 uint64_t big = __ballot(digit_owner && nl_d > kOwnLines);
                 while (big)
                 {
@@ -337,7 +372,7 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
                     const uint32_t bd = (uint32_t) __builtin_amdgcn_readlane((int) sd, l);
                     const uint32_t b0 = (uint32_t) __builtin_amdgcn_readlane((int) line0, l);
                     const uint32_t bn = (uint32_t) __builtin_amdgcn_readlane((int) nl_d, l);
-                    for (uint32_t j = kOwnLines + lane; j < bn; j += kWave) s.ltab[b0 + j] = (uint16_t) bd;
+                    for (uint32_t j = kOwnLines + lane; j < bn; j += kWave) s.ltab[b0 + j] = (uint8_t) bd;
                 }
             }
         }
@@ -379,6 +414,7 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
         stamp(3);
 
         // ---- write the full lines: quad = 4 consecutive elements of one line = one 16-byte store per array
+        auto write_out = [&]() {
         if (ABLATE < 4)
         {
             const uint32_t quads = s.total_lines * (LINE / 4);
@@ -402,7 +438,7 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
                     const uint32_t q0 = (l - line0) * LINE + sub * 4; // index in (carry ++ run) of the quad's first element
                     g0[u] = info.x + q0;                               // its global index (a multiple of 4)
                     from_run[u] = info.y + q0;                         // ranked position, were it an element of the run
-                    from_carry[u] = (uint32_t) TILE + d * LINE + q0;
+                    from_carry[u] = (uint32_t) TILE + d * CSTRIDE + q0;
                     in_carry[u] = (int) carried - (int) q0;            // elements e < in_carry of the quad are carried ones
                     owned[u] = info.w;
                 }
@@ -471,38 +507,11 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
             else
                 write_lines(std::integral_constant<int, 2>(), tid);
         }
+        };
+        write_out();
         stamp(4);
         __syncthreads(); // the carried elements have been read: their slots may be rewritten
         stamp(5);
-
-        // ---- new carry: the elements of every digit past its last full line move to the digit's carry slots
-        auto copy_tails = [&]() {
-            if (PRIO & 2) __builtin_amdgcn_s_setprio(2);
-            {
-                constexpr int ITEMS = RADIX * (int) (LINE / 4); // (digit, quad of slots)
-#pragma unroll
-                for (int it = 0; it < (ITEMS + THREADS - 1) / THREADS; it++)
-                {
-                    const uint32_t item = it * THREADS + tid;
-                    if (ITEMS % THREADS == 0 || item < (uint32_t) ITEMS)
-                    {
-                        const uint32_t d = item / (LINE / 4), s0 = (item % (LINE / 4)) * 4;
-                        const uint2 t = s.tail[d];
-                        const uint32_t lo = t.y & 0xFFu, hi = t.y >> 8;
-                        KeyT k[4];
-                        uint32_t v[4];
-                        // slots below lo read the element of slot lo (a valid position), slots from hi up read past the run
-                        // (inside the buffer): neither is written
-#pragma unroll
-                        for (int e = 0; e < 4; e++) s.buf.get(t.x + (s0 + e > lo ? s0 + e : lo), k[e], v[e]);
-#pragma unroll
-                        for (int e = 0; e < 4; e++)
-                            if (s0 + e >= lo && s0 + e < hi) s.buf.put((uint32_t) TILE + d * LINE + s0 + e, k[e], v[e]);
-                    }
-                }
-            }
-            if (PRIO & 2) __builtin_amdgcn_s_setprio(0);
-        };
         // ---- tail copy (LDS-bound) and the rest of the next tile's ranking (VALU-bound, wave-private state: nobody else
         //      touches this wave's counter row between this tile's staging and the scan of the next tile, so the tile
         //      ends without a barrier).  The two are independent: on every SIMD two waves copy first and two rank first, so
@@ -526,7 +535,7 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
     __syncthreads();
     if (ABLATE < 4)
     {
-        for (uint32_t e = tid; e < (uint32_t) Smem::CARRY; e += THREADS)
+        for (uint32_t e = tid; e < (uint32_t) RADIX * LINE; e += THREADS)
         {
             const uint32_t d = e / LINE, slot = e % LINE;
             const uint4 info = s.dinfo[d];
@@ -535,7 +544,7 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
             {
                 KeyT k;
                 uint32_t v;
-                s.buf.get((uint32_t) TILE + e, k, v);
+                s.buf.get((uint32_t) TILE + d * CSTRIDE + slot, k, v);
                 dst_keys[g] = codec_out.decode(k);
                 if (VALS) dst_vals[g] = v;
             }

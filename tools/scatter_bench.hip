@@ -279,7 +279,7 @@ void run_lines(Ctx& c, uint32_t shift, uint32_t mask_override = 0)
     CK(hipMemset(c.vals2, 0xff, c.n * 4));
     float t_scatter = time_min(c, 5, [&] {
         hipLaunchKernelGGL(scatter, dim3(nb), dim3(THREADS), sizeof(Smem), 0, skeys, VALS ? svals : nullptr, c.keys2, VALS ? c.vals2 : nullptr,
-                           c.table, totals, (uint32_t) n_eff, shift, mask, tiles, (unsigned long long*) nullptr, 0u, (PassPlan*) nullptr, 0u, (const uint2*) nullptr, 0u);
+                           c.table, totals, (uint32_t) n_eff, shift, mask, tiles, (unsigned long long*) nullptr, 0u, (PassPlan*) nullptr, 0u, (const uint2*) nullptr, 0u, (const uint32_t*) nullptr);
     });
     CK(hipGetLastError());
     CK(hipDeviceSynchronize());
@@ -292,7 +292,7 @@ void run_lines(Ctx& c, uint32_t shift, uint32_t mask_override = 0)
     CK(hipMalloc(&st, 128));
     CK(hipMemset(st, 0, 128));
     hipLaunchKernelGGL(scatter_st, dim3(nb), dim3(THREADS), sizeof(Smem), 0, skeys, VALS ? svals : nullptr, c.keys2, VALS ? c.vals2 : nullptr, c.table,
-                       totals, (uint32_t) n_eff, shift, mask, tiles, st, 0u, (PassPlan*) nullptr, 0u, (const uint2*) nullptr, 0u);
+                       totals, (uint32_t) n_eff, shift, mask, tiles, st, 0u, (PassPlan*) nullptr, 0u, (const uint2*) nullptr, 0u, (const uint32_t*) nullptr);
     unsigned long long hst[16];
     CK(hipMemcpy(hst, st, 128, hipMemcpyDeviceToHost));
     CK(hipFree(st));
@@ -303,7 +303,7 @@ void run_lines(Ctx& c, uint32_t shift, uint32_t mask_override = 0)
         for (int r = 0; r < 5; r++)
         {
             hipLaunchKernelGGL(scatter, dim3(nb), dim3(THREADS), sizeof(Smem), 0, skeys, VALS ? svals : nullptr, c.keys2, VALS ? c.vals2 : nullptr,
-                               c.table, totals, (uint32_t) n_eff, shift, mask, tiles, (unsigned long long*) nullptr, 0u, (PassPlan*) nullptr, 0u, (const uint2*) nullptr, 0u);
+                               c.table, totals, (uint32_t) n_eff, shift, mask, tiles, (unsigned long long*) nullptr, 0u, (PassPlan*) nullptr, 0u, (const uint2*) nullptr, 0u, (const uint32_t*) nullptr);
             CK(hipEventRecord(c.ev[0]));
             hipLaunchKernelGGL((radix_count_kernel<uint32_t, BITS, THREADS, TILE>), dim3(nb), dim3(THREADS), 0, 0, c.keys2, c.table + (1 << 20), (uint32_t) n_eff,
                                shift + BITS, mask, tiles, 0u);
@@ -682,6 +682,15 @@ int main(int argc, char** argv)
     if (getenv("SB_SRCOFF"))
     {
         run_lines<8, 1024, 10, true, 0, 4, true, true>(c, shift);
+        return 0;
+    }
+    if (getenv("SB_R3"))
+    {
+        for (int rep = 0; rep < 2; rep++)
+        {
+            run_lines<8, 1024, 10, true, 0, 4, true, true>(c, shift);
+            run_lines<4, 1024, 12, true, 0, 4, true, true>(c, shift);
+        }
         return 0;
     }
     if (getenv("SB_LINES"))
