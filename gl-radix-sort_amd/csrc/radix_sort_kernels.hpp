@@ -404,6 +404,50 @@ __global__ __launch_bounds__(THREADS) void radix_row_scan_kernel(uint32_t* __res
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Mid-size sorts (one tile per workgroup, all workgroups resident): ONE read of the keys for the digit totals of every
+// pass (k_radix_sort_counting_shader's global_count, RadixSort.hpp:52-56, for all passes at once), after which every pass
+// is a single launch of the chained scatter kernel.  ghist[p][d] += this tile's keys with value d in digit p (global
+// atomics: RADIX per pass and workgroup); the workgroup also clears its rows of the passes' chain words.
+// shifts / widths: one byte per pass.
+// ---------------------------------------------------------------------------------------------------------
+template<int THREADS, int TILE, int MAX_PASSES = 4>
+__global__ __launch_bounds__(THREADS) void radix_hist_kernel(const uint32_t* __restrict__ keys, uint32_t* __restrict__ ghist,
+                                                             uint32_t* __restrict__ chain, uint32_t n, uint32_t passes,
+                                                             uint32_t shifts, uint32_t widths)
+{
+    constexpr int RADIX = 256;
+    __shared__ uint32_t hist[MAX_PASSES][RADIX];
+    const uint32_t tid = threadIdx.x, b = blockIdx.x, tiles = gridDim.x;
+    for (int i = tid; i < MAX_PASSES * RADIX; i += THREADS) (&hist[0][0])[i] = 0;
+    // per pass: local[d][row_words] (one word per tile) then group[d][grow_words] (one word per group of 16 tiles)
+    const uint32_t row_words = (tiles + 15u) & ~15u, grow_words = (row_words / 16u + 15u) & ~15u;
+    const size_t pass_words = (size_t) RADIX * (row_words + grow_words);
+    for (uint32_t p = 0; p < passes; p++)
+        for (uint32_t i = tid; i < (uint32_t) RADIX; i += THREADS)
+        {
+            chain[p * pass_words + (size_t) i * row_words + b] = 0u;
+            if (b % 16u == 0u) chain[p * pass_words + (size_t) RADIX * row_words + (size_t) i * grow_words + b / 16u] = 0u;
+        }
+    __syncthreads();
+    const uint64_t base = (uint64_t) b * TILE;
+    for (uint32_t i = tid; i < (uint32_t) TILE; i += THREADS)
+    {
+        if (base + i < n)
+        {
+            const uint32_t k = keys[base + i];
+            for (uint32_t p = 0; p < passes; p++)
+                atomicAdd(&hist[p][__builtin_amdgcn_ubfe(k, (shifts >> (8 * p)) & 255u, (widths >> (8 * p)) & 255u)], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < passes * RADIX; i += THREADS)
+    {
+        const uint32_t c = (&hist[0][0])[i];
+        if (c) atomicAdd(&ghist[i], c);
+    }
+}
+
 constexpr uint32_t kFusedScanMaxBlocks = 32; // FUSED_SCAN scatter: every workgroup reads RADIX x nb counts itself, at most this many per thread
                                              // (THREADS / RADIX threads share a row; the host raises the limit for 4-bit digits: launch_pass)
 
@@ -510,13 +554,19 @@ struct ScatterSmem
 //               staging area.  ROUNDS / PREFETCH / DMA are measured alternatives kept for tools/scatter_bench.hip
 //               (level with or slower than the defaults), not used by the library.
 template<typename KeyT, int BITS, int THREADS, int KPT, bool CARRY = true, int ABLATE = 0, bool STAMPS = false,
-         int MIN_WAVES_PER_SIMD = 1, int ROUNDS = 1, bool PREFETCH = false, bool DMA = false, bool XF = false, bool VALS = true, bool FUSED_SCAN = false>
+         int MIN_WAVES_PER_SIMD = 1, int ROUNDS = 1, bool PREFETCH = false, bool DMA = false, bool XF = false, bool VALS = true, bool FUSED_SCAN = false,
+         bool CHAINED = false>
 __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_kernel(
     const KeyT* __restrict__ keys_a, const uint32_t* __restrict__ vals_a, KeyT* __restrict__ keys_b,
     uint32_t* __restrict__ vals_b, const uint32_t* __restrict__ table, const uint32_t* __restrict__ totals,
     uint32_t n, uint32_t shift, uint32_t mask, uint32_t tiles_total, unsigned long long* stamps = nullptr,
-    uint32_t xform = 0, PassPlan* plan = nullptr, uint32_t pass = 0)
+    uint32_t xform = 0, PassPlan* plan = nullptr, uint32_t pass = 0, uint32_t* __restrict__ chain = nullptr)
 {
+    // CHAINED (mid-size sorts, one tile per workgroup, every workgroup resident at once): no count kernel and no row scan.
+    // `totals` are the digit totals of this pass from the up-front histogram kernel (radix_hist_kernel); a workgroup's
+    // offset inside every digit is the sum of the digit counts of the tiles before it, which every workgroup publishes
+    // (chain[tile * RADIX + d] = count + 1; 0 = not yet) as soon as it has ranked its tile.
+    static_assert(!CHAINED || (!CARRY && !FUSED_SCAN && ROUNDS == 1 && !PREFETCH), "chained passes run the plain one-tile form");
     // Source and destination arrays: (a -> b) as passed, or (b -> a) when the plan says that the data sits in b.  The
     // body only ever touches memory through the four local pointers below.
     const KeyT* __restrict__ src_keys = keys_a;
@@ -615,7 +665,7 @@ __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_ker
 #pragma unroll
         for (int w = 0; w < WAVES; w++)
             if ((uint32_t) w < wave) woff += s.scan_tmp[w];
-        if (tid < RADIX) digit_base = woff + excl + (FUSED_SCAN ? before : table[(size_t) tid * nb + b]);
+        if (tid < RADIX) digit_base = woff + excl + (CHAINED ? 0u : FUSED_SCAN ? before : table[(size_t) tid * nb + b]);
     }
     uint32_t carry_start = digit_base; // CARRY: elements [carry_start, digit_base) of the digit are held in s.carry
     for (int i = tid; i < WAVES * Smem::WCNT_STRIDE; i += THREADS) (&s.wcnt[0][0])[i] = 0;
@@ -841,6 +891,81 @@ __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_ker
         __syncthreads();
         stamp(4); // offsets
 
+        if (CHAINED)
+        {
+            // Publish this tile's digit counts, then add up those of every tile before it -- in two levels, so that a tile reads
+            // at most 15 + tiles / 16 words per digit instead of one per predecessor (reading them all cost 33 MB of polling loads
+            // per pass at 256 tiles: 60 us per pass): tiles form groups of 16; the last tile of a group publishes the group's
+            // total; a tile adds the totals of the groups before its own and the counts of the tiles before it inside its
+            // group.  chain = local[d][row_words] then group[d][grow_words]; a word is value + 1, 0 = not yet.  All
+            // workgroups are resident and publish before they wait, and a group total waits for plain counts only: the waits end.
+            constexpr uint32_t PARTS = THREADS / RADIX >= 1 ? THREADS / RADIX : 1;
+            constexpr uint32_t GROUP = 16;
+            const uint32_t row_words = (tiles_total + GROUP - 1) & ~(GROUP - 1);
+            const uint32_t grow_words = (row_words / GROUP + GROUP - 1) & ~(GROUP - 1);
+            uint32_t* const local = chain;
+            uint32_t* const group = chain + (size_t) RADIX * row_words;
+            uint32_t* scratch = reinterpret_cast<uint32_t*>(&s.stage); // (the staging area is not in use yet)
+            uint32_t len = 0;
+            if (tid < RADIX)
+            {
+                const uint32_t ts = s.tstart[tid];
+                const uint32_t te = tid + 1 < RADIX ? s.tstart[tid + 1] : (uint32_t) TILE;
+                len = te - ts;
+                if (tid == MASK) len -= (uint32_t) TILE - tile_valid;
+                __hip_atomic_store(&local[(size_t) tid * row_words + b], len + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            // 16 independent loads of one aligned group of words, repeated until the first `want` of them are published
+            auto sum_ready = [&](const uint32_t* words, uint32_t want) {
+                uint32_t spins = 0;
+                for (;;)
+                {
+                    uint32_t v[GROUP];
+#pragma unroll
+                    for (uint32_t j = 0; j < GROUP; j++)
+                    {
+#ifdef GLU_CHAIN_POLL_RMW
+                        v[j] = __hip_atomic_fetch_add(const_cast<uint32_t*>(&words[j]), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+                        v[j] = __hip_atomic_load(&words[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+                    }
+                    bool ready = true;
+                    uint32_t total = 0;
+#pragma unroll
+                    for (uint32_t j = 0; j < GROUP; j++)
+                    {
+                        ready = ready && (j >= want || v[j] != 0u);
+                        total += j < want ? v[j] - 1u : 0u;
+                    }
+                    if (ready) return total;
+                    if (++spins > (1u << 22)) __builtin_trap(); // fail loudly, never hang
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            };
+            const uint32_t part = tid / RADIX, d = tid % RADIX;
+            const uint32_t my_group = b / GROUP;
+            uint32_t sum = 0;
+            if (part == 0)
+            {
+                // the tiles before this one inside its group; the group's last tile owes the group's total
+                if (b % GROUP) sum = sum_ready(local + (size_t) d * row_words + my_group * GROUP, b % GROUP);
+                if (b % GROUP == GROUP - 1)
+                    __hip_atomic_store(&group[(size_t) d * grow_words + my_group], sum + len + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            // the groups before this one (shared by the other threads of the digit; by the same thread when there is only one)
+            if (part < PARTS && (part > 0 || PARTS == 1))
+                for (uint32_t g0 = (PARTS == 1 ? 0u : part - 1u) * GROUP; g0 < my_group; g0 += (PARTS == 1 ? 1u : PARTS - 1u) * GROUP)
+                    sum += sum_ready(group + (size_t) d * grow_words + g0, my_group - g0 < GROUP ? my_group - g0 : GROUP);
+            if (part < PARTS) scratch[tid] = sum;
+            __syncthreads();
+            if (tid < RADIX)
+            {
+#pragma unroll
+                for (uint32_t k = 0; k < PARTS; k++) digit_base += scratch[k * RADIX + tid];
+            }
+            __syncthreads(); // the staging area is free again
+        }
         // ---- thread d: where digit d of this tile goes, advance the running base
         if (tid < RADIX)
         {
