@@ -432,9 +432,6 @@ struct glu_radix_sort_s
     Scratch pair_table;  // the follower's count table + digit totals,
     Scratch pair_ranges; // the element range of every follower workgroup,
     Scratch pair_sub;    // and (4-bit digits) the leader's table per sub-block: [16][num_blocks * 16]
-    Scratch chain;       // chained mid-size sorts: digit totals of every pass [4][256] + one word per (pass, tile, digit)
-    int chained = 0;     // GLU_HIP_SORT_CHAINED: 1 = mid-size sorts (one tile per workgroup, all resident) run as one histogram launch + one
-                         // look-back scatter launch per pass; 0 = count / row scan / scatter per pass
     Scratch seg_desc;    // segmented passes (glu_dist's local sort): sub-block descriptors of the pass being enqueued
     Scratch seg_zero;    // and RADIX zero words (the digit totals a segmented scatter adds to its absolute table entries)
     bool last_planned = false; // the last sort on this object ran with a device-side plan (glu_radix_sort_read_plan)
@@ -497,7 +494,6 @@ namespace
 // (tools/pairs_ladder.py; GLU_HIP_SORT_PAIR_MIN=elements overrides: tests, tuning)
 constexpr size_t kPairMinKeyBytes = (size_t) 1 << 28;
 constexpr size_t kPlanMinCount = (size_t) 1 << 22; // planned sorts: see PlanArgs below
-constexpr int kChainedMaxPassesDecl = 4;           // (= kChainedMaxPasses, defined with the chained sort below)
 
 // CUs the pass kernels of `s` may fill (glu_dist reserves some for RCCL kernels that run beside them)
 inline uint32_t usable_cus(const glu_radix_sort_s* s)
@@ -512,8 +508,6 @@ glu_status sort_prepare(glu_radix_sort_s* s, size_t count, size_t key_size, bool
     if (with_vals) GLU_TRY(s->vals.reserve(count * sizeof(uint32_t)));
     uint64_t cap = (uint64_t) g_dev.num_cus * kMaxBlocksPerCu;
     GLU_TRY(s->table.reserve((kMaxRadix * cap + kMaxRadix) * sizeof(uint32_t)));
-    if (s->chained && key_size == 4 && with_vals)
-        GLU_TRY(s->chain.reserve((size_t) kChainedMaxPassesDecl * 256 * 4 * (40 + (size_t) g_dev.num_cus * kMaxBlocksPerCu * 17 / 16)));
     if (s->plan.size < sizeof(PassPlan))
     {
         GLU_TRY(s->plan.reserve(sizeof(PassPlan)));
@@ -861,82 +855,6 @@ glu_status sort_single_block(KeyT* keys, uint32_t* vals, size_t count, uint32_t 
 }
 
 
-// Mid-size sorts of (uint32 key, uint32 value) pairs with 8-bit digits, one tile per workgroup and every workgroup resident at
-// once (up to 3 x CUs tiles of 4096 pairs): one histogram launch for the digit totals of all passes, then ONE launch per
-// pass -- the scatter kernel publishes its tile's digit counts and adds up those of the tiles before it (CHAINED) instead of
-// a count kernel and a row scan in front of it.  5 dependent launches instead of 8-12.
-constexpr int kChainedMaxPasses = 4;
-bool chained_applicable(const glu_radix_sort_s* s, size_t count, uint32_t first_bit, uint32_t end_bit)
-{
-    using G = PairGeometry<uint32_t, 8, false>;
-    if (!s->chained || s->digit_bits != 8 || s->force_small) return false;
-    const size_t tiles = (count + G::TILE - 1) / G::TILE;
-    const uint32_t passes = (end_bit - first_bit + 7) / 8;
-    return passes >= 1 && passes <= (uint32_t) kChainedMaxPasses && tiles >= 2 && tiles <= (size_t) usable_cus(s) * G::BLOCKS_PER_CU;
-}
-
-glu_status sort_chained(glu_radix_sort_s* s, uint32_t* keys, uint32_t* vals, size_t count, uint32_t first_bit, uint32_t end_bit,
-                        hipStream_t stream)
-{
-    using G = PairGeometry<uint32_t, 8, false>;
-    constexpr int RADIX = 256;
-    const uint32_t tiles = (uint32_t) ((count + G::TILE - 1) / G::TILE);
-    const uint32_t passes = (end_bit - first_bit + 7) / 8;
-    const size_t row_words = ((size_t) tiles + 15) & ~(size_t) 15, grow_words = (row_words / 16 + 15) & ~(size_t) 15;
-    const size_t pass_words = (size_t) RADIX * (row_words + grow_words);
-    const size_t words = (size_t) kChainedMaxPasses * RADIX + (size_t) kChainedMaxPasses * pass_words;
-    GLU_TRY(s->chain.reserve(std::max<size_t>(words * sizeof(uint32_t), (size_t) kChainedMaxPasses * RADIX * 4 * (40 + (size_t) g_dev.num_cus * kMaxBlocksPerCu * 17 / 16))));
-    uint32_t* ghist = (uint32_t*) s->chain.ptr;
-    uint32_t* chain = ghist + kChainedMaxPasses * RADIX;
-    uint32_t shifts = 0, widths = 0;
-    for (uint32_t p = 0; p < passes; p++)
-    {
-        const uint32_t shift = first_bit + 8 * p, bits = std::min<uint32_t>(8, end_bit - shift);
-        shifts |= shift << (8 * p);
-        widths |= bits << (8 * p);
-    }
-    using Smem = ScatterSmem<uint32_t, 8, G::THREADS, G::KPT, false, 1, true>;
-    auto scatter = radix_scatter_kernel<uint32_t, 8, G::THREADS, G::KPT, false, 0, false, G::BLOCKS_PER_CU * G::THREADS / 256, 1, false, false, false, true, false, true>;
-    static std::once_flag lds_opt_in;
-    static hipError_t lds_opt_in_result = hipSuccess;
-    std::call_once(lds_opt_in, [&] {
-        lds_opt_in_result = hipFuncSetAttribute((const void*) scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sizeof(Smem));
-    });
-    HIP_TRY(lds_opt_in_result);
-    s->mark(stream);
-    HIP_TRY(hipMemsetAsync(ghist, 0, (size_t) kChainedMaxPasses * RADIX * sizeof(uint32_t), stream));
-    hipLaunchKernelGGL((radix_hist_kernel<G::THREADS, G::TILE, kChainedMaxPasses>), dim3(tiles), dim3(G::THREADS), 0, stream, (const uint32_t*) keys,
-                       ghist, chain, (uint32_t) count, passes, shifts, widths);
-    HIP_TRY(hipGetLastError());
-    s->mark(stream);
-    s->mark(stream);
-    uint32_t* kbuf[2] = {keys, (uint32_t*) s->keys.ptr};
-    uint32_t* vbuf[2] = {vals, (uint32_t*) s->vals.ptr};
-    int cur = 0;
-    for (uint32_t p = 0; p < passes; p++)
-    {
-        const uint32_t shift = (shifts >> (8 * p)) & 255u, bits = (widths >> (8 * p)) & 255u;
-        if (p > 0)
-        {
-            s->mark(stream);
-            s->mark(stream);
-            s->mark(stream);
-        }
-        hipLaunchKernelGGL(scatter, dim3(tiles), dim3(G::THREADS), sizeof(Smem), stream, (const uint32_t*) kbuf[cur], (const uint32_t*) vbuf[cur],
-                           kbuf[cur ^ 1], vbuf[cur ^ 1], (const uint32_t*) nullptr, (const uint32_t*) (ghist + p * RADIX), (uint32_t) count, shift,
-                           (1u << bits) - 1u, tiles, (unsigned long long*) nullptr, 0u, (PassPlan*) nullptr, 0u, chain + (size_t) p * pass_words);
-        HIP_TRY(hipGetLastError());
-        s->mark(stream);
-        cur ^= 1;
-    }
-    if (cur == 1)
-    {
-        HIP_TRY(hipMemcpyAsync(keys, kbuf[1], count * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
-        HIP_TRY(hipMemcpyAsync(vals, vbuf[1], count * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
-    }
-    return GLU_OK;
-}
-
 // vals == nullptr: keys-only sort (no value traffic, no value scratch)
 template<typename KeyT>
 glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t count, uint32_t first_bit, uint32_t end_bit,
@@ -956,15 +874,6 @@ glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t cou
         GLU_TRY(sort_single_block<KeyT>(keys, vals, count, first_bit, end_bit, stream, key_xf | (key_xf << 2)));
         s->mark(stream);
         return GLU_OK;
-    }
-
-    if constexpr (sizeof(KeyT) == 4)
-    {
-        if (vals && key_xf == KEY_XF_NONE && chained_applicable(s, count, first_bit, end_bit))
-        {
-            s->last_planned = false;
-            return sort_chained(s, keys, vals, count, first_bit, end_bit, stream);
-        }
     }
 
     KeyT* kbuf[2] = {keys, (KeyT*) s->keys.ptr};
@@ -1334,7 +1243,6 @@ glu_status glu_radix_sort_create(glu_radix_sort* out)
     }
     if (const char* e = getenv("GLU_HIP_SORT_NT_STORES")) s->nt_stores = atoi(e) != 0;
     if (const char* e = getenv("GLU_HIP_SORT_LARGE_MIN")) s->large_min = (size_t) atoll(e);
-    if (const char* e = getenv("GLU_HIP_SORT_CHAINED")) s->chained = atoi(e);
     *out = s;
     return GLU_OK;
 }
@@ -1347,7 +1255,7 @@ glu_status glu_radix_sort_destroy(glu_radix_sort sort)
     // library queue, before its scratch goes away (RAII of the reference: RadixSort.hpp:194-200, gl_utils.hpp:184-188)
     (void) hipDeviceSynchronize();
     for (Scratch* sc : {&sort->keys, &sort->vals, &sort->table, &sort->plan, &sort->pair_t2, &sort->pair_table, &sort->pair_ranges,
-                        &sort->pair_sub, &sort->seg_desc, &sort->seg_zero, &sort->chain})
+                        &sort->pair_sub, &sort->seg_desc, &sort->seg_zero})
         sc->release();
     for (hipEvent_t e : sort->events) (void) hipEventDestroy(e);
     for (glu_radix_sort_s::SegStage& st : sort->seg_stage)
@@ -1626,7 +1534,7 @@ glu_status glu_radix_sort_scratch_size(glu_radix_sort sort, size_t* bytes)
     GLU_TRY(enter());
     if (!sort || !bytes) return fail(GLU_ERROR_INVALID_ARGUMENT, "NULL argument");
     *bytes = sort->keys.size + sort->vals.size + sort->table.size + sort->plan.size + sort->pair_t2.size + sort->pair_table.size +
-             sort->pair_ranges.size + sort->pair_sub.size + sort->chain.size + sort->seg_desc.size + sort->seg_zero.size;
+             sort->pair_ranges.size + sort->pair_sub.size + sort->seg_desc.size + sort->seg_zero.size;
     return GLU_OK;
 }
 

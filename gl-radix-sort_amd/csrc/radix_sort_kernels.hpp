@@ -405,6 +405,7 @@ __global__ __launch_bounds__(THREADS) void radix_row_scan_kernel(uint32_t* __res
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// (Measured alternative, not used by the library: see CHAINED in radix_scatter_kernel.)
 // Mid-size sorts (one tile per workgroup, all workgroups resident): ONE read of the keys for the digit totals of every
 // pass (k_radix_sort_counting_shader's global_count, RadixSort.hpp:52-56, for all passes at once), after which every pass
 // is a single launch of the chained scatter kernel.  ghist[p][d] += this tile's keys with value d in digit p (global
@@ -562,7 +563,9 @@ __global__ __launch_bounds__(THREADS, MIN_WAVES_PER_SIMD) void radix_scatter_ker
     uint32_t n, uint32_t shift, uint32_t mask, uint32_t tiles_total, unsigned long long* stamps = nullptr,
     uint32_t xform = 0, PassPlan* plan = nullptr, uint32_t pass = 0, uint32_t* __restrict__ chain = nullptr)
 {
-    // CHAINED (mid-size sorts, one tile per workgroup, every workgroup resident at once): no count kernel and no row scan.
+    // CHAINED -- a measured alternative kept for tools/chained_probe.hip, NOT used by the library (one
+    // cross-CU hand-off costs 2.5-3.6 us on this chip, more than the count and row-scan launches it replaces; a sort of 2^20
+    // pairs took 186 us this way against 67 us).  Mid-size sorts, one tile per workgroup, every workgroup resident at once: no count kernel and no row scan.
     // `totals` are the digit totals of this pass from the up-front histogram kernel (radix_hist_kernel); a workgroup's
     // offset inside every digit is the sum of the digit counts of the tiles before it, which every workgroup publishes
     // (chain[tile * RADIX + d] = count + 1; 0 = not yet) as soon as it has ranked its tile.
