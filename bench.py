@@ -44,8 +44,8 @@ def parse_args():
                    help="do not record per-kernel HIP events in the timed region (roofline fields become null)")
     p.add_argument("--no-alt", action="store_true", help="skip the extra 4-bit-digit (reference pass structure) measurement")
     p.add_argument("--pipeline-depth", type=int, default=2,
-                   help="N>1: besides the headline (one sort at a time) also measure this many consecutive sorts in flight "
-                        "(own stream, buffers and communicator each); 1 = skip")
+                   help="N>1: consecutive independent sorts in flight in the line's timed region (own stream, buffers and "
+                        "communicator each; the one-at-a-time figure is reported beside it as value_depth1); 1 = one at a time only")
     p.add_argument("--reserved-cus", type=int, default=8,
                    help="N>1, pipelined measurement: CUs the sort kernels leave to the RCCL kernels of the other sort in flight")
     p.add_argument("--transport", default="native", choices=["native", "torch"],
@@ -423,18 +423,25 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             return float(tt.item())
 
-        # the timed region of the line (`value`, `ms_per_step`): one sort at a time, like N = 1
+        # Two timed regions of K sorts each.  depth 1: one sort at a time on one stream (partition -> exchange -> local sort,
+        # each waiting for the one before).  depth 2: the K sorts alternate between two glu_dist objects (own stream, buffers
+        # and communicator), so that the exchange of sort i + 1 runs under the local sort of sort i -- how a caller with a
+        # stream of independent batches uses the API, and the regime the line's `value` reports: K sorts enqueued as fast
+        # as the API allows, barrier + synchronize on both sides, like the N = 1 line (where one GPU has nothing to overlap).
+        # `value_depth1` / `ms_per_step_depth1` stand beside it; the per-kernel roofline numbers come from the depth-1 region.
         r1 = run_depth(1)
-        elapsed = r1["elapsed"]
-        result["pipeline_depth"] = 1
-        result["value_depth1"] = round(n * world * K / max_over_ranks(elapsed) / 1e6, 1)
+        elapsed1 = max_over_ranks(r1["elapsed"])
+        result["value_depth1"] = round(n * world * K / elapsed1 / 1e6, 1)
+        result["ms_per_step_depth1"] = round(elapsed1 / K * 1e3, 4)
         depth = max(1, args.pipeline_depth)
+        elapsed = r1["elapsed"]
         if depth > 1:
-            # batch throughput with `depth` independent sorts in flight: a different regime, reported beside the headline
             r2 = run_depth(depth)
-            result["value_depth%d" % depth] = round(n * world * K / max_over_ranks(r2["elapsed"]) / 1e6, 1)
+            elapsed = r2["elapsed"]
+            result["value_depth%d" % depth] = round(n * world * K / max_over_ranks(elapsed) / 1e6, 1)
             result["phases_ms_rank0_depth%d" % depth] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in r2["phases"].items()}
             del r2
+        result["pipeline_depth"] = depth
         dsort, handle, profs, sorters = r1["dsort"], r1["handle"], r1["profs"], r1["sorters"]
         result["native_c_abi"] = bool(dsort.native)
         result["local_sort"] = (dsort._slots[0]["native"].last_local_sort() if dsort.native else dsort.last_local_sort)
@@ -488,7 +495,8 @@ def main():
         result["shard_pairs_rank0"] = int(cnt)
         workload = ("2^%d uint32 key+val pairs per GPU (%d GPUs, 2^%.2f total), uniform-random keys; top-8-bit bucket "
                     "partition + one RCCL all-to-all over xGMI + local sort") % (log2n, world, log2n + __import__("math").log2(world))
-        parallelism = "bucket-sharded x%d (1 grouped RCCL exchange), one sort at a time (value_depth%d: %d in flight)" % (world, depth, depth)
+        parallelism = ("bucket-sharded x%d (1 grouped RCCL exchange per sort), %d independent sorts in flight (value_depth1: one at a time)"
+                       % (world, depth)) if depth > 1 else "bucket-sharded x%d (1 grouped RCCL exchange per sort), one sort at a time" % world
 
     # max over ranks
     if dist is not None:

@@ -4,6 +4,7 @@
 
 #include <cstdint>
 #include <type_traits>
+#include <vector>
 
 #include "BlellochScan.hpp"
 #include "hip_utils.hpp"
@@ -70,6 +71,26 @@ namespace glu
             static_assert(std::is_same<KeyT, uint32_t>::value || std::is_same<KeyT, uint64_t>::value, "unsigned keys");
             GLU_CHECK_STATUS(glu_radix_sort_run_bit_range_ptr(m_impl, device_keys, device_vals, count, sizeof(KeyT) * 8,
                                                               begin_bit, end_bit, stream));
+        }
+
+        /// One piece of the input of sort_segments: elements [begin, begin + length) of the input arrays, part of `segment`.
+        struct Piece
+        {
+            uint64_t begin, length;
+            uint32_t segment;
+        };
+        /// Segmented stable sort on raw device pointers (not in the reference; the local sort of the sharded sort): the
+        /// pieces -- together exactly `count` elements -- are grouped into `num_segments` segments (a segment = its pieces
+        /// laid end to end in the order they are listed); the output arrays receive the segments in ascending order, each
+        /// stably sorted by its low `key_bits` key bits (0, 8, 16, 24 or 32).  in != out; the input arrays are clobbered.
+        void sort_segments(uint32_t* in_keys, uint32_t* in_vals, uint32_t* out_keys, uint32_t* out_vals, size_t count,
+                           const std::vector<Piece>& pieces, uint32_t num_segments, uint32_t key_bits, void* stream = nullptr)
+        {
+            std::vector<uint64_t> begin(pieces.size()), length(pieces.size());
+            std::vector<uint32_t> segment(pieces.size());
+            for (size_t i = 0; i < pieces.size(); i++) begin[i] = pieces[i].begin, length[i] = pieces[i].length, segment[i] = pieces[i].segment;
+            GLU_CHECK_STATUS(glu_radix_sort_run_segments_ptr(m_impl, in_keys, in_vals, out_keys, out_vals, count, begin.data(), length.data(),
+                                                             segment.data(), pieces.size(), num_segments, key_bits, stream));
         }
 
         /// 64-bit keys with 32-bit values (not in the reference); num_steps counts 4-bit digits, 0 = all 64 bits.

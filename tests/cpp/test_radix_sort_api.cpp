@@ -272,6 +272,46 @@ TEST_CASE("RadixSort-raw-pointer-overload")
     CHECK(paired);
 }
 
+TEST_CASE("RadixSort-segmented-sort")
+{
+    // the local sort of the sharded sort: pieces (source rank, bucket) -> buckets in order, each stably sorted by 24 bits
+    std::mt19937 gen(77);
+    const size_t n = 700001;
+    const uint32_t sources = 3, segments = 8;
+    std::vector<GLuint> keys(n), vals(n);
+    for (auto& k : keys) k = gen() & 0x00FF0FFFu; // duplicate-heavy low 24 bits
+    std::iota(vals.begin(), vals.end(), 0u);
+    std::vector<RadixSort::Piece> pieces;
+    uint64_t at = 0;
+    for (uint32_t s = 0; s < sources; s++)
+        for (uint32_t g = 0; g < segments; g++)
+        {
+            uint64_t len = (s == sources - 1 && g == segments - 1) ? n - at : (gen() % (2 * n / (sources * segments)));
+            if (at + len > n) len = n - at;
+            pieces.push_back({at, len, g});
+            at += len;
+        }
+    CHECK(at == n);
+    ShaderStorageBuffer kin(keys), vin(vals), kout(n * sizeof(GLuint)), vout(n * sizeof(GLuint));
+    RadixSort radix_sort;
+    radix_sort.sort_segments(static_cast<uint32_t*>(kin.device_ptr()), static_cast<uint32_t*>(vin.device_ptr()),
+                             static_cast<uint32_t*>(kout.device_ptr()), static_cast<uint32_t*>(vout.device_ptr()), n, pieces, segments, 24);
+    std::vector<GLuint> gk = kout.get_data<GLuint>(), gv = vout.get_data<GLuint>();
+    // expected: per segment, its pieces laid end to end, std::stable_sort by the low 24 bits
+    std::vector<GLuint> ek, ev;
+    for (uint32_t g = 0; g < segments; g++)
+    {
+        std::vector<std::pair<GLuint, GLuint>> seg;
+        for (const auto& pc : pieces)
+            if (pc.segment == g)
+                for (uint64_t i = pc.begin; i < pc.begin + pc.length; i++) seg.push_back({keys[i], vals[i]});
+        std::stable_sort(seg.begin(), seg.end(), [](const auto& a, const auto& b) { return (a.first & 0xFFFFFFu) < (b.first & 0xFFFFFFu); });
+        for (const auto& e : seg) ek.push_back(e.first), ev.push_back(e.second);
+    }
+    CHECK(gk == ek);
+    CHECK(gv == ev);
+}
+
 TEST_CASE("RadixSort-two-host-threads")
 {
     // glu_hip.h: distinct handles may be used from distinct host threads.  Two threads, each with its own sorter and

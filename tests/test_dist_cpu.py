@@ -32,6 +32,32 @@ class OracleLocalOps:
         vals.numpy().view(np.uint32)[:count] = v
 
 
+class OracleSegmentedOps(OracleLocalOps):
+    """The same stand-in with the segmented local sort of the device ops (HipLocalOps.sort_segments): every segment = its
+    pieces laid end to end in the order they are listed, stably sorted by the low key_bits bits, segments in order."""
+
+    calls = 0
+
+    def sort_segments(self, in_keys, in_vals, out_keys, out_vals, count, begin, length, seg, nseg, key_bits):
+        type(self).calls += 1
+        k = in_keys.numpy().view(np.uint32)
+        v = in_vals.numpy().view(np.uint32)
+        ok, ov = out_keys.numpy().view(np.uint32), out_vals.numpy().view(np.uint32)
+        at = 0
+        for g in range(nseg):
+            idx = [i for i in range(len(seg)) if seg[i] == g]
+            if not idx:
+                continue
+            gk = np.concatenate([k[int(begin[i]):int(begin[i] + length[i])] for i in idx])
+            gv = np.concatenate([v[int(begin[i]):int(begin[i] + length[i])] for i in idx])
+            sk, sv = O.stable_sort_pairs(gk, gv, key_bits)
+            ok[at:at + sk.size] = sk
+            ov[at:at + sk.size] = sv
+            at += sk.size
+        assert at == count
+        k[:count] = 0xDEADBEEF  # the input arrays are scratch for the device ops: nobody may rely on them afterwards
+
+
 def make_keys(kind, n, seed):
     rng = np.random.default_rng(seed)
     if kind == "uniform":
@@ -134,7 +160,29 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, kind, n_local, q):
+def test_shard_pieces_lists_the_shard_as_it_arrives():
+    """(source, bucket) order, empty pieces dropped, begins = running sum over the source-major layout."""
+    rng = np.random.default_rng(5)
+    world = 4
+    h = rng.integers(0, 50, (world, 256))
+    h[:, 100:140] = 0  # buckets without elements
+    owner = D.plan_bucket_to_rank(h.sum(axis=0), world)
+    for rank in range(world):
+        begin, length, seg, nseg = D.shard_pieces(h, owner, rank)
+        mine = np.nonzero(owner == rank)[0]
+        assert nseg == mine.size and (length > 0).all()
+        _, recv = D.split_counts(h, owner, rank)
+        assert int(length.sum()) == int(recv.sum())
+        at, want = 0, []
+        for s in range(world):
+            for j, b in enumerate(mine):
+                if h[s, b]:
+                    want.append((at, int(h[s, b]), j))
+                at += int(h[s, b])
+        assert list(zip(begin.tolist(), length.tolist(), seg.tolist())) == want
+
+
+def _worker(rank, world, port, kind, n_local, q, segmented=False):
     import torch
     import torch.distributed as dist
 
@@ -145,24 +193,30 @@ def _worker(rank, world, port, kind, n_local, q):
         keys = make_keys(kind, n_local + 13 * rank, 7 + rank)
         base = sum(n_local + 13 * r for r in range(rank))
         vals = np.arange(base, base + keys.size, dtype=np.uint32)
-        sorter = D.DistributedRadixSort(local_ops=OracleLocalOps())
+        sorter = D.DistributedRadixSort(local_ops=OracleSegmentedOps() if segmented else OracleLocalOps())
+        if segmented:
+            sorter.segmented_min = 1  # every shard takes the segmented local sort (the library's threshold is 2^24 pairs)
         kt = torch.from_numpy(keys.view(np.int32).copy())
         vt = torch.from_numpy(vals.view(np.int32).copy())
         rk, rv, cnt = sorter.sort(kt, vt)
+        assert sorter.last_local_sort == ("segmented" if segmented and cnt else "ordinary")
         q.put((rank, rk.numpy().view(np.uint32)[:cnt].copy(), rv.numpy().view(np.uint32)[:cnt].copy()))
     finally:
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("segmented", [False, True])
 @pytest.mark.parametrize("kind", ["uniform", "dups", "hot"])
-def test_two_process_gloo_sort_matches_oracle(kind):
+def test_two_process_gloo_sort_matches_oracle(kind, segmented):
+    """segmented: the local sort after the exchange is the segmented one (the shard's pieces, grouped by bucket, sorted by
+    their low 24 bits) instead of the ordinary sort of all 32 bits: same result."""
     import torch.multiprocessing as mp
 
     world, n_local = 2, 20000
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, n_local, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, n_local, q, segmented)) for r in range(world)]
     for p in procs:
         p.start()
     results = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])

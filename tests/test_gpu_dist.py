@@ -576,5 +576,7 @@ def test_bench_multi_gpu_command_line_rehearsal(built):
     assert len(lines) == 1, p.stdout
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["verified"] is True and line["native_c_abi"] is True
-    assert line["value"] == line["value_depth1"] and "value_depth2" in line and "rehearsal" in line
+    # the line's value is the two-in-flight throughput; the one-at-a-time figure stands beside it
+    assert line["pipeline_depth"] == 2 and line["value"] == line["value_depth2"] and "value_depth1" in line and "rehearsal" in line
+    assert line["local_sort"] in ("segmented", "ordinary")
     assert line["phases_ms_rank0"]["sorts"] == line["steps"]

@@ -1,11 +1,12 @@
-"""Builds profiles/traffic_r02*.json and profiles/r02/traffic_all_kernels.json from the per-kernel PMC summaries that
-tools/refresh_profiles_r02.sh leaves in profiles/r02/ (FETCH_SIZE and WRITE_SIZE were collected in separate rocprofv3
+"""Builds profiles/traffic_<round>*.json and profiles/<round>/traffic_all_kernels.json (round = argv[1], default r02) from
+the per-kernel PMC summaries that tools/refresh_profiles_<round>.sh leaves in profiles/<round>/ (FETCH_SIZE and WRITE_SIZE were collected in separate rocprofv3
 --pmc passes; on gfx950 FETCH_SIZE counts half of a coalesced streaming read, MI355X_MICROARCH.md HBM section, so it is
 doubled -- the count kernel, which reads exactly 4 B per key and writes nothing, calibrates that in the same run).
-usage: python tools/make_traffic_json.py"""
-import json, os, re
+usage: python tools/make_traffic_json.py [r03]"""
+import json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-P = os.path.join(ROOT, "profiles", "r02")
+ROUND = sys.argv[1] if len(sys.argv) > 1 else "r02"
+P = os.path.join(ROOT, "profiles", ROUND)
 
 
 def parse(path):
@@ -51,8 +52,8 @@ def entry(f, w, subs, alg_bytes, what, launches_note=""):
 corr = ("FETCH_SIZE is doubled (MI355X_MICROARCH.md, HBM section: on gfx950 FETCH_SIZE reads 1/2 of a coalesced streaming "
         "read; the count kernel of the 4-bit sort of the same run, which reads 4 B per key and little else, reports 52x xxx KB for 2^28 keys "
         "= 1/2 of 1 GiB). WRITE_SIZE is exact. Units: KB = 1024 B.")
-src = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, tools/refresh_profiles_r02.sh), MI355X, round 2; "
-       "per-dispatch averages in profiles/r02/pmc_{fetch,write}_size_{bench,configs}.txt")
+src = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, tools/refresh_profiles_%s.sh), MI355X, round %s; "
+       "per-dispatch averages in profiles/%s/pmc_{fetch,write}_size_{bench,configs}.txt" % (ROUND, ROUND[1:].lstrip("0"), ROUND))
 e8 = entry(bench_f, bench_w, ("radix_scatter_lines_kernel<unsigned int, 8",), N * 16, "dominant kernel of the headline sort (2^28 u32 pairs, 8-bit digits)")
 e4 = entry(bench_f, bench_w, ("radix_scatter_lines_kernel<unsigned int, 4",), N * 16, "scatter of the reference pass structure (4-bit digits)")
 all_k = {
@@ -77,7 +78,7 @@ all_k["kernels"].append({"kernel": "glu_hip::reduce_kernel<0, unsigned int, 1, t
                          "hbm_read_bytes_per_launch": int(fk * 2 * 1024 * 2), "algorithmic_bytes_per_launch": N * 4,
                          "ratio": round(fk * 2 * 1024 * 2 / (N * 4), 4)})
 json.dump(all_k, open(os.path.join(P, "traffic_all_kernels.json"), "w"), indent=1)
-for e, key, name in ((e8, "radix_sort_u32_pairs_2^28_uniform_bits8", "traffic_r02.json"), (e4, "radix_sort_u32_pairs_2^28_uniform_bits4", "traffic_r02_bits4.json")):
+for e, key, name in ((e8, "radix_sort_u32_pairs_2^28_uniform_bits8", "traffic_%s.json" % ROUND), (e4, "radix_sort_u32_pairs_2^28_uniform_bits4", "traffic_%s_bits4.json" % ROUND)):
     d = {"workload_key": key, "source": src, "corrections": corr}
     d.update(e)
     json.dump(d, open(os.path.join(ROOT, "profiles", name), "w"), indent=1)
