@@ -346,6 +346,11 @@ glu_status glu_dist_prepare(glu_dist d, size_t local_count, size_t recv_capacity
     }
     // partition pass: table only; local sort: scratch for the receive side
     GLU_TRY(sort_prepare(d->sorter, std::max(local_count, recv_capacity), sizeof(uint32_t), true));
+    // segmented local sort: one table row per sub-block (at most pieces + workgroups: world x buckets owned + CUs) and the
+    // descriptor image of its two pass shapes
+    const size_t rows = (size_t) kDistBuckets * (size_t) std::min(d->world, 16) + (size_t) g_dev.num_cus;
+    GLU_TRY(d->sorter->table.reserve(rows * kDistBuckets * sizeof(uint32_t)));
+    GLU_TRY(d->sorter->seg_desc.reserve(std::max<size_t>((size_t) 1 << 16, rows * 6 * sizeof(uint32_t))));
     return GLU_OK;
 }
 

@@ -109,6 +109,23 @@ __global__ __launch_bounds__(THREADS) void phase_kernel(const uint32_t* __restri
             }
             acc += buf[(tid * 7 + r) % TILE].x;
         }
+        if (MODE == 15 || MODE == 16)
+        {
+            // does a wave64 instruction whose EXEC mask covers one 32-lane half only issue in half the time?
+            uint32_t a = key[0], b = key[1], c = key[2], d = key[3];
+            if (MODE == 15 ? lane < 32 : (lane & 1) == 0)
+            {
+#pragma unroll
+                for (int i = 0; i < 100; i++)
+                {
+                    asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x90" : "+v"(a) : "v"(c), "v"(b));
+                    asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x90" : "+v"(c) : "v"(a), "v"(d));
+                    asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x90" : "+v"(b) : "v"(d), "v"(a));
+                    asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x90" : "+v"(d) : "v"(b), "v"(c));
+                }
+            }
+            acc += a + b + c + d;
+        }
         if (MODE >= 6 && MODE <= 14)
         {
             uint32_t a = key[0], b = key[1], c = key[2], d = key[3];
@@ -261,6 +278,8 @@ int main()
     run<12>("cmp->vcc", in, out, cyc, blocks, reps, 4 * 400.0, "cycles per v_cmp_e32 writing VCC");
     run<13>("shift imm", in, out, cyc, blocks, reps, 4 * 400.0, "cycles per VOP2 shift with an inline constant");
     run<14>("and sgpr", in, out, cyc, blocks, reps, 4 * 400.0, "cycles per v_and_b32 with an SGPR operand");
+    run<15>("half exec", in, out, cyc, blocks, reps, 4 * 400.0, "cycles per v_bitop3 (vector operands) with EXEC = lanes 0-31 only");
+    run<16>("even lanes", in, out, cyc, blocks, reps, 4 * 400.0, "cycles per v_bitop3 (vector operands) with EXEC = even lanes only");
     run<10>("cmp+2bitop", in, out, cyc, blocks, reps, 4 * 400.0, "cycles per instruction of (cmp -> sgpr, bitop3, bitop3, bfe)");
     return 0;
 }
