@@ -198,7 +198,7 @@ void run_variant(Ctx& c, int blocks_per_cu, uint32_t shift, uint32_t mask_overri
     });
     float t_scatter = time_min(c, 5, [&] {
         hipLaunchKernelGGL(scatter, dim3(nb), dim3(THREADS), sizeof(Smem), 0, c.keys, VALS ? c.vals : nullptr, c.keys2,
-                           VALS ? c.vals2 : nullptr, c.table, totals, (uint32_t) c.n, shift, mask, tiles, (unsigned long long*) nullptr, 0u, (PassPlan*) nullptr, 0u);
+                           VALS ? c.vals2 : nullptr, c.table, totals, (uint32_t) c.n, shift, mask, tiles, (unsigned long long*) nullptr, 0u, (PassPlan*) nullptr, 0u, (uint32_t*) nullptr);
     });
     CK(hipGetLastError());
     if (getenv("SB_TRACE"))
@@ -209,7 +209,7 @@ void run_variant(Ctx& c, int blocks_per_cu, uint32_t shift, uint32_t mask_overri
         {
             float t = time_min(c, groups > 60 ? 50 : 1, [&] { // long traces: best of 50 launches per point
                 hipLaunchKernelGGL(scatter, dim3(nb), dim3(THREADS), sizeof(Smem), 0, c.keys, c.vals, c.keys2, c.vals2, c.table,
-                                   totals, (uint32_t) c.n, shift, mask, tiles, (unsigned long long*) nullptr, 0u, (PassPlan*) nullptr, 0u);
+                                   totals, (uint32_t) c.n, shift, mask, tiles, (unsigned long long*) nullptr, 0u, (PassPlan*) nullptr, 0u, (uint32_t*) nullptr);
             });
             printf(" %.3f", t);
         }
@@ -219,7 +219,7 @@ void run_variant(Ctx& c, int blocks_per_cu, uint32_t shift, uint32_t mask_overri
     CK(hipMalloc(&st, 64));
     CK(hipMemset(st, 0, 64));
     hipLaunchKernelGGL(scatter_st, dim3(nb), dim3(THREADS), sizeof(Smem), 0, c.keys, VALS ? c.vals : nullptr, c.keys2,
-                       VALS ? c.vals2 : nullptr, c.table, totals, (uint32_t) c.n, shift, mask, tiles, st, 0u, (PassPlan*) nullptr, 0u);
+                       VALS ? c.vals2 : nullptr, c.table, totals, (uint32_t) c.n, shift, mask, tiles, st, 0u, (PassPlan*) nullptr, 0u, (uint32_t*) nullptr);
     unsigned long long hst[8];
     CK(hipMemcpy(hst, st, 64, hipMemcpyDeviceToHost));
     CK(hipFree(st));
@@ -481,7 +481,7 @@ int main(int argc, char** argv)
                 hipLaunchKernelGGL((radix_row_scan_kernel<256>), dim3(256), dim3(256), 0, 0, c.table, totals, nb);
                 float t = time_min(c, 7, [&] {
                     hipLaunchKernelGGL(scatter, dim3(nb), dim3(1024), sizeof(Smem), 0, sk, sv, dk, dv, c.table, totals, (uint32_t) c.n, shift, 255u, tiles,
-                                       (unsigned long long*) nullptr, 0u, (PassPlan*) nullptr, 0u);
+                                       (unsigned long long*) nullptr, 0u, (PassPlan*) nullptr, 0u, (uint32_t*) nullptr);
                 });
                 printf(" %.3f", t);
             }
@@ -519,7 +519,7 @@ int main(int argc, char** argv)
             hipLaunchKernelGGL((radix_row_scan_kernel<256>), dim3(256), dim3(256), 0, 0, c.table, totals, nb);
             float t = time_min(c, 7, [&] {
                 hipLaunchKernelGGL(scatter, dim3(nb), dim3(1024), sizeof(Smem), 0, sk, sv, dk, dv, c.table, totals, (uint32_t) c.n, shift, 255u, tiles,
-                                   (unsigned long long*) nullptr, 0u, (PassPlan*) nullptr, 0u);
+                                   (unsigned long long*) nullptr, 0u, (PassPlan*) nullptr, 0u, (uint32_t*) nullptr);
             });
             float tc = time_min(c, 5, [&] { hipLaunchKernelGGL((copy_width_kernel<4, 4>), dim3(256), dim3(1024), 0, 0, sk, sv, dk, dv, c.n); });
             printf("units mod16: sk %2zu sv %2zu dk %2zu dv %2zu | sv-sk %2zu dv-dk %2zu dk-sk %2zu dv-sv %2zu | scatter %.3f copy %.3f\n", o[0] % 16, o[1] % 16, o[2] % 16,
@@ -593,7 +593,7 @@ int main(int argc, char** argv)
             {
                 if (after_scatter)
                     hipLaunchKernelGGL(scatter, dim3(nb), dim3(1024), sizeof(Smem), 0, c.keys, c.vals, c.keys2, c.vals2, c.table, totals, (uint32_t) c.n, shift,
-                                       255u, tiles, (unsigned long long*) nullptr, 0u, (PassPlan*) nullptr, 0u);
+                                       255u, tiles, (unsigned long long*) nullptr, 0u, (PassPlan*) nullptr, 0u, (uint32_t*) nullptr);
                 CK(hipEventRecord(c.ev[0]));
                 hipLaunchKernelGGL((radix_count_kernel<uint32_t, 8, 1024, 12288>), dim3(nb), dim3(1024), 0, 0, k, table2, (uint32_t) c.n, shift + 8, 255u, tiles, 0u);
                 CK(hipEventRecord(c.ev[1]));
