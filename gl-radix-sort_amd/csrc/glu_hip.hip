@@ -1461,6 +1461,39 @@ glu_status glu_radix_sort_run_segments_ptr(glu_radix_sort sort, uint32_t* in_key
     return seg_run_plan(sort, plan, in_keys, in_vals, out_keys, out_vals, pick_stream(stream));
 }
 
+glu_status glu_radix_sort_plan_segments(const uint64_t* piece_begin, const uint64_t* piece_len, const uint32_t* piece_segment,
+                                        size_t num_pieces, uint32_t num_segments, uint32_t num_workgroups, uint32_t* sub_blocks,
+                                        size_t sub_block_capacity, uint32_t* workgroup_first, uint32_t* segment_first,
+                                        uint64_t* segment_start, size_t* num_sub_blocks)
+{
+    // host only (no device needed): the cut of a segmented pass into sub-blocks, for inspection and tests
+    if (num_pieces > 0 && (!piece_begin || !piece_len || !piece_segment)) return fail(GLU_ERROR_INVALID_ARGUMENT, "NULL piece array");
+    if (num_workgroups == 0 || !num_sub_blocks) return fail(GLU_ERROR_INVALID_ARGUMENT, "bad arguments");
+    std::vector<SegPiece> pieces(num_pieces);
+    uint64_t total = 0;
+    for (size_t i = 0; i < num_pieces; i++)
+    {
+        if (piece_segment[i] >= num_segments) return fail(GLU_ERROR_INVALID_ARGUMENT, "piece %zu names segment %u of %u", i, piece_segment[i], num_segments);
+        pieces[i] = SegPiece{piece_begin[i], piece_len[i], piece_segment[i]};
+        total += piece_len[i];
+    }
+    if (total > 0xFFFF0000ull) return fail(GLU_ERROR_INVALID_ARGUMENT, "the pieces hold %llu elements: more than 32-bit indexing", (unsigned long long) total);
+    std::stable_sort(pieces.begin(), pieces.end(), [](const SegPiece& a, const SegPiece& b) { return a.seg < b.seg; });
+    std::vector<uint64_t> start(num_segments + 1, 0);
+    for (const SegPiece& pc : pieces) start[pc.seg + 1] += pc.len;
+    for (uint32_t g = 0; g < num_segments; g++) start[g + 1] += start[g];
+    SegImage img;
+    seg_build_image(pieces.data(), pieces.size(), num_segments, start.data(), total, num_workgroups, img);
+    *num_sub_blocks = img.nsb;
+    if (img.nsb > sub_block_capacity) return fail(GLU_ERROR_INVALID_ARGUMENT, "%u sub-blocks, room for %zu", img.nsb, sub_block_capacity);
+    if (sub_blocks) memcpy(sub_blocks, img.words.data(), (size_t) img.nsb * 2 * sizeof(uint32_t));
+    if (workgroup_first) memcpy(workgroup_first, img.words.data() + img.off_first, ((size_t) num_workgroups + 1) * sizeof(uint32_t));
+    if (segment_first) memcpy(segment_first, img.words.data() + img.off_list, ((size_t) num_segments + 1) * sizeof(uint32_t));
+    if (segment_start)
+        for (uint32_t g = 0; g <= num_segments; g++) segment_start[g] = start[g];
+    return GLU_OK;
+}
+
 glu_status glu_radix_sort_set_digit_bits(glu_radix_sort sort, uint32_t bits)
 {
     GLU_TRY(enter());

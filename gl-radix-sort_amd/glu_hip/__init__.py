@@ -62,6 +62,7 @@ SYMBOLS = [
     ("glu_radix_sort_run_bit_range_ptr", _int, [_vp, _vp, _vp, _sz, _u32, _u32, _u32, _vp]),
     ("glu_radix_sort_partition_ptr", _int, [_vp, _vp, _vp, _vp, _vp, _sz, _u32, _u32, _vp, _vp]),
     ("glu_radix_sort_run_segments_ptr", _int, [_vp, _vp, _vp, _vp, _vp, _sz, _P(_u64), _P(_u64), _P(_u32), _sz, _u32, _u32, _vp]),
+    ("glu_radix_sort_plan_segments", _int, [_P(_u64), _P(_u64), _P(_u32), _sz, _u32, _u32, _P(_u32), _sz, _P(_u32), _P(_u32), _P(_u64), _P(_sz)]),
     ("glu_radix_sort_set_digit_bits", _int, [_vp, _u32]),
     ("glu_radix_sort_get_digit_bits", _int, [_vp, _P(_u32)]),
     ("glu_radix_sort_scratch_size", _int, [_vp, _P(_sz)]),
@@ -403,6 +404,24 @@ def measure_elapsed_time(callback):
 
 DIST_UNIQUE_ID_BYTES = 128
 DIST_BUCKETS = 256
+
+
+def plan_segments(piece_begin, piece_len, piece_segment, num_segments, num_workgroups):
+    """glu_radix_sort_plan_segments (host only): -> (sub_blocks [n][2], workgroup_first, segment_first, segment_start)."""
+    pb = np.ascontiguousarray(piece_begin, dtype=np.uint64)
+    pl = np.ascontiguousarray(piece_len, dtype=np.uint64)
+    ps = np.ascontiguousarray(piece_segment, dtype=np.uint32)
+    cap = pb.shape[0] + num_workgroups
+    subs = np.zeros((cap, 2), dtype=np.uint32)
+    wg = np.zeros(num_workgroups + 1, dtype=np.uint32)
+    sf = np.zeros(num_segments + 1, dtype=np.uint32)
+    ss = np.zeros(num_segments + 1, dtype=np.uint64)
+    n = _sz(0)
+    check(lib().glu_radix_sort_plan_segments(pb.ctypes.data_as(_P(_u64)), pl.ctypes.data_as(_P(_u64)), ps.ctypes.data_as(_P(_u32)),
+                                             pb.shape[0], num_segments, num_workgroups, subs.ctypes.data_as(_P(_u32)), cap,
+                                             wg.ctypes.data_as(_P(_u32)), sf.ctypes.data_as(_P(_u32)), ss.ctypes.data_as(_P(_u64)),
+                                             ctypes.byref(n)))
+    return subs[:n.value], wg, sf, ss
 
 
 def dist_unique_id():

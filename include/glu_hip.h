@@ -209,6 +209,18 @@ GLU_API glu_status glu_radix_sort_run_segments_ptr(glu_radix_sort sort, uint32_t
                                                    const uint64_t* piece_begin, const uint64_t* piece_len,
                                                    const uint32_t* piece_segment, size_t num_pieces, uint32_t num_segments,
                                                    uint32_t key_bits, void* stream);
+/* The host half of glu_radix_sort_run_segments_ptr as a pure function (no device needed: unit-testable): how a segmented pass
+ * over these pieces is cut into sub-blocks for `num_workgroups` workgroups.  A sub-block is the part of one piece that falls
+ * into one workgroup's equal share of the elements; sub-blocks are numbered segment-major, in the order of each segment's
+ * elements.  sub_blocks: [*num_sub_blocks][2] = (begin, end) element range in the input arrays (room for sub_block_capacity
+ * pairs; at most num_pieces + num_workgroups are needed); workgroup_first: [num_workgroups + 1], workgroup w runs the
+ * sub-blocks [workgroup_first[w], workgroup_first[w + 1]); segment_first: [num_segments + 1] first sub-block of every
+ * segment; segment_start: [num_segments + 1] where every segment starts in the output.  Any output array may be NULL. */
+GLU_API glu_status glu_radix_sort_plan_segments(const uint64_t* piece_begin, const uint64_t* piece_len,
+                                                const uint32_t* piece_segment, size_t num_pieces, uint32_t num_segments,
+                                                uint32_t num_workgroups, uint32_t* sub_blocks, size_t sub_block_capacity,
+                                                uint32_t* workgroup_first, uint32_t* segment_first, uint64_t* segment_start,
+                                                size_t* num_sub_blocks);
 /* Digit width (bits per counting pass) the sort uses internally: 4 (the reference's pass structure: 8 passes
  * for 32-bit keys) or 8 (4 passes).  The sorted result is identical; see DESIGN.md. */
 GLU_API glu_status glu_radix_sort_set_digit_bits(glu_radix_sort sort, uint32_t bits);
