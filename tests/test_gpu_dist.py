@@ -128,7 +128,7 @@ def test_small_range_keys_fall_back_to_a_lower_partition_byte(built):
         assert shift == expect_shift, (bits, shift, expect_shift)
 
 
-def _gpu_worker(rank, world, port, n_local, q):
+def _gpu_worker(rank, world, port, n_local, q, segmented=False):
     """One of `world` processes sharing GPU 0: real device ops (HipLocalOps), gloo as the transport (RCCL refuses two
     ranks on one GPU) -- exercises uneven splits, the plan and the receive ordering with the real kernels."""
     import os
@@ -157,6 +157,8 @@ def _gpu_worker(rank, world, port, n_local, q):
         base = sum(n_local + 1000 * r for r in range(rank))
         vals = np.arange(base, base + n, dtype=np.uint32)
         sorter = D.DistributedRadixSort(slots=2)  # two slots: consecutive sorts run on alternating streams / buffers
+        if segmented:
+            sorter.segmented_min = 1  # the segmented local sort for every shard (the default threshold is 2^24 pairs)
         kt = torch.from_numpy(keys.view(np.int32).copy()).cuda()
         vt = torch.from_numpy(vals.view(np.int32).copy()).cuda()
         handles = [sorter.sort_async(kt, vt) for _ in range(3)]  # same input three times, overlapping in flight
@@ -164,13 +166,15 @@ def _gpu_worker(rank, world, port, n_local, q):
         first = handles[1].synchronize()
         rk, rv, cnt = handles[2].synchronize()
         assert cnt == first[2] and bool((rk[:cnt] == first[0][:cnt]).all()) and bool((rv[:cnt] == first[1][:cnt]).all())
+        assert sorter.last_local_sort == ("segmented" if segmented else "ordinary")
         q.put((rank, keys, vals, rk[:cnt].cpu().numpy().view(np.uint32).copy(), rv[:cnt].cpu().numpy().view(np.uint32).copy()))
     finally:
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("segmented", [False, True])
 @pytest.mark.parametrize("world", [2, 3])
-def test_multi_process_one_gpu_gloo_transport(built, world):
+def test_multi_process_one_gpu_gloo_transport(built, world, segmented):
     import socket
 
     import torch.multiprocessing as mp
@@ -181,7 +185,7 @@ def test_multi_process_one_gpu_gloo_transport(built, world):
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_gpu_worker, args=(r, world, port, 1 << 20, q)) for r in range(world)]
+    procs = [ctx.Process(target=_gpu_worker, args=(r, world, port, 1 << 20, q, segmented)) for r in range(world)]
     for p in procs:
         p.start()
     results = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
