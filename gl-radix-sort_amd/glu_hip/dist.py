@@ -358,18 +358,37 @@ class DistributedRadixSort:
         stream = t.cuda.current_stream(keys.device).cuda_stream
         b = slot["bufs"]
         if b is None or b["n_local"] < n_local:
-            cap = int(n_local * self.capacity_factor) + 4096
-            b = {"n_local": n_local, "cap": cap,
-                 "recv_k": t.empty(cap, dtype=t.int32, device=keys.device),
-                 "recv_v": t.empty(cap, dtype=t.int32, device=keys.device)}
-            slot["bufs"] = b
-            nd.prepare(n_local, cap)
+            try:
+                cap = int(n_local * self.capacity_factor) + 4096
+                b = {"n_local": n_local, "cap": cap,
+                     "recv_k": t.empty(cap, dtype=t.int32, device=keys.device),
+                     "recv_v": t.empty(cap, dtype=t.int32, device=keys.device)}
+                nd.prepare(n_local, cap)
+                slot["bufs"] = b
+            except Exception:
+                # the other ranks are on their way into the histogram exchange: take part in it, reporting a failure
+                # (a slice without arrays), so that every rank's begin returns it
+                try:
+                    nd.sort_begin(0, 0, max(n_local, 1), stream)
+                except Exception:
+                    pass
+                raise
         n_recv = nd.sort_begin(keys.data_ptr() if n_local else 0, vals.data_ptr() if n_local else 0, n_local, stream)
         if n_recv > b["cap"]:  # a skewed plan: this rank owns more than its share (buckets are never split)
-            b["cap"] = int(n_recv * 1.1) + 4096
-            b["recv_k"] = t.empty(b["cap"], dtype=t.int32, device=keys.device)
-            b["recv_v"] = t.empty(b["cap"], dtype=t.int32, device=keys.device)
-            nd.prepare(n_local, b["cap"])
+            try:
+                cap = int(n_recv * 1.1) + 4096
+                rk = t.empty(cap, dtype=t.int32, device=keys.device)
+                rv = t.empty(cap, dtype=t.int32, device=keys.device)
+                nd.prepare(n_local, cap)
+                b["cap"], b["recv_k"], b["recv_v"] = cap, rk, rv
+            except Exception:
+                # this rank cannot take its shard: the others are about to enter the exchange, so it still calls finish --
+                # with no room, which makes every rank's finish return the failure instead of leaving them waiting
+                try:
+                    nd.sort_finish(0, 0, 0, stream)
+                except Exception:
+                    pass
+                raise
         nd.sort_finish(b["recv_k"].data_ptr(), b["recv_v"].data_ptr(), b["cap"], stream)
         return b["recv_k"][:n_recv], b["recv_v"][:n_recv], n_recv
 
