@@ -409,7 +409,7 @@ template<> struct GeometryFor<uint32_t, 8, true, false> : Geometry<1024, 20, 1, 
 #define GLU_LINES_KPT_U32 10 // pairs per thread of the line kernel, 4-byte keys, 8-bit digits (tuning builds override)
 #endif
 #ifndef GLU_LINES_KPT_U64
-#define GLU_LINES_KPT_U64 8 // same, 8-byte keys
+#define GLU_LINES_KPT_U64 6 // same, 8-byte keys with values (round 3: 16 KiB of LDS hold back first halves of value lines; 8 before)
 #endif
 template<typename KeyT, int BITS, bool VALS>
 struct LinesGeometry : Geometry<1024, GLU_LINES_KPT_U32, 1, true> {};

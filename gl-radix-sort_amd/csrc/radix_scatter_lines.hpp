@@ -56,6 +56,13 @@ struct LineSmem
                          // of combined element 0 (= first ranked position - carried count), .z first line | carried << 16,
                          // .w first global index of the digit that this workgroup owns
     uint32_t tail[RADIX]; // new carry: slots [lo, hi) <- ranked positions (p + slot) mod 2^16; p | lo << 16 | hi << 24
+    // 8-byte keys with values: a line is 16 elements = a whole 128-byte line of keys but HALF a line of values.  When the last
+    // line a digit emits in a tile is the first half of a value line (its second half follows a tile period later, when the
+    // L2 has long dropped the half-written line: fill reads, traffic 1.13 x algorithmic), its 16 values wait here instead
+    // and leave together with the second half.
+    static constexpr bool SHADOW = sizeof(KeyT) == 8 && VALS;
+    uint32_t shadow[SHADOW ? RADIX * LINE : 1];
+    uint32_t shadow_out[SHADOW ? RADIX : 1]; // global index of the shadowed line that leaves in this tile's scan phase, or ~0
     uint8_t ltab[(MAXLINES + 3) & ~3]; // digit of every line written this tile
     uint32_t scan_tmp[WAVES];
     uint32_t total_lines;
@@ -123,6 +130,9 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
     uint32_t digit_base = 0;  // global index of the digit's next element
     uint32_t carry_start = 0; // 32-aligned global index of the digit's first carried element; carried = digit_base - carry_start
     uint32_t owned_from = 0;  // first global index of the digit inside this workgroup's range
+    constexpr bool SHADOW = Smem::SHADOW;
+    bool shadow_valid = false; // SHADOW: s.shadow[sd] holds the values of the line at global index shadow_pos (keys written already)
+    uint32_t shadow_pos = 0;
 
     unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tprev = 0;
@@ -332,12 +342,36 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
                     n_d = n_raw - (sd == MASK ? (uint32_t) TILE - tile_valid : 0u);
                     c_d = digit_base - carry_start;
                     nl_d = (c_d + n_d) / LINE;
+                    // (SHADOW) the first line this tile is the second half of the value line whose first half waits in the shadow
+                    if (SHADOW) s.shadow_out[sd] = shadow_valid && nl_d > 0 ? shadow_pos : 0xFFFFFFFFu;
                 }
                 uint32_t wtotal;
                 excl = wave_exclusive_sum(n_raw | (nl_d << 16), lane, wtotal);
                 if (lane == 0) s.scan_tmp[wave] = wtotal;
             }
             __syncthreads();
+            if (SHADOW && wave >= SCAN_WAVES)
+            {
+                // the waves that hold no digit in this phase send the waiting first halves off: 4 lanes x 16 bytes per half
+                // line in one store instruction (the second half follows in this tile's write-out, microseconds later).
+                // (One thread per digit storing its 64 bytes with four instructions made the pass 30 % slower: every
+                // instruction then writes 16 bytes each of 64 different lines.)
+                typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+                constexpr uint32_t TT = THREADS - SCAN_WAVES * kWave, ITEMS = RADIX * (LINE / 4);
+                for (uint32_t item = tid - SCAN_WAVES * kWave; item < ITEMS; item += TT)
+                {
+                    const uint32_t d = item / (LINE / 4), q = item % (LINE / 4);
+                    const uint32_t out = s.shadow_out[d];
+                    if (out != 0xFFFFFFFFu)
+                    {
+                        const u32x4_t vv = *reinterpret_cast<const u32x4_t*>(&s.shadow[d * LINE + q * 4]);
+                        if (NT_STORES)
+                            __builtin_nontemporal_store(vv, reinterpret_cast<u32x4_t*>(dst_vals + out + 4 * q));
+                        else
+                            *reinterpret_cast<u32x4_t*>(dst_vals + out + 4 * q) = vv;
+                    }
+                }
+            }
             if (wave < SCAN_WAVES)
             {
                 if (SCAN_WAVES > 1) excl += sum_of_preceding_waves(s.scan_tmp, SCAN_WAVES, wave, lane);
@@ -352,7 +386,23 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
                         running += c[w];
                     }
                     const uint32_t m = c_d + n_d, c_new = m & (LINE - 1), k = n_d < c_new ? n_d : c_new;
-                    s.dinfo[sd] = make_uint4(carry_start, pos - c_d, line0 | (c_d << 16), owned_from);
+                    uint32_t orphan_line = 0x3FFu; // SHADOW: the line (index in this tile's line table) whose values go to s.shadow
+                    if (SHADOW)
+                    {
+                        static_assert(!SHADOW || (Smem::MAXLINES < 0x3FF && LINE == 16), "line numbers in 10 bits, carried count in 4");
+                        if (shadow_valid && nl_d > 0) shadow_valid = false; // (its values are leaving: the other waves, above)
+                        if (nl_d > 0)
+                        {
+                            const uint32_t last_pos = carry_start + (nl_d - 1) * LINE; // global index of the last line emitted
+                            if (((last_pos / LINE) & 1u) == 0u && last_pos >= owned_from)
+                            {
+                                orphan_line = line0 + nl_d - 1;
+                                shadow_valid = true;
+                                shadow_pos = last_pos;
+                            }
+                        }
+                    }
+                    s.dinfo[sd] = make_uint4(carry_start, pos - c_d, line0 | (c_d << 16) | (SHADOW ? orphan_line << 20 : 0u), owned_from);
                     s.tail[sd] = ((pos + n_d - c_new) & 0xFFFFu) | ((c_new - k) << 16) | (c_new << 24);
                     digit_base += n_d;
                     carry_start += nl_d * LINE;
@@ -426,6 +476,7 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
             {
                 uint32_t g0[QB], from_run[QB], from_carry[QB], owned[QB];
                 int in_carry[QB];
+                int to_shadow[SHADOW ? QB : 1]; // SHADOW: >= 0: the quad's values go to these shadow slots, not to memory
 #pragma unroll
                 for (int u = 0; u < QB; u++)
                 {
@@ -434,7 +485,8 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
                     const uint32_t l = qi / (LINE / 4), sub = qi % (LINE / 4);
                     const uint32_t d = s.ltab[l];
                     const uint4 info = s.dinfo[d];
-                    const uint32_t line0 = info.z & 0xFFFFu, carried = info.z >> 16;
+                    const uint32_t line0 = info.z & 0xFFFFu, carried = SHADOW ? (info.z >> 16) & 0xFu : info.z >> 16;
+                    if (SHADOW) to_shadow[u] = l == ((info.z >> 20) & 0x3FFu) ? (int) (d * LINE + sub * 4) : -1;
                     const uint32_t q0 = (l - line0) * LINE + sub * 4; // index in (carry ++ run) of the quad's first element
                     g0[u] = info.x + q0;                               // its global index (a multiple of 4)
                     from_run[u] = info.y + q0;                         // ranked position, were it an element of the run
@@ -481,7 +533,9 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
                         if (VALS)
                         {
                             u32x4_t vv = {v[0], v[1], v[2], v[3]};
-                            if (NT_STORES)
+                            if (SHADOW && to_shadow[u] >= 0)
+                                *reinterpret_cast<u32x4_t*>(&s.shadow[to_shadow[u]]) = vv; // (a fully owned line: see the scan phase)
+                            else if (NT_STORES)
                                 __builtin_nontemporal_store(vv, reinterpret_cast<u32x4_t*>(dst_vals + g0[u]));
                             else
                                 *reinterpret_cast<u32x4_t*>(dst_vals + g0[u]) = vv;
@@ -533,6 +587,15 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
     // ---- what is still carried at the end of this workgroup's range: the (partial) last line of every digit
     if (digit_owner) s.dinfo[sd] = make_uint4(carry_start, digit_base - carry_start, 0u, owned_from);
     __syncthreads();
+    if (SHADOW && digit_owner && shadow_valid)
+    {
+        // a first half of a value line whose second half belongs to the workgroup after this one (or does not exist)
+        typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+        const u32x4_t* sh = reinterpret_cast<const u32x4_t*>(&s.shadow[sd * LINE]);
+#pragma unroll
+        for (int q = 0; q < (int) LINE / 4; q++) *reinterpret_cast<u32x4_t*>(dst_vals + shadow_pos + 4 * q) = sh[q];
+        shadow_valid = false;
+    }
     if (ABLATE < 4)
     {
         for (uint32_t e = tid; e < (uint32_t) RADIX * LINE; e += THREADS)
