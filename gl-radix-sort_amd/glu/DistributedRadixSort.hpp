@@ -3,7 +3,9 @@
 // The reference (loryruta/gl-radix-sort) is single-device; this is the C++ face of the glu_dist_* entry points of
 // glu_hip.h: rank r holds slice r of the array, the sort partitions by the top 8 key bits, exchanges once over RCCL /
 // xGMI, and sorts locally.  The ranks' shards concatenated in rank order equal glu::RadixSort of the whole array
-// (stable); shard sizes follow the data.  Same failure convention as the other operators (print + exit(1)).
+// (stable); shard sizes follow the data.  Same failure convention as the other operators (print + exit(1)); the C
+// entry points underneath agree on a rank's failure before anything is exchanged, so when one rank's call fails EVERY
+// rank prints and exits -- none is left waiting in a collective.
 #ifndef GLU_DISTRIBUTEDRADIXSORT_HPP
 #define GLU_DISTRIBUTEDRADIXSORT_HPP
 
@@ -69,6 +71,16 @@ namespace glu
             GLU_CHECK_STATUS(glu_buffer_device_ptr(key_buffer, &k));
             GLU_CHECK_STATUS(glu_buffer_device_ptr(val_buffer, &v));
             return (*this)(static_cast<const uint32_t*>(k), static_cast<const uint32_t*>(v), local_count, nullptr);
+        }
+
+        /// true if the local sort of the last sort ran as three segmented passes over the low 24 bits (the shard arrives as one
+        /// message per source rank, each grouped by bucket: RadixSort::sort_segments), false for the ordinary sort of all 32
+        /// bits (small or very fragmented shards, a partition on a lower key byte).
+        [[nodiscard]] bool last_local_sort_was_segmented() const
+        {
+            uint32_t seg = 0;
+            GLU_CHECK_STATUS(glu_dist_last_local_sort(m_impl, &seg));
+            return seg != 0;
         }
 
         [[nodiscard]] int world_size() const

@@ -192,6 +192,7 @@ TEST_CASE("DistributedRadixSort-one-rank-rccl")
         }
         DistributedRadixSort::Shard shard = dsort(kb.handle(), vb.handle(), n);
         REQUIRE(shard.count == n);
+        CHECK(!dsort.last_local_sort_was_segmented()); // shards below 2^24 pairs take the ordinary local sort
         std::vector<GLuint> out_k(n), out_v(n);
         GLU_CHECK_STATUS(glu_device_synchronize());
         if (n)
@@ -216,6 +217,37 @@ TEST_CASE("DistributedRadixSort-one-rank-rccl")
             CHECK(in_k == keys);
         }
     }
+}
+
+TEST_CASE("DistributedRadixSort-one-rank-segmented-local-sort")
+{
+    // a shard of 2^24 pairs: the exchange lands in the sorter's scratch and three segmented passes produce the shard
+    DistributedRadixSort::UniqueId id = DistributedRadixSort::unique_id();
+    DistributedRadixSort dsort(id, 1, 0);
+    const size_t n = (size_t(1) << 24) + 12345;
+    std::mt19937 gen(11);
+    std::vector<GLuint> keys(n), vals(n);
+    for (auto& k : keys) k = (gen() % 16 == 0) ? 0x7F00FF00u : GLuint(gen());
+    std::iota(vals.begin(), vals.end(), 0u);
+    ShaderStorageBuffer kb(keys), vb(vals);
+    dsort.prepare_internal_buffers(n, n);
+    DistributedRadixSort::Shard shard = dsort(kb.handle(), vb.handle(), n);
+    REQUIRE(shard.count == n);
+    CHECK(dsort.last_local_sort_was_segmented());
+    GLU_CHECK_STATUS(glu_device_synchronize());
+    std::vector<GLuint> out_k(n), out_v(n);
+    GLuint kh = 0, vh = 0;
+    GLU_CHECK_STATUS(glu_buffer_wrap(shard.keys, n * sizeof(GLuint), &kh));
+    GLU_CHECK_STATUS(glu_buffer_wrap(shard.vals, n * sizeof(GLuint), &vh));
+    GLU_CHECK_STATUS(glu_buffer_read(kh, out_k.data(), n * sizeof(GLuint), 0));
+    GLU_CHECK_STATUS(glu_buffer_read(vh, out_v.data(), n * sizeof(GLuint), 0));
+    glu_buffer_destroy(kh);
+    glu_buffer_destroy(vh);
+    std::vector<GLuint> order(vals);
+    std::stable_sort(order.begin(), order.end(), [&](GLuint a, GLuint b) { return keys[a] < keys[b]; });
+    bool same = true;
+    for (size_t i = 0; i < n; i++) same = same && out_v[i] == order[i] && out_k[i] == keys[order[i]];
+    CHECK(same);
 }
 
 int main(int argc, char** argv) { return mini_test::run(argc, argv); }
