@@ -18,6 +18,7 @@ import ctypes
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -51,6 +52,9 @@ def parse_args():
     p.add_argument("--transport", default="native", choices=["native", "torch"],
                    help="N>1: native = the whole sharded sort inside libglu_hip.so (glu_dist_*: its own RCCL communicator, one grouped "
                         "exchange); torch = torch.distributed collectives around the same C-ABI device work")
+    p.add_argument("--no-transport-fallback", action="store_true",
+                   help="N>1, native transport: do not measure the torch.distributed transport first (it is the line rank 0 prints "
+                        "if the native run raises or hangs)")
     p.add_argument("--force-dist", action="store_true",
                    help="run the multi-GPU code path (partition + all-to-all + local sort) even with one rank")
     p.add_argument("--rehearse-one-gpu", action="store_true",
@@ -224,6 +228,27 @@ def main():
         torch.cuda.synchronize()
 
     result = {}
+
+    def make_line(res, elapsed, units, workload, parallelism):
+        line = {
+            "metric": "Mkeys/s sorting 2^28 uint32 key+val; % HBM roofline; 1/2/4/8 GPU",
+            "value": round(units / elapsed / 1e6, 1),
+            "unit": "Mkeys/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": round(elapsed / K * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic",
+            "config": {"workload": workload, "pairs_per_gpu": n, "key_distribution": args.keys,
+                       "parallelism": parallelism, "device": G.device_info()},
+        }
+        line.update(res)
+        return line
+
     if world == 1 and not args.force_dist:
         sorter = G.RadixSort(digit_bits=args.digit_bits)
         sorter.prepare_internal_buffers(n)
@@ -387,141 +412,186 @@ def main():
 
         keys0, vals0 = make_input(torch, n, args.keys, rank, device, index_base=rank * n)
 
-        def run_depth(depth):
-            """W warm-up sorts, then K timed sorts with `depth` sorts in flight (depth 1 = strictly one after the other, the
-            same regime as the N = 1 line; depth 2 = consecutive independent sorts on two streams / buffer sets /
-            communicators, so that the exchange of sort i+1 can run under the local sort of sort i)."""
-            dsort = D.DistributedRadixSort(slots=depth, profile=not args.no_kernel_events,
-                                           native=True if args.rehearse_one_gpu else args.transport == "native")
-            if args.digit_bits is not None:
-                for srt in dsort.local_sorters():
-                    srt.set_digit_bits(args.digit_bits)
-            if dsort.native and depth > 1 and args.reserved_cus:
-                for slot in dsort._slots:  # leave CUs to the RCCL kernels of the other sort in flight
-                    slot["native"].set_reserved_cus(args.reserved_cus)
-            for i in range(W):
-                dsort.sort_async(keys0, vals0)
-            barrier()
-            dsort.phase_times()  # drop the warm-up stamps
-            sorters = dsort.local_sorters()
-            for srt in sorters:
-                srt.set_profiling(not args.no_kernel_events)
+        def sharded(native):
+            """The whole N > 1 measurement over one transport (native = glu_dist_* inside libglu_hip.so with its own RCCL
+            communicator; otherwise torch.distributed collectives around the same C-ABI device work).  Collective."""
+            res = {}
+            hang = os.environ.get("GLU_BENCH_TEST_NATIVE_HANG")  # tests of the watchdog below: this rank never arrives
+            if native and hang is not None and int(hang) == rank:
+                time.sleep(1e6)
+            def run_depth(depth):
+                """W warm-up sorts, then K timed sorts with `depth` sorts in flight (depth 1 = strictly one after the other, the
+                same regime as the N = 1 line; depth 2 = consecutive independent sorts on two streams / buffer sets /
+                communicators, so that the exchange of sort i+1 can run under the local sort of sort i)."""
+                dsort = D.DistributedRadixSort(slots=depth, profile=not args.no_kernel_events,
+                                               native=native)
+                if args.digit_bits is not None:
+                    for srt in dsort.local_sorters():
+                        srt.set_digit_bits(args.digit_bits)
+                if dsort.native and depth > 1 and args.reserved_cus:
+                    for slot in dsort._slots:  # leave CUs to the RCCL kernels of the other sort in flight
+                        slot["native"].set_reserved_cus(args.reserved_cus)
+                for i in range(W):
+                    dsort.sort_async(keys0, vals0)
+                barrier()
+                dsort.phase_times()  # drop the warm-up stamps
+                sorters = dsort.local_sorters()
+                for srt in sorters:
+                    srt.set_profiling(not args.no_kernel_events)
+                t0 = time.perf_counter()
+                handle = None
+                for i in range(K):
+                    handle = dsort.sort_async(keys0, vals0)
+                barrier()
+                dt = time.perf_counter() - t0
+                profs = [srt.read_profile() for srt in sorters]
+                for srt in sorters:
+                    srt.set_profiling(False)
+                return {"dsort": dsort, "elapsed": dt, "handle": handle, "profs": profs, "sorters": sorters,
+                        "phases": dsort.phase_times()}
+
+            def max_over_ranks(x):
+                tt = torch.tensor([x], dtype=torch.float64, device=device)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                return float(tt.item())
+
+            # Two timed regions of K sorts each.  depth 1: one sort at a time on one stream (partition -> exchange -> local sort,
+            # each waiting for the one before).  depth 2: the K sorts alternate between two glu_dist objects (own stream, buffers
+            # and communicator), so that the exchange of sort i + 1 runs under the local sort of sort i -- how a caller with a
+            # stream of independent batches uses the API, and the regime the line's `value` reports: K sorts enqueued as fast
+            # as the API allows, barrier + synchronize on both sides, like the N = 1 line (where one GPU has nothing to overlap).
+            # `value_depth1` / `ms_per_step_depth1` stand beside it; the per-kernel roofline numbers come from the depth-1 region.
+            r1 = run_depth(1)
+            elapsed1 = max_over_ranks(r1["elapsed"])
+            res["value_depth1"] = round(n * world * K / elapsed1 / 1e6, 1)
+            res["ms_per_step_depth1"] = round(elapsed1 / K * 1e3, 4)
+            depth = max(1, args.pipeline_depth)
+            elapsed = r1["elapsed"]
+            if depth > 1:
+                r2 = run_depth(depth)
+                elapsed = r2["elapsed"]
+                res["value_depth%d" % depth] = round(n * world * K / max_over_ranks(elapsed) / 1e6, 1)
+                res["phases_ms_rank0_depth%d" % depth] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in r2["phases"].items()}
+                del r2
+            res["pipeline_depth"] = depth
+            dsort, handle, profs, sorters = r1["dsort"], r1["handle"], r1["profs"], r1["sorters"]
+            res["native_c_abi"] = bool(dsort.native)
+            res["local_sort"] = (dsort._slots[0]["native"].last_local_sort() if dsort.native else dsort.last_local_sort)
+            if args.rehearse_one_gpu:
+                res["rehearsal"] = "NOT A MEASUREMENT: %d ranks share one GPU and exchange through files (tests/cpp/mock_rccl.cpp)" % world
+            rk, rv, cnt = handle.synchronize()
+            # rank 0's view: the scatter kernel (1 partition launch over n pairs + 4 sort launches over its shard per sort)
+            # and the device time of every phase of a sort
+            launches = sum(int(pf["passes"]) for pf in profs)
+            scatter_ms = sum(pf["scatter_ms"] for pf in profs) / max(launches, 1)
+            per_sort = max(launches // max(K, 1), 1)
+            alg_bytes = 2 * (KEY_BYTES + VAL_BYTES) * (n + (per_sort - 1) * int(cnt)) // per_sort
+            if launches and scatter_ms > 0:
+                achieved = alg_bytes / (scatter_ms * 1e-3) / 1e9
+                res["roofline"] = {
+                    "bound": "hbm", "kernel": "radix_scatter_lines_kernel<u32,%d> (rank 0)" % sorters[0].digit_bits,
+                    "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                    "traffic": None, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(scatter_ms, 4),
+                    "launches_timed": launches,
+                    "count_kernel_avg_ms": round(sum(pf["count_ms"] for pf in profs) / launches, 4),
+                }
+            phases = r1["phases"]
+            res["phases_ms_rank0"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in phases.items()}
+            units = n * world * K
+            verified = None
+            if not args.no_verify:
+                flipped = rk ^ (-2**31)
+                ok = bool((flipped[1:] >= flipped[:-1]).all())
+                # rank boundaries: my last key <= next rank's first key; counts add up
+                first = flipped[:1].to(torch.int64) if cnt > 0 else torch.full((1,), 2**40, device=device)
+                last = flipped[-1:].to(torch.int64) if cnt > 0 else torch.full((1,), -2**40, device=device)
+                edges = torch.stack([first, last]).reshape(1, 2)
+                gathered = [torch.zeros_like(edges) for _ in range(world)]
+                dist.all_gather(gathered, edges)
+                total = torch.tensor([cnt], dtype=torch.int64, device=device)
+                dist.all_reduce(total)
+                if rank == 0:
+                    prev_last = None
+                    for e in gathered:
+                        f, l = int(e[0, 0]), int(e[0, 1])
+                        if f > l:
+                            continue  # empty shard
+                        if prev_last is not None and f < prev_last:
+                            ok = False
+                        prev_last = l
+                ok = ok and int(total.item()) == n * world
+                flag = torch.tensor([1 if ok else 0], device=device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                verified = bool(flag.item())
+            res["verified"] = verified
+            res["shard_pairs_rank0"] = int(cnt)
+            workload = ("2^%d uint32 key+val pairs per GPU (%d GPUs, 2^%.2f total), uniform-random keys; top-8-bit bucket "
+                        "partition + one RCCL all-to-all over xGMI + local sort") % (log2n, world, log2n + __import__("math").log2(world))
+            parallelism = ("bucket-sharded x%d (1 grouped RCCL exchange per sort), %d independent sorts in flight (value_depth1: one at a time)"
+                           % (world, depth)) if depth > 1 else "bucket-sharded x%d (1 grouped RCCL exchange per sort), one sort at a time" % world
+
+            t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            del r1, dsort, handle, profs, sorters, rk, rv
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+            return res, float(t.item()), units, workload, parallelism
+
+        # The native transport has only ever met more than one rank through a test double (no multi-GPU box reaches the
+        # development loop), so the line must not depend on it: the torch.distributed transport is measured first and kept as
+        # the fallback line; a native run that raises, or does not finish by the deadline, makes rank 0 print that line
+        # (with `native_error`) and every rank leave.
+        want_native = args.rehearse_one_gpu or args.transport == "native"
+        fallback = None
+        bail_lock = threading.Lock()
+        state = {"armed": False}
+
+        def bail(reason):
+            with bail_lock:
+                if not state["armed"]:
+                    return
+                state["armed"] = False
+                if rank == 0 and fallback is not None:
+                    fallback["native_error"] = reason
+                    os.write(json_fd, (json.dumps(fallback) + "\n").encode())
+                sys.stderr.write("[bench rank %d] native transport abandoned: %s\n" % (rank, reason))
+                sys.stderr.flush()
+                try:  # where every thread of this rank stands (a hang is diagnosed from the launcher's log)
+                    import faulthandler
+
+                    faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
+                except Exception:
+                    pass
+                os._exit(0)
+
+        watchdog = None
+        if want_native and not args.no_transport_fallback:
             t0 = time.perf_counter()
-            handle = None
-            for i in range(K):
-                handle = dsort.sort_async(keys0, vals0)
-            barrier()
-            dt = time.perf_counter() - t0
-            profs = [srt.read_profile() for srt in sorters]
-            for srt in sorters:
-                srt.set_profiling(False)
-            return {"dsort": dsort, "elapsed": dt, "handle": handle, "profs": profs, "sorters": sorters,
-                    "phases": dsort.phase_times()}
-
-        def max_over_ranks(x):
-            tt = torch.tensor([x], dtype=torch.float64, device=device)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            return float(tt.item())
-
-        # Two timed regions of K sorts each.  depth 1: one sort at a time on one stream (partition -> exchange -> local sort,
-        # each waiting for the one before).  depth 2: the K sorts alternate between two glu_dist objects (own stream, buffers
-        # and communicator), so that the exchange of sort i + 1 runs under the local sort of sort i -- how a caller with a
-        # stream of independent batches uses the API, and the regime the line's `value` reports: K sorts enqueued as fast
-        # as the API allows, barrier + synchronize on both sides, like the N = 1 line (where one GPU has nothing to overlap).
-        # `value_depth1` / `ms_per_step_depth1` stand beside it; the per-kernel roofline numbers come from the depth-1 region.
-        r1 = run_depth(1)
-        elapsed1 = max_over_ranks(r1["elapsed"])
-        result["value_depth1"] = round(n * world * K / elapsed1 / 1e6, 1)
-        result["ms_per_step_depth1"] = round(elapsed1 / K * 1e3, 4)
-        depth = max(1, args.pipeline_depth)
-        elapsed = r1["elapsed"]
-        if depth > 1:
-            r2 = run_depth(depth)
-            elapsed = r2["elapsed"]
-            result["value_depth%d" % depth] = round(n * world * K / max_over_ranks(elapsed) / 1e6, 1)
-            result["phases_ms_rank0_depth%d" % depth] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in r2["phases"].items()}
-            del r2
-        result["pipeline_depth"] = depth
-        dsort, handle, profs, sorters = r1["dsort"], r1["handle"], r1["profs"], r1["sorters"]
-        result["native_c_abi"] = bool(dsort.native)
-        result["local_sort"] = (dsort._slots[0]["native"].last_local_sort() if dsort.native else dsort.last_local_sort)
-        if args.rehearse_one_gpu:
-            result["rehearsal"] = "NOT A MEASUREMENT: %d ranks share one GPU and exchange through files (tests/cpp/mock_rccl.cpp)" % world
-        rk, rv, cnt = handle.synchronize()
-        # rank 0's view: the scatter kernel (1 partition launch over n pairs + 4 sort launches over its shard per sort)
-        # and the device time of every phase of a sort
-        launches = sum(int(pf["passes"]) for pf in profs)
-        scatter_ms = sum(pf["scatter_ms"] for pf in profs) / max(launches, 1)
-        per_sort = max(launches // max(K, 1), 1)
-        alg_bytes = 2 * (KEY_BYTES + VAL_BYTES) * (n + (per_sort - 1) * int(cnt)) // per_sort
-        if launches and scatter_ms > 0:
-            achieved = alg_bytes / (scatter_ms * 1e-3) / 1e9
-            result["roofline"] = {
-                "bound": "hbm", "kernel": "radix_scatter_lines_kernel<u32,%d> (rank 0)" % sorters[0].digit_bits,
-                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                "traffic": None, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(scatter_ms, 4),
-                "launches_timed": launches,
-                "count_kernel_avg_ms": round(sum(pf["count_ms"] for pf in profs) / launches, 4),
-            }
-        phases = r1["phases"]
-        result["phases_ms_rank0"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in phases.items()}
-        units = n * world * K
-        verified = None
-        if not args.no_verify:
-            flipped = rk ^ (-2**31)
-            ok = bool((flipped[1:] >= flipped[:-1]).all())
-            # rank boundaries: my last key <= next rank's first key; counts add up
-            first = flipped[:1].to(torch.int64) if cnt > 0 else torch.full((1,), 2**40, device=device)
-            last = flipped[-1:].to(torch.int64) if cnt > 0 else torch.full((1,), -2**40, device=device)
-            edges = torch.stack([first, last]).reshape(1, 2)
-            gathered = [torch.zeros_like(edges) for _ in range(world)]
-            dist.all_gather(gathered, edges)
-            total = torch.tensor([cnt], dtype=torch.int64, device=device)
-            dist.all_reduce(total)
+            fres, felapsed, funits, fworkload, fpar = sharded(False)
+            took = time.perf_counter() - t0
             if rank == 0:
-                prev_last = None
-                for e in gathered:
-                    f, l = int(e[0, 0]), int(e[0, 1])
-                    if f > l:
-                        continue  # empty shard
-                    if prev_last is not None and f < prev_last:
-                        ok = False
-                    prev_last = l
-            ok = ok and int(total.item()) == n * world
-            flag = torch.tensor([1 if ok else 0], device=device)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            verified = bool(flag.item())
-        result["verified"] = verified
-        result["shard_pairs_rank0"] = int(cnt)
-        workload = ("2^%d uint32 key+val pairs per GPU (%d GPUs, 2^%.2f total), uniform-random keys; top-8-bit bucket "
-                    "partition + one RCCL all-to-all over xGMI + local sort") % (log2n, world, log2n + __import__("math").log2(world))
-        parallelism = ("bucket-sharded x%d (1 grouped RCCL exchange per sort), %d independent sorts in flight (value_depth1: one at a time)"
-                       % (world, depth)) if depth > 1 else "bucket-sharded x%d (1 grouped RCCL exchange per sort), one sort at a time" % world
-
-    # max over ranks
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+                fallback = make_line(fres, felapsed, funits, fworkload, fpar)
+            deadline = float(os.environ.get("GLU_BENCH_NATIVE_DEADLINE_S", "0")) or (120.0 + 5.0 * took)
+            state["armed"] = True
+            watchdog = threading.Timer(deadline, bail, args=("did not finish within %.0f s" % deadline,))
+            watchdog.daemon = True
+            watchdog.start()
+        try:
+            result, elapsed, units, workload, parallelism = sharded(want_native)
+        except BaseException as e:  # noqa: a rank that fails alone must not take the launcher down before rank 0 has printed
+            if not state["armed"]:
+                raise
+            bail("%s: %s" % (type(e).__name__, e))
+        with bail_lock:
+            state["armed"] = False
+        if watchdog is not None:
+            watchdog.cancel()
+        if fallback is not None:
+            result["torch_transport"] = {k: fallback[k] for k in ("value", "ms_per_step", "value_depth1", "ms_per_step_depth1", "verified",
+                                                                  "local_sort", "phases_ms_rank0") if k in fallback}
 
     if rank == 0:
-        line = {
-            "metric": "Mkeys/s sorting 2^28 uint32 key+val; % HBM roofline; 1/2/4/8 GPU",
-            "value": round(units / elapsed / 1e6, 1),
-            "unit": "Mkeys/s",
-            "n_gpus": world,
-            "steps": K,
-            "warmup": W,
-            "ms_per_step": round(elapsed / K * 1e3, 4),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "u32",
-            "data": "synthetic",
-            "config": {"workload": workload, "pairs_per_gpu": n, "key_distribution": args.keys,
-                       "parallelism": parallelism, "device": G.device_info()},
-        }
-        line.update(result)
+        line = make_line(result, elapsed, units, workload, parallelism)
         if world == 1 and not args.force_dist and not args.no_cpu_baseline:
             if args.cpu_sample_log2 is None:
                 # BASELINE.md section 3: the same input array as the GPU sorted, whole, one run per configuration

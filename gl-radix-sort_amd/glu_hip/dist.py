@@ -284,20 +284,29 @@ class DistributedRadixSort:
         dist = self.dist
         backend = dist.get_backend(self.group)
         if backend == "gloo":
-            # gloo has no all_to_all_single: same exchange as pairwise send/recv (CPU tests only)
+            # gloo has no all_to_all_single: same exchange as pairwise send/recv (CPU tests; the one-GPU rehearsal of
+            # bench.py).  Device tensors are staged through host copies: gloo's point-to-point ops hand the tensor's data
+            # pointer to the socket layer without any stream ordering.
+            on_device = inp.is_cuda
+            if on_device:
+                self.torch.cuda.current_stream(inp.device).synchronize()
+            src = inp.cpu() if on_device else inp
+            dst = self.torch.empty(out.shape, dtype=out.dtype, device="cpu") if on_device else out
             reqs = []
             so = np.concatenate([[0], np.cumsum(send_counts)])
             ro = np.concatenate([[0], np.cumsum(recv_counts)])
             for peer in range(self.world):
                 if peer == self.rank:
-                    out[ro[peer]:ro[peer + 1]].copy_(inp[so[peer]:so[peer + 1]])
+                    dst[ro[peer]:ro[peer + 1]].copy_(src[so[peer]:so[peer + 1]])
                     continue
                 if send_counts[peer]:
-                    reqs.append(dist.isend(inp[so[peer]:so[peer + 1]].contiguous(), peer, group=self.group))
+                    reqs.append(dist.isend(src[so[peer]:so[peer + 1]].contiguous(), peer, group=self.group))
                 if recv_counts[peer]:
-                    reqs.append(dist.irecv(out[ro[peer]:ro[peer + 1]], peer, group=self.group))
+                    reqs.append(dist.irecv(dst[ro[peer]:ro[peer + 1]], peer, group=self.group))
             for r in reqs:
                 r.wait()
+            if on_device:
+                out.copy_(dst)
         else:
             dist.all_to_all_single(out, inp, [int(c) for c in recv_counts], [int(c) for c in send_counts],
                                    group=self.group)

@@ -584,3 +584,25 @@ def test_bench_multi_gpu_command_line_rehearsal(built):
     assert line["pipeline_depth"] == 2 and line["value"] == line["value_depth2"] and "value_depth1" in line and "rehearsal" in line
     assert line["local_sort"] in ("segmented", "ordinary")
     assert line["phases_ms_rank0"]["sorts"] == line["steps"]
+    # the torch.distributed transport was measured first (it is the fallback line) and stands beside the native figures
+    assert line["torch_transport"]["verified"] is True and line["torch_transport"]["value"] > 0
+
+
+def test_bench_multi_gpu_falls_back_when_the_native_transport_hangs(built):
+    """bench.py's safety net for the first real multi-GPU run: rank 1 never arrives in the native transport
+    (GLU_BENCH_TEST_NATIVE_HANG), the watchdog fires, rank 0 prints the torch.distributed transport's line with
+    `native_error`, every rank exits 0."""
+    import json
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GRAFT_REPO_ROOT=root, GLU_BENCH_TEST_NATIVE_HANG="1", GLU_BENCH_NATIVE_DEADLINE_S="20")
+    p = subprocess.run(["bash", os.path.join(root, "tools", "rehearse_multi_gpu.sh"), "2", "18"], capture_output=True, text=True,
+                       env=env, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["verified"] is True and line["native_c_abi"] is False
+    assert "did not finish" in line["native_error"] and line["value"] > 0
+
