@@ -181,10 +181,14 @@ __device__ __forceinline__ bool plan_digit_is_constant(const PassPlan* plan, uin
     return (((plan->bits_or[w] & plan->bits_nor[w]) >> (shift & 31u)) & mask) == 0;
 }
 
-// OR / AND of the keys a thread has seen -> the plan (once per wave)
+// OR / AND of the keys a thread has seen -> the plan, once per WORKGROUP.  Called by every thread of the workgroup (it
+// holds a barrier).  (Once per wave, the first version, cost a 6 M-pair sort 60 of its 250 us: the 4096 waves of a balanced
+// launch finish together, every one of them still reads zeros in the plan's words, and their same-address atomics then
+// take ~10 ns each, one after the other -- tools/trace_one_sort.sh.)
 template<typename KeyT>
 __device__ __forceinline__ void plan_publish_bits(PassPlan* plan, KeyT acc_or, KeyT acc_and, uint32_t lane)
 {
+    __shared__ uint32_t wave_bits[16][4]; // per wave: or lo, nor lo, or hi, nor hi
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1)
     {
@@ -199,21 +203,23 @@ __device__ __forceinline__ void plan_publish_bits(PassPlan* plan, KeyT acc_or, K
             acc_and &= (KeyT) __shfl_xor((unsigned long long) acc_and, o);
         }
     }
+    const uint32_t wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
     if (lane == 0)
     {
-        // Thousands of waves OR into the same four words, and same-address atomics take ~10 ns each one after the other
-        // (75 us per launch when every wave did them): a wave that has nothing to add -- nearly all of them, the words fill
-        // up with the first few -- only reads.  (A stale read can only show fewer bits than there are: one atomic too many.)
-        auto add = [](uint32_t* word, uint32_t bits) {
-            if ((*reinterpret_cast<volatile uint32_t*>(word) | bits) != *reinterpret_cast<volatile uint32_t*>(word)) atomicOr(word, bits);
-        };
-        add(&plan->bits_or[0], (uint32_t) acc_or);
-        add(&plan->bits_nor[0], ~(uint32_t) acc_and);
-        if constexpr (sizeof(KeyT) == 8)
-        {
-            add(&plan->bits_or[1], (uint32_t) ((uint64_t) acc_or >> 32));
-            add(&plan->bits_nor[1], ~(uint32_t) ((uint64_t) acc_and >> 32));
-        }
+        wave_bits[wave][0] = (uint32_t) acc_or;
+        wave_bits[wave][1] = ~(uint32_t) acc_and;
+        wave_bits[wave][2] = sizeof(KeyT) == 8 ? (uint32_t) ((uint64_t) acc_or >> 32) : 0u;
+        wave_bits[wave][3] = sizeof(KeyT) == 8 ? ~(uint32_t) ((uint64_t) acc_and >> 32) : 0u;
+    }
+    __syncthreads();
+    if (threadIdx.x < (sizeof(KeyT) == 8 ? 4u : 2u))
+    {
+        uint32_t bits = 0;
+        for (uint32_t w = 0; w < waves; w++) bits |= wave_bits[w][threadIdx.x];
+        // a workgroup that has nothing to add -- nearly all of them when they finish at different times, the words fill up
+        // with the first few -- only reads.  (A stale read can only show fewer bits than there are: one atomic too many.)
+        uint32_t* word = threadIdx.x == 0 ? &plan->bits_or[0] : threadIdx.x == 1 ? &plan->bits_nor[0] : threadIdx.x == 2 ? &plan->bits_or[1] : &plan->bits_nor[1];
+        if ((*reinterpret_cast<volatile uint32_t*>(word) | bits) != *reinterpret_cast<volatile uint32_t*>(word)) atomicOr(word, bits);
     }
 }
 

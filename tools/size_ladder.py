@@ -1,14 +1,15 @@
 """Sort time over a fine size ladder (x1.25 steps): a quick way to spot cliffs at the switch points between the
 one-workgroup path, the fused-scan path, the small and the large geometry and the pass plan.
-usage (GPU box): python tools/size_ladder.py [keys|pairs|u64]"""
+usage (GPU box): python tools/size_ladder.py [keys|pairs|u64] [first n] [last n]"""
 import sys
 sys.path.insert(0, "gl-radix-sort_amd")
 import numpy as np, glu_hip as G
 
 mode = sys.argv[1] if len(sys.argv) > 1 else "pairs"
-n = 3000.0
+n = float(sys.argv[2]) if len(sys.argv) > 2 else 3000.0
+n_end = float(sys.argv[3]) if len(sys.argv) > 3 else float(1 << 27)
 prev = None
-while n < (1 << 27):
+while n < n_end:
     m = int(n)
     dt = np.uint64 if mode == "u64" else np.uint32
     keys = np.random.default_rng(m).integers(0, 2 ** (64 if mode == "u64" else 32), m, dtype=dt)
