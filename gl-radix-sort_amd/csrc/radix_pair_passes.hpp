@@ -90,24 +90,15 @@ __global__ __launch_bounds__(1024) void radix_pair_count_kernel(const KeyT* __re
     const KeyCodec<KeyT, XF> codec_in(xform & 3u);
 
     // every lane of the wave is active when this runs
-    auto tally = [&](KeyT raw) {
+    auto both_digits = [&](KeyT raw) {
         const KeyT k = codec_in.encode(raw);
-        const uint32_t d = digit_of<KeyT>(k, shift, mask), e = digit_of<KeyT>(k, shift2, mask2);
-        const uint32_t de = d | (e << 8);
-        const uint32_t de0 = __builtin_amdgcn_readfirstlane(de);
-        if (__ballot(de != de0) == 0) // the whole wave on one counter (constant / heavily duplicated keys): one add each
-        {
-            if (lane == 0)
-            {
-                atomicAdd(&my_hist[de0 & 255u], 64u);
-                atomicAdd(&s.hist2[pair_word(de0 & 255u, de0 >> 8)], 64u << (16u * ((de0 >> 8) & 1u)));
-            }
-        }
-        else
-        {
-            atomicAdd(&my_hist[d], 1u);
-            atomicAdd(&s.hist2[pair_word(d, e)], 1u << (16u * (e & 1u)));
-        }
+        return digit_of<KeyT>(k, shift, mask) | (digit_of<KeyT>(k, shift2, mask2) << 8);
+    };
+    auto tally = [&](auto peel, KeyT raw) {
+        wave_tally<decltype(peel)::value>(both_digits(raw), lane, [&](uint32_t de, uint32_t c) {
+            atomicAdd(&my_hist[de & 255u], c);
+            atomicAdd(&s.hist2[pair_word(de & 255u, de >> 8)], c << (16u * ((de >> 8) & 1u)));
+        });
     };
     auto tally_one = [&](KeyT raw) { // lanes may be inactive
         if (COLLECT) acc_or |= raw, acc_and &= raw;
@@ -122,30 +113,38 @@ __global__ __launch_bounds__(1024) void radix_pair_count_kernel(const KeyT* __re
     const bool vec_ok = (reinterpret_cast<uintptr_t>(keys) & 15u) == 0;
     const uint64_t nvec = vec_ok ? (end - begin) / VEC : 0;
     const VecT* vkeys = reinterpret_cast<const VecT*>(keys + begin);
-    auto tally_vec = [&](const VecT& a) {
+    auto tally_vec = [&](auto peel, const VecT& a) {
         if constexpr (sizeof(KeyT) == 4)
         {
             if (COLLECT) acc_or |= a.x | a.y | a.z | a.w, acc_and &= a.x & a.y & a.z & a.w;
-            tally(a.x); tally(a.y); tally(a.z); tally(a.w);
+            tally(peel, a.x); tally(peel, a.y); tally(peel, a.z); tally(peel, a.w);
         }
         else
         {
             if (COLLECT) acc_or |= a.x | a.y, acc_and &= a.x & a.y;
-            tally(a.x); tally(a.y);
+            tally(peel, a.x); tally(peel, a.y);
         }
     };
     uint64_t vbase = 0;
-    for (; vbase + 4 * THREADS <= nvec; vbase += 4 * THREADS) // block-uniform trip count, 4 x 16 B in flight per lane
-    {
-        VecT a = load_streaming(&vkeys[vbase + tid]);
-        VecT b = load_streaming(&vkeys[vbase + tid + THREADS]);
-        VecT c = load_streaming(&vkeys[vbase + tid + 2 * THREADS]);
-        VecT d = load_streaming(&vkeys[vbase + tid + 3 * THREADS]);
-        tally_vec(a);
-        tally_vec(b);
-        tally_vec(c);
-        tally_vec(d);
-    }
+    // (the loop twice, chosen once per wave from its first keys: see wave_tally.  An explicit prefetch of the next
+    // iteration's four vectors made the kernel 8 % slower)
+    auto main_loop = [&](auto peel) {
+        for (; vbase + 4 * THREADS <= nvec; vbase += 4 * THREADS) // block-uniform trip count, 4 x 16 B in flight per lane
+        {
+            VecT a = load_streaming(&vkeys[vbase + tid]);
+            VecT b = load_streaming(&vkeys[vbase + tid + THREADS]);
+            VecT c = load_streaming(&vkeys[vbase + tid + 2 * THREADS]);
+            VecT d = load_streaming(&vkeys[vbase + tid + 3 * THREADS]);
+            tally_vec(peel, a);
+            tally_vec(peel, b);
+            tally_vec(peel, c);
+            tally_vec(peel, d);
+        }
+    };
+    if (4 * THREADS <= nvec && wave_many_equal(both_digits(vkeys[tid].x)))
+        main_loop(std::true_type());
+    else
+        main_loop(std::false_type());
     uint64_t i = begin + vbase * VEC + tid;
     for (; i + 7ull * THREADS < end; i += 8ull * THREADS)
     {
@@ -387,29 +386,22 @@ __global__ __launch_bounds__(256) void radix_pair4_count_kernel(const KeyT* __re
         return digit_of<KeyT>(k, shift, mask) | (digit_of<KeyT>(k, shift2, mask2) << 4);
     };
     // every lane of the wave is active when this runs
-    auto tally = [&](KeyT raw) {
-        const uint32_t c = combined(raw);
-        const uint32_t c0 = __builtin_amdgcn_readfirstlane(c);
-        if (__ballot(c != c0) == 0)
-        {
-            if (lane == 0) atomicAdd(&my_hist[c0], 64u);
-        }
-        else
-            atomicAdd(&my_hist[c], 1u);
+    auto tally = [&](auto peel, KeyT raw) {
+        wave_tally<decltype(peel)::value>(combined(raw), lane, [&](uint32_t cv, uint32_t c) { atomicAdd(&my_hist[cv], c); });
     };
     constexpr int VEC = 16 / sizeof(KeyT);
     using VecT = typename std::conditional<sizeof(KeyT) == 4, uint4, ulonglong2>::type;
     const bool vec_ok = (reinterpret_cast<uintptr_t>(keys) & 15u) == 0;
-    auto tally_vec = [&](const VecT& a) {
+    auto tally_vec = [&](auto peel, const VecT& a) {
         if constexpr (sizeof(KeyT) == 4)
         {
             if (COLLECT) acc_or |= a.x | a.y | a.z | a.w, acc_and &= a.x & a.y & a.z & a.w;
-            tally(a.x); tally(a.y); tally(a.z); tally(a.w);
+            tally(peel, a.x); tally(peel, a.y); tally(peel, a.z); tally(peel, a.w);
         }
         else
         {
             if (COLLECT) acc_or |= a.x | a.y, acc_and &= a.x & a.y;
-            tally(a.x); tally(a.y);
+            tally(peel, a.x); tally(peel, a.y);
         }
     };
     if (begin < end) // (block-uniform)
@@ -417,17 +409,23 @@ __global__ __launch_bounds__(256) void radix_pair4_count_kernel(const KeyT* __re
         const uint64_t nvec = vec_ok ? (end - begin) / VEC : 0;
         const VecT* vkeys = reinterpret_cast<const VecT*>(keys + begin);
         uint64_t vbase = 0;
-        for (; vbase + 4 * THREADS <= nvec; vbase += 4 * THREADS) // block-uniform trip count, 4 x 16 B in flight per lane
-        {
-            VecT a = load_streaming(&vkeys[vbase + tid]);
-            VecT bq = load_streaming(&vkeys[vbase + tid + THREADS]);
-            VecT c = load_streaming(&vkeys[vbase + tid + 2 * THREADS]);
-            VecT d = load_streaming(&vkeys[vbase + tid + 3 * THREADS]);
-            tally_vec(a);
-            tally_vec(bq);
-            tally_vec(c);
-            tally_vec(d);
-        }
+        auto main_loop = [&](auto peel) { // (twice, chosen once per wave from its first keys: see wave_tally)
+            for (; vbase + 4 * THREADS <= nvec; vbase += 4 * THREADS) // block-uniform trip count, 4 x 16 B in flight per lane
+            {
+                VecT a = load_streaming(&vkeys[vbase + tid]);
+                VecT bq = load_streaming(&vkeys[vbase + tid + THREADS]);
+                VecT c = load_streaming(&vkeys[vbase + tid + 2 * THREADS]);
+                VecT d = load_streaming(&vkeys[vbase + tid + 3 * THREADS]);
+                tally_vec(peel, a);
+                tally_vec(peel, bq);
+                tally_vec(peel, c);
+                tally_vec(peel, d);
+            }
+        };
+        if (4 * THREADS <= nvec && wave_many_equal(combined(vkeys[tid].x)))
+            main_loop(std::true_type());
+        else
+            main_loop(std::false_type());
         for (uint64_t i = begin + vbase * VEC + tid; i < end; i += THREADS)
         {
             const KeyT raw = keys[i];

@@ -35,17 +35,11 @@ __global__ __launch_bounds__(THREADS) void radix_seg_count_kernel(const uint32_t
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t* my_hist = hist[wave];
     auto dig = [&](uint32_t k) { return digit_of<uint32_t>(k, shift, mask); };
-    // every lane of the wave is active when this runs: a wave whose 64 digits are equal (constant / heavily duplicated
-    // keys) makes one add instead of a 64-way same-address LDS atomic
-    auto tally = [&](uint32_t d) {
-        const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
-        if (__ballot(d != d0) == 0)
-        {
-            if (lane == 0) atomicAdd(&my_hist[d0], 64u);
-        }
-        else
-            atomicAdd(&my_hist[d], 1u);
+    // every lane of the wave is active when this runs (wave_tally: one add per group of equal digits when they are few)
+    auto tally = [&](auto peel, uint32_t d) {
+        wave_tally<decltype(peel)::value>(d, lane, [&](uint32_t dv, uint32_t c) { atomicAdd(&my_hist[dv], c); });
     };
+    auto tally_vec = [&](auto peel, const uint4& a) { tally(peel, dig(a.x)); tally(peel, dig(a.y)); tally(peel, dig(a.z)); tally(peel, dig(a.w)); };
     const uint32_t sb_first = seg_first[blockIdx.x], sb_last = seg_first[blockIdx.x + 1];
     for (int i = tid; i < WAVES * RADIX; i += THREADS) (&hist[0][0])[i] = 0;
     __syncthreads();
@@ -60,17 +54,23 @@ __global__ __launch_bounds__(THREADS) void radix_seg_count_kernel(const uint32_t
         const uint64_t nvec = (end - vstart) / 4;
         const uint4* vkeys = reinterpret_cast<const uint4*>(keys + vstart);
         uint64_t vbase = 0;
-        for (; vbase + 4 * THREADS <= nvec; vbase += 4 * THREADS) // block-uniform trip count, 4 x 16 B in flight per lane
-        {
-            const uint4 a = load_streaming(&vkeys[vbase + tid]);
-            const uint4 b = load_streaming(&vkeys[vbase + tid + THREADS]);
-            const uint4 c = load_streaming(&vkeys[vbase + tid + 2 * THREADS]);
-            const uint4 d = load_streaming(&vkeys[vbase + tid + 3 * THREADS]);
-            tally(dig(a.x)); tally(dig(a.y)); tally(dig(a.z)); tally(dig(a.w));
-            tally(dig(b.x)); tally(dig(b.y)); tally(dig(b.z)); tally(dig(b.w));
-            tally(dig(c.x)); tally(dig(c.y)); tally(dig(c.z)); tally(dig(c.w));
-            tally(dig(d.x)); tally(dig(d.y)); tally(dig(d.z)); tally(dig(d.w));
-        }
+        auto main_loop = [&](auto peel) { // (twice, chosen once per wave and sub-block from its first keys: see wave_tally)
+            for (; vbase + 4 * THREADS <= nvec; vbase += 4 * THREADS) // block-uniform trip count, 4 x 16 B in flight per lane
+            {
+                const uint4 a = load_streaming(&vkeys[vbase + tid]);
+                const uint4 b = load_streaming(&vkeys[vbase + tid + THREADS]);
+                const uint4 c = load_streaming(&vkeys[vbase + tid + 2 * THREADS]);
+                const uint4 d = load_streaming(&vkeys[vbase + tid + 3 * THREADS]);
+                tally_vec(peel, a);
+                tally_vec(peel, b);
+                tally_vec(peel, c);
+                tally_vec(peel, d);
+            }
+        };
+        if (4 * THREADS <= nvec && wave_many_equal(dig(vkeys[tid].x)))
+            main_loop(std::true_type());
+        else
+            main_loop(std::false_type());
         for (uint64_t v = vbase + tid; v < nvec; v += THREADS) // lanes may be inactive: plain atomics
         {
             const uint4 a = vkeys[v];

@@ -181,6 +181,62 @@ __device__ __forceinline__ bool plan_digit_is_constant(const PassPlan* plan, uin
     return (((plan->bits_or[w] & plan->bits_nor[w]) >> (shift & 31u)) & mask) == 0;
 }
 
+// One counter update per key for a whole wave: add(value, count) is called by every lane that must add `count` to the
+// counter of `value`.  Every lane of the wave is active when this runs.
+//   * all 64 values equal (constant keys, sorted input): one add of 64 by lane 0;
+//   * PEEL (the caller saw many equal values in this stretch of the input, wave_many_equal): few distinct keys in any
+//     order make 32-way same-address LDS atomics, 32 turns each, and the pair kernel's shared counters are hit by all 16
+//     waves at once.  Groups of equal values are peeled off one by one, a ballot and one add by the group's first lane
+//     each, for as long as they hold at least kTallyPeelMin lanes; whoever is left adds for himself.
+//   * else every lane adds 1.
+// 2^26 pairs with two distinct key values in random order: first pair-count kernel 276 -> 156 us (tools/trace_one_sort.sh).
+// The choice is made once per wave (from the first keys of its share of the input) between two copies of the count loop:
+// a test per key cost uniform keys 10 % of the pair-count kernel, one per loop iteration 4.5 % (same-box A/B, tools/ab_lib.sh).
+constexpr int kTallyPeelMin = 8, kTallyPeelRounds = 8;
+__device__ __forceinline__ bool wave_many_equal(uint32_t v) // wave-uniform
+{
+    const uint64_t same = __ballot(v == (uint32_t) __builtin_amdgcn_readfirstlane(v));
+    return same != ~0ull && __popcll(same) >= kTallyPeelMin;
+}
+template<bool PEEL, typename F>
+__device__ __forceinline__ void wave_tally(uint32_t v, uint32_t lane, F&& add)
+{
+    const uint32_t v0 = __builtin_amdgcn_readfirstlane(v);
+    if constexpr (!PEEL)
+    {
+        if (__ballot(v != v0) == 0)
+        {
+            // (the empty asm keeps the compiler from merging the two branches into one predicated body with selects: 2.5 %
+            // of the pair-count kernel on uniform keys)
+            asm volatile("");
+            if (lane == 0) add(v0, 64u);
+        }
+        else
+            add(v, 1u);
+    }
+    else
+    {
+        const uint64_t same = __ballot(v == v0);
+        if (same == ~0ull)
+        {
+            if (lane == 0) add(v0, 64u);
+            return;
+        }
+        uint64_t todo = ~0ull, grp = same;
+        uint32_t vg = v0, first = 0;
+        for (int round = 0; __popcll(grp) >= kTallyPeelMin;)
+        {
+            if (lane == first) add(vg, (uint32_t) __popcll(grp));
+            todo &= ~grp;
+            if (todo == 0 || ++round == kTallyPeelRounds) break;
+            first = (uint32_t) __ffsll((unsigned long long) todo) - 1u; // (wave-uniform: todo is made of ballots)
+            vg = (uint32_t) __builtin_amdgcn_readlane((int) v, (int) first);
+            grp = __ballot(v == vg); // (a group smaller than kTallyPeelMin ends the loop: it and the rest add one by one)
+        }
+        if ((todo >> lane) & 1ull) add(v, 1u);
+    }
+}
+
 // OR / AND of the keys a thread has seen -> the plan, once per WORKGROUP.  Called by every thread of the workgroup (it
 // holds a barrier).  (Once per wave, the first version, cost a 6 M-pair sort 60 of its 250 us: the 4096 waves of a balanced
 // launch finish together, every one of them still reads zeros in the plan's words, and their same-address atomics then
@@ -272,18 +328,8 @@ __global__ __launch_bounds__(THREADS) void radix_count_kernel(const KeyT* __rest
     KeyT acc_or = 0, acc_and = (KeyT) ~(KeyT) 0; // of the raw keys this thread reads
 
     // every lane of the wave is active when this runs (wave-uniform trip counts below)
-    auto tally = [&](uint32_t d) {
-        // all-equal digits in the wave (constant / heavily duplicated keys): one add instead of a
-        // 64-way same-address LDS atomic
-        const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
-        if (__ballot(d != d0) == 0)
-        {
-            if (lane == 0) atomicAdd(&my_hist[d0], 64u);
-        }
-        else
-        {
-            atomicAdd(&my_hist[d], 1u);
-        }
+    auto tally = [&](auto peel, uint32_t d) {
+        wave_tally<decltype(peel)::value>(d, lane, [&](uint32_t dv, uint32_t c) { atomicAdd(&my_hist[dv], c); });
     };
 
     constexpr int VEC = 16 / sizeof(KeyT); // 16-byte loads
@@ -295,33 +341,40 @@ __global__ __launch_bounds__(THREADS) void radix_count_kernel(const KeyT* __rest
     const VecT* vkeys = reinterpret_cast<const VecT*>(keys + begin);
     const KeyCodec<KeyT, XF> codec_in(xform & 3u);
     auto dig = [&](KeyT k) { return digit_of<KeyT>(codec_in.encode(k), shift, MASK); };
-    auto tally_vec = [&](const VecT& a) {
+    auto tally_vec = [&](auto peel, const VecT& a) {
         if constexpr (sizeof(KeyT) == 4)
         {
             if (COLLECT) acc_or |= a.x | a.y | a.z | a.w, acc_and &= a.x & a.y & a.z & a.w;
-            tally(dig(a.x)); tally(dig(a.y)); tally(dig(a.z)); tally(dig(a.w));
+            tally(peel, dig(a.x)); tally(peel, dig(a.y)); tally(peel, dig(a.z)); tally(peel, dig(a.w));
         }
         else
         {
             if (COLLECT) acc_or |= a.x | a.y, acc_and &= a.x & a.y;
-            tally(dig(a.x)); tally(dig(a.y));
+            tally(peel, dig(a.x)); tally(peel, dig(a.y));
         }
     };
     uint64_t vbase = 0;
-    for (; vbase + 4 * THREADS <= nvec; vbase += 4 * THREADS) // block-uniform trip count, 4 x 16 B in flight per lane
-    {
-        // non-temporal loads: the keys are read once; leaving them out of the Infinity Cache keeps the dirty lines of the
-        // scatter that ran just before from being evicted under this kernel (0.255 -> 0.22 ms behind a scatter, 0.19 ->
-        // 0.17 ms alone at 2^28 keys)
-        VecT a = load_streaming(&vkeys[vbase + tid]);
-        VecT b = load_streaming(&vkeys[vbase + tid + THREADS]);
-        VecT c = load_streaming(&vkeys[vbase + tid + 2 * THREADS]);
-        VecT d = load_streaming(&vkeys[vbase + tid + 3 * THREADS]);
-        tally_vec(a);
-        tally_vec(b);
-        tally_vec(c);
-        tally_vec(d);
-    }
+    // (the loop twice, chosen once per wave from its first keys: see wave_tally)
+    auto main_loop = [&](auto peel) {
+        for (; vbase + 4 * THREADS <= nvec; vbase += 4 * THREADS) // block-uniform trip count, 4 x 16 B in flight per lane
+        {
+            // non-temporal loads: the keys are read once; leaving them out of the Infinity Cache keeps the dirty lines of the
+            // scatter that ran just before from being evicted under this kernel (0.255 -> 0.22 ms behind a scatter, 0.19 ->
+            // 0.17 ms alone at 2^28 keys)
+            VecT a = load_streaming(&vkeys[vbase + tid]);
+            VecT b = load_streaming(&vkeys[vbase + tid + THREADS]);
+            VecT c = load_streaming(&vkeys[vbase + tid + 2 * THREADS]);
+            VecT d = load_streaming(&vkeys[vbase + tid + 3 * THREADS]);
+            tally_vec(peel, a);
+            tally_vec(peel, b);
+            tally_vec(peel, c);
+            tally_vec(peel, d);
+        }
+    };
+    if (4 * THREADS <= nvec && wave_many_equal(dig(vkeys[tid].x)))
+        main_loop(std::true_type());
+    else
+        main_loop(std::false_type());
     // tail (< 4 * THREADS vectors + a partial vector): plain per-key atomics, lanes may be inactive
     uint64_t i = begin + vbase * VEC + tid;
     for (; i + 7ull * THREADS < end; i += 8ull * THREADS) // 8 loads in flight per lane

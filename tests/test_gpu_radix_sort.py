@@ -73,6 +73,24 @@ def test_sizes_full_32_bit_keys(G, bits, n):
 
 
 @pytest.mark.parametrize("bits", DIGIT_BITS)
+@pytest.mark.parametrize("key_bytes", [4, 8])
+@pytest.mark.parametrize("distinct", [2, 3, 7, 9, 20])
+def test_few_distinct_keys_in_random_order(G, bits, key_bytes, distinct):
+    """A handful of key values in random order: the count kernels take their duplicate-peeling path (wave_tally in
+    radix_sort_kernels.hpp: groups of >= 8 equal digits in a wave are added by one lane; 7 and 9 distinct values sit on
+    both sides of that limit), in unplanned (2^21) and planned (2^22) sorts."""
+    for n in ((1 << 21) + 12345, (1 << 22) + 5):
+        rng = np.random.default_rng(distinct * 1000 + bits + key_bytes + (n & 1))
+        dt = np.uint64 if key_bytes == 8 else np.uint32
+        palette = rng.integers(0, 2 ** (8 * key_bytes), distinct, dtype=dt)
+        keys = palette[rng.integers(0, distinct, n)]
+        vals = np.arange(n, dtype=np.uint32)
+        gk, gv = gpu_sort(G, keys, vals, bits=bits, key_bytes=key_bytes)
+        ek, ev = O.stable_sort_pairs(keys, vals)
+        assert (gk == ek).all() and (gv == ev).all()
+
+
+@pytest.mark.parametrize("bits", DIGIT_BITS)
 @pytest.mark.parametrize("kind", ["zero", "ones", "few", "sorted", "reversed", "low_bits", "high_bits", "two_values"])
 def test_key_distributions_are_stable(G, bits, kind):
     n = 300007

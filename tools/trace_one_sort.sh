@@ -1,14 +1,20 @@
 #!/bin/bash
 # kernel trace of the last of six sorts of N uniform pairs (start offset and duration of every launch, us)
-#   bash tools/trace_one_sort.sh N [tag]     (GPU box; environment knobs of the library pass through)
-N=${1:-6000000}; TAG=${2:-t}
+#   bash tools/trace_one_sort.sh N [tag] [uniform|zero|two|runs64]     (GPU box; environment knobs of the library pass through)
+N=${1:-6000000}; TAG=${2:-t}; KIND=${3:-uniform}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cat > /tmp/one_sort.py <<PY
 import sys
 sys.path.insert(0, "$R/gl-radix-sort_amd")
 import numpy as np, glu_hip as G
 m = $N
-keys = np.random.default_rng(1).integers(0, 2**32, m, dtype=np.uint32); vals = np.arange(m, dtype=np.uint32)
+rng = np.random.default_rng(1)
+kind = "$KIND"
+if kind == "zero": keys = np.zeros(m, dtype=np.uint32)
+elif kind == "two": keys = rng.integers(0, 2, m, dtype=np.uint32) * np.uint32(0x01010101)
+elif kind == "runs64": keys = np.repeat(rng.integers(0, 2**32, (m + 63) // 64, dtype=np.uint32), 64)[:m].copy()
+else: keys = rng.integers(0, 2**32, m, dtype=np.uint32)
+vals = np.arange(m, dtype=np.uint32)
 s = G.RadixSort(); s.prepare_internal_buffers(m)
 for r in range(6):
     kb = G.ShaderStorageBuffer(keys); vb = G.ShaderStorageBuffer(vals); s(kb, vb, m, 0)
