@@ -22,7 +22,7 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_bench_write -- python
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_cfg_fetch -- python3 $R/tools/measure_configs.py > /dev/null 2> $OUT/pmc_cf.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_cfg_write -- python3 $R/tools/measure_configs.py > /dev/null 2> $OUT/pmc_cw.err
 SB_R3=1 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_sb_fetch -- $R/tools/scatter_bench 28 > /dev/null 2> $OUT/pmc_sb.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_dist -- python3 $R/bench.py --force-dist --log2-keys 27 --steps 10 --warmup 3 --pipeline-depth 1 --no-verify > $OUT/bench_force_dist_2p27_under_rocprof.json 2> $OUT/prof_dist.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_dist -- python3 $R/bench.py --force-dist --log2-keys 27 --steps 10 --warmup 3 --pipeline-depth 1 --no-verify --no-transport-fallback > $OUT/bench_force_dist_2p27_under_rocprof.json 2> $OUT/prof_dist.err
 cd $R
 python tools/pmc_summary.py $OUT/pmc_bench_fetch glu_hip > $OUT/pmc_fetch_size_bench.txt
 python tools/pmc_summary.py $OUT/pmc_bench_write glu_hip > $OUT/pmc_write_size_bench.txt
