@@ -1696,6 +1696,19 @@ glu_status scan_level(Elem<S, N>* data, size_t count, size_t partitions, Elem<S,
     if (chunks * partitions > 0x7FFFFFFFull) return fail(GLU_ERROR_INVALID_ARGUMENT, "scan too large");
     const bool aligned = ((uintptr_t) data % 16 == 0) && (partitions == 1 || (count * sizeof(T)) % 16 == 0);
     const dim3 grid((uint32_t) (chunks * partitions));
+    // many small partitions: a workgroup takes CHUNK consecutive elements = several whole partitions (the array is one
+    // contiguous run of partitions, so only the array's own alignment matters)
+    if (partitions >= 2 && count <= (size_t) C::WAVE_ELEMS && (count & (count - 1)) == 0 && partitions * count > (size_t) C::CHUNK)
+    {
+        const uint64_t total = (uint64_t) partitions * count;
+        const dim3 sgrid((uint32_t) ((total + C::CHUNK - 1) / C::CHUNK));
+        if ((uintptr_t) data % 16 == 0)
+            hipLaunchKernelGGL((scan_small_partitions_kernel<S, N, true>), sgrid, dim3(C::THREADS), 0, stream, data, total, (uint32_t) count);
+        else
+            hipLaunchKernelGGL((scan_small_partitions_kernel<S, N, false>), sgrid, dim3(C::THREADS), 0, stream, data, total, (uint32_t) count);
+        HIP_TRY(hipGetLastError());
+        return GLU_OK;
+    }
     if (chunks == 1)
     {
         if (aligned)

@@ -200,9 +200,15 @@ __device__ __forceinline__ uint64_t chain_pack(uint32_t epoch, uint64_t flag, ui
 {
     return ((uint64_t) epoch << 34) | (flag << 32) | value;
 }
-constexpr int kChainThreads = 1024;
+#ifndef GLU_CHAIN_THREADS // (tuning builds override the two: tools/scan_chain_sweep.sh)
+#define GLU_CHAIN_THREADS 1024
+#endif
+#ifndef GLU_CHAIN_GROUPS
+#define GLU_CHAIN_GROUPS 8
+#endif
+constexpr int kChainThreads = GLU_CHAIN_THREADS;
 constexpr int kChainMinChunks = 256;
-constexpr int kChainGroups = 8;               // 16-byte load groups per thread in the chained kernel
+constexpr int kChainGroups = GLU_CHAIN_GROUPS; // 16-byte load groups per thread in the chained kernel
 constexpr uint32_t kChainSpinLimit = 1u << 24; // polls before the kernel gives up loudly (trap) instead of hanging
 
 // In-place exclusive scan of every chunk.
@@ -365,6 +371,78 @@ __global__ __launch_bounds__(CHAINED ? kChainThreads : 256) void scan_chunks_ker
                 if (e0 + k < valid) base[e0 + k] = p.v[k];
         }
         run = combine<OP_SUM>(run, gtot[g]);
+    }
+}
+
+// MANY SMALL PARTITIONS: count is a power of two and at most one wave's span of a chunk (ScanCfg::WAVE_ELEMS: 1024 elements
+// of 4 bytes), so no partition crosses a wave.  A workgroup takes CHUNK consecutive elements of the whole array -- CHUNK / count
+// partitions -- instead of one partition (a 256-element partition would use one of its 16 wave-groups: 2^18 partitions of 256
+// elements took 387 us, the same 2^26 elements as one partition 104 us).  Same arithmetic order as scan_chunks_kernel inside a
+// partition (lane-local, wave scan of the lane sums, running sum over the wave's groups), so the results are the same bits.
+//   count >= 64 * VEC (a whole group or more): plain wave scan per group, the running sum restarts at partition starts;
+//   VEC < count < 64 * VEC: segmented wave scan, count / VEC lanes per partition;
+//   count <= VEC: inside one lane's vector.
+template<typename S, int N, bool ALIGNED>
+__global__ __launch_bounds__(256) void scan_small_partitions_kernel(Elem<S, N>* __restrict__ data, uint64_t total, uint32_t count)
+{
+    using T = Elem<S, N>;
+    using C = ScanCfg<T>;
+    constexpr uint32_t GS = kW * C::VEC; // elements of one group
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint64_t cbeg = (uint64_t) blockIdx.x * C::CHUNK;
+    const uint32_t valid = (total - cbeg) < (uint64_t) C::CHUNK ? (uint32_t) (total - cbeg) : (uint32_t) C::CHUNK;
+    T* base = data + cbeg;
+
+    T x[C::GROUPS][C::VEC];
+    scan_load<S, N, ALIGNED, C::GROUPS>(base, valid, wave, lane, x);
+
+    const uint32_t seg_lanes = count > (uint32_t) C::VEC ? count / C::VEC : 1u; // lanes of one partition (power of two)
+    const uint32_t pos = seg_lanes >= (uint32_t) kW ? lane : (lane & (seg_lanes - 1u));
+    T run = zero_elem<S, N>();
+#pragma unroll
+    for (int g = 0; g < C::GROUPS; g++)
+    {
+        // lane-local exclusive prefixes; partitions shorter than the vector restart inside it
+        T loc[C::VEC];
+        T acc = zero_elem<S, N>();
+#pragma unroll
+        for (int k = 0; k < C::VEC; k++)
+        {
+            if (count < (uint32_t) C::VEC && ((uint32_t) k & (count - 1u)) == 0) acc = zero_elem<S, N>();
+            loc[k] = acc;
+            acc = combine<OP_SUM>(acc, x[g][k]);
+        }
+        T excl = zero_elem<S, N>();
+        T gtot = zero_elem<S, N>();
+        if (count > (uint32_t) C::VEC) // (kernel-uniform)
+        {
+            T incl = acc;
+#pragma unroll
+            for (int off = 1; off < kW; off <<= 1)
+            {
+                T t = shfl_up_t(incl, off);
+                if ((uint32_t) off < seg_lanes && pos >= (uint32_t) off) incl = combine<OP_SUM>(t, incl);
+            }
+            gtot = shfl_t(incl, kW - 1); // (used when a partition is at least a group)
+            T up = shfl_up_t(incl, 1);
+            if (pos != 0) excl = up;
+        }
+        const uint32_t gbeg = wave * C::WAVE_ELEMS + g * GS;
+        if (count < GS || (gbeg & (count - 1u)) == 0) run = zero_elem<S, N>();
+        T out = combine<OP_SUM>(run, excl);
+        Pack<T, C::VEC> p;
+#pragma unroll
+        for (int k = 0; k < C::VEC; k++) p.v[k] = combine<OP_SUM>(out, loc[k]);
+        const uint32_t e0 = gbeg + lane * C::VEC;
+        if (ALIGNED && e0 + C::VEC <= valid)
+            *reinterpret_cast<Pack<T, C::VEC>*>(base + e0) = p;
+        else
+        {
+#pragma unroll
+            for (int k = 0; k < C::VEC; k++)
+                if (e0 + k < valid) base[e0 + k] = p.v[k];
+        }
+        run = combine<OP_SUM>(run, gtot);
     }
 }
 

@@ -121,6 +121,32 @@ def test_scan_all_data_types(G, dt):
     assert (got == exp).all()
 
 
+@pytest.mark.parametrize("dt", range(12))
+def test_scan_many_small_partitions(G, dt):
+    """Power-of-two partitions of at most one wave's span (1024 4-byte elements) take the kernel that packs several
+    partitions into a workgroup (scan_small_partitions_kernel): partitions inside one lane's vector, inside a wave's
+    group, of one group, of several groups; a last workgroup that is not full; an unaligned array."""
+    npdt, comps = O.dtype_info(dt)
+    rng = np.random.default_rng(100 + dt)
+    is_float = np.issubdtype(npdt, np.floating)
+    for count in (1, 2, 4, 8, 32, 64, 128, 256, 512, 1024, 2048):
+        for parts, offset in ((4097, 0), (37 + (8192 // count), 0), (999 + (4096 // count), 1)):
+            raw = rng.integers(-50, 50, (count * parts + offset) * comps)
+            d = (raw * (0.25 if is_float else 1)).astype(npdt)  # every partial sum exact in float32
+            b = G.ShaderStorageBuffer(d)
+            esize = d.itemsize * comps
+            G.BlellochScan(dt).run_ptr(b.device_ptr() + offset * esize, count, parts)
+            got = b.get_data(npdt)
+            assert (got[:offset * comps] == d[:offset * comps]).all()
+            got = got[offset * comps:].reshape(parts, count, comps)
+            x = d[offset * comps:].reshape(parts, count, comps)
+            exp = np.zeros_like(x)
+            if count > 1:
+                c = np.cumsum(x.astype(np.float64 if is_float else np.int64), axis=1)[:, :-1]
+                exp[:, 1:] = c.astype(npdt) if is_float else (c & 0xFFFFFFFF).astype(np.uint32).view(npdt).reshape(parts, count - 1, comps)
+            assert (got == exp).all(), (dt, count, parts, offset)
+
+
 def test_reduce_simple_known_answers(G, golden):
     g = golden["reference"]["reduce_simple_uint"]
     data = np.array(g["input"], dtype=np.uint32)
