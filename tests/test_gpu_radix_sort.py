@@ -662,6 +662,18 @@ def test_full_size_2_28_duplicate_heavy(G):
 
 
 @pytest.mark.parametrize("bits", [8, 4])
+def test_full_size_2_28_three_key_values_in_random_order(G, bits):
+    """Full size with three distinct keys in random order: the pair-count kernels' duplicate-peeling loop (wave_tally), the
+    16-bit two-digit counters next to their overflow, followers sent back to counting, constant digits skipped."""
+    n = 1 << 28
+    rng = np.random.default_rng(12 + bits)
+    keys = np.array([0x00000000, 0x7F00FF01, 0xFFFFFFFF], dtype=np.uint32)[rng.integers(0, 3, n)]
+    vals = np.arange(n, dtype=np.uint32)
+    gk, gv = gpu_sort(G, keys, vals, bits=bits)
+    _check_sorted_properties(keys, gk, gv)
+
+
+@pytest.mark.parametrize("bits", [8, 4])
 def test_full_size_2_28_u64(G, bits):
     """BASELINE.json config 5: N = 2^28 uint64 keys + uint32 payload; 8-bit digits (8 passes) and the reference's
     4-bit digits (16 passes)."""
