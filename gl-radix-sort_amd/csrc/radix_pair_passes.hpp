@@ -94,12 +94,12 @@ __global__ __launch_bounds__(1024) void radix_pair_count_kernel(const KeyT* __re
         const KeyT k = codec_in.encode(raw);
         return digit_of<KeyT>(k, shift, mask) | (digit_of<KeyT>(k, shift2, mask2) << 8);
     };
-    auto tally = [&](auto peel, KeyT raw) {
-        wave_tally<decltype(peel)::value>(both_digits(raw), lane, [&](uint32_t de, uint32_t c) {
-            atomicAdd(&my_hist[de & 255u], c);
-            atomicAdd(&s.hist2[pair_word(de & 255u, de >> 8)], c << (16u * ((de >> 8) & 1u)));
-        });
+    TallyRun run;
+    auto add_count = [&](uint32_t de, uint32_t c) {
+        atomicAdd(&my_hist[de & 255u], c);
+        atomicAdd(&s.hist2[pair_word(de & 255u, de >> 8)], c << (16u * ((de >> 8) & 1u)));
     };
+    auto tally = [&](auto peel, KeyT raw) { wave_tally_mode(peel, both_digits(raw), lane, run, add_count); };
     auto tally_one = [&](KeyT raw) { // lanes may be inactive
         if (COLLECT) acc_or |= raw, acc_and &= raw;
         const KeyT k = codec_in.encode(raw);
@@ -141,10 +141,7 @@ __global__ __launch_bounds__(1024) void radix_pair_count_kernel(const KeyT* __re
             tally_vec(peel, d);
         }
     };
-    if (4 * THREADS <= nvec && wave_many_equal(both_digits(vkeys[tid].x)))
-        main_loop(std::true_type());
-    else
-        main_loop(std::false_type());
+    if (4 * THREADS <= nvec) wave_tally_dispatch(both_digits(vkeys[tid].x), lane, run, main_loop, add_count);
     uint64_t i = begin + vbase * VEC + tid;
     for (; i + 7ull * THREADS < end; i += 8ull * THREADS)
     {
@@ -386,9 +383,9 @@ __global__ __launch_bounds__(256) void radix_pair4_count_kernel(const KeyT* __re
         return digit_of<KeyT>(k, shift, mask) | (digit_of<KeyT>(k, shift2, mask2) << 4);
     };
     // every lane of the wave is active when this runs
-    auto tally = [&](auto peel, KeyT raw) {
-        wave_tally<decltype(peel)::value>(combined(raw), lane, [&](uint32_t cv, uint32_t c) { atomicAdd(&my_hist[cv], c); });
-    };
+    TallyRun run;
+    auto add_count = [&](uint32_t cv, uint32_t c) { atomicAdd(&my_hist[cv], c); };
+    auto tally = [&](auto peel, KeyT raw) { wave_tally_mode(peel, combined(raw), lane, run, add_count); };
     constexpr int VEC = 16 / sizeof(KeyT);
     using VecT = typename std::conditional<sizeof(KeyT) == 4, uint4, ulonglong2>::type;
     const bool vec_ok = (reinterpret_cast<uintptr_t>(keys) & 15u) == 0;
@@ -422,10 +419,7 @@ __global__ __launch_bounds__(256) void radix_pair4_count_kernel(const KeyT* __re
                 tally_vec(peel, d);
             }
         };
-        if (4 * THREADS <= nvec && wave_many_equal(combined(vkeys[tid].x)))
-            main_loop(std::true_type());
-        else
-            main_loop(std::false_type());
+        if (4 * THREADS <= nvec) wave_tally_dispatch(combined(vkeys[tid].x), lane, run, main_loop, add_count);
         for (uint64_t i = begin + vbase * VEC + tid; i < end; i += THREADS)
         {
             const KeyT raw = keys[i];

@@ -36,9 +36,9 @@ __global__ __launch_bounds__(THREADS) void radix_seg_count_kernel(const uint32_t
     uint32_t* my_hist = hist[wave];
     auto dig = [&](uint32_t k) { return digit_of<uint32_t>(k, shift, mask); };
     // every lane of the wave is active when this runs (wave_tally: one add per group of equal digits when they are few)
-    auto tally = [&](auto peel, uint32_t d) {
-        wave_tally<decltype(peel)::value>(d, lane, [&](uint32_t dv, uint32_t c) { atomicAdd(&my_hist[dv], c); });
-    };
+    TallyRun run;
+    auto add_count = [&](uint32_t dv, uint32_t c) { atomicAdd(&my_hist[dv], c); };
+    auto tally = [&](auto peel, uint32_t d) { wave_tally_mode(peel, d, lane, run, add_count); };
     auto tally_vec = [&](auto peel, const uint4& a) { tally(peel, dig(a.x)); tally(peel, dig(a.y)); tally(peel, dig(a.z)); tally(peel, dig(a.w)); };
     const uint32_t sb_first = seg_first[blockIdx.x], sb_last = seg_first[blockIdx.x + 1];
     for (int i = tid; i < WAVES * RADIX; i += THREADS) (&hist[0][0])[i] = 0;
@@ -67,10 +67,7 @@ __global__ __launch_bounds__(THREADS) void radix_seg_count_kernel(const uint32_t
                 tally_vec(peel, d);
             }
         };
-        if (4 * THREADS <= nvec && wave_many_equal(dig(vkeys[tid].x)))
-            main_loop(std::true_type());
-        else
-            main_loop(std::false_type());
+        if (4 * THREADS <= nvec) wave_tally_dispatch(dig(vkeys[tid].x), lane, run, main_loop, add_count);
         for (uint64_t v = vbase + tid; v < nvec; v += THREADS) // lanes may be inactive: plain atomics
         {
             const uint4 a = vkeys[v];

@@ -237,6 +237,69 @@ __device__ __forceinline__ void wave_tally(uint32_t v, uint32_t lane, F&& add)
     }
 }
 
+// Third copy of the count loop, for waves whose first 64 keys are all equal (constant keys -- the reference README's
+// benchmark input --, sorted or run-structured input): consecutive all-equal steps with the same value only grow a
+// wave-uniform run length; the counters are touched when the value changes (and every 2^15 keys, so that one add never
+// exceeds what a 16-bit counter of the pair kernel can take without its overflow being seen).  2^28 all-zero keys: the
+// whole sort (one read of the keys and fourteen launches that return at once) 0.342 -> 0.318 ms in a same-box A/B
+// (tools/ab_zero.sh); uniform keys unchanged.  A step that is not all-equal takes the peeling path.
+struct TallyRun
+{
+    uint32_t value = 0, count = 0; // wave-uniform
+};
+template<typename F>
+__device__ __forceinline__ void wave_tally_flush(TallyRun& run, uint32_t lane, F&& add)
+{
+    if (run.count != 0 && lane == 0) add(run.value, run.count);
+    run.count = 0;
+}
+template<typename F>
+__device__ __forceinline__ void wave_tally_runs(uint32_t v, uint32_t lane, TallyRun& run, F&& add)
+{
+    const uint32_t v0 = __builtin_amdgcn_readfirstlane(v);
+    if (__ballot(v != v0) == 0)
+    {
+        if (v0 != run.value || run.count >= (1u << 15))
+        {
+            wave_tally_flush(run, lane, add);
+            run.value = v0;
+        }
+        run.count += 64u;
+    }
+    else
+        wave_tally<true>(v, lane, add);
+}
+__device__ __forceinline__ bool wave_all_equal(uint32_t v) // wave-uniform
+{
+    return __ballot(v != (uint32_t) __builtin_amdgcn_readfirstlane(v)) == 0;
+}
+// mode tags of the count loops: 0 = plain, 1 = peel groups of equal values, 2 = run lengths
+using TallyPlain = std::integral_constant<int, 0>;
+using TallyPeel = std::integral_constant<int, 1>;
+using TallyRuns = std::integral_constant<int, 2>;
+template<typename Mode, typename F>
+__device__ __forceinline__ void wave_tally_mode(Mode, uint32_t v, uint32_t lane, TallyRun& run, F&& add)
+{
+    if constexpr (Mode::value == 2)
+        wave_tally_runs(v, lane, run, add);
+    else
+        wave_tally<Mode::value == 1>(v, lane, add);
+}
+// runs `loop(mode)` in the mode the wave's first value suggests
+template<typename L, typename F>
+__device__ __forceinline__ void wave_tally_dispatch(uint32_t first_value, uint32_t lane, TallyRun& run, L&& loop, F&& add)
+{
+    if (wave_all_equal(first_value))
+    {
+        loop(TallyRuns());
+        wave_tally_flush(run, lane, add);
+    }
+    else if (wave_many_equal(first_value))
+        loop(TallyPeel());
+    else
+        loop(TallyPlain());
+}
+
 // OR / AND of the keys a thread has seen -> the plan, once per WORKGROUP.  Called by every thread of the workgroup (it
 // holds a barrier).  (Once per wave, the first version, cost a 6 M-pair sort 60 of its 250 us: the 4096 waves of a balanced
 // launch finish together, every one of them still reads zeros in the plan's words, and their same-address atomics then
@@ -328,9 +391,9 @@ __global__ __launch_bounds__(THREADS) void radix_count_kernel(const KeyT* __rest
     KeyT acc_or = 0, acc_and = (KeyT) ~(KeyT) 0; // of the raw keys this thread reads
 
     // every lane of the wave is active when this runs (wave-uniform trip counts below)
-    auto tally = [&](auto peel, uint32_t d) {
-        wave_tally<decltype(peel)::value>(d, lane, [&](uint32_t dv, uint32_t c) { atomicAdd(&my_hist[dv], c); });
-    };
+    TallyRun run;
+    auto add_count = [&](uint32_t dv, uint32_t c) { atomicAdd(&my_hist[dv], c); };
+    auto tally = [&](auto peel, uint32_t d) { wave_tally_mode(peel, d, lane, run, add_count); };
 
     constexpr int VEC = 16 / sizeof(KeyT); // 16-byte loads
     using VecT = typename std::conditional<sizeof(KeyT) == 4, uint4, ulonglong2>::type;
@@ -354,7 +417,7 @@ __global__ __launch_bounds__(THREADS) void radix_count_kernel(const KeyT* __rest
         }
     };
     uint64_t vbase = 0;
-    // (the loop twice, chosen once per wave from its first keys: see wave_tally)
+    // (the loop three times, chosen once per wave from its first keys: see wave_tally / wave_tally_runs)
     auto main_loop = [&](auto peel) {
         for (; vbase + 4 * THREADS <= nvec; vbase += 4 * THREADS) // block-uniform trip count, 4 x 16 B in flight per lane
         {
@@ -371,10 +434,7 @@ __global__ __launch_bounds__(THREADS) void radix_count_kernel(const KeyT* __rest
             tally_vec(peel, d);
         }
     };
-    if (4 * THREADS <= nvec && wave_many_equal(dig(vkeys[tid].x)))
-        main_loop(std::true_type());
-    else
-        main_loop(std::false_type());
+    if (4 * THREADS <= nvec) wave_tally_dispatch(dig(vkeys[tid].x), lane, run, main_loop, add_count);
     // tail (< 4 * THREADS vectors + a partial vector): plain per-key atomics, lanes may be inactive
     uint64_t i = begin + vbase * VEC + tid;
     for (; i + 7ull * THREADS < end; i += 8ull * THREADS) // 8 loads in flight per lane
