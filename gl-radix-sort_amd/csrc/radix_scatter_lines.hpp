@@ -74,6 +74,14 @@ struct LineSmem
 // tuning only (s_setprio around the LDS-bound phases: measured, no effect).  STAMPS: s_memtime per phase of the first and
 // the last wave into stamps[0..15] (tools/scatter_bench.hip).
 //
+// RANK_ATOMIC (measured in round 3, NOT used by the library; tools/scatter_bench.hip SB_RA=1): an item's rank inside its wave
+// from ONE returning LDS atomic add on the wave's counter row (two 16-bit counters per word) instead of eight ballots.  A
+// stable pass needs the lanes of one instruction that add to the same counter served in lane order: gfx950 does that
+// (tools/lds_atomic_order.hip: 0 of 5.2 x 10^9 items out of order), the ISA document does not promise it.  It takes a fifth
+// off the kernel's compute (17.1 k -> 13.5 k cycles per tile with 48 workgroups) and nothing off its time on the whole chip
+// (0.75-0.77 ms on a fast device either way, 0.912 -> 0.89 ms on a slow one, no difference inside the sort on five devices:
+// DESIGN.md section 4.2) -- the kernel is not bound by its instruction issue, so the undocumented order is not relied upon.
+//
 // SEG (segmented passes: the local sort of the sharded sort, glu_dist_impl.hpp): the workgroup runs the whole pass body once
 // per SUB-BLOCK of its list [seg_first[b], seg_first[b + 1]): element range `ranges[i]` of the source arrays, counted on its
 // own (radix_seg_count_kernel), with `table[i * RADIX + d]` = the ABSOLUTE destination index of the sub-block's first
@@ -81,7 +89,8 @@ struct LineSmem
 // sub-blocks).  Everything else -- ranking, line carry, whole-line stores, element-wise stores at the two ends of a
 // (sub-block, digit) range -- is the pass as above; `totals`, `plan`, `share` are not used.
 template<typename KeyT, int BITS, int THREADS, int KPT, bool XF = false, bool VALS = true, int ABLATE = 0, bool STAMPS = false,
-         int RANK_SPLIT = (KPT + 2) / 3, bool STAGGER = true, bool NT_STORES = false, int PRIO = 0, bool SEG = false>
+         int RANK_SPLIT = (KPT + 2) / 3, bool STAGGER = true, bool NT_STORES = false, int PRIO = 0, bool SEG = false,
+         bool RANK_ATOMIC = false>
 __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
     const KeyT* __restrict__ keys_a, const uint32_t* __restrict__ vals_a, KeyT* __restrict__ keys_b,
     uint32_t* __restrict__ vals_b, const uint32_t* __restrict__ table, const uint32_t* __restrict__ totals, uint32_t n,
@@ -237,6 +246,13 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
         {
             nkey[i] = src_keys[pf_base + i * kWave]; // (non-temporal loads here: 2 % slower inside the sort, same-box A/B)
             const uint32_t d = digit_of<KeyT>(key[i], shift, MASK);
+            if constexpr (RANK_ATOMIC)
+            {
+                const uint32_t half = (d & 1u) * 16u;
+                const uint32_t old = atomicAdd(reinterpret_cast<uint32_t*>(my_cnt) + (d >> 1), 1u << half); // ds_add_rtn_u32
+                rank[i] = (old >> half) & 0xFFFFu; // the digit's count before this instruction + the lower lanes with it
+                continue;
+            }
             uint16_t* const cnt = my_cnt + d;
             const uint32_t prev = *cnt; // issued first: its LDS latency hides under the ballots below
             uint32_t plo = ~0u, phi = ~0u;

@@ -249,7 +249,8 @@ void run_variant(Ctx& c, int blocks_per_cu, uint32_t shift, uint32_t mask_overri
 }
 
 // the 128-byte-line scatter (radix_scatter_lines.hpp) behind the production count + row scan
-template<int BITS, int THREADS, int KPT, bool VALS = true, int ABLATE = 0, int RS = (KPT + 2) / 3, bool STAGGER = true, bool NT = false, int PRIO = 0>
+template<int BITS, int THREADS, int KPT, bool VALS = true, int ABLATE = 0, int RS = (KPT + 2) / 3, bool STAGGER = true, bool NT = false, int PRIO = 0,
+         bool RA = false>
 void run_lines(Ctx& c, uint32_t shift, uint32_t mask_override = 0)
 {
     constexpr int RADIX = 1 << BITS;
@@ -268,8 +269,9 @@ void run_lines(Ctx& c, uint32_t shift, uint32_t mask_override = 0)
     uint32_t* totals = c.table + (size_t) RADIX * nb;
     const uint32_t mask = mask_override ? mask_override : RADIX - 1;
     if (mask_override) printf("mask %u: ", mask);
-    auto scatter = radix_scatter_lines_kernel<uint32_t, BITS, THREADS, KPT, false, VALS, ABLATE, false, RS, STAGGER, NT, PRIO>;
-    auto scatter_st = radix_scatter_lines_kernel<uint32_t, BITS, THREADS, KPT, false, VALS, ABLATE, true, RS, STAGGER, NT, PRIO>;
+    auto scatter = radix_scatter_lines_kernel<uint32_t, BITS, THREADS, KPT, false, VALS, ABLATE, false, RS, STAGGER, NT, PRIO, false, RA>;
+    auto scatter_st = radix_scatter_lines_kernel<uint32_t, BITS, THREADS, KPT, false, VALS, ABLATE, true, RS, STAGGER, NT, PRIO, false, RA>;
+    if (RA) printf("rank: returning LDS atomics: ");
     CK(hipFuncSetAttribute((const void*) scatter_st, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sizeof(Smem)));
     CK(hipFuncSetAttribute((const void*) scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sizeof(Smem)));
     hipLaunchKernelGGL((radix_count_kernel<uint32_t, BITS, THREADS, TILE>), dim3(nb), dim3(THREADS), 0, 0, skeys, c.table, (uint32_t) n_eff, shift, mask,
@@ -682,6 +684,15 @@ int main(int argc, char** argv)
     if (getenv("SB_SRCOFF"))
     {
         run_lines<8, 1024, 10, true, 0, 4, true, true>(c, shift);
+        return 0;
+    }
+    if (getenv("SB_RA")) // round 3: ballot ranking against one returning LDS atomic per item, with the phase stamps
+    {
+        for (int rep = 0; rep < 2; rep++)
+        {
+            run_lines<8, 1024, 10, true, 0, 4, true, true>(c, shift);
+            run_lines<8, 1024, 10, true, 0, 4, true, true, 0, true>(c, shift);
+        }
         return 0;
     }
     if (getenv("SB_R3"))
