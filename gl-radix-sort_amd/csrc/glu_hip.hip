@@ -1455,6 +1455,12 @@ glu_status glu_radix_sort_run_segments_ptr(glu_radix_sort sort, uint32_t* in_key
     if (count == 0) return GLU_OK;
     if (!in_keys || !in_vals || !out_keys || !out_vals) return fail(GLU_ERROR_INVALID_ARGUMENT, "NULL array");
     if (in_keys == out_keys || in_vals == out_vals) return fail(GLU_ERROR_INVALID_ARGUMENT, "the segmented sort needs distinct input and output arrays");
+    // the sub-block descriptors of a call travel through a ring of pinned staging buffers that later calls overwrite, and a
+    // prepared sorter may wait for a staging buffer's previous copy: a captured graph would replay neither correctly
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    (void) hipStreamIsCapturing(pick_stream(stream), &capturing);
+    if (capturing != hipStreamCaptureStatusNone)
+        return fail(GLU_ERROR_INVALID_STATE, "glu_radix_sort_run_segments_ptr cannot be captured into a graph (its descriptors are staged per call)");
     const bool aligned = (((uintptr_t) in_keys | (uintptr_t) in_vals | (uintptr_t) out_keys | (uintptr_t) out_vals) & 15u) == 0;
     SegPlan plan;
     seg_make_plan(sort, std::move(pieces), num_segments, count, key_bits, aligned, plan);

@@ -203,7 +203,8 @@ GLU_API glu_status glu_radix_sort_partition_ptr(glu_radix_sort sort, const uint3
  * (RadixSort.hpp:142-182) applied per segment, all segments in one launch sequence of the sort's own kernels; the first
  * pass reads the pieces where they lie, so the regrouping costs no pass of its own.  in != out; the input arrays are used
  * as scratch (their contents are lost).  Enqueues on `stream` (the piece arrays are read before the call returns); after
- * glu_radix_sort_prepare(sort, count) it allocates nothing on the device. */
+ * glu_radix_sort_prepare(sort, count) it allocates nothing on the device.  Not capturable into a graph (the sub-block
+ * descriptors of a call are staged through pinned buffers that later calls reuse): GLU_ERROR_INVALID_STATE under capture. */
 GLU_API glu_status glu_radix_sort_run_segments_ptr(glu_radix_sort sort, uint32_t* in_keys, uint32_t* in_vals,
                                                    uint32_t* out_keys, uint32_t* out_vals, size_t count,
                                                    const uint64_t* piece_begin, const uint64_t* piece_len,

@@ -174,3 +174,15 @@ def test_segmented_sort_argument_checks(G):
     with pytest.raises(G.GluError):  # key_bits not a multiple of 8
         s.run_segments_ptr(k.data_ptr(), v.data_ptr(), k2.data_ptr(), v2.data_ptr(), 100, *one, 1, 12)
     s.run_segments_ptr(0, 0, 0, 0, 0, np.zeros(0, np.uint64), np.zeros(0, np.uint64), np.zeros(0, np.uint32), 0, 24)  # empty: fine
+    # under stream capture the call is refused (its descriptors are staged per call): the graph stays empty
+    side = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    s.prepare_internal_buffers(100)
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            with pytest.raises(G.GluError) as e:
+                s.run_segments_ptr(k.data_ptr(), v.data_ptr(), k2.data_ptr(), v2.data_ptr(), 100, *one, 1, 24,
+                                   stream=torch.cuda.current_stream().cuda_stream)
+            assert "captured" in e.value.message
+    s.run_segments_ptr(k.data_ptr(), v.data_ptr(), k2.data_ptr(), v2.data_ptr(), 100, *one, 1, 24)  # and works afterwards
+    torch.cuda.synchronize()
