@@ -245,7 +245,15 @@ glu_status glu_buffer_create_with_data(const void* data, size_t size, glu_buffer
     if (!data) return fail(GLU_ERROR_INVALID_ARGUMENT, "data is NULL");
     if (size == 0) return fail(GLU_ERROR_INVALID_ARGUMENT, "size is 0");
     GLU_TRY(glu_buffer_create(size, out));
-    return glu_buffer_write(*out, data, size, 0);
+    const glu_status st = glu_buffer_write(*out, data, size, 0);
+    if (st != GLU_OK)
+    {
+        const std::string message = g_last_error; // (the destroy below must not replace the reason)
+        (void) glu_buffer_destroy(*out);
+        *out = 0;
+        g_last_error = message;
+    }
+    return st;
 }
 
 glu_status glu_buffer_wrap(void* device_ptr, size_t size, glu_buffer* out)
