@@ -251,7 +251,10 @@ def main():
 
     if world == 1 and not args.force_dist:
         sorter = G.RadixSort(digit_bits=args.digit_bits)
+        t_prep = time.perf_counter()
         sorter.prepare_internal_buffers(n)
+        # (prepare places the two scratch arrays by measurement: glu_radix_sort_scratch_placement, include/glu_hip.h)
+        result["scratch_placement"] = dict(sorter.scratch_placement(), prepare_s=round(time.perf_counter() - t_prep, 3))
         keys0, vals0 = make_input(torch, n, args.keys, 0, device)
         # one pristine copy per step so that nothing but the sort runs inside the timed region
         free_bytes = torch.cuda.mem_get_info()[0]

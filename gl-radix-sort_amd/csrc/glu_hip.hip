@@ -462,6 +462,9 @@ struct glu_radix_sort_s
     bool no_single_block = false; // GLU_HIP_SORT_NO_SINGLE_BLOCK=1: never take the one-workgroup path (tests / tuning)
     bool no_fused_scan = false;   // GLU_HIP_SORT_NO_FUSED_SCAN=1: always launch the row-scan kernel (tests / tuning)
     bool no_plan = false;         // GLU_HIP_SORT_NO_PLAN=1: never skip constant-digit passes (tests / tuning)
+    bool tune_scratch = true;     // GLU_HIP_SCRATCH_TUNE=0: take the first allocation of the scratch arrays (see tune_scratch_placement)
+    bool tuning = false;          // (inside tune_scratch_placement)
+    uint32_t tuned_spacer_mib = 0, tuned_candidates = 0; double tuned_ms = 0, tuned_worst_ms = 0; // what the last tuning saw and chose
     bool no_lines = false;        // GLU_HIP_SORT_NO_LINES=1: never use the 128-byte-line scatter kernel (tests / tuning)
     bool nt_stores = true;        // GLU_HIP_SORT_NT_STORES=0: plain instead of non-temporal line stores in the line scatter (tuning)
     bool no_bit_shortcut = false; // GLU_HIP_SORT_NO_BIT_SHORTCUT=1: passes on key bits that do not vary still count (tests / tuning)
@@ -509,9 +512,17 @@ inline uint32_t usable_cus(const glu_radix_sort_s* s)
     return (uint32_t) std::max<int>(1, g_dev.num_cus - (int) s->reserved_cus);
 }
 
+constexpr size_t kTuneMinKeyBytes = (size_t) 512 << 20; // scratch arrays from this size up are placed by measurement
+glu_status tune_scratch_placement(glu_radix_sort_s* s, size_t count, size_t key_size);
+
 glu_status sort_prepare(glu_radix_sort_s* s, size_t count, size_t key_size, bool with_vals = true)
 {
     if (count <= 1) return GLU_OK;
+    // large key + value scratch that has to be (re)allocated anyway: where the two arrays lie to each other decides between
+    // discrete speeds of every pass, so a few placements are tried and the fastest is kept
+    if (with_vals && s->tune_scratch && !s->tuning && count * key_size >= kTuneMinKeyBytes &&
+        (s->keys.size < count * key_size || s->vals.size < count * sizeof(uint32_t)))
+        GLU_TRY(tune_scratch_placement(s, count, key_size));
     GLU_TRY(s->keys.reserve(count * key_size));
     if (with_vals) GLU_TRY(s->vals.reserve(count * sizeof(uint32_t)));
     uint64_t cap = (uint64_t) g_dev.num_cus * kMaxBlocksPerCu;
@@ -1000,6 +1011,144 @@ glu_status sort_run(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t coun
     return sort_bits<KeyT>(s, keys, vals, count, 0u, (uint32_t) steps * 4, stream, key_xf);
 }
 
+// Placement of the two large scratch arrays by measurement (sort_prepare).  Two 1 GiB arrays that hipMalloc hands out one
+// after the other lie 1 GiB + 2 MiB apart, and whether the key scratch and the value scratch then collide in the memory
+// system is a property of where they fell, the same for every caller array the sort is later given (tools/placement_scratch.py,
+// profiles/r03/placement_scratch_spacers.txt: of eight sorter objects in one process the same three sort every caller pair
+// in 3.76-3.80 ms and the others in 3.9-4.05 ms).  User space cannot choose physical pages, but it can choose among
+// allocations: the value array is allocated behind spacers of 0 .. 6 GiB, every candidate sorts a scratch copy of
+// pseudo-random pairs twice (events on the library queue), the fastest pair of arrays is kept and everything else freed.
+// One-off, inside prepare (the reference's prepare_internal_buffers is where its allocations happen too); a sort never
+// allocates or measures.  GLU_HIP_SCRATCH_TUNE=0 switches it off.
+__global__ void tune_fill_kernel(uint32_t* __restrict__ p, size_t words, uint32_t salt)
+{
+    for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (size_t) gridDim.x * blockDim.x)
+    {
+        uint32_t x = (uint32_t) i * 2654435761u + salt;
+        x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 12; x *= 0x297A2D39u; x ^= x >> 15;
+        p[i] = x;
+    }
+}
+
+glu_status tune_scratch_placement(glu_radix_sort_s* s, size_t count, size_t key_size)
+{
+    const size_t kbytes = count * key_size, vbytes = count * sizeof(uint32_t);
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return GLU_OK;
+    // sixteen candidates, the value array behind spacers of 0, 0.5 .. 7.5 GiB (which spacer wins differs from process to
+    // process: 24 candidates on two devices showed no period, about one in four is fast; GLU_HIP_SCRATCH_TUNE_LIST=step_mib:count)
+    size_t step_mib = 512, candidates = 16;
+    if (const char* e = getenv("GLU_HIP_SCRATCH_TUNE_LIST")) sscanf(e, "%zu:%zu", &step_mib, &candidates);
+    std::vector<size_t> spacers_mib;
+    for (size_t i = 0; i < std::max<size_t>(candidates, 1); i++) spacers_mib.push_back(i * step_mib);
+    // room for the caller-side copies, one candidate with its spacer and the best so far (twice over, to be safe)
+    if (free_b < 2 * (2 * (kbytes + vbytes) + (spacers_mib.back() << 20)) + ((size_t) 1 << 30)) return GLU_OK;
+    hipStream_t st = g_dev.queue;
+    void *a = nullptr, *b = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    struct Cand { void* k = nullptr; void* v = nullptr; double ms = 1e30; uint32_t spacer = 0; } best;
+    double worst = 0;
+    s->tuning = true;
+    const bool was_profiling = s->profiling;
+    s->profiling = false; // the calibration sorts are not the caller's
+    s->keys.release();
+    s->vals.release();
+    auto cleanup = [&](glu_status status) {
+        s->profiling = was_profiling;
+        (void) hipStreamSynchronize(st);
+        if (a) (void) hipFree(a);
+        if (b) (void) hipFree(b);
+        if (e0) (void) hipEventDestroy(e0);
+        if (e1) (void) hipEventDestroy(e1);
+        s->keys.ptr = best.k, s->keys.size = best.k ? kbytes : 0;
+        s->vals.ptr = best.v, s->vals.size = best.v ? vbytes : 0;
+        s->tuning = false;
+        return status;
+    };
+#define TUNE_TRY(expr)                                                                                                 \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        hipError_t e_ = (expr);                                                                                        \
+        if (e_ != hipSuccess) return cleanup(fail(GLU_ERROR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_)));   \
+    } while (0)
+    TUNE_TRY(hipMalloc(&a, kbytes));
+    TUNE_TRY(hipMalloc(&b, vbytes));
+    TUNE_TRY(hipEventCreate(&e0));
+    TUNE_TRY(hipEventCreate(&e1));
+    for (size_t spacer_mib : spacers_mib)
+    {
+        void *k = nullptr, *sp = nullptr, *v = nullptr;
+        if (hipMalloc(&k, kbytes) != hipSuccess)
+        {
+            (void) hipGetLastError();
+            break; // out of memory: the best so far (or the plain allocation of sort_prepare, which reports the failure)
+        }
+        if (spacer_mib && hipMalloc(&sp, spacer_mib << 20) != hipSuccess)
+        {
+            (void) hipGetLastError();
+            (void) hipFree(k);
+            continue;
+        }
+        if (hipMalloc(&v, vbytes) != hipSuccess)
+        {
+            (void) hipGetLastError();
+            (void) hipFree(k);
+            if (sp) (void) hipFree(sp);
+            continue;
+        }
+        if (sp) (void) hipFree(sp); // the arrays stay where they are
+        s->keys.ptr = k, s->keys.size = kbytes;
+        s->vals.ptr = v, s->vals.size = vbytes;
+        double ms = 1e30;
+        glu_status status = GLU_OK;
+        for (int rep = 0; rep < 3 && status == GLU_OK; rep++) // the first run is a warm-up
+        {
+            hipLaunchKernelGGL(tune_fill_kernel, dim3(g_dev.num_cus * 8), dim3(256), 0, st, (uint32_t*) a, kbytes / 4, 0x5EEDu + rep);
+            hipLaunchKernelGGL(tune_fill_kernel, dim3(g_dev.num_cus * 8), dim3(256), 0, st, (uint32_t*) b, vbytes / 4, 77u);
+            (void) hipEventRecord(e0, st);
+            status = key_size == 8 ? sort_run<uint64_t>(s, (uint64_t*) a, (uint32_t*) b, count, 0, st)
+                                   : sort_run<uint32_t>(s, (uint32_t*) a, (uint32_t*) b, count, 0, st);
+            (void) hipEventRecord(e1, st);
+            if (status == GLU_OK && hipEventSynchronize(e1) == hipSuccess && rep > 0)
+            {
+                float t = 0;
+                if (hipEventElapsedTime(&t, e0, e1) == hipSuccess) ms = std::min(ms, (double) t);
+            }
+        }
+        s->keys.ptr = nullptr, s->keys.size = 0;
+        s->vals.ptr = nullptr, s->vals.size = 0;
+        if (status != GLU_OK)
+        {
+            (void) hipStreamSynchronize(st);
+            (void) hipFree(k);
+            (void) hipFree(v);
+            return cleanup(status);
+        }
+        if (ms < 1e29) worst = std::max(worst, ms);
+        if (getenv("GLU_VERBOSE")) fprintf(stderr, "[glu_hip]   candidate: keys %p values %p (spacer %zu MiB): %.3f ms\n", k, v, spacer_mib, ms);
+        if (ms < best.ms)
+        {
+            if (best.k) (void) hipFree(best.k);
+            if (best.v) (void) hipFree(best.v);
+            best.k = k, best.v = v, best.ms = ms, best.spacer = (uint32_t) spacer_mib;
+        }
+        else
+        {
+            (void) hipFree(k);
+            (void) hipFree(v);
+        }
+    }
+#undef TUNE_TRY
+    s->tuned_spacer_mib = best.spacer;
+    s->tuned_ms = best.ms;
+    s->tuned_worst_ms = worst;
+    s->tuned_candidates = (uint32_t) spacers_mib.size();
+    if (getenv("GLU_VERBOSE"))
+        fprintf(stderr, "[glu_hip] scratch placement: value array behind a %u MiB spacer, calibration sort %.3f ms (slowest candidate %.3f ms)\n",
+                best.spacer, best.ms, worst);
+    return cleanup(GLU_OK);
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // segmented sort (radix_seg_passes.hpp): glu_radix_sort_run_segments_ptr
 // ------------------------------------------------------------------------------------------------------------
@@ -1240,6 +1389,7 @@ glu_status glu_radix_sort_create(glu_radix_sort* out)
     if (const char* e = getenv("GLU_HIP_SORT_NO_FUSED_SCAN")) s->no_fused_scan = atoi(e) != 0;
     if (const char* e = getenv("GLU_HIP_SORT_NO_PLAN")) s->no_plan = atoi(e) != 0;
     if (const char* e = getenv("GLU_HIP_SORT_NO_LINES")) s->no_lines = atoi(e) != 0;
+    if (const char* e = getenv("GLU_HIP_SCRATCH_TUNE")) s->tune_scratch = atoi(e) != 0;
     if (const char* e = getenv("GLU_HIP_SORT_PAIRS")) s->pairs = atoi(e) != 0;
     if (const char* e = getenv("GLU_HIP_SORT_EQUAL_SHARES")) s->equal_shares = atoi(e) != 0;
     if (const char* e = getenv("GLU_HIP_SORT_NO_BIT_SHORTCUT")) s->no_bit_shortcut = atoi(e) != 0;
@@ -1573,6 +1723,15 @@ glu_status glu_radix_sort_read_profile(glu_radix_sort sort, double* count_ms, do
     if (scan_ms) *scan_ms = acc[1];
     if (scatter_ms) *scatter_ms = acc[2];
     if (passes) *passes = n;
+    return GLU_OK;
+}
+
+glu_status glu_radix_sort_scratch_placement(glu_radix_sort sort, uint32_t* candidates, double* chosen_ms, double* slowest_ms)
+{
+    if (!sort) return fail(GLU_ERROR_INVALID_ARGUMENT, "sort is NULL");
+    if (candidates) *candidates = sort->tuned_candidates;
+    if (chosen_ms) *chosen_ms = sort->tuned_ms;
+    if (slowest_ms) *slowest_ms = sort->tuned_worst_ms;
     return GLU_OK;
 }
 

@@ -66,6 +66,7 @@ SYMBOLS = [
     ("glu_radix_sort_set_digit_bits", _int, [_vp, _u32]),
     ("glu_radix_sort_get_digit_bits", _int, [_vp, _P(_u32)]),
     ("glu_radix_sort_scratch_size", _int, [_vp, _P(_sz)]),
+    ("glu_radix_sort_scratch_placement", _int, [_vp, _P(_u32), _P(ctypes.c_double), _P(ctypes.c_double)]),
     ("glu_radix_sort_set_profiling", _int, [_vp, _int]),
     ("glu_radix_sort_read_profile", _int, [_vp, _P(ctypes.c_double), _P(ctypes.c_double), _P(ctypes.c_double), _P(_u64)]),
     ("glu_radix_sort_read_plan", _int, [_vp, _P(_u32), _P(_u32), _P(_u32), _sz]),
@@ -255,6 +256,13 @@ class RadixSort:
         s = _sz(0)
         check(lib().glu_radix_sort_scratch_size(self._h, ctypes.byref(s)))
         return s.value
+
+    def scratch_placement(self):
+        """What the last prepare measured when it placed the large scratch arrays (glu_radix_sort_scratch_placement):
+        {"candidates": n, "chosen_ms": t, "slowest_ms": t}; candidates == 0: no measurement was made."""
+        n, a, b = _u32(0), ctypes.c_double(0), ctypes.c_double(0)
+        check(lib().glu_radix_sort_scratch_placement(self._h, ctypes.byref(n), ctypes.byref(a), ctypes.byref(b)))
+        return {"candidates": int(n.value), "chosen_ms": float(a.value), "slowest_ms": float(b.value)}
 
     def set_profiling(self, enable):
         check(lib().glu_radix_sort_set_profiling(self._h, 1 if enable else 0))

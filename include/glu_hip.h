@@ -226,6 +226,14 @@ GLU_API glu_status glu_radix_sort_plan_segments(const uint64_t* piece_begin, con
  * for 32-bit keys) or 8 (4 passes).  The sorted result is identical; see DESIGN.md. */
 GLU_API glu_status glu_radix_sort_set_digit_bits(glu_radix_sort sort, uint32_t bits);
 GLU_API glu_status glu_radix_sort_get_digit_bits(glu_radix_sort sort, uint32_t* bits);
+/* Where the two large scratch arrays lie to each other decides between discrete speeds of every pass on this memory system,
+ * so glu_radix_sort_prepare* places key + value scratch of 512 MiB of keys or more BY MEASUREMENT: the value array is
+ * allocated behind spacers of 0 .. 7.5 GiB (16 candidates), each candidate sorts pseudo-random pairs of the prepared count
+ * twice on the library queue, the fastest pair of arrays is kept, everything else is freed again (one-off: about 0.6 s for
+ * 2^28 pairs; a sort never allocates or measures; GLU_HIP_SCRATCH_TUNE=0 takes the first allocation as the reference's
+ * prepare_internal_buffers does, RadixSort.hpp:237-271).  This reports what the last such measurement saw: the number of
+ * candidates (0 = none was made), the calibration sort time of the chosen and of the slowest one. */
+GLU_API glu_status glu_radix_sort_scratch_placement(glu_radix_sort sort, uint32_t* candidates, double* chosen_ms, double* slowest_ms);
 /* Bytes of scratch currently owned by the sort object (keys + vals + tables). */
 GLU_API glu_status glu_radix_sort_scratch_size(glu_radix_sort sort, size_t* bytes);
 /* Per-kernel device timing (the measure_gl_elapsed_time idea, glu/gl_utils.hpp:249-265, at kernel granularity):

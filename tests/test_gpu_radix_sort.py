@@ -652,6 +652,40 @@ def test_full_size_2_28_properties(G, bits):
     _check_sorted_properties(keys, gk, gv)
 
 
+def test_scratch_placement_by_measurement(G, monkeypatch):
+    """prepare() of 512 MiB of keys or more tries several placements of the value scratch and keeps the fastest
+    (glu_radix_sort_scratch_placement): same results as without, one measurement per growth, every temporary freed."""
+    import torch
+
+    n = 1 << 27
+    rng = np.random.default_rng(123)
+    keys = rng.integers(0, 2**32, n, dtype=np.uint32)
+    vals = np.arange(n, dtype=np.uint32)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    monkeypatch.setenv("GLU_HIP_SCRATCH_TUNE_LIST", "768:5")
+    tuned = G.RadixSort()
+    tuned.prepare_internal_buffers(n)
+    p = tuned.scratch_placement()
+    assert p["candidates"] == 5 and 0 < p["chosen_ms"] <= p["slowest_ms"] < 1e3
+    size = tuned.scratch_size()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 <= size + (64 << 20)  # the candidates, their spacers and the calibration arrays are gone
+    tuned.prepare_internal_buffers(n)  # no growth: no second measurement, same arrays
+    assert tuned.scratch_size() == size and tuned.scratch_placement() == p
+    monkeypatch.setenv("GLU_HIP_SCRATCH_TUNE", "0")
+    plain = G.RadixSort()
+    plain.prepare_internal_buffers(n)
+    assert plain.scratch_placement()["candidates"] == 0 and plain.scratch_size() == size
+    out = []
+    for s in (tuned, plain):
+        kb, vb = G.ShaderStorageBuffer(keys), G.ShaderStorageBuffer(vals)
+        s(kb, vb, n)
+        out.append((kb.get_data(np.uint32), vb.get_data(np.uint32)))
+    assert (out[0][0] == out[1][0]).all() and (out[0][1] == out[1][1]).all()
+    _check_sorted_properties(keys, out[0][0], out[0][1])
+
+
 def test_full_size_2_28_duplicate_heavy(G):
     n = 1 << 28
     rng = np.random.default_rng(11)
