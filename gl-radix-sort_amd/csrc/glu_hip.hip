@@ -1036,11 +1036,11 @@ glu_status tune_scratch_placement(glu_radix_sort_s* s, size_t count, size_t key_
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return GLU_OK;
     // sixteen candidates, the value array behind spacers of 0, 0.5 .. 7.5 GiB (which spacer wins differs from process to
-    // process: 24 candidates on two devices showed no period, about one in four is fast; GLU_HIP_SCRATCH_TUNE_LIST=step_mib:count)
-    size_t step_mib = 512, candidates = 16;
-    if (const char* e = getenv("GLU_HIP_SCRATCH_TUNE_LIST")) sscanf(e, "%zu:%zu", &step_mib, &candidates);
+    // process: 24 candidates on two devices showed no period, about one in four is fast; GLU_HIP_SCRATCH_TUNE_LIST=step_mib:count[:first_mib])
+    size_t step_mib = 512, candidates = 16, first_mib = 0;
+    if (const char* e = getenv("GLU_HIP_SCRATCH_TUNE_LIST")) sscanf(e, "%zu:%zu:%zu", &step_mib, &candidates, &first_mib);
     std::vector<size_t> spacers_mib;
-    for (size_t i = 0; i < std::max<size_t>(candidates, 1); i++) spacers_mib.push_back(i * step_mib);
+    for (size_t i = 0; i < std::max<size_t>(candidates, 1); i++) spacers_mib.push_back(first_mib + i * step_mib);
     // room for the caller-side copies, one candidate with its spacer and the best so far (twice over, to be safe)
     if (free_b < 2 * (2 * (kbytes + vbytes) + (spacers_mib.back() << 20)) + ((size_t) 1 << 30)) return GLU_OK;
     hipStream_t st = g_dev.queue;

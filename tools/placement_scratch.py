@@ -1,5 +1,6 @@
-"""EXPERIMENT: sorters whose value scratch is allocated behind a spacer of S MiB (GLU_HIP_SCRATCH_SPACER_MIB), timed in ONE
-process on the same caller pairs drawn from 10 consecutive 1 GiB buffers."""
+"""Sorter objects whose value scratch is allocated behind a spacer of S MiB (one candidate placement each:
+GLU_HIP_SCRATCH_TUNE_LIST=512:1:S), timed in ONE process on the same caller pairs drawn from 10 consecutive 1 GiB buffers:
+a sorter object is fast or slow for every caller pair."""
 import os, sys
 sys.path.insert(0, "gl-radix-sort_amd")
 import numpy as np, glu_hip as G
@@ -12,7 +13,7 @@ bufs = [G.ShaderStorageBuffer(size=4 * n) for _ in range(10)]
 pairs = [(0, 1), (2, 3), (4, 5), (6, 7), (8, 9), (1, 6), (3, 8)]
 sorters = []
 for spacer in (0, 2048, 4096, 6144, 0, 4096, 1024, 3072):
-    os.environ["GLU_HIP_SCRATCH_SPACER_MIB"] = str(spacer)
+    os.environ["GLU_HIP_SCRATCH_TUNE_LIST"] = "512:1:%d" % spacer
     q = G.RadixSort(); q.prepare_internal_buffers(n)
     sorters.append((spacer, q))
 print("pairs", pairs)
