@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -1035,9 +1036,15 @@ glu_status tune_scratch_placement(glu_radix_sort_s* s, size_t count, size_t key_
     const size_t kbytes = count * key_size, vbytes = count * sizeof(uint32_t);
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return GLU_OK;
-    // sixteen candidates, the value array behind spacers of 0, 0.5 .. 7.5 GiB (which spacer wins differs from process to
-    // process: 24 candidates on two devices showed no period, about one in four is fast; GLU_HIP_SCRATCH_TUNE_LIST=step_mib:count[:first_mib])
+    // up to 16 candidates, the value array behind spacers of 0, 0.5 .. 7.5 GiB (which spacer wins differs from process to
+    // process: 24 candidates on two devices showed no period, about one in four is fast).  The search ends as soon as one
+    // candidate is 4.5 % faster than the slowest seen -- the speeds are discrete, fast and slow lie 5-8 % apart; four
+    // candidates and 0.07 s in four of five cold processes -- or after a second: on some devices no placement out of 32 is
+    // fast, and spacers of many GiB take a quarter of a second each to allocate and free (7.9 s for 32 candidates up to
+    // 15.5 GiB).  GLU_HIP_SCRATCH_TUNE_LIST=step_mib:count[:first_mib] fixes the list (no early end).
     size_t step_mib = 512, candidates = 16, first_mib = 0;
+    const auto t_begin = std::chrono::steady_clock::now();
+    const bool fixed_list = getenv("GLU_HIP_SCRATCH_TUNE_LIST") != nullptr;
     if (const char* e = getenv("GLU_HIP_SCRATCH_TUNE_LIST")) sscanf(e, "%zu:%zu:%zu", &step_mib, &candidates, &first_mib);
     std::vector<size_t> spacers_mib;
     for (size_t i = 0; i < std::max<size_t>(candidates, 1); i++) spacers_mib.push_back(first_mib + i * step_mib);
@@ -1048,6 +1055,7 @@ glu_status tune_scratch_placement(glu_radix_sort_s* s, size_t count, size_t key_
     hipEvent_t e0 = nullptr, e1 = nullptr;
     struct Cand { void* k = nullptr; void* v = nullptr; double ms = 1e30; uint32_t spacer = 0; } best;
     double worst = 0;
+    uint32_t tried = 0;
     s->tuning = true;
     const bool was_profiling = s->profiling;
     s->profiling = false; // the calibration sorts are not the caller's
@@ -1137,12 +1145,15 @@ glu_status tune_scratch_placement(glu_radix_sort_s* s, size_t count, size_t key_
             (void) hipFree(k);
             (void) hipFree(v);
         }
+        tried++;
+        if (!fixed_list && tried >= 4 && best.ms <= 0.955 * worst) break;
+        if (!fixed_list && std::chrono::steady_clock::now() - t_begin > std::chrono::milliseconds(1000)) break;
     }
 #undef TUNE_TRY
     s->tuned_spacer_mib = best.spacer;
     s->tuned_ms = best.ms;
     s->tuned_worst_ms = worst;
-    s->tuned_candidates = (uint32_t) spacers_mib.size();
+    s->tuned_candidates = tried;
     if (getenv("GLU_VERBOSE"))
         fprintf(stderr, "[glu_hip] scratch placement: value array behind a %u MiB spacer, calibration sort %.3f ms (slowest candidate %.3f ms)\n",
                 best.spacer, best.ms, worst);
