@@ -1071,6 +1071,7 @@ glu_status tune_scratch_placement(glu_radix_sort_s* s, size_t count, size_t key_
         s->keys.ptr = best.k, s->keys.size = best.k ? kbytes : 0;
         s->vals.ptr = best.v, s->vals.size = best.v ? vbytes : 0;
         s->tuning = false;
+        s->last_planned = false; // glu_radix_sort_read_plan: the calibration sorts were not the caller's
         return status;
     };
 #define TUNE_TRY(expr)                                                                                                 \
