@@ -1033,7 +1033,8 @@ __global__ void tune_fill_kernel(uint32_t* __restrict__ p, size_t words, uint32_
 
 glu_status tune_scratch_placement(glu_radix_sort_s* s, size_t count, size_t key_size)
 {
-    const size_t kbytes = count * key_size, vbytes = count * sizeof(uint32_t);
+    // (grow-only: an array that is already larger than this count needs keeps its size)
+    const size_t kbytes = std::max(count * key_size, s->keys.size), vbytes = std::max(count * sizeof(uint32_t), s->vals.size);
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return GLU_OK;
     // up to 16 candidates, the value array behind spacers of 0, 0.5 .. 7.5 GiB (which spacer wins differs from process to
@@ -1152,9 +1153,9 @@ glu_status tune_scratch_placement(glu_radix_sort_s* s, size_t count, size_t key_
     }
 #undef TUNE_TRY
     s->tuned_spacer_mib = best.spacer;
-    s->tuned_ms = best.ms;
-    s->tuned_worst_ms = worst;
-    s->tuned_candidates = tried;
+    s->tuned_ms = best.k ? best.ms : 0.0;
+    s->tuned_worst_ms = best.k ? worst : 0.0;
+    s->tuned_candidates = best.k ? tried : 0u;
     if (getenv("GLU_VERBOSE"))
         fprintf(stderr, "[glu_hip] scratch placement: value array behind a %u MiB spacer, calibration sort %.3f ms (slowest candidate %.3f ms)\n",
                 best.spacer, best.ms, worst);

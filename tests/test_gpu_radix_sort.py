@@ -684,6 +684,13 @@ def test_scratch_placement_by_measurement(G, monkeypatch):
         out.append((kb.get_data(np.uint32), vb.get_data(np.uint32)))
     assert (out[0][0] == out[1][0]).all() and (out[0][1] == out[1][1]).all()
     _check_sorted_properties(keys, out[0][0], out[0][1])
+    # grow-only: a sorter prepared for a keys-only sort twice the size keeps that key scratch when pairs are prepared after it
+    monkeypatch.delenv("GLU_HIP_SCRATCH_TUNE")
+    grown = G.RadixSort()
+    grown.prepare_internal_buffers(2 * n, with_vals=False)
+    keys_only = grown.scratch_size()
+    grown.prepare_internal_buffers(n)
+    assert grown.scratch_placement()["candidates"] == 5 and grown.scratch_size() >= keys_only + 4 * n
 
 
 def test_full_size_2_28_duplicate_heavy(G):
