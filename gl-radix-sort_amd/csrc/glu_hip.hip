@@ -1039,8 +1039,8 @@ glu_status tune_scratch_placement(glu_radix_sort_s* s, size_t count, size_t key_
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return GLU_OK;
     // up to 16 candidates, the value array behind spacers of 0, 0.5 .. 7.5 GiB (which spacer wins differs from process to
     // process: 24 candidates on two devices showed no period, about one in four is fast).  The search ends as soon as one
-    // candidate is 4.5 % faster than the slowest seen -- the speeds are discrete, fast and slow lie 5-8 % apart; four
-    // candidates and 0.07 s in four of five cold processes -- or after a second: on some devices no placement out of 32 is
+    // candidate of at least eight is 7 % faster than the slowest seen -- the speeds are discrete, fast and slow lie 5-8 %
+    // apart, and the fast ones differ among themselves by 2-3 %; eight candidates take 0.13 s -- or after a second: on some devices no placement out of 32 is
     // fast, and spacers of many GiB take a quarter of a second each to allocate and free (7.9 s for 32 candidates up to
     // 15.5 GiB).  GLU_HIP_SCRATCH_TUNE_LIST=step_mib:count[:first_mib] fixes the list (no early end).
     size_t step_mib = 512, candidates = 16, first_mib = 0;
@@ -1148,7 +1148,7 @@ glu_status tune_scratch_placement(glu_radix_sort_s* s, size_t count, size_t key_
             (void) hipFree(v);
         }
         tried++;
-        if (!fixed_list && tried >= 4 && best.ms <= 0.955 * worst) break;
+        if (!fixed_list && tried >= 8 && best.ms <= 0.93 * worst) break;
         if (!fixed_list && std::chrono::steady_clock::now() - t_begin > std::chrono::milliseconds(1000)) break;
     }
 #undef TUNE_TRY

@@ -228,9 +228,9 @@ GLU_API glu_status glu_radix_sort_set_digit_bits(glu_radix_sort sort, uint32_t b
 GLU_API glu_status glu_radix_sort_get_digit_bits(glu_radix_sort sort, uint32_t* bits);
 /* Where the two large scratch arrays lie to each other decides between discrete speeds of every pass on this memory system,
  * so glu_radix_sort_prepare* places key + value scratch of 512 MiB of keys or more BY MEASUREMENT: the value array is
- * allocated behind spacers of 0, 0.5 .. 7.5 GiB (at most 16 candidates; the search ends with the first candidate that is
- * 4.5 % faster than the slowest seen, or after a second), each candidate sorts pseudo-random pairs of the prepared count
- * three times on the library queue, the fastest pair of arrays is kept, everything else is freed again (0.07-1 s, once; a
+ * allocated behind spacers of 0, 0.5 .. 7.5 GiB (8 to 16 candidates; the search ends when one of them is 7 % faster
+ * than the slowest seen, or after a second), each candidate sorts pseudo-random pairs of the prepared count
+ * three times on the library queue, the fastest pair of arrays is kept, everything else is freed again (0.13-1 s, usually 0.3 s, once; a
  * sort never allocates or measures; GLU_HIP_SCRATCH_TUNE=0 takes the first allocation as the reference's
  * prepare_internal_buffers does, RadixSort.hpp:237-271).  This reports what the last such measurement saw: the number of
  * candidates (0 = none was made), the calibration sort time of the chosen and of the slowest one. */
