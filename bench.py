@@ -3,6 +3,9 @@
   python bench.py [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
+Both forms work for N > 1: the plain command (no WORLD_SIZE in the environment) starts the second form as a CHILD process
+before anything touches a GPU, forwards rank 0's JSON line and returns the child's exit code (launch_ranks below).
+
 A "step" is one full sort of one batch of synthetic unsorted input that is already resident in HBM.
   N = 1   BASELINE.json configs[2]: 2^28 uniform-random uint32 keys + uint32 values (vals = iota), in place in the
           caller's two arrays, scratch pre-allocated (the reference's benchmark does the same,
@@ -12,6 +15,13 @@ A "step" is one full sort of one batch of synthetic unsorted input that is alrea
           partition -> one all-to-all (RCCL over xGMI) -> local sort (gl-radix-sort_amd/glu_hip/dist.py).
 Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (the scatter pass) from HIP-event timings
 taken inside the timed region; `cpu_baseline` is std::sort on the host cores over a bounded sample.
+For every N, `value` / `ms_per_step` are ONE SORT AT A TIME (K sorts enqueued back to back on one stream), so that the
+1/2/4/8-GPU curve compares like with like; N > 1 also reports the two-sorts-in-flight throughput as `value_depth2` and
+`one_gpu` = this very run's single-GPU figures (2^28 pairs on every rank's own GPU, depth 1 and depth 2), with
+`speedup_vs_1gpu_depth1` / `speedup_vs_1gpu_depth2` taken against them.
+Exit codes: 0 = a line was printed (a line that carries `native_error` is the torch.distributed transport's measurement:
+the native transport raised or hung and was abandoned -- every rank then leaves with 0 so that the launcher keeps the
+line); anything else = no valid line.
 """
 import argparse
 import ctypes
@@ -55,6 +65,10 @@ def parse_args():
     p.add_argument("--no-transport-fallback", action="store_true",
                    help="N>1, native transport: do not measure the torch.distributed transport first (it is the line rank 0 prints "
                         "if the native run raises or hangs)")
+    p.add_argument("--no-one-gpu", action="store_true",
+                   help="N>1: skip the single-GPU figures of the same run (one_gpu, speedup_vs_1gpu_*)")
+    p.add_argument("--one-gpu-log2", type=int, default=None,
+                   help="N>1: pairs of the single-GPU figures = 2^this (default 28, the N = 1 workload; pairs per GPU + 1 in a rehearsal)")
     p.add_argument("--force-dist", action="store_true",
                    help="run the multi-GPU code path (partition + all-to-all + local sort) even with one rank")
     p.add_argument("--rehearse-one-gpu", action="store_true",
@@ -154,6 +168,47 @@ def cpu_baseline(sample_log2, keys_host=None, vals_host=None):
     }
 
 
+def one_gpu_figures(torch, G, device, log2n, K, W, kind, digit_bits, barrier, max_over_ranks):
+    """N > 1 runs: what ONE GPU of this node does on the N = 1 workload, measured in this very run and the same way as the
+    line's own figures -- K sorts of pristine copies between barrier + synchronize pairs, max over ranks (every rank sorts
+    on its own GPU at the same time) -- once one sort at a time and once with two independent sorts in flight (two sorter
+    objects on two streams: one GPU has no exchange to hide, so that figure says what the pipelining alone is worth)."""
+    n = 1 << log2n
+    keys0, vals0 = make_input(torch, n, kind, 0, device)
+    sets = [(keys0.clone(), vals0.clone()) for _ in range(K + W)]
+    out = {"pairs": n, "steps": K, "warmup": W}
+    for depth in (1, 2):
+        streams = [torch.cuda.Stream(device=device) for _ in range(depth)]
+        sorters = [G.RadixSort(digit_bits=digit_bits) for _ in range(depth)]
+        for srt in sorters:
+            srt.prepare_internal_buffers(n)
+        if depth > 1:
+            for k, v in sets:
+                k.copy_(keys0)
+                v.copy_(vals0)
+
+        def step(i):
+            k, v = sets[i]
+            sorters[i % depth].run_ptr(k.data_ptr(), v.data_ptr(), n, 0, streams[i % depth].cuda_stream)
+
+        barrier()
+        for i in range(W):
+            step(i)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(W, W + K):
+            step(i)
+        barrier()
+        elapsed = max_over_ranks(time.perf_counter() - t0)
+        out["value_depth%d" % depth] = round(n * K / elapsed / 1e6, 1)
+        out["ms_per_step_depth%d" % depth] = round(elapsed / K * 1e3, 4)
+        del sorters
+    out["verified"] = verify_sorted(torch, keys0, sets[-1][0], sets[-1][1], True)
+    del sets
+    torch.cuda.empty_cache()
+    return out
+
+
 def load_traffic(workload_key):
     """HBM bytes per scatter launch from committed rocprofv3 PMC passes (profiles/traffic_*.json), if they were
     collected for this exact workload; otherwise null."""
@@ -171,8 +226,47 @@ def load_traffic(workload_key):
         return None
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start `python -m torch.distributed.run ... bench.py <same arguments>` as a
+    child process (this parent never touches a GPU and nothing is exec'ed over a process that did), forward rank 0's JSON
+    line to stdout and return the child's exit code."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stderr.write("[bench] launching %d ranks: %s\n" % (args.gpus, " ".join(cmd)))
+    sys.stderr.flush()
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", "8")  # (torchrun would set 1 and say so; the CPU side of a rank is the launch loop)
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env)
+    line = None
+    for raw in child.stdout:
+        text = raw.decode(errors="replace")
+        try:
+            if "metric" in json.loads(text):
+                line = text.strip()
+                continue
+        except ValueError:
+            pass
+        sys.stderr.write(text)  # anything else a rank wrote to the real stdout
+    rc = child.wait()
+    if line is not None:
+        sys.stdout.write(line + "\n")
+        sys.stdout.flush()
+    elif rc == 0:
+        sys.stderr.write("[bench] the ranks exited with 0 but printed no JSON line\n")
+        rc = 1
+    return rc
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
     # stdout must carry exactly ONE line (the JSON): RCCL prints a version banner to the C-level stdout at exit, so
     # keep a private copy of the real stdout for the JSON and point fd 1 (and Python's sys.stdout) at stderr.
     sys.stdout.flush()
@@ -185,9 +279,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
-                         "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    if args.gpus != world:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libglu_hip has no CPU fallback")
 
@@ -459,11 +552,10 @@ def main():
                 return float(tt.item())
 
             # Two timed regions of K sorts each.  depth 1: one sort at a time on one stream (partition -> exchange -> local sort,
-            # each waiting for the one before).  depth 2: the K sorts alternate between two glu_dist objects (own stream, buffers
-            # and communicator), so that the exchange of sort i + 1 runs under the local sort of sort i -- how a caller with a
-            # stream of independent batches uses the API, and the regime the line's `value` reports: K sorts enqueued as fast
-            # as the API allows, barrier + synchronize on both sides, like the N = 1 line (where one GPU has nothing to overlap).
-            # `value_depth1` / `ms_per_step_depth1` stand beside it; the per-kernel roofline numbers come from the depth-1 region.
+            # each waiting for the one before) -- the regime of the N = 1 line, and what `value` / `ms_per_step` report for every N.
+            # depth 2: the K sorts alternate between two glu_dist objects (own stream, buffers and communicator), so that the
+            # exchange of sort i + 1 runs under the local sort of sort i -- how a caller with a stream of independent batches
+            # uses the API; reported beside the headline as `value_depth2`.  The per-kernel roofline numbers come from depth 1.
             r1 = run_depth(1)
             elapsed1 = max_over_ranks(r1["elapsed"])
             res["value_depth1"] = round(n * world * K / elapsed1 / 1e6, 1)
@@ -472,8 +564,8 @@ def main():
             elapsed = r1["elapsed"]
             if depth > 1:
                 r2 = run_depth(depth)
-                elapsed = r2["elapsed"]
-                res["value_depth%d" % depth] = round(n * world * K / max_over_ranks(elapsed) / 1e6, 1)
+                res["value_depth%d" % depth] = round(n * world * K / max_over_ranks(r2["elapsed"]) / 1e6, 1)
+                res["ms_per_step_depth%d" % depth] = round(max_over_ranks(r2["elapsed"]) / K * 1e3, 4)
                 res["phases_ms_rank0_depth%d" % depth] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in r2["phases"].items()}
                 del r2
             res["pipeline_depth"] = depth
@@ -530,8 +622,9 @@ def main():
             res["shard_pairs_rank0"] = int(cnt)
             workload = ("2^%d uint32 key+val pairs per GPU (%d GPUs, 2^%.2f total), uniform-random keys; top-8-bit bucket "
                         "partition + one RCCL all-to-all over xGMI + local sort") % (log2n, world, log2n + __import__("math").log2(world))
-            parallelism = ("bucket-sharded x%d (1 grouped RCCL exchange per sort), %d independent sorts in flight (value_depth1: one at a time)"
-                           % (world, depth)) if depth > 1 else "bucket-sharded x%d (1 grouped RCCL exchange per sort), one sort at a time" % world
+            parallelism = "bucket-sharded x%d (1 grouped RCCL exchange per sort), one sort at a time" % world
+            if depth > 1:
+                parallelism += " (value_depth%d: %d independent sorts in flight)" % (depth, depth)
 
             t = torch.tensor([elapsed], dtype=torch.float64, device=device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -582,13 +675,26 @@ def main():
         try:
             result, elapsed, units, workload, parallelism = sharded(want_native)
         except BaseException as e:  # noqa: a rank that fails alone must not take the launcher down before rank 0 has printed
-            if not state["armed"]:
+            if watchdog is None:
                 raise
-            bail("%s: %s" % (type(e).__name__, e))
+            bail("%s: %s" % (type(e).__name__, e))  # (waits for a bail the watchdog has begun: that one ends the process)
+            raise
         with bail_lock:
             state["armed"] = False
         if watchdog is not None:
             watchdog.cancel()
+        if not args.no_one_gpu:
+            def max_over(x):
+                tt = torch.tensor([x], dtype=torch.float64, device=device)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                return float(tt.item())
+
+            one_log2 = args.one_gpu_log2 if args.one_gpu_log2 is not None else (min(28, log2n + 1) if args.rehearse_one_gpu else 28)
+            one = one_gpu_figures(torch, G, device, one_log2, K, W, args.keys, args.digit_bits, barrier, max_over)
+            result["one_gpu"] = one
+            for d in (1, 2):
+                if "value_depth%d" % d in result:
+                    result["speedup_vs_1gpu_depth%d" % d] = round(result["value_depth%d" % d] / one["value_depth%d" % d], 3)
         if fallback is not None:
             result["torch_transport"] = {k: fallback[k] for k in ("value", "ms_per_step", "value_depth1", "ms_per_step_depth1", "verified",
                                                                   "local_sort", "phases_ms_rank0") if k in fallback}

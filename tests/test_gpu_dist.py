@@ -3,6 +3,7 @@ libglu_hip.so (glu_dist_*: partition pass, ncclAllGather of the histograms, plan
 on a 1-rank RCCL group, the only RCCL world one GPU allows; several ranks sharing the GPU go through gloo with the real
 kernels doing the device work (uneven splits, plan, receive order, the receive arrays growing under a skewed plan)."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -580,12 +581,47 @@ def test_bench_multi_gpu_command_line_rehearsal(built):
     assert len(lines) == 1, p.stdout
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["verified"] is True and line["native_c_abi"] is True
-    # the line's value is the two-in-flight throughput; the one-at-a-time figure stands beside it
-    assert line["pipeline_depth"] == 2 and line["value"] == line["value_depth2"] and "value_depth1" in line and "rehearsal" in line
+    # the line's value is the one-sort-at-a-time figure, like the N = 1 line; the two-in-flight throughput stands beside it
+    assert line["pipeline_depth"] == 2 and line["value"] == line["value_depth1"] and line["value_depth2"] > 0 and "rehearsal" in line
+    # ... and so do this run's own single-GPU figures, taken the same way, with the speed-ups against them
+    one = line["one_gpu"]
+    assert one["verified"] is True and one["value_depth1"] > 0 and one["value_depth2"] > 0
+    for d in (1, 2):
+        assert abs(line["speedup_vs_1gpu_depth%d" % d] - line["value_depth%d" % d] / one["value_depth%d" % d]) < 2e-3
     assert line["local_sort"] in ("segmented", "ordinary")
     assert line["phases_ms_rank0"]["sorts"] == line["steps"]
     # the torch.distributed transport was measured first (it is the fallback line) and stands beside the native figures
     assert line["torch_transport"]["verified"] is True and line["torch_transport"]["value"] > 0
+
+
+def test_bench_plain_command_launches_its_own_ranks(built):
+    """`python bench.py --gpus 2 ...` with no launcher and no WORLD_SIZE (the shape of the driver's N = 1 command): bench.py
+    starts torchrun as a child process, forwards rank 0's one JSON line and returns the child's exit code."""
+    import json
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(GRAFT_REPO_ROOT=root, PLAIN="1")
+    p = subprocess.run(["bash", os.path.join(root, "tools", "rehearse_multi_gpu.sh"), "2", "18"], capture_output=True, text=True,
+                       env=env, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert "launching 2 ranks" in p.stderr
+    lines = p.stdout.splitlines()
+    assert len(lines) == 1, p.stdout  # exactly one line on stdout: the JSON
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["verified"] is True and line["native_c_abi"] is True and line["value"] > 0
+
+
+def test_bench_plain_command_returns_the_ranks_failure(built):
+    """... and a launch whose ranks fail (here: no transport library for the rehearsal) prints no line and does not return 0."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "GLU_HIP_RCCL_LIB")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--log2-keys", "16",
+                        "--rehearse-one-gpu"], capture_output=True, text=True, env=env, timeout=600, cwd=root)
+    assert p.returncode != 0 and p.stdout.strip() == "", (p.returncode, p.stdout)
 
 
 def test_bench_multi_gpu_falls_back_when_the_native_transport_hangs(built):
