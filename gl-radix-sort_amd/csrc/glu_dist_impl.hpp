@@ -229,6 +229,11 @@ glu_dist_s::Marks* dist_marks(glu_dist_s* d, bool begin_new)
 
 extern "C" {
 
+glu_status glu_dist_available(void)
+{
+    return rccl_ready(); // dlopen + the nine symbols, nothing else: no device call, no bootstrap socket, no thread
+}
+
 glu_status glu_dist_unique_id(void* id_out, size_t id_bytes)
 {
     GLU_TRY(enter());
@@ -345,7 +350,7 @@ glu_status glu_dist_prepare(glu_dist d, size_t local_count, size_t recv_capacity
         GLU_TRY(d->recv_v.reserve(recv_capacity * sizeof(uint32_t)));
     }
     // partition pass: table only; local sort: scratch for the receive side
-    GLU_TRY(sort_prepare(d->sorter, std::max(local_count, recv_capacity), sizeof(uint32_t), true));
+    GLU_TRY(sort_prepare(d->sorter, std::max(local_count, recv_capacity), sizeof(uint32_t), true, /*may_place=*/true));
     // segmented local sort: one table row per sub-block (at most pieces + workgroups: world x buckets owned + CUs) and the
     // descriptor image of its two pass shapes
     const size_t rows = (size_t) kDistBuckets * (size_t) std::min(d->world, 16) + (size_t) g_dev.num_cus;

@@ -516,13 +516,18 @@ inline uint32_t usable_cus(const glu_radix_sort_s* s)
 constexpr size_t kTuneMinKeyBytes = (size_t) 512 << 20; // scratch arrays from this size up are placed by measurement
 glu_status tune_scratch_placement(glu_radix_sort_s* s, size_t count, size_t key_size);
 
-glu_status sort_prepare(glu_radix_sort_s* s, size_t count, size_t key_size, bool with_vals = true)
+// may_place: only the explicit prepare entry points (glu_radix_sort_prepare*, glu_dist_prepare) pass true.  The lazy call at
+// the head of every sort, of a segmented sort and of glu_dist_sort_finish takes the plain allocation: a sort call, a
+// collective or a stream capture never measures, never runs calibration sorts and never makes transient allocations.
+glu_status sort_prepare(glu_radix_sort_s* s, size_t count, size_t key_size, bool with_vals = true, bool may_place = false)
 {
     if (count <= 1) return GLU_OK;
     // large key + value scratch that has to be (re)allocated anyway: where the two arrays lie to each other decides between
     // discrete speeds of every pass, so a few placements are tried and the fastest is kept
-    if (with_vals && s->tune_scratch && !s->tuning && count * key_size >= kTuneMinKeyBytes &&
-        (s->keys.size < count * key_size || s->vals.size < count * sizeof(uint32_t)))
+    const bool grows = s->keys.size < count * key_size || (with_vals && s->vals.size < count * sizeof(uint32_t));
+    if (grows && !s->tuning) // the arrays the last placement search chose (if any) are about to be replaced
+        s->tuned_candidates = 0, s->tuned_ms = s->tuned_worst_ms = 0.0, s->tuned_spacer_mib = 0;
+    if (may_place && with_vals && s->tune_scratch && !s->tuning && count * key_size >= kTuneMinKeyBytes && grows)
         GLU_TRY(tune_scratch_placement(s, count, key_size));
     GLU_TRY(s->keys.reserve(count * key_size));
     if (with_vals) GLU_TRY(s->vals.reserve(count * sizeof(uint32_t)));
@@ -1019,8 +1024,9 @@ glu_status sort_run(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t coun
 // in 3.76-3.80 ms and the others in 3.9-4.05 ms).  User space cannot choose physical pages, but it can choose among
 // allocations: the value array is allocated behind spacers of 0 .. 6 GiB, every candidate sorts a scratch copy of
 // pseudo-random pairs twice (events on the library queue), the fastest pair of arrays is kept and everything else freed.
-// One-off, inside prepare (the reference's prepare_internal_buffers is where its allocations happen too); a sort never
-// allocates or measures.  GLU_HIP_SCRATCH_TUNE=0 switches it off.
+// One-off, and only inside the explicit prepare entry points (glu_radix_sort_prepare*, glu_dist_prepare; the reference's
+// prepare_internal_buffers is where its allocations happen too).  A sort on an object that was not prepared for its size
+// grows the scratch with two plain hipMallocs and reports zero candidates.  GLU_HIP_SCRATCH_TUNE=0 switches it off.
 __global__ void tune_fill_kernel(uint32_t* __restrict__ p, size_t words, uint32_t salt)
 {
     for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (size_t) gridDim.x * blockDim.x)
@@ -1050,7 +1056,18 @@ glu_status tune_scratch_placement(glu_radix_sort_s* s, size_t count, size_t key_
     std::vector<size_t> spacers_mib;
     for (size_t i = 0; i < std::max<size_t>(candidates, 1); i++) spacers_mib.push_back(first_mib + i * step_mib);
     // room for the caller-side copies, one candidate with its spacer and the best so far (twice over, to be safe)
-    if (free_b < 2 * (2 * (kbytes + vbytes) + (spacers_mib.back() << 20)) + ((size_t) 1 << 30)) return GLU_OK;
+    const size_t need_b = 2 * (2 * (kbytes + vbytes) + (spacers_mib.back() << 20)) + ((size_t) 1 << 30);
+    s->tuned_candidates = 0, s->tuned_ms = s->tuned_worst_ms = 0.0, s->tuned_spacer_mib = 0;
+    if (free_b < need_b)
+    {
+        if (getenv("GLU_VERBOSE"))
+            fprintf(stderr, "[glu_hip] scratch placement skipped: %zu MiB free, the search wants %zu MiB; plain allocation\n", free_b >> 20,
+                    need_b >> 20);
+        return GLU_OK;
+    }
+    // the calibration sorts run on the library queue and rewrite this object's tables: nothing of the caller's may still be
+    // using them on another stream
+    if (hipDeviceSynchronize() != hipSuccess) return fail(GLU_ERROR_DEVICE, "hipDeviceSynchronize failed before the scratch placement");
     hipStream_t st = g_dev.queue;
     void *a = nullptr, *b = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1165,6 +1182,7 @@ glu_status tune_scratch_placement(glu_radix_sort_s* s, size_t count, size_t key_
 // ------------------------------------------------------------------------------------------------------------
 // segmented sort (radix_seg_passes.hpp): glu_radix_sort_run_segments_ptr
 // ------------------------------------------------------------------------------------------------------------
+constexpr uint32_t kSegMaxSegments = 1u << 24; // (one workgroup per segment in the scan kernel, host vectors of this length)
 struct SegPiece
 {
     uint64_t begin, len;
@@ -1189,7 +1207,7 @@ void seg_build_image(const SegPiece* pieces, size_t npieces, uint32_t nseg, cons
     img.nwg = nwg;
     img.nseg = nseg;
     const uint64_t share = std::max<uint64_t>(1, (total + nwg - 1) / nwg);
-    std::vector<uint32_t> subs, first(nwg + 1, 0), list(nseg + 1, 0);
+    std::vector<uint32_t> subs, first((size_t) nwg + 1, 0), list((size_t) nseg + 1, 0);
     subs.reserve(2 * (npieces + nwg));
     uint64_t pos = 0; // position in the pieces laid end to end
     uint32_t seg_seen = 0;
@@ -1293,7 +1311,7 @@ void seg_make_plan(glu_radix_sort_s* s, std::vector<SegPiece>&& pieces, uint32_t
     plan.count = count;
     plan.bits = bits;
     plan.passes = bits / 8;
-    plan.seg_start.assign(nseg + 1, 0);
+    plan.seg_start.assign((size_t) nseg + 1, 0);
     for (const SegPiece& pc : plan.pieces) plan.seg_start[pc.seg + 1] += pc.len;
     for (uint32_t g = 0; g < nseg; g++) plan.seg_start[g + 1] += plan.seg_start[g];
     plan.by_copies = count < kSegMinCount || !aligned || plan.passes == 0;
@@ -1442,7 +1460,7 @@ glu_status glu_radix_sort_prepare(glu_radix_sort sort, size_t count)
 {
     GLU_TRY(enter());
     if (!sort) return fail(GLU_ERROR_INVALID_ARGUMENT, "sort is NULL");
-    return sort_prepare(sort, count, sizeof(uint32_t));
+    return sort_prepare(sort, count, sizeof(uint32_t), true, true);
 }
 
 glu_status glu_radix_sort_prepare_ex(glu_radix_sort sort, size_t count, size_t key_bytes, int with_vals)
@@ -1450,14 +1468,14 @@ glu_status glu_radix_sort_prepare_ex(glu_radix_sort sort, size_t count, size_t k
     GLU_TRY(enter());
     if (!sort) return fail(GLU_ERROR_INVALID_ARGUMENT, "sort is NULL");
     if (key_bytes != 4 && key_bytes != 8) return fail(GLU_ERROR_INVALID_ARGUMENT, "key_bytes must be 4 or 8 (got %zu)", key_bytes);
-    return sort_prepare(sort, count, key_bytes, with_vals != 0);
+    return sort_prepare(sort, count, key_bytes, with_vals != 0, true);
 }
 
 glu_status glu_radix_sort_prepare_u64(glu_radix_sort sort, size_t count)
 {
     GLU_TRY(enter());
     if (!sort) return fail(GLU_ERROR_INVALID_ARGUMENT, "sort is NULL");
-    return sort_prepare(sort, count, sizeof(uint64_t));
+    return sort_prepare(sort, count, sizeof(uint64_t), true, true);
 }
 
 glu_status glu_radix_sort_run_ptr(glu_radix_sort sort, uint32_t* keys, uint32_t* vals, size_t count, size_t num_steps,
@@ -1611,6 +1629,7 @@ glu_status glu_radix_sort_run_segments_ptr(glu_radix_sort sort, uint32_t* in_key
     if (count > 0xFFFF0000ull) return fail(GLU_ERROR_INVALID_ARGUMENT, "count %zu does not fit 32-bit indexing", count);
     if (num_pieces > 0 && (!piece_begin || !piece_len || !piece_segment)) return fail(GLU_ERROR_INVALID_ARGUMENT, "NULL piece array");
     if (num_segments == 0 && num_pieces > 0) return fail(GLU_ERROR_INVALID_ARGUMENT, "pieces but no segments");
+    if (num_segments > kSegMaxSegments) return fail(GLU_ERROR_INVALID_ARGUMENT, "num_segments %u exceeds %u", num_segments, kSegMaxSegments);
     std::vector<SegPiece> pieces(num_pieces);
     uint64_t total = 0;
     for (size_t i = 0; i < num_pieces; i++)
@@ -1624,6 +1643,22 @@ glu_status glu_radix_sort_run_segments_ptr(glu_radix_sort sort, uint32_t* in_key
     }
     if (total != count) return fail(GLU_ERROR_INVALID_ARGUMENT, "the pieces hold %llu elements, count is %zu", (unsigned long long) total, count);
     if (count == 0) return GLU_OK;
+    {
+        // the pieces must tile [0, count): together they hold count elements, so it is enough that none overlaps another
+        std::vector<std::pair<uint64_t, uint64_t>> spans;
+        spans.reserve(num_pieces);
+        for (const SegPiece& pc : pieces)
+            if (pc.len) spans.emplace_back(pc.begin, pc.len);
+        std::sort(spans.begin(), spans.end());
+        uint64_t end = 0;
+        for (const auto& sp : spans)
+        {
+            if (sp.first != end)
+                return fail(GLU_ERROR_INVALID_ARGUMENT, "the pieces do not tile the input: element %llu is in %s piece",
+                            (unsigned long long) std::min(sp.first, end), sp.first < end ? "more than one" : "no");
+            end = sp.first + sp.second;
+        }
+    }
     if (!in_keys || !in_vals || !out_keys || !out_vals) return fail(GLU_ERROR_INVALID_ARGUMENT, "NULL array");
     if (in_keys == out_keys || in_vals == out_vals) return fail(GLU_ERROR_INVALID_ARGUMENT, "the segmented sort needs distinct input and output arrays");
     // the sub-block descriptors of a call travel through a ring of pinned staging buffers that later calls overwrite, and a
@@ -1646,6 +1681,8 @@ glu_status glu_radix_sort_plan_segments(const uint64_t* piece_begin, const uint6
     // host only (no device needed): the cut of a segmented pass into sub-blocks, for inspection and tests
     if (num_pieces > 0 && (!piece_begin || !piece_len || !piece_segment)) return fail(GLU_ERROR_INVALID_ARGUMENT, "NULL piece array");
     if (num_workgroups == 0 || !num_sub_blocks) return fail(GLU_ERROR_INVALID_ARGUMENT, "bad arguments");
+    if (num_segments > kSegMaxSegments) return fail(GLU_ERROR_INVALID_ARGUMENT, "num_segments %u exceeds %u", num_segments, kSegMaxSegments);
+    if (num_workgroups > (1u << 20)) return fail(GLU_ERROR_INVALID_ARGUMENT, "num_workgroups %u exceeds %u", num_workgroups, 1u << 20);
     std::vector<SegPiece> pieces(num_pieces);
     uint64_t total = 0;
     for (size_t i = 0; i < num_pieces; i++)
@@ -1656,7 +1693,7 @@ glu_status glu_radix_sort_plan_segments(const uint64_t* piece_begin, const uint6
     }
     if (total > 0xFFFF0000ull) return fail(GLU_ERROR_INVALID_ARGUMENT, "the pieces hold %llu elements: more than 32-bit indexing", (unsigned long long) total);
     std::stable_sort(pieces.begin(), pieces.end(), [](const SegPiece& a, const SegPiece& b) { return a.seg < b.seg; });
-    std::vector<uint64_t> start(num_segments + 1, 0);
+    std::vector<uint64_t> start((size_t) num_segments + 1, 0);
     for (const SegPiece& pc : pieces) start[pc.seg + 1] += pc.len;
     for (uint32_t g = 0; g < num_segments; g++) start[g + 1] += start[g];
     SegImage img;

@@ -79,6 +79,7 @@ SYMBOLS = [
     ("glu_reduce_destroy", _int, [_vp]),
     ("glu_reduce_run", _int, [_vp, _u32, _sz]),
     ("glu_reduce_run_ptr", _int, [_vp, _vp, _sz, _vp]),
+    ("glu_dist_available", _int, []),
     ("glu_dist_unique_id", _int, [_vp, _sz]),
     ("glu_dist_create", _int, [_vp, _sz, _int, _int, _P(_vp)]),
     ("glu_dist_destroy", _int, [_vp]),
@@ -430,6 +431,11 @@ def plan_segments(piece_begin, piece_len, piece_segment, num_segments, num_workg
                                              wg.ctypes.data_as(_P(_u32)), sf.ctypes.data_as(_P(_u32)), ss.ctypes.data_as(_P(_u64)),
                                              ctypes.byref(n)))
     return subs[:n.value], wg, sf, ss
+
+
+def dist_available():
+    """glu_dist_available: raises GluError unless this process can load RCCL with the entry points glu_dist_* needs."""
+    check(lib().glu_dist_available())
 
 
 def dist_unique_id():

@@ -217,7 +217,7 @@ class DistributedRadixSort:
         """One glu_dist per slot: rank 0 draws the RCCL unique id, the torch process group carries it to the others.
         Every step's outcome is agreed between the ranks before the next one, so that either every rank has an object or
         every rank falls back to the torch transport (nobody is left inside ncclCommInitRank or a broadcast)."""
-        from . import Dist, dist_unique_id
+        from . import Dist, dist_available, dist_unique_id
 
         self.native_error = None
         uid, err = None, None
@@ -233,7 +233,7 @@ class DistributedRadixSort:
         mine = err
         if mine is None and self.rank != 0:
             try:
-                dist_unique_id()  # can this rank load RCCL at all?  (the id itself is thrown away)
+                dist_available()  # can this rank load RCCL at all?  (dlopen + symbols only)
             except Exception as e:
                 mine = str(e)
         if not self._all_agree(mine is None):

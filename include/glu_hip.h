@@ -133,7 +133,15 @@ GLU_API glu_status glu_buffer_copy(glu_buffer src, glu_buffer dst, size_t size, 
 GLU_API glu_status glu_radix_sort_create(glu_radix_sort* out);
 GLU_API glu_status glu_radix_sort_destroy(glu_radix_sort sort);
 /* RadixSort::prepare_internal_buffers(count)           (RadixSort.hpp:237-271): grow-only scratch for
- * `count` pairs with 32-bit keys. */
+ * `count` pairs with 32-bit keys.
+ * Cost: for less than 512 MiB of keys, the allocations.  From there on (2^27 32-bit keys) prepare also PLACES the key and
+ * value scratch by measurement (glu_radix_sort_scratch_placement below): 0.13-1 s of host time, usually 0.3 s, up to 48
+ * calibration sorts on the library queue behind a hipDeviceSynchronize, and transiently about 2 x (4 arrays of the prepared
+ * size + 7.5 GiB of spacers) of device memory.  When hipMemGetInfo reports less free memory than that the search is skipped
+ * (GLU_VERBOSE says so) and the arrays are two plain hipMallocs: everything works, large sorts run 5-8 % slower on some
+ * placements.  Only the glu_radix_sort_prepare* / glu_dist_prepare calls do this: a sort on an object that was not prepared
+ * for its size grows the scratch with plain allocations (hipFree + hipMalloc: a device-wide synchronisation, not
+ * capturable) and never measures. */
 GLU_API glu_status glu_radix_sort_prepare(glu_radix_sort sort, size_t count);
 /* Same for 64-bit keys (BASELINE.json config 5). */
 GLU_API glu_status glu_radix_sort_prepare_u64(glu_radix_sort sort, size_t count);
@@ -197,7 +205,8 @@ GLU_API glu_status glu_radix_sort_partition_ptr(glu_radix_sort sort, const uint3
 /* Segmented stable sort (not in the reference; it is the local sort of the sharded sort below, where a rank's shard
  * arrives as one message per source rank, each grouped by top-byte bucket): the input arrays hold `num_pieces` pieces,
  * piece i = elements [piece_begin[i], piece_begin[i] + piece_len[i]) of in_keys / in_vals, together exactly `count`
- * elements; piece i belongs to segment piece_segment[i] < num_segments.  Segment g = its pieces laid end to end in the
+ * elements and no element twice (the pieces tile [0, count): GLU_ERROR_INVALID_ARGUMENT otherwise); piece i belongs to
+ * segment piece_segment[i] < num_segments <= 2^24.  Segment g = its pieces laid end to end in the
  * order they are listed.  The output arrays receive the segments in ascending order of g, each stably sorted by the low
  * `key_bits` key bits (0, 8, 16, 24 or 32; 0 = only the regrouping).  Each pass is the reference's stable counting pass
  * (RadixSort.hpp:142-182) applied per segment, all segments in one launch sequence of the sort's own kernels; the first
@@ -230,10 +239,12 @@ GLU_API glu_status glu_radix_sort_get_digit_bits(glu_radix_sort sort, uint32_t* 
  * so glu_radix_sort_prepare* places key + value scratch of 512 MiB of keys or more BY MEASUREMENT: the value array is
  * allocated behind spacers of 0, 0.5 .. 7.5 GiB (8 to 16 candidates; the search ends when one of them is 7 % faster
  * than the slowest seen, or after a second), each candidate sorts pseudo-random pairs of the prepared count
- * three times on the library queue, the fastest pair of arrays is kept, everything else is freed again (0.13-1 s, usually 0.3 s, once; a
- * sort never allocates or measures; GLU_HIP_SCRATCH_TUNE=0 takes the first allocation as the reference's
- * prepare_internal_buffers does, RadixSort.hpp:237-271).  This reports what the last such measurement saw: the number of
- * candidates (0 = none was made), the calibration sort time of the chosen and of the slowest one. */
+ * three times on the library queue, the fastest pair of arrays is kept, everything else is freed again (0.13-1 s, usually 0.3 s, once,
+ * inside an explicit prepare call only -- no sort, no glu_dist_sort_* call measures or makes transient allocations;
+ * GLU_HIP_SCRATCH_TUNE=0 takes the first allocation as the reference's prepare_internal_buffers does,
+ * RadixSort.hpp:237-271).  This reports what the last such measurement saw: the number of candidates (0 = none was made:
+ * switched off, too little free memory, arrays below 512 MiB, or the scratch was grown by a sort and not by prepare), the
+ * calibration sort time of the chosen and of the slowest one. */
 GLU_API glu_status glu_radix_sort_scratch_placement(glu_radix_sort sort, uint32_t* candidates, double* chosen_ms, double* slowest_ms);
 /* Bytes of scratch currently owned by the sort object (keys + vals + tables). */
 GLU_API glu_status glu_radix_sort_scratch_size(glu_radix_sort sort, size_t* bytes);
@@ -302,6 +313,10 @@ GLU_API glu_status glu_reduce_run_ptr(glu_reduce reduce, void* data, size_t coun
  * after the ranks have agreed is not recoverable (it is reported by the rank that sees it; destroy the object). */
 
 #define GLU_DIST_UNIQUE_ID_BYTES 128
+/* Can this process load RCCL (GLU_HIP_RCCL_LIB, librccl.so.1, ...) with the nine entry points the sharded sort needs?
+ * dlopen + dlsym only -- no device call and none of ncclGetUniqueId's side effects (a bootstrap listener socket and
+ * thread per call): what a rank other than 0 asks before the ranks agree to use glu_dist_*. */
+GLU_API glu_status glu_dist_available(void);
 /* Rank 0: ncclGetUniqueId; the caller carries the bytes to the other ranks (MPI, torch.distributed, a file ...). */
 GLU_API glu_status glu_dist_unique_id(void* id_out, size_t id_bytes);
 /* ncclCommInitRank on the library's device (glu_set_device) + a local glu_radix_sort; collective over all ranks. */

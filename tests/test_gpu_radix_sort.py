@@ -693,6 +693,44 @@ def test_scratch_placement_by_measurement(G, monkeypatch):
     assert grown.scratch_placement()["candidates"] == 5 and grown.scratch_size() >= keys_only + 4 * n
 
 
+def test_a_sort_never_searches_for_a_scratch_placement(G, monkeypatch):
+    """Only the explicit prepare calls place the scratch by measurement.  The first sort of 2^27 pairs on an object that was
+    never prepared takes two plain allocations: zero candidates, no calibration sorts (host time of the enqueue well under
+    what the search costs), and a sort that outgrows what an explicit prepare had placed resets the report."""
+    import time
+
+    import torch
+
+    n = 1 << 27
+    monkeypatch.setenv("GLU_HIP_SCRATCH_TUNE_LIST", "512:4")  # (a fixed list: the search, where it runs, tries all four)
+    kt = torch.randint(-2**31, 2**31, (n,), dtype=torch.int32, device="cuda")
+    vt = torch.arange(n, dtype=torch.int32, device="cuda")
+    G.RadixSort()(G.ShaderStorageBuffer(np.arange(4096, dtype=np.uint32)), G.ShaderStorageBuffer(np.arange(4096, dtype=np.uint32)), 4096)
+    torch.cuda.synchronize()
+    lazy = G.RadixSort()
+    stream = torch.cuda.Stream()
+    t0 = time.perf_counter()
+    lazy.run_ptr(kt.data_ptr(), vt.data_ptr(), n, 0, stream.cuda_stream)
+    host_ms = (time.perf_counter() - t0) * 1e3
+    torch.cuda.synchronize()
+    assert lazy.scratch_placement()["candidates"] == 0
+    assert host_ms < 50.0, host_ms  # (the search: >= 4 x 3 calibration sorts of 2 ms + allocations)
+    k = kt.cpu().numpy().view(np.uint32)
+    assert (k[1:] >= k[:-1]).all()
+    # an explicit prepare of a larger size does search; a later sort that outgrows it again does not, and says so
+    placed = G.RadixSort()
+    placed.prepare_internal_buffers(n)
+    assert placed.scratch_placement()["candidates"] == 4
+    n2 = n + (1 << 20)
+    kt2 = torch.randint(-2**31, 2**31, (n2,), dtype=torch.int32, device="cuda")
+    vt2 = torch.arange(n2, dtype=torch.int32, device="cuda")
+    placed.run_ptr(kt2.data_ptr(), vt2.data_ptr(), n2, 0, stream.cuda_stream)
+    torch.cuda.synchronize()
+    assert placed.scratch_placement()["candidates"] == 0
+    k = kt2.cpu().numpy().view(np.uint32)
+    assert (k[1:] >= k[:-1]).all()
+
+
 def test_full_size_2_28_duplicate_heavy(G):
     n = 1 << 28
     rng = np.random.default_rng(11)

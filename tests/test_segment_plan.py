@@ -88,3 +88,22 @@ def test_empty_input_and_argument_checks():
     assert len(subs) == 0 and not wg_first.any() and not seg_first.any() and not seg_start.any()
     with pytest.raises(G.GluError):
         G.plan_segments([0], [10], [5], 3, 4)  # segment out of range
+
+
+def test_an_absurd_segment_count_is_refused_not_indexed():
+    """num_segments sizes host vectors (num_segments + 1 entries): 0xFFFFFFFF used to wrap that to zero and index it."""
+    import ctypes
+
+    L = G.lib()
+    pb = np.array([0], dtype=np.uint64)
+    pl = np.array([10], dtype=np.uint64)
+    ps = np.array([0], dtype=np.uint32)
+    n = ctypes.c_size_t(0)
+    u64p, u32p = ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32)
+    for nseg in (0xFFFFFFFF, (1 << 24) + 1):
+        rc = L.glu_radix_sort_plan_segments(pb.ctypes.data_as(u64p), pl.ctypes.data_as(u64p), ps.ctypes.data_as(u32p), 1, nseg, 4,
+                                            None, 0, None, None, None, ctypes.byref(n))
+        assert rc == G.GLU_ERROR_INVALID_ARGUMENT and b"num_segments" in L.glu_last_error()
+    rc = L.glu_radix_sort_plan_segments(pb.ctypes.data_as(u64p), pl.ctypes.data_as(u64p), ps.ctypes.data_as(u32p), 1, 1, 0xFFFFFFFF,
+                                        None, 0, None, None, None, ctypes.byref(n))
+    assert rc == G.GLU_ERROR_INVALID_ARGUMENT
