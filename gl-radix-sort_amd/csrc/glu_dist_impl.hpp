@@ -194,6 +194,7 @@ struct glu_dist_s
     bool seg_enabled = true;                // GLU_HIP_DIST_SEG=0: always the ordinary local sort
     bool seg_forced = false;                // GLU_HIP_DIST_SEG=2: segmented whenever the shard has 2^16 pairs, however fragmented (tests)
     int test_fail_begin = -1, test_fail_finish = -1; // GLU_HIP_DIST_TEST_FAIL=begin:<rank> / finish:<rank>: that rank reports a failure
+    int test_fault = 0; // GLU_HIP_DIST_TEST_FAULT=no_hist_wait: 1 = a stream dependency is left out on purpose (negative control of the tests)
     uint32_t last_local_sort = 0;           // 1 = the last sort's local sort was segmented, 0 = ordinary (glu_dist_last_local_sort)
     std::vector<int> owner;
     std::vector<uint64_t> send_counts, recv_counts;
@@ -263,6 +264,7 @@ glu_status glu_dist_create(const void* unique_id, size_t id_bytes, int world_siz
         if (atoll(e) > 0) d->shard_limit = (uint64_t) atoll(e);
     if (const char* e = getenv("GLU_HIP_DIST_SEG_MIN")) d->seg_min = (size_t) atoll(e);
     if (const char* e = getenv("GLU_HIP_DIST_SEG")) d->seg_enabled = atoi(e) != 0, d->seg_forced = atoi(e) == 2;
+    if (const char* e = getenv("GLU_HIP_DIST_TEST_FAULT")) d->test_fault = strcmp(e, "no_hist_wait") == 0 ? 1 : 0;
     if (const char* e = getenv("GLU_HIP_DIST_TEST_FAIL"))
     {
         if (strncmp(e, "begin:", 6) == 0) d->test_fail_begin = atoi(e + 6);
@@ -493,7 +495,9 @@ glu_status glu_dist_sort_begin(glu_dist d, const uint32_t* keys, const uint32_t*
         if (marks && shift == 32 - kDistTopBits) HIP_TRY(hipEventRecord(marks->e[1], st));
 
         // 2. every rank learns every rank's row (R x 264 words): side stream, beside the scatter kernel
-        HIP_TRY(hipStreamWaitEvent(d->aux, d->ev_hist, 0));
+        // (test_fault 1 = fault injection for tests/test_gpu_dist.py::test_async_transport_catches_a_missing_stream_dependency:
+        // the all-gather is then NOT ordered behind the histogram -- what the asynchronous test double must catch)
+        if (d->test_fault != 1) HIP_TRY(hipStreamWaitEvent(d->aux, d->ev_hist, 0));
         if (marks && shift == 32 - kDistTopBits) HIP_TRY(hipEventRecord(marks->e[4], d->aux));
         NCCL_TRY(rccl().AllGather(hist, all_hist, kDistRow, ncclUint32, d->comm, d->aux));
         HIP_TRY(hipMemcpyAsync(d->all_hist_host, all_hist, (size_t) d->world * kDistRow * sizeof(uint32_t), hipMemcpyDeviceToHost, d->aux));

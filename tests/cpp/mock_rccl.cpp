@@ -4,8 +4,17 @@
 // (plan with world > 1, send / receive offsets, receive order, empty shards, the lower-byte fallback agreed between
 // ranks) would never run before the 8-GPU bench does.  This library lets several PROCESSES sharing one GPU act as ranks:
 // GLU_HIP_RCCL_LIB=<this .so> makes libglu_hip.so bind it instead of librccl; the ranks exchange through files in
-// $GLU_MOCK_RCCL_DIR (device -> host -> file -> host -> device).  It is not a transport anybody should ship: every call
-// synchronises the stream and blocks on the host.  What it keeps of the real semantics is what the caller relies on:
+// $GLU_MOCK_RCCL_DIR (device -> host -> file -> host -> device).  It is not a transport anybody should ship.  Two modes:
+//   * default (synchronous): every call synchronises the stream and blocks on the host.  That proves offsets, counts and the
+//     plan, but it HIDES stream-order bugs: whatever the caller forgot to order before the collective has finished anyway.
+//   * GLU_MOCK_RCCL_ASYNC=1 (asynchronous, like the real library): a call only ENQUEUES.  It records an event on the
+//     caller's stream, launches a one-lane kernel there that waits for a flag in pinned host memory, hands the work to the
+//     communicator's worker thread and returns at once; ncclGroupEnd does not wait either.  The worker waits for the event
+//     (= the stream has reached the collective), moves the bytes on a private non-blocking stream at THAT moment, then
+//     raises the flag and the caller's stream runs on.  A send buffer that is not yet written when the stream gets there, a
+//     receive buffer still in use, a histogram gathered before its kernel ran: the data is wrong and the test fails, as it
+//     would (sometimes) with RCCL.  Errors of the worker surface at the next call on the communicator.
+// What both keep of the real semantics is what the caller relies on:
 //   * ncclAllGather: rank r's `count` elements land at recv + r * count on every rank;
 //   * ncclSend / ncclRecv inside ncclGroupStart .. ncclGroupEnd: the i-th send of rank a to rank b pairs with the i-th
 //     receive of rank b from rank a; a size mismatch is an error (real RCCL would hang or corrupt: here the test fails);
@@ -17,8 +26,12 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdint>
+#include <deque>
+#include <mutex>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -28,13 +41,7 @@
 
 namespace
 {
-struct MockComm
-{
-    int nranks = 1, rank = 0;
-    std::string tag;
-    uint64_t gather_seq = 0;
-    std::vector<uint64_t> send_seq, recv_seq; // per peer
-};
+struct MockComm;
 
 struct Op
 {
@@ -44,7 +51,49 @@ struct Op
     int peer;
     MockComm* comm;
     hipStream_t stream;
+    std::string path;           // asynchronous mode: named when the call is made (call order pairs sends with receives)
+    const void* gather_send = nullptr; // asynchronous all-gather: ptr = receive array, bytes per rank
+    bool gather = false;
 };
+
+struct Job
+{
+    std::vector<Op> ops;
+    std::vector<hipEvent_t> ready; // one per stream the operations were enqueued on
+    uint32_t seq = 0;
+};
+
+struct MockComm
+{
+    int nranks = 1, rank = 0;
+    std::string tag;
+    uint64_t gather_seq = 0;
+    std::vector<uint64_t> send_seq, recv_seq; // per peer
+    // asynchronous mode
+    bool async = false;
+    int device = 0;
+    std::thread worker;
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<Job> jobs;
+    bool stop = false;
+    uint32_t* flag = nullptr; // pinned, coherent: number of jobs the worker has completed
+    uint32_t enqueued = 0;
+    std::atomic<int> failed{(int) ncclSuccess};
+    hipStream_t copy_stream = nullptr;
+};
+
+// the caller's stream stops here until the worker has finished job `target` (or gave up: the worker always raises the flag;
+// the bound only keeps a dead worker from hanging the device)
+__global__ void mock_wait_kernel(const uint32_t* flag, uint32_t target)
+{
+    const uint64_t t0 = wall_clock64();
+    while ((int32_t) (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - target) < 0)
+    {
+        if (wall_clock64() - t0 > 150ull * 100000000ull) break; // 150 s of the 100 MHz wall clock
+        __builtin_amdgcn_s_sleep(127);
+    }
+}
 
 thread_local int g_depth = 0;
 thread_local std::vector<Op> g_ops;
@@ -87,10 +136,12 @@ bool write_file(const std::string& path, const void* data, size_t bytes)
 ncclResult_t read_file(const std::string& path, void* data, size_t bytes)
 {
     const auto t0 = std::chrono::steady_clock::now();
+    const char* limit_env = getenv("GLU_MOCK_RCCL_TIMEOUT_S");
+    const int limit_s = limit_env && atoi(limit_env) > 0 ? atoi(limit_env) : 120;
     struct stat st;
     while (stat(path.c_str(), &st) != 0)
     {
-        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120))
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(limit_s))
         {
             fprintf(stderr, "[mock_rccl] timed out waiting for %s\n", path.c_str());
             return ncclSystemError;
@@ -109,31 +160,132 @@ ncclResult_t read_file(const std::string& path, void* data, size_t bytes)
     return ok ? ncclSuccess : ncclSystemError;
 }
 
-ncclResult_t run_ops(std::vector<Op>& ops)
+std::string p2p_path(MockComm* c, bool send, int peer)
 {
-    for (const Op& op : ops)
-        if (hipStreamSynchronize(op.stream) != hipSuccess) return ncclUnhandledCudaError;
+    return send ? std::string(dir()) + "/" + c->tag + ".p2p." + std::to_string(c->rank) + "." + std::to_string(peer) + "." +
+                      std::to_string(c->send_seq[peer]++)
+                : std::string(dir()) + "/" + c->tag + ".p2p." + std::to_string(peer) + "." + std::to_string(c->rank) + "." +
+                      std::to_string(c->recv_seq[peer]++);
+}
+
+// synchronous copy; in the worker thread on the communicator's private non-blocking stream (the null stream would wait
+// for the very streams that are parked in mock_wait_kernel)
+bool copy_now(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t copy_stream)
+{
+    if (!bytes) return true;
+    if (!copy_stream) return hipMemcpy(dst, src, bytes, kind) == hipSuccess;
+    return hipMemcpyAsync(dst, src, bytes, kind, copy_stream) == hipSuccess && hipStreamSynchronize(copy_stream) == hipSuccess;
+}
+
+ncclResult_t gather_now(MockComm* c, const void* send, void* recv, size_t bytes, const std::string& base, hipStream_t copy_stream)
+{
+    std::vector<unsigned char> host(bytes);
+    if (!copy_now(host.data(), send, bytes, hipMemcpyDeviceToHost, copy_stream)) return ncclUnhandledCudaError;
+    if (!write_file(base + std::to_string(c->rank), host.data(), bytes)) return ncclSystemError;
+    for (int r = 0; r < c->nranks; r++)
+    {
+        if (ncclResult_t res = read_file(base + std::to_string(r), host.data(), bytes); res != ncclSuccess) return res;
+        if (!copy_now((unsigned char*) recv + (size_t) r * bytes, host.data(), bytes, hipMemcpyHostToDevice, copy_stream))
+            return ncclUnhandledCudaError;
+    }
+    return ncclSuccess;
+}
+
+// the data movement of one call / one group (paths already named); copy_stream == nullptr: on the calling thread, after
+// the caller's streams were synchronised
+ncclResult_t move_ops(std::vector<Op>& ops, hipStream_t copy_stream)
+{
     std::vector<unsigned char> host;
     for (const Op& op : ops) // all sends first: nobody waits for a peer before its own data is out
     {
-        if (!op.send) continue;
+        if (!op.send || op.gather) continue;
         host.resize(op.bytes);
-        if (op.bytes && hipMemcpy(host.data(), op.ptr, op.bytes, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
-        const std::string path = std::string(dir()) + "/" + op.comm->tag + ".p2p." + std::to_string(op.comm->rank) + "." +
-                                 std::to_string(op.peer) + "." + std::to_string(op.comm->send_seq[op.peer]++);
-        if (!write_file(path, host.data(), op.bytes)) return ncclSystemError;
+        if (!copy_now(host.data(), op.ptr, op.bytes, hipMemcpyDeviceToHost, copy_stream)) return ncclUnhandledCudaError;
+        if (!write_file(op.path, host.data(), op.bytes)) return ncclSystemError;
     }
     for (const Op& op : ops)
     {
+        if (op.gather)
+        {
+            if (ncclResult_t r = gather_now(op.comm, op.gather_send, op.ptr, op.bytes, op.path, copy_stream); r != ncclSuccess) return r;
+            continue;
+        }
         if (op.send) continue;
         host.resize(op.bytes);
-        const std::string path = std::string(dir()) + "/" + op.comm->tag + ".p2p." + std::to_string(op.peer) + "." +
-                                 std::to_string(op.comm->rank) + "." + std::to_string(op.comm->recv_seq[op.peer]++);
-        if (ncclResult_t r = read_file(path, host.data(), op.bytes); r != ncclSuccess) return r;
-        unlink(path.c_str());
-        if (op.bytes && hipMemcpy(op.ptr, host.data(), op.bytes, hipMemcpyHostToDevice) != hipSuccess) return ncclUnhandledCudaError;
+        if (ncclResult_t r = read_file(op.path, host.data(), op.bytes); r != ncclSuccess) return r;
+        unlink(op.path.c_str());
+        if (!copy_now(op.ptr, host.data(), op.bytes, hipMemcpyHostToDevice, copy_stream)) return ncclUnhandledCudaError;
     }
     return ncclSuccess;
+}
+
+void worker_main(MockComm* c)
+{
+    (void) hipSetDevice(c->device);
+    for (;;)
+    {
+        Job job;
+        {
+            std::unique_lock<std::mutex> lock(c->m);
+            c->cv.wait(lock, [&] { return c->stop || !c->jobs.empty(); });
+            if (c->jobs.empty()) return;
+            job = std::move(c->jobs.front());
+            c->jobs.pop_front();
+        }
+        ncclResult_t res = ncclSuccess;
+        for (hipEvent_t e : job.ready) // the caller's stream has reached the collective: its inputs are what they are NOW
+        {
+            if (hipEventSynchronize(e) != hipSuccess) res = ncclUnhandledCudaError;
+            (void) hipEventDestroy(e);
+        }
+        if (res == ncclSuccess) res = move_ops(job.ops, c->copy_stream);
+        if (res != ncclSuccess)
+        {
+            fprintf(stderr, "[mock_rccl] rank %d: asynchronous operation %u failed (%d)\n", c->rank, job.seq, (int) res);
+            c->failed.store((int) res);
+        }
+        __atomic_store_n(c->flag, job.seq, __ATOMIC_RELEASE); // the caller's stream runs on
+    }
+}
+
+// asynchronous mode: event + wait kernel on every stream of the operations, the rest is the worker's
+ncclResult_t enqueue_ops(MockComm* c, std::vector<Op>& ops)
+{
+    if (int f = c->failed.load(); f != (int) ncclSuccess) return (ncclResult_t) f;
+    Job job;
+    job.seq = ++c->enqueued;
+    std::vector<hipStream_t> streams;
+    for (const Op& op : ops)
+    {
+        bool seen = false;
+        for (hipStream_t s : streams) seen = seen || s == op.stream;
+        if (!seen) streams.push_back(op.stream);
+    }
+    for (hipStream_t s : streams)
+    {
+        hipEvent_t e;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess || hipEventRecord(e, s) != hipSuccess) return ncclUnhandledCudaError;
+        job.ready.push_back(e);
+        hipLaunchKernelGGL(mock_wait_kernel, dim3(1), dim3(1), 0, s, c->flag, job.seq);
+        if (hipGetLastError() != hipSuccess) return ncclUnhandledCudaError;
+    }
+    job.ops = std::move(ops);
+    {
+        std::lock_guard<std::mutex> lock(c->m);
+        c->jobs.push_back(std::move(job));
+    }
+    c->cv.notify_one();
+    return ncclSuccess;
+}
+
+ncclResult_t run_ops(std::vector<Op>& ops)
+{
+    if (ops.empty()) return ncclSuccess;
+    for (Op& op : ops) op.path = p2p_path(op.comm, op.send, op.peer);
+    if (ops.front().comm->async) return enqueue_ops(ops.front().comm, ops);
+    for (const Op& op : ops)
+        if (hipStreamSynchronize(op.stream) != hipSuccess) return ncclUnhandledCudaError;
+    return move_ops(ops, nullptr);
 }
 
 ncclResult_t p2p(bool send, void* ptr, size_t count, ncclDataType_t type, int peer, ncclComm_t comm, hipStream_t stream)
@@ -141,7 +293,7 @@ ncclResult_t p2p(bool send, void* ptr, size_t count, ncclDataType_t type, int pe
     MockComm* c = reinterpret_cast<MockComm*>(comm);
     if (!c || peer < 0 || peer >= c->nranks || type_size(type) == 0) return ncclInvalidArgument;
     if (count && !ptr) return ncclInvalidArgument;
-    Op op{send, ptr, count * type_size(type), peer, c, stream};
+    Op op{send, ptr, count * type_size(type), peer, c, stream, std::string()};
     if (g_depth > 0)
     {
         g_ops.push_back(op);
@@ -175,13 +327,37 @@ ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId id, int
     c->tag = hex;
     c->send_seq.assign(nranks, 0);
     c->recv_seq.assign(nranks, 0);
+    if (const char* e = getenv("GLU_MOCK_RCCL_ASYNC"); e && atoi(e) != 0)
+    {
+        c->async = true;
+        if (hipGetDevice(&c->device) != hipSuccess || hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+            hipHostMalloc((void**) &c->flag, 64, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess)
+        {
+            delete c;
+            return ncclUnhandledCudaError;
+        }
+        *c->flag = 0;
+        c->worker = std::thread(worker_main, c);
+    }
     *comm = reinterpret_cast<ncclComm_t>(c);
     return ncclSuccess;
 }
 
 ncclResult_t ncclCommDestroy(ncclComm_t comm)
 {
-    delete reinterpret_cast<MockComm*>(comm);
+    MockComm* c = reinterpret_cast<MockComm*>(comm);
+    if (c && c->async)
+    {
+        {
+            std::lock_guard<std::mutex> lock(c->m);
+            c->stop = true; // (the worker finishes what is queued first)
+        }
+        c->cv.notify_one();
+        c->worker.join();
+        (void) hipStreamDestroy(c->copy_stream);
+        (void) hipHostFree(c->flag);
+    }
+    delete c;
     return ncclSuccess;
 }
 
@@ -202,18 +378,17 @@ ncclResult_t ncclAllGather(const void* send, void* recv, size_t count, ncclDataT
     MockComm* c = reinterpret_cast<MockComm*>(comm);
     const size_t bytes = count * type_size(type);
     if (!c || type_size(type) == 0 || (bytes && (!send || !recv))) return ncclInvalidArgument;
-    if (hipStreamSynchronize(stream) != hipSuccess) return ncclUnhandledCudaError;
-    std::vector<unsigned char> host(bytes);
-    if (bytes && hipMemcpy(host.data(), send, bytes, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
     const std::string base = std::string(dir()) + "/" + c->tag + ".gather." + std::to_string(c->gather_seq++) + ".";
-    if (!write_file(base + std::to_string(c->rank), host.data(), bytes)) return ncclSystemError;
-    for (int r = 0; r < c->nranks; r++)
+    if (c->async)
     {
-        if (ncclResult_t res = read_file(base + std::to_string(r), host.data(), bytes); res != ncclSuccess) return res;
-        if (bytes && hipMemcpy((unsigned char*) recv + (size_t) r * bytes, host.data(), bytes, hipMemcpyHostToDevice) != hipSuccess)
-            return ncclUnhandledCudaError;
+        Op op{false, recv, bytes, c->rank, c, stream, base};
+        op.gather = true;
+        op.gather_send = send;
+        std::vector<Op> one{op};
+        return enqueue_ops(c, one);
     }
-    return ncclSuccess;
+    if (hipStreamSynchronize(stream) != hipSuccess) return ncclUnhandledCudaError;
+    return gather_now(c, send, recv, bytes, base, nullptr);
 }
 
 ncclResult_t ncclSend(const void* ptr, size_t count, ncclDataType_t type, int peer, ncclComm_t comm, hipStream_t stream)

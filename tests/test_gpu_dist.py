@@ -348,10 +348,12 @@ def _mock_cases(world):
     return cases
 
 
-def _mock_rank_worker(rank, world, unique_id, mock_lib, mock_dir, q, seg_mode=None):
+def _mock_rank_worker(rank, world, unique_id, mock_lib, mock_dir, q, seg_mode=None, mock_async=False):
     import os
     import sys
 
+    if mock_async:  # the test double only enqueues, like RCCL (tests/cpp/mock_rccl.cpp): stream-order bugs become wrong data
+        os.environ["GLU_MOCK_RCCL_ASYNC"] = "1"
     if seg_mode is not None:
         os.environ["GLU_HIP_DIST_SEG"] = seg_mode  # "2": segmented local sort for every shard of 2^16 pairs up; "0": never
 
@@ -371,6 +373,12 @@ def _mock_rank_worker(rank, world, unique_id, mock_lib, mock_dir, q, seg_mode=No
     first = G.Dist(unique_id, world, rank)
     second = G.Dist(unique_id[::-1], world, rank)  # a second communicator: two sorts in flight below
     out = []
+    hip = ctypes.CDLL("libamdhip64.so")
+    streams = []
+    for _ in range(2):  # two caller streams (non-blocking), one per object, for the back-to-back sequence below
+        st = ctypes.c_void_p()
+        assert hip.hipStreamCreateWithFlags(ctypes.byref(st), 1) == 0
+        streams.append(st)
 
     def read_back(ptr, n):
         host = np.empty(n, dtype=np.uint32)
@@ -399,6 +407,21 @@ def _mock_rank_worker(rank, world, unique_id, mock_lib, mock_dir, q, seg_mode=No
         same = n1 == cnt and n2 == cnt
         for b, ref in ((rk1, gk), (rv1, gv), (rk2, gk), (rv2, gv)):
             same = same and bool((b.get_data(np.uint32)[:cnt] == ref).all())
+        # back to back with no host synchronisation in between, each object on its own caller stream: a sort of a DIFFERENT
+        # input (the slice reversed) followed at once by the sort of the real one on the same object -- its partition
+        # arrays, histogram rows, landing arrays and scratch are reused while the sort before is still in flight -- and the
+        # other object's sort of the real input beside them.  Only stream order keeps the three apart.
+        rev_k = G.ShaderStorageBuffer(np.ascontiguousarray(keys[::-1])) if keys.size else None
+        rev_v = G.ShaderStorageBuffer(np.ascontiguousarray(vals[::-1])) if keys.size else None
+        rkp, rvp = (rev_k.device_ptr(), rev_v.device_ptr()) if keys.size else (None, None)
+        G.synchronize()
+        first.sort_ptr(rkp, rvp, keys.size, stream=streams[0])
+        b2k, b2v, b2n = second.sort_ptr(kp, vp, keys.size, stream=streams[1])
+        b1k, b1v, b1n = first.sort_ptr(kp, vp, keys.size, stream=streams[0])
+        G.synchronize()
+        same = same and b1n == cnt and b2n == cnt
+        for ptr, ref in ((b1k, gk), (b1v, gv), (b2k, gk), (b2v, gv)):
+            same = same and bool((read_back(ptr, cnt) == ref).all())
         if keys.size:  # the input is untouched
             same = same and bool((kb.get_data(np.uint32) == keys).all()) and bool((vb.get_data(np.uint32) == vals).all())
         out.append((name, first.partition_shift(), gk, gv, same, first.last_local_sort()))
@@ -407,12 +430,15 @@ def _mock_rank_worker(rank, world, unique_id, mock_lib, mock_dir, q, seg_mode=No
     q.put((rank, out))
 
 
-@pytest.mark.parametrize("seg_mode", ["2", "0", None])
+@pytest.mark.parametrize("seg_mode,mock_async", [("2", False), ("0", False), (None, False), ("2", True), (None, True)],
+                         ids=["seg-sync", "noseg-sync", "default-sync", "seg-async", "default-async"])
 @pytest.mark.parametrize("world", [2, 3, 8])
-def test_native_multi_rank_sort_over_mock_transport(built, world, seg_mode, tmp_path):
+def test_native_multi_rank_sort_over_mock_transport(built, world, seg_mode, mock_async, tmp_path):
     """seg_mode "2": every shard of 2^16 pairs or more takes the segmented local sort (the exchange then lands in the
     sorter's scratch and the first pass regroups the source-major shard by bucket), "0": never, None: the library's rule
-    (these shards are below its 2^24 threshold)."""
+    (these shards are below its 2^24 threshold).  mock_async: the test double only ENQUEUES its collectives on the caller's
+    stream and returns (GLU_MOCK_RCCL_ASYNC, like the real library), so a missing stream dependency shows as wrong data;
+    the synchronous mode proves offsets and the plan only."""
     import torch.multiprocessing as mp
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -421,7 +447,8 @@ def test_native_multi_rank_sort_over_mock_transport(built, world, seg_mode, tmp_
     unique_id = os.urandom(128)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_mock_rank_worker, args=(r, world, unique_id, mock_lib, str(tmp_path), q, seg_mode)) for r in range(world)]
+    procs = [ctx.Process(target=_mock_rank_worker, args=(r, world, unique_id, mock_lib, str(tmp_path), q, seg_mode, mock_async))
+             for r in range(world)]
     for p in procs:
         p.start()
     import queue
@@ -457,9 +484,90 @@ def test_native_multi_rank_sort_over_mock_transport(built, world, seg_mode, tmp_
             assert max(sizes) <= ek.size / world + hottest, (sizes, hottest)
 
 
-def _mock_failure_worker(rank, world, unique_id, mock_lib, mock_dir, q, env):
+def _mock_fault_worker(rank, world, unique_id, mock_lib, mock_dir, q, fault):
     import os
     import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (os.path.join(root, "gl-radix-sort_amd"), os.path.join(root, "oracle"), os.path.join(root, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(GLU_HIP_RCCL_LIB=mock_lib, GLU_MOCK_RCCL_DIR=mock_dir, GLU_MOCK_RCCL_ASYNC="1", GLU_MOCK_RCCL_TIMEOUT_S="20")
+    if fault:
+        os.environ["GLU_HIP_DIST_TEST_FAULT"] = fault
+    import ctypes
+
+    import numpy as np
+    import glu_hip as G
+
+    G.set_device(0)
+    d = G.Dist(unique_id, world, rank)
+    n = 3 * (1 << 20) + 1000 * rank
+    verdicts = []
+    for attempt in range(3):  # a different input every time: a histogram left over from the sort before is a wrong one
+        keys = np.random.default_rng(50 + 7 * attempt + rank).integers(0, 2**32 >> (8 * attempt), n, dtype=np.uint32) << np.uint32(8 * attempt)
+        vals = np.arange(n, dtype=np.uint32)
+        kb, vb = G.ShaderStorageBuffer(keys), G.ShaderStorageBuffer(vals)
+        G.synchronize()
+        try:
+            kp, vp, cnt = d.sort_ptr(kb.device_ptr(), vb.device_ptr(), n)
+            G.synchronize()
+            host = np.empty(cnt, dtype=np.uint32)
+            h = ctypes.c_uint32(0)
+            if cnt:
+                G.check(G.lib().glu_buffer_wrap(ctypes.c_void_p(kp), cnt * 4, ctypes.byref(h)))
+                G.check(G.lib().glu_buffer_read(h, host.ctypes.data_as(ctypes.c_void_p), cnt * 4, 0))
+                G.check(G.lib().glu_buffer_destroy(h))
+            verdicts.append(("sorted" if (host[1:] >= host[:-1]).all() else "unsorted", int(cnt)))
+        except G.GluError as e:
+            verdicts.append(("error", str(e)))
+            break  # (the ranks may no longer agree on what comes next)
+    q.put((rank, verdicts))
+    os._exit(0)  # (after a fault the object may be unusable: no orderly destroy)
+
+
+@pytest.mark.parametrize("fault", [None, "no_hist_wait"])
+def test_async_transport_catches_a_missing_stream_dependency(built, fault, tmp_path):
+    """Negative control of the asynchronous test double: GLU_HIP_DIST_TEST_FAULT=no_hist_wait leaves out the one
+    hipStreamWaitEvent that orders the histogram all-gather (side stream) behind the partition's count + scan kernels.  With
+    a transport that only enqueues, the gather then reads the histogram before it exists: the rows do not add up to the slice
+    sizes (every rank refuses) or the shards come out wrong.  Without the fault the same three sorts are right."""
+    import queue
+
+    import torch.multiprocessing as mp
+
+    world = 2
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    mock_lib = os.path.join(root, "tests", "cpp", "bin", "libmock_rccl.so")
+    unique_id = os.urandom(128)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_mock_fault_worker, args=(r, world, unique_id, mock_lib, str(tmp_path), q, fault)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        results = dict(q.get(timeout=300) for _ in range(world))
+    except queue.Empty:
+        for p in procs:
+            p.kill()
+        raise AssertionError("a rank hung or died (exit codes %s)" % [p.exitcode for p in procs])
+    for p in procs:
+        p.join(timeout=60)
+    total = sum(3 * (1 << 20) + 1000 * r for r in range(world))
+    clean = all(len(v) == 3 and all(x[0] == "sorted" for x in v) for v in results.values()) and \
+        all(sum(results[r][i][1] for r in range(world)) == total for i in range(3))
+    if fault is None:
+        assert clean, results
+    else:
+        assert not clean, "the asynchronous transport did not notice the missing hipStreamWaitEvent: %r" % (results,)
+
+
+def _mock_failure_worker(rank, world, unique_id, mock_lib, mock_dir, q, env, mock_async=False):
+    import os
+    import sys
+
+    if mock_async:
+        os.environ["GLU_MOCK_RCCL_ASYNC"] = "1"
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for p in (os.path.join(root, "gl-radix-sort_amd"), os.path.join(root, "oracle"), os.path.join(root, "tests")):
@@ -512,9 +620,10 @@ def _mock_failure_worker(rank, world, unique_id, mock_lib, mock_dir, q, env):
     q.put((rank, outcomes))
 
 
+@pytest.mark.parametrize("mock_async", [False, True], ids=["sync", "async"])
 @pytest.mark.parametrize("env", [{"GLU_HIP_DIST_TEST_SHARD_LIMIT": "150000"}, {"GLU_HIP_DIST_TEST_FAIL": "begin:2"},
                                  {"GLU_HIP_DIST_TEST_FAIL": "finish:0"}, {}])
-def test_native_failures_are_collective(built, env, tmp_path):
+def test_native_failures_are_collective(built, env, mock_async, tmp_path):
     """One rank's shard over the (test-lowered) limit, a rank whose allocation fails before the histogram exchange or before
     the data exchange, a rank that cannot provide receive arrays: EVERY rank returns a failure from that call and none
     hangs in a collective; with nothing wrong any more the same objects sort."""
@@ -527,7 +636,8 @@ def test_native_failures_are_collective(built, env, tmp_path):
     unique_id = os.urandom(128)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_mock_failure_worker, args=(r, world, unique_id, mock_lib, str(tmp_path), q, env)) for r in range(world)]
+    procs = [ctx.Process(target=_mock_failure_worker, args=(r, world, unique_id, mock_lib, str(tmp_path), q, env, mock_async))
+             for r in range(world)]
     for p in procs:
         p.start()
     try:
@@ -565,7 +675,8 @@ def test_native_failures_are_collective(built, env, tmp_path):
         assert sum(results[r][3][1] for r in range(world)) == sum(100000 + 10 * r for r in range(world))
 
 
-def test_bench_multi_gpu_command_line_rehearsal(built):
+@pytest.mark.parametrize("mock_async", ["0", "1"], ids=["sync", "async"])
+def test_bench_multi_gpu_command_line_rehearsal(built, mock_async):
     """The driver's N > 1 bench launch (torchrun, one rank per process) with 2 ranks sharing the GPU: gloo process group,
     glu_dist over the file transport.  Not a measurement -- it checks that the launch, the collectives, the verification
     and the JSON line of bench.py's multi-GPU branch work."""
@@ -573,7 +684,8 @@ def test_bench_multi_gpu_command_line_rehearsal(built):
     import subprocess
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, GRAFT_REPO_ROOT=root)
+    env = dict(os.environ, GRAFT_REPO_ROOT=root, GLU_MOCK_RCCL_ASYNC=mock_async)  # (async: the depth-2 pair of communicators
+    #                                                                                  really has two exchanges in flight)
     p = subprocess.run(["bash", os.path.join(root, "tools", "rehearse_multi_gpu.sh"), "2", "20"], capture_output=True, text=True,
                        env=env, timeout=900)
     assert p.returncode == 0, p.stderr[-2000:]

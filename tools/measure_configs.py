@@ -1,5 +1,8 @@
-"""Times the BASELINE.json configurations that fit one GPU (device time via the library timer, best of 5 on
-restored inputs).  python tools/measure_configs.py"""
+"""Times the BASELINE.json configurations that fit one GPU (device time via the library timer on restored inputs).
+Configurations of 2^26 elements and more are timed on ten PLACEMENTS of their arrays (five caller pairs x two sorter
+objects) and every line leads with the MEDIAN of the ten, minimum and maximum in brackets: where the arrays lie in HBM moves
+these numbers by 5-8 %, and the median is what a caller gets.  Smaller ones: best of 5.
+python tools/measure_configs.py"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "gl-radix-sort_amd"))
@@ -11,9 +14,10 @@ rng = np.random.default_rng(0x5EED)
 
 
 def time_sort(keys, vals, bits, key_bytes=4, reps=5):
-    """Best device time over `placements`: the caller's arrays are allocated 5 times and the sorter (its scratch) twice for the
+    """Device time over `placements`: the caller's arrays are allocated 5 times and the sorter (its scratch) twice for the
     2^28 configurations, because where the arrays lie in HBM decides between discrete speeds of the scatter kernel (C5:
-    1.31 / 1.39 / 1.50 ms per pass).  time_sort.spread = (min, median, max) over the placements."""
+    1.31 / 1.39 / 1.50 ms per pass).  Returns the MEDIAN over the placements (the best of `reps` for
+    the small configurations, which have one placement); time_sort.spread = (min, median, max, placements)."""
     n = keys.size
     many = n >= 1 << 26
     sorters = []
@@ -33,7 +37,7 @@ def time_sort(keys, vals, bits, key_bytes=4, reps=5):
                 t_here = min(t_here, G.measure_elapsed_time(lambda: s(k, v, n, 0, key_bytes=key_bytes)))
             times.append(t_here)
     times.sort()
-    best = times[0]
+    best = times[len(times) // 2] if many else times[0]
     time_sort.spread = (times[0] * 1e-6, times[len(times) // 2] * 1e-6, times[-1] * 1e-6, len(times))
     s = sorters[0]
     # bytes really moved per pair: a pass whose count table came from its leader's two-digit histogram did not read the keys
@@ -74,7 +78,7 @@ for name, log2n, kind, key_bytes in (("C2 2^20 u32+u32 uniform", 20, "uniform", 
             continue
         own = "" if moved is None or abs(moved - bpp) < 0.01 else "; moved %.1f B/pair: %.1f %%" % (moved, n * moved / t / 8e12 * 100)
         sp = time_sort.spread
-        spread = "" if sp[3] == 1 else "  [%d placements: min %.3f median %.3f max %.3f ms]" % (sp[3], sp[0], sp[1], sp[2])
+        spread = "" if sp[3] == 1 else "  [median of %d placements; min %.3f max %.3f ms]" % (sp[3], sp[0], sp[2])
         print("%-46s digits %d-bit: %8.3f ms  %9.1f Mkeys/s  %6.0f GB/s at %d B/pair (%.1f %% of 8 TB/s%s)%s" % (
             name, bits, t * 1e3, n / t / 1e6, n * bpp / t / 1e9, bpp, n * bpp / t / 8e12 * 100, own, spread), flush=True)
 
@@ -83,9 +87,13 @@ d = rng.integers(0, 2**32, n, dtype=np.uint32)
 b = G.ShaderStorageBuffer(d)
 sc = G.BlellochScan(G.DataType_Uint)
 sc(b, n)
-t = min(G.measure_elapsed_time(lambda: sc(b, n)) for _ in range(5)) * 1e-9
-print("BlellochScan 2^28 u32: %.3f ms  %.0f GB/s at 8 B/elem (%.1f %%)" % (t * 1e3, n * 8 / t / 1e9, n * 8 / t / 8e12 * 100))
+ts = sorted(G.measure_elapsed_time(lambda: sc(b, n)) for _ in range(9))
+t = ts[len(ts) // 2] * 1e-9
+print("BlellochScan 2^28 u32: %.3f ms  %.0f GB/s at 8 B/elem (%.1f %%)  [median of 9 runs; min %.3f max %.3f ms]" % (
+    t * 1e3, n * 8 / t / 1e9, n * 8 / t / 8e12 * 100, ts[0] * 1e-6, ts[-1] * 1e-6))
 rd = G.Reduce(G.DataType_Uint, G.ReduceOperator_Sum)
 rd(b, n)
-t = min(G.measure_elapsed_time(lambda: rd(b, n)) for _ in range(5)) * 1e-9
-print("Reduce 2^28 u32 sum:   %.3f ms  %.0f GB/s at 4 B/elem (%.1f %%)" % (t * 1e3, n * 4 / t / 1e9, n * 4 / t / 8e12 * 100))
+ts = sorted(G.measure_elapsed_time(lambda: rd(b, n)) for _ in range(9))
+t = ts[len(ts) // 2] * 1e-9
+print("Reduce 2^28 u32 sum:   %.3f ms  %.0f GB/s at 4 B/elem (%.1f %%)  [median of 9 runs; min %.3f max %.3f ms]" % (
+    t * 1e3, n * 4 / t / 1e9, n * 4 / t / 8e12 * 100, ts[0] * 1e-6, ts[-1] * 1e-6))

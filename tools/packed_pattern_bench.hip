@@ -149,10 +149,11 @@ int main(int argc, char** argv)
     const int wgs = 256;
     const uint32_t per_wg = (uint32_t) (n / wgs);
     const uint32_t region_len = (uint32_t) (n / 256);
-    enum { F22, F21, F12, F11, C22, C21, C12, F22L, F21L, F12L, SORT4_SEP, SORT4_PACKED, NFORMS };
+    enum { F22, F21, F12, F11, C22, C21, C12, F22L, F21L, F12L, SORT4_SEP, SORT4_PACKED, SORT4_ALL_PACKED, NFORMS };
     const char* names[NFORMS] = {"2->2 runs of 32 (1+1 lines)", "2->1 runs of 32 (2 lines)", "1->2 runs of 32", "1->1 runs of 32",
                                  "copy 2->2", "copy 2->1", "copy 1->2", "2->2 runs of 64 (2+2 lines)", "2->1 runs of 64 (4 lines)",
-                                 "1->2 runs of 64", "4 passes, separate scratch (sum)", "4 passes, packed scratch (sum)"};
+                                 "1->2 runs of 64", "4 passes, separate scratch (sum)", "4 passes, packed scratch (sum)",
+                                 "2->1, 1->1, 1->1, 1->2 (sum)"};
     Stat st[NFORMS];
     for (int p = 0; p < placements; p++)
     {
@@ -164,7 +165,7 @@ int main(int argc, char** argv)
             CK(hipMalloc(&s, bytes));
             spacers.push_back(s);
         };
-        u32x4 *ka, *va, *kb, *vb, *pp;
+        u32x4 *ka, *va, *kb, *vb, *pp, *pq;
         const size_t gap = (size_t) p * (512u << 20) / 2 + (p ? (96u << 20) : 0);
         CK(hipMalloc(&ka, n * 4 + slack));
         spacer(gap);
@@ -175,6 +176,8 @@ int main(int argc, char** argv)
         CK(hipMalloc(&vb, n * 4 + slack));
         spacer(gap / 3);
         CK(hipMalloc(&pp, n * 8 + slack));
+        spacer(gap / 5);
+        CK(hipMalloc(&pq, n * 8 + slack)); // a second packed array: passes 1 and 2 of a fully packed pipeline (1->1)
         CK(hipMemset(ka, 1, n * 4));
         CK(hipMemset(va, 2, n * 4));
         CK(hipMemset(pp, 3, n * 8));
@@ -198,9 +201,11 @@ int main(int argc, char** argv)
         const float f22b = time_it([&] { LP(32, false, false, kb, vb, nullptr, ka, va, nullptr); });
         const float f21 = time_it([&] { LP(32, false, true, ka, va, nullptr, nullptr, nullptr, pp); });
         const float f12 = time_it([&] { LP(32, true, false, nullptr, nullptr, pp, ka, va, nullptr); });
-        const float f11 = 0.f; // (would need a second packed array)
+        const float f11 = time_it([&] { LP(32, true, true, nullptr, nullptr, pp, nullptr, nullptr, pq); });
+        const float f11b = time_it([&] { LP(32, true, true, nullptr, nullptr, pq, nullptr, nullptr, pp); });
         st[F22].add(f22), st[F21].add(f21), st[F12].add(f12), st[F11].add(f11);
         st[SORT4_SEP].add(2 * (f22 + f22b)), st[SORT4_PACKED].add(2 * (f21 + f12));
+        st[SORT4_ALL_PACKED].add(f21 + f11 + f11b + f12);
         st[F22L].add(time_it([&] { LP(64, false, false, ka, va, nullptr, kb, vb, nullptr); }));
         st[F21L].add(time_it([&] { LP(64, false, true, ka, va, nullptr, nullptr, nullptr, pp); }));
         st[F12L].add(time_it([&] { LP(64, true, false, nullptr, nullptr, pp, ka, va, nullptr); }));
@@ -209,7 +214,7 @@ int main(int argc, char** argv)
         st[C22].add(time_it([&] { LC(false, false, ka, va, nullptr, kb, vb, nullptr); }));
         st[C21].add(time_it([&] { LC(false, true, ka, va, nullptr, nullptr, nullptr, pp); }));
         st[C12].add(time_it([&] { LC(true, false, nullptr, nullptr, pp, ka, va, nullptr); }));
-        for (void* q : {(void*) ka, (void*) va, (void*) kb, (void*) vb, (void*) pp}) CK(hipFree(q));
+        for (void* q : {(void*) ka, (void*) va, (void*) kb, (void*) vb, (void*) pp, (void*) pq}) CK(hipFree(q));
         for (void* s : spacers) CK(hipFree(s));
     }
     printf("2^%d pairs, %d placements; 16 B/pair per launch\n", log2n, placements);
