@@ -1846,8 +1846,6 @@ struct glu_scan_s
     uint32_t epoch = 0;
     bool chained = true; // GLU_HIP_SCAN_CHAINED=0 falls back to reduce-then-scan
     size_t chain_min_chunks = kChainMinChunks; // GLU_HIP_SCAN_CHAINED=2: chained from 2 chunks up (tests)
-    bool chained_stream = true;  // GLU_HIP_SCAN_STREAM=0: one workgroup per chunk (scan_chunks_kernel<CHAINED>) instead of the persistent kernel
-    uint32_t stream_wgs_per_cu = 2; // GLU_HIP_SCAN_STREAM_WGS
 };
 
 struct glu_reduce_s
@@ -1885,15 +1883,9 @@ glu_status scan_chained(glu_scan_s* scan, Elem<S, N>* data, size_t count, size_t
     using C = ScanCfg<T, kChainGroups, kChainThreads>;
     const size_t chunks = (count + C::CHUNK - 1) / C::CHUNK;
     const size_t words = chunks * partitions;
-    // (the persistent kernel cuts smaller chunks: one chain word each)
-    using CS = ScanCfg<T, kStreamGroups, kChainThreads>;
-    const size_t s_chunks = (count + CS::CHUNK - 1) / CS::CHUNK;
-    const size_t s_words = s_chunks * partitions;
-    const bool streamed = scan->chained_stream && s_words <= 0x7FFFFFFFull;
-    const size_t need_words = streamed ? std::max(words, s_words) : words;
-    if (scan->chain.size < need_words * sizeof(unsigned long long))
+    if (scan->chain.size < words * sizeof(unsigned long long))
     {
-        GLU_TRY(scan->chain.reserve(need_words * sizeof(unsigned long long)));
+        GLU_TRY(scan->chain.reserve(words * sizeof(unsigned long long)));
         HIP_TRY(hipMemsetAsync(scan->chain.ptr, 0, scan->chain.size, stream)); // epoch 0 = never ready
         scan->epoch = 0;
     }
@@ -1905,22 +1897,6 @@ glu_status scan_chained(glu_scan_s* scan, Elem<S, N>* data, size_t count, size_t
     }
     HIP_TRY(hipMemsetAsync(scan->ticket.ptr, 0, 16, stream));
     const bool aligned = ((uintptr_t) data % 16 == 0) && (partitions == 1 || (count * sizeof(T)) % 16 == 0);
-    if (streamed)
-    {
-        // persistent workgroups that take chunk after chunk in ticket order, the next chunk's loads in flight during the
-        // look-back (scan_chained_stream_kernel)
-        const dim3 sgrid((uint32_t) std::min<size_t>(s_words, (size_t) g_dev.num_cus * scan->stream_wgs_per_cu));
-        if (aligned)
-            hipLaunchKernelGGL((scan_chained_stream_kernel<S, N, true>), sgrid, dim3(CS::THREADS), 0, stream, data, (uint64_t) count,
-                               (uint32_t) s_chunks, (uint32_t) s_words, (unsigned long long*) scan->chain.ptr, (uint32_t*) scan->ticket.ptr,
-                               scan->epoch);
-        else
-            hipLaunchKernelGGL((scan_chained_stream_kernel<S, N, false>), sgrid, dim3(CS::THREADS), 0, stream, data, (uint64_t) count,
-                               (uint32_t) s_chunks, (uint32_t) s_words, (unsigned long long*) scan->chain.ptr, (uint32_t*) scan->ticket.ptr,
-                               scan->epoch);
-        HIP_TRY(hipGetLastError());
-        return GLU_OK;
-    }
     const dim3 grid((uint32_t) words);
     if (aligned)
         hipLaunchKernelGGL((scan_chunks_kernel<S, N, true, true>), grid, dim3(C::THREADS), 0, stream, data, (const T*) nullptr,
@@ -2006,11 +1982,9 @@ struct ScanRunner
                 if (size_only)
                 {
                     GLU_TRY(scan->ticket.reserve(256));
-                    constexpr size_t kStreamChunk = ScanCfg<T, kStreamGroups, kChainThreads>::CHUNK;
-                    const size_t chain_words = std::max(chunks, scan->chained_stream ? (count + kStreamChunk - 1) / kStreamChunk : (size_t) 0) * partitions;
-                    if (scan->chain.size < chain_words * 8)
+                    if (scan->chain.size < chunks * partitions * 8)
                     {
-                        GLU_TRY(scan->chain.reserve(chain_words * 8));
+                        GLU_TRY(scan->chain.reserve(chunks * partitions * 8));
                         HIP_TRY(hipMemset(scan->chain.ptr, 0, scan->chain.size));
                         scan->epoch = 0;
                     }
@@ -2093,9 +2067,6 @@ glu_status glu_scan_create(glu_data_type data_type, glu_scan* out)
         s->chained = atoi(e) != 0;
         if (atoi(e) == 2) s->chain_min_chunks = 2;
     }
-    if (const char* e = getenv("GLU_HIP_SCAN_STREAM")) s->chained_stream = atoi(e) != 0;
-    if (const char* e = getenv("GLU_HIP_SCAN_STREAM_WGS"))
-        if (atoi(e) >= 1 && atoi(e) <= 8) s->stream_wgs_per_cu = (uint32_t) atoi(e);
     *out = s;
     return GLU_OK;
 }

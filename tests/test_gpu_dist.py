@@ -296,6 +296,27 @@ def test_two_ranks_2p26_each_skewed_plan_grows_receive_buffers(built):
 # (GLU_HIP_RCCL_LIB) that exchanges through files.  Everything else is the product: partition kernels, the histogram
 # gather, the plan, the send / receive offsets of the grouped exchange, the local sort.
 
+def _collect(q, procs, world, timeout):
+    """One result per rank from the queue; gives up at once when a rank has died without delivering (instead of waiting
+    out the timeout while the surviving ranks sit in a collective)."""
+    import queue
+    import time
+
+    results, deadline = {}, time.time() + timeout
+    while len(results) < world:
+        try:
+            rank, out = q.get(timeout=2)
+            results[rank] = out
+        except queue.Empty:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            if dead or time.time() > deadline:
+                for p in procs:
+                    if p.is_alive():
+                        p.kill()
+                raise AssertionError("a rank %s (exit codes %s)" % ("died" if dead else "hung", [p.exitcode for p in procs]))
+    return results
+
+
 def _mock_cases(world):
     """(name, expected partition shift or None, per-rank (keys, vals)) -- vals are global indices."""
     cases = []
@@ -415,10 +436,10 @@ def _mock_rank_worker(rank, world, unique_id, mock_lib, mock_dir, q, seg_mode=No
         rev_v = G.ShaderStorageBuffer(np.ascontiguousarray(vals[::-1])) if keys.size else None
         rkp, rvp = (rev_k.device_ptr(), rev_v.device_ptr()) if keys.size else (None, None)
         G.synchronize()
-        first.sort_ptr(rkp, rvp, keys.size, stream=streams[0])
-        b2k, b2v, b2n = second.sort_ptr(kp, vp, keys.size, stream=streams[1])
-        b1k, b1v, b1n = first.sort_ptr(kp, vp, keys.size, stream=streams[0])
-        G.synchronize()
+        first.sort_ptr(rkp, rvp, keys.size, stream=streams[0].value)
+        b2k, b2v, b2n = second.sort_ptr(kp, vp, keys.size, stream=streams[1].value)
+        b1k, b1v, b1n = first.sort_ptr(kp, vp, keys.size, stream=streams[0].value)
+        assert hip.hipDeviceSynchronize() == 0  # (G.synchronize waits for the library queue only: these ran on caller streams)
         same = same and b1n == cnt and b2n == cnt
         for ptr, ref in ((b1k, gk), (b1v, gv), (b2k, gk), (b2v, gv)):
             same = same and bool((read_back(ptr, cnt) == ref).all())
@@ -451,14 +472,7 @@ def test_native_multi_rank_sort_over_mock_transport(built, world, seg_mode, mock
              for r in range(world)]
     for p in procs:
         p.start()
-    import queue
-
-    try:
-        results = dict(q.get(timeout=900) for _ in range(world))
-    except queue.Empty:
-        for p in procs:
-            p.join(timeout=5)
-        raise AssertionError("a rank produced nothing (exit codes %s)" % [p.exitcode for p in procs])
+    results = _collect(q, procs, world, 900)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -523,6 +537,8 @@ def _mock_fault_worker(rank, world, unique_id, mock_lib, mock_dir, q, fault):
             verdicts.append(("error", str(e)))
             break  # (the ranks may no longer agree on what comes next)
     q.put((rank, verdicts))
+    q.close()
+    q.join_thread()  # (the result is on its way before the process leaves)
     os._exit(0)  # (after a fault the object may be unusable: no orderly destroy)
 
 
@@ -545,12 +561,7 @@ def test_async_transport_catches_a_missing_stream_dependency(built, fault, tmp_p
     procs = [ctx.Process(target=_mock_fault_worker, args=(r, world, unique_id, mock_lib, str(tmp_path), q, fault)) for r in range(world)]
     for p in procs:
         p.start()
-    try:
-        results = dict(q.get(timeout=300) for _ in range(world))
-    except queue.Empty:
-        for p in procs:
-            p.kill()
-        raise AssertionError("a rank hung or died (exit codes %s)" % [p.exitcode for p in procs])
+    results = _collect(q, procs, world, 300)
     for p in procs:
         p.join(timeout=60)
     total = sum(3 * (1 << 20) + 1000 * r for r in range(world))
@@ -640,12 +651,7 @@ def test_native_failures_are_collective(built, env, mock_async, tmp_path):
              for r in range(world)]
     for p in procs:
         p.start()
-    try:
-        results = dict(q.get(timeout=300) for _ in range(world))
-    except queue.Empty:
-        for p in procs:
-            p.kill()
-        raise AssertionError("a rank hung or died (exit codes %s)" % [p.exitcode for p in procs])
+    results = _collect(q, procs, world, 300)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
