@@ -194,7 +194,10 @@ struct glu_dist_s
     bool seg_enabled = true;                // GLU_HIP_DIST_SEG=0: always the ordinary local sort
     bool seg_forced = false;                // GLU_HIP_DIST_SEG=2: segmented whenever the shard has 2^16 pairs, however fragmented (tests)
     int test_fail_begin = -1, test_fail_finish = -1; // GLU_HIP_DIST_TEST_FAIL=begin:<rank> / finish:<rank>: that rank reports a failure
-    int test_fault = 0; // GLU_HIP_DIST_TEST_FAULT=no_hist_wait: 1 = a stream dependency is left out on purpose (negative control of the tests)
+    // GLU_HIP_DIST_TEST_FAULT: a stream dependency is left out on purpose (negative controls of tests/test_gpu_dist.py).
+    // 1 = no_hist_wait: the histogram all-gather is not ordered behind the count + scan kernels; 2 = local_sort_unordered: the
+    // local sort runs on the side stream, not behind the exchange (right with a transport that completes inside the call)
+    int test_fault = 0;
     uint32_t last_local_sort = 0;           // 1 = the last sort's local sort was segmented, 0 = ordinary (glu_dist_last_local_sort)
     std::vector<int> owner;
     std::vector<uint64_t> send_counts, recv_counts;
@@ -264,7 +267,8 @@ glu_status glu_dist_create(const void* unique_id, size_t id_bytes, int world_siz
         if (atoll(e) > 0) d->shard_limit = (uint64_t) atoll(e);
     if (const char* e = getenv("GLU_HIP_DIST_SEG_MIN")) d->seg_min = (size_t) atoll(e);
     if (const char* e = getenv("GLU_HIP_DIST_SEG")) d->seg_enabled = atoi(e) != 0, d->seg_forced = atoi(e) == 2;
-    if (const char* e = getenv("GLU_HIP_DIST_TEST_FAULT")) d->test_fault = strcmp(e, "no_hist_wait") == 0 ? 1 : 0;
+    if (const char* e = getenv("GLU_HIP_DIST_TEST_FAULT"))
+        d->test_fault = strcmp(e, "no_hist_wait") == 0 ? 1 : (strcmp(e, "local_sort_unordered") == 0 ? 2 : 0);
     if (const char* e = getenv("GLU_HIP_DIST_TEST_FAIL"))
     {
         if (strncmp(e, "begin:", 6) == 0) d->test_fail_begin = atoi(e + 6);
@@ -679,20 +683,22 @@ glu_status dist_sort_finish(glu_dist_s* d, uint32_t* recv_keys, uint32_t* recv_v
         NCCL_TRY(res);
         NCCL_TRY(end);
     }
+    // (fault injection, glu_dist_s::test_fault == 2: what follows the exchange runs on the side stream, not behind it)
+    hipStream_t sort_stream = d->test_fault == 2 ? d->aux : st;
     if (d->send_counts[d->rank])
     {
         const size_t bytes = (size_t) d->send_counts[d->rank] * sizeof(uint32_t);
-        HIP_TRY(hipMemcpyAsync(land_k + roff[d->rank], part_k + soff[d->rank], bytes, hipMemcpyDeviceToDevice, st));
-        HIP_TRY(hipMemcpyAsync(land_v + roff[d->rank], part_v + soff[d->rank], bytes, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(land_k + roff[d->rank], part_k + soff[d->rank], bytes, hipMemcpyDeviceToDevice, sort_stream));
+        HIP_TRY(hipMemcpyAsync(land_v + roff[d->rank], part_v + soff[d->rank], bytes, hipMemcpyDeviceToDevice, sort_stream));
     }
     glu_dist_s::Marks* marks = dist_marks(d, false);
     if (marks) HIP_TRY(hipEventRecord(marks->e[2], st));
 
     // 5. local stable sort of the received pairs
     if (segmented)
-        GLU_TRY(seg_run_plan(d->sorter, plan, land_k, land_v, recv_keys, recv_vals, st));
+        GLU_TRY(seg_run_plan(d->sorter, plan, land_k, land_v, recv_keys, recv_vals, sort_stream));
     else if (n_recv > 1)
-        GLU_TRY(sort_run<uint32_t>(d->sorter, recv_keys, recv_vals, n_recv, 0, st));
+        GLU_TRY(sort_run<uint32_t>(d->sorter, recv_keys, recv_vals, n_recv, 0, sort_stream));
     if (marks) HIP_TRY(hipEventRecord(marks->e[3], st));
     return GLU_OK;
 }

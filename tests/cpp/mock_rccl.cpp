@@ -9,9 +9,10 @@
 //     plan, but it HIDES stream-order bugs: whatever the caller forgot to order before the collective has finished anyway.
 //   * GLU_MOCK_RCCL_ASYNC=1 (asynchronous, like the real library): a call only ENQUEUES.  It records an event on the
 //     caller's stream, launches a one-lane kernel there that waits for a flag in pinned host memory, hands the work to the
-//     communicator's worker thread and returns at once; ncclGroupEnd does not wait either.  The worker waits for the event
-//     (= the stream has reached the collective), moves the bytes on a private non-blocking stream at THAT moment, then
-//     raises the flag and the caller's stream runs on.  A send buffer that is not yet written when the stream gets there, a
+//     communicator's worker thread and returns at once; ncclGroupEnd does not wait either.  What is sent is copied into pinned
+//     buffers by the caller's stream itself, in stream order, in front of the event; the worker waits for the event (= the
+//     stream has reached the collective), moves the bytes between pinned buffers and files, then raises the flag, and the
+//     caller's stream runs on into the copies of what was received (enqueued with the call, behind the wait kernel).  A send buffer that is not yet written when the stream gets there, a
 //     receive buffer still in use, a histogram gathered before its kernel ran: the data is wrong and the test fails, as it
 //     would (sometimes) with RCCL.  Errors of the worker surface at the next call on the communicator.
 // What both keep of the real semantics is what the caller relies on:
@@ -54,12 +55,23 @@ struct Op
     std::string path;           // asynchronous mode: named when the call is made (call order pairs sends with receives)
     const void* gather_send = nullptr; // asynchronous all-gather: ptr = receive array, bytes per rank
     bool gather = false;
+    unsigned char* out_stage = nullptr; // asynchronous mode: pinned copies of what leaves / arrives (see enqueue_ops)
+    unsigned char* in_stage = nullptr;
+};
+
+struct Stage // a pinned host buffer of the communicator's pool
+{
+    unsigned char* host = nullptr;
+    size_t capacity = 0;
+    bool busy = false;
 };
 
 struct Job
 {
     std::vector<Op> ops;
-    std::vector<hipEvent_t> ready; // one per stream the operations were enqueued on
+    std::vector<hipEvent_t> ready; // one per stream: everything the operations send has reached its pinned copy
+    std::vector<hipEvent_t> done;  // one per stream: everything received has been copied to its destination
+    std::vector<Stage*> stages;
     uint32_t seq = 0;
 };
 
@@ -80,7 +92,8 @@ struct MockComm
     uint32_t* flag = nullptr; // pinned, coherent: number of jobs the worker has completed
     uint32_t enqueued = 0;
     std::atomic<int> failed{(int) ncclSuccess};
-    hipStream_t copy_stream = nullptr;
+    std::vector<Stage*> pool;  // pinned staging buffers, grow-only, freed with the communicator (calling thread only)
+    std::deque<Job> retired;   // jobs the worker has finished; their buffers are free again once their `done` events have fired
 };
 
 // the caller's stream stops here until the worker has finished job `target` (or gave up: the worker always raises the flag;
@@ -102,6 +115,12 @@ const char* dir()
 {
     const char* d = getenv("GLU_MOCK_RCCL_DIR");
     return d && *d ? d : "/tmp";
+}
+
+bool verbose() // GLU_MOCK_RCCL_VERBOSE: every operation is logged to stderr
+{
+    static const bool v = getenv("GLU_MOCK_RCCL_VERBOSE") != nullptr;
+    return v;
 }
 
 size_t type_size(ncclDataType_t t)
@@ -168,57 +187,61 @@ std::string p2p_path(MockComm* c, bool send, int peer)
                       std::to_string(c->recv_seq[peer]++);
 }
 
-// synchronous copy; in the worker thread on the communicator's private non-blocking stream (the null stream would wait
-// for the very streams that are parked in mock_wait_kernel)
-bool copy_now(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t copy_stream)
+void log_row(const MockComm* c, const std::string& base, int r, const unsigned char* row, size_t bytes)
 {
-    if (!bytes) return true;
-    if (!copy_stream) return hipMemcpy(dst, src, bytes, kind) == hipSuccess;
-    return hipMemcpyAsync(dst, src, bytes, kind, copy_stream) == hipSuccess && hipStreamSynchronize(copy_stream) == hipSuccess;
+    if (!verbose() || bytes < 1028) return;
+    uint64_t sum = 0;
+    for (size_t i = 0; i < 256; i++) sum += reinterpret_cast<const uint32_t*>(row)[i];
+    fprintf(stderr, "[mock_rccl %d] %s row of rank %d: first 256 words add up to %llu, word 256 = %u\n", c->rank,
+            base.c_str() + base.rfind('/') + 1, r, (unsigned long long) sum, reinterpret_cast<const uint32_t*>(row)[256]);
 }
 
-ncclResult_t gather_now(MockComm* c, const void* send, void* recv, size_t bytes, const std::string& base, hipStream_t copy_stream)
+// ---- synchronous mode: on the calling thread, after the caller's streams were synchronised ---------------------------
+ncclResult_t gather_now(MockComm* c, const void* send, void* recv, size_t bytes, const std::string& base)
 {
     std::vector<unsigned char> host(bytes);
-    if (!copy_now(host.data(), send, bytes, hipMemcpyDeviceToHost, copy_stream)) return ncclUnhandledCudaError;
+    if (bytes && hipMemcpy(host.data(), send, bytes, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
     if (!write_file(base + std::to_string(c->rank), host.data(), bytes)) return ncclSystemError;
     for (int r = 0; r < c->nranks; r++)
     {
         if (ncclResult_t res = read_file(base + std::to_string(r), host.data(), bytes); res != ncclSuccess) return res;
-        if (!copy_now((unsigned char*) recv + (size_t) r * bytes, host.data(), bytes, hipMemcpyHostToDevice, copy_stream))
+        log_row(c, base, r, host.data(), bytes);
+        if (bytes && hipMemcpy((unsigned char*) recv + (size_t) r * bytes, host.data(), bytes, hipMemcpyHostToDevice) != hipSuccess)
             return ncclUnhandledCudaError;
     }
     return ncclSuccess;
 }
 
-// the data movement of one call / one group (paths already named); copy_stream == nullptr: on the calling thread, after
-// the caller's streams were synchronised
-ncclResult_t move_ops(std::vector<Op>& ops, hipStream_t copy_stream)
+ncclResult_t move_ops_now(std::vector<Op>& ops)
 {
     std::vector<unsigned char> host;
     for (const Op& op : ops) // all sends first: nobody waits for a peer before its own data is out
     {
-        if (!op.send || op.gather) continue;
+        if (!op.send) continue;
         host.resize(op.bytes);
-        if (!copy_now(host.data(), op.ptr, op.bytes, hipMemcpyDeviceToHost, copy_stream)) return ncclUnhandledCudaError;
+        if (op.bytes && hipMemcpy(host.data(), op.ptr, op.bytes, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
         if (!write_file(op.path, host.data(), op.bytes)) return ncclSystemError;
     }
     for (const Op& op : ops)
     {
-        if (op.gather)
-        {
-            if (ncclResult_t r = gather_now(op.comm, op.gather_send, op.ptr, op.bytes, op.path, copy_stream); r != ncclSuccess) return r;
-            continue;
-        }
         if (op.send) continue;
         host.resize(op.bytes);
         if (ncclResult_t r = read_file(op.path, host.data(), op.bytes); r != ncclSuccess) return r;
         unlink(op.path.c_str());
-        if (!copy_now(op.ptr, host.data(), op.bytes, hipMemcpyHostToDevice, copy_stream)) return ncclUnhandledCudaError;
+        if (op.bytes && hipMemcpy(op.ptr, host.data(), op.bytes, hipMemcpyHostToDevice) != hipSuccess) return ncclUnhandledCudaError;
     }
     return ncclSuccess;
 }
 
+// ---- asynchronous mode --------------------------------------------------------------------------------------------------
+// Everything the GPU does for a collective is enqueued BY THE CALLER'S THREAD ON THE CALLER'S STREAM when the call is made:
+//     copies of what is sent into pinned buffers -> event `ready` -> mock_wait_kernel -> copies of what is received out of
+//     pinned buffers -> event `done`
+// and the worker thread only waits for `ready` on the host, moves bytes between pinned buffers and files, and raises the flag.
+// (A first version let the worker copy on a private stream.  HIP multiplexes its streams onto a few hardware queues, in
+// order: the worker's copy could land in the queue behind the very wait kernel that was waiting for it.)  What shares a
+// hardware queue with a parked stream is delayed, as behind an RCCL kernel that waits for its peers; nothing the worker
+// needs is ever behind a wait kernel of a LATER operation, because a rank issues its operations in one order.
 void worker_main(MockComm* c)
 {
     (void) hipSetDevice(c->device);
@@ -233,25 +256,93 @@ void worker_main(MockComm* c)
             c->jobs.pop_front();
         }
         ncclResult_t res = ncclSuccess;
-        for (hipEvent_t e : job.ready) // the caller's stream has reached the collective: its inputs are what they are NOW
-        {
+        for (hipEvent_t e : job.ready) // the caller's stream has reached the collective: what it sends is what it is NOW
             if (hipEventSynchronize(e) != hipSuccess) res = ncclUnhandledCudaError;
-            (void) hipEventDestroy(e);
+        for (const Op& op : job.ops) // all sends (and own gather rows) first: nobody waits for a peer before its data is out
+        {
+            if (res != ncclSuccess) break;
+            if (op.gather)
+            {
+                if (!write_file(op.path + std::to_string(c->rank), op.out_stage, op.bytes)) res = ncclSystemError;
+            }
+            else if (op.send && !write_file(op.path, op.out_stage, op.bytes))
+                res = ncclSystemError;
         }
-        if (res == ncclSuccess) res = move_ops(job.ops, c->copy_stream);
+        for (const Op& op : job.ops)
+        {
+            if (res != ncclSuccess) break;
+            if (op.gather)
+            {
+                for (int r = 0; r < c->nranks && res == ncclSuccess; r++)
+                {
+                    res = read_file(op.path + std::to_string(r), op.in_stage + (size_t) r * op.bytes, op.bytes);
+                    if (res == ncclSuccess) log_row(c, op.path, r, op.in_stage + (size_t) r * op.bytes, op.bytes);
+                }
+            }
+            else if (!op.send)
+            {
+                res = read_file(op.path, op.in_stage, op.bytes);
+                if (res == ncclSuccess) unlink(op.path.c_str());
+            }
+        }
         if (res != ncclSuccess)
         {
             fprintf(stderr, "[mock_rccl] rank %d: asynchronous operation %u failed (%d)\n", c->rank, job.seq, (int) res);
             c->failed.store((int) res);
         }
-        __atomic_store_n(c->flag, job.seq, __ATOMIC_RELEASE); // the caller's stream runs on
+        if (verbose()) fprintf(stderr, "[mock_rccl %d] operation %u of %s: bytes moved, stream released\n", c->rank, job.seq, c->tag.c_str());
+        const uint32_t seq = job.seq;
+        {
+            std::lock_guard<std::mutex> lock(c->m);
+            c->retired.push_back(std::move(job));
+        }
+        __atomic_store_n(c->flag, seq, __ATOMIC_RELEASE); // the caller's stream runs on: the copies out of the pinned buffers
     }
 }
 
-// asynchronous mode: event + wait kernel on every stream of the operations, the rest is the worker's
+// calling thread: buffers of jobs that are finished on both sides (worker and stream) return to the pool
+void collect_retired(MockComm* c)
+{
+    std::lock_guard<std::mutex> lock(c->m);
+    while (!c->retired.empty())
+    {
+        Job& j = c->retired.front();
+        bool fired = true;
+        for (hipEvent_t e : j.done) fired = fired && hipEventQuery(e) == hipSuccess;
+        if (!fired) break;
+        for (hipEvent_t e : j.ready) (void) hipEventDestroy(e);
+        for (hipEvent_t e : j.done) (void) hipEventDestroy(e);
+        for (Stage* st : j.stages) st->busy = false;
+        c->retired.pop_front();
+    }
+}
+
+unsigned char* acquire_stage(MockComm* c, Job& job, size_t bytes)
+{
+    if (bytes == 0) return nullptr;
+    Stage* pick = nullptr;
+    for (Stage* st : c->pool)
+        if (!st->busy && st->capacity >= bytes && (!pick || st->capacity < pick->capacity)) pick = st;
+    if (!pick)
+    {
+        pick = new Stage();
+        pick->capacity = std::max<size_t>(bytes, 4096);
+        if (hipHostMalloc((void**) &pick->host, pick->capacity, hipHostMallocDefault) != hipSuccess)
+        {
+            delete pick;
+            return nullptr;
+        }
+        c->pool.push_back(pick);
+    }
+    pick->busy = true;
+    job.stages.push_back(pick);
+    return pick->host;
+}
+
 ncclResult_t enqueue_ops(MockComm* c, std::vector<Op>& ops)
 {
     if (int f = c->failed.load(); f != (int) ncclSuccess) return (ncclResult_t) f;
+    collect_retired(c);
     Job job;
     job.seq = ++c->enqueued;
     std::vector<hipStream_t> streams;
@@ -261,7 +352,14 @@ ncclResult_t enqueue_ops(MockComm* c, std::vector<Op>& ops)
         for (hipStream_t s : streams) seen = seen || s == op.stream;
         if (!seen) streams.push_back(op.stream);
     }
-    for (hipStream_t s : streams)
+    for (Op& op : ops) // 1. what leaves: device -> pinned copy, in stream order
+    {
+        const void* src = op.gather ? op.gather_send : (op.send ? op.ptr : nullptr);
+        if (!src || !op.bytes) continue;
+        op.out_stage = acquire_stage(c, job, op.bytes);
+        if (!op.out_stage || hipMemcpyAsync(op.out_stage, src, op.bytes, hipMemcpyDeviceToHost, op.stream) != hipSuccess) return ncclUnhandledCudaError;
+    }
+    for (hipStream_t s : streams) // 2. `ready`, then the stream parks until the worker has moved the bytes
     {
         hipEvent_t e;
         if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess || hipEventRecord(e, s) != hipSuccess) return ncclUnhandledCudaError;
@@ -269,6 +367,21 @@ ncclResult_t enqueue_ops(MockComm* c, std::vector<Op>& ops)
         hipLaunchKernelGGL(mock_wait_kernel, dim3(1), dim3(1), 0, s, c->flag, job.seq);
         if (hipGetLastError() != hipSuccess) return ncclUnhandledCudaError;
     }
+    for (Op& op : ops) // 3. what arrives: pinned copy -> device, behind the wait kernel
+    {
+        if (op.send && !op.gather) continue;
+        const size_t bytes = op.gather ? op.bytes * (size_t) c->nranks : op.bytes;
+        if (!bytes) continue;
+        op.in_stage = acquire_stage(c, job, bytes);
+        if (!op.in_stage || hipMemcpyAsync(op.ptr, op.in_stage, bytes, hipMemcpyHostToDevice, op.stream) != hipSuccess) return ncclUnhandledCudaError;
+    }
+    for (hipStream_t s : streams)
+    {
+        hipEvent_t e;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess || hipEventRecord(e, s) != hipSuccess) return ncclUnhandledCudaError;
+        job.done.push_back(e);
+    }
+    if (verbose()) fprintf(stderr, "[mock_rccl %d] operation %u of %s enqueued\n", c->rank, job.seq, c->tag.c_str());
     job.ops = std::move(ops);
     {
         std::lock_guard<std::mutex> lock(c->m);
@@ -282,10 +395,14 @@ ncclResult_t run_ops(std::vector<Op>& ops)
 {
     if (ops.empty()) return ncclSuccess;
     for (Op& op : ops) op.path = p2p_path(op.comm, op.send, op.peer);
+    if (verbose())
+        for (const Op& op : ops)
+            fprintf(stderr, "[mock_rccl %d] %s %zu bytes %s %d as %s\n", op.comm->rank, op.send ? "send" : "recv", op.bytes, op.send ? "to" : "from",
+                    op.peer, op.path.c_str() + op.path.rfind('/') + 1);
     if (ops.front().comm->async) return enqueue_ops(ops.front().comm, ops);
     for (const Op& op : ops)
         if (hipStreamSynchronize(op.stream) != hipSuccess) return ncclUnhandledCudaError;
-    return move_ops(ops, nullptr);
+    return move_ops_now(ops);
 }
 
 ncclResult_t p2p(bool send, void* ptr, size_t count, ncclDataType_t type, int peer, ncclComm_t comm, hipStream_t stream)
@@ -330,7 +447,7 @@ ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId id, int
     if (const char* e = getenv("GLU_MOCK_RCCL_ASYNC"); e && atoi(e) != 0)
     {
         c->async = true;
-        if (hipGetDevice(&c->device) != hipSuccess || hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+        if (hipGetDevice(&c->device) != hipSuccess ||
             hipHostMalloc((void**) &c->flag, 64, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess)
         {
             delete c;
@@ -354,7 +471,17 @@ ncclResult_t ncclCommDestroy(ncclComm_t comm)
         }
         c->cv.notify_one();
         c->worker.join();
-        (void) hipStreamDestroy(c->copy_stream);
+        (void) hipDeviceSynchronize(); // (every stream has passed its wait kernels: the worker finished all jobs)
+        for (Job& j : c->retired)
+        {
+            for (hipEvent_t e : j.ready) (void) hipEventDestroy(e);
+            for (hipEvent_t e : j.done) (void) hipEventDestroy(e);
+        }
+        for (Stage* st : c->pool)
+        {
+            (void) hipHostFree(st->host);
+            delete st;
+        }
         (void) hipHostFree(c->flag);
     }
     delete c;
@@ -379,6 +506,7 @@ ncclResult_t ncclAllGather(const void* send, void* recv, size_t count, ncclDataT
     const size_t bytes = count * type_size(type);
     if (!c || type_size(type) == 0 || (bytes && (!send || !recv))) return ncclInvalidArgument;
     const std::string base = std::string(dir()) + "/" + c->tag + ".gather." + std::to_string(c->gather_seq++) + ".";
+    if (verbose()) fprintf(stderr, "[mock_rccl %d] all-gather %zu bytes as %s\n", c->rank, bytes, base.c_str() + base.rfind('/') + 1);
     if (c->async)
     {
         Op op{false, recv, bytes, c->rank, c, stream, base};
@@ -388,7 +516,7 @@ ncclResult_t ncclAllGather(const void* send, void* recv, size_t count, ncclDataT
         return enqueue_ops(c, one);
     }
     if (hipStreamSynchronize(stream) != hipSuccess) return ncclUnhandledCudaError;
-    return gather_now(c, send, recv, bytes, base, nullptr);
+    return gather_now(c, send, recv, bytes, base);
 }
 
 ncclResult_t ncclSend(const void* ptr, size_t count, ncclDataType_t type, int peer, ncclComm_t comm, hipStream_t stream)

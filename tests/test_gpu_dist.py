@@ -498,7 +498,7 @@ def test_native_multi_rank_sort_over_mock_transport(built, world, seg_mode, mock
             assert max(sizes) <= ek.size / world + hottest, (sizes, hottest)
 
 
-def _mock_fault_worker(rank, world, unique_id, mock_lib, mock_dir, q, fault):
+def _mock_fault_worker(rank, world, unique_id, mock_lib, mock_dir, q, fault, mock_async=True):
     import os
     import sys
 
@@ -506,7 +506,8 @@ def _mock_fault_worker(rank, world, unique_id, mock_lib, mock_dir, q, fault):
     for p in (os.path.join(root, "gl-radix-sort_amd"), os.path.join(root, "oracle"), os.path.join(root, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
-    os.environ.update(GLU_HIP_RCCL_LIB=mock_lib, GLU_MOCK_RCCL_DIR=mock_dir, GLU_MOCK_RCCL_ASYNC="1", GLU_MOCK_RCCL_TIMEOUT_S="20")
+    os.environ.update(GLU_HIP_RCCL_LIB=mock_lib, GLU_MOCK_RCCL_DIR=mock_dir, GLU_MOCK_RCCL_ASYNC="1" if mock_async else "0",
+                      GLU_MOCK_RCCL_TIMEOUT_S="20")
     if fault:
         os.environ["GLU_HIP_DIST_TEST_FAULT"] = fault
     import ctypes
@@ -515,24 +516,30 @@ def _mock_fault_worker(rank, world, unique_id, mock_lib, mock_dir, q, fault):
     import glu_hip as G
 
     G.set_device(0)
+    hip = ctypes.CDLL("libamdhip64.so")
     d = G.Dist(unique_id, world, rank)
     n = 3 * (1 << 20) + 1000 * rank
     verdicts = []
+    busy = G.ShaderStorageBuffer(size=1 << 30)
     for attempt in range(3):  # a different input every time: a histogram left over from the sort before is a wrong one
         keys = np.random.default_rng(50 + 7 * attempt + rank).integers(0, 2**32 >> (8 * attempt), n, dtype=np.uint32) << np.uint32(8 * attempt)
         vals = np.arange(n, dtype=np.uint32)
         kb, vb = G.ShaderStorageBuffer(keys), G.ShaderStorageBuffer(vals)
         G.synchronize()
         try:
+            # half a millisecond of other work on the library queue in front of the sort: the partition's kernels wait behind
+            # it, and a side stream that is NOT ordered behind them gathers the histogram long before it exists
+            G.check(G.lib().glu_buffer_fill_u32(busy.handle(), attempt))
             kp, vp, cnt = d.sort_ptr(kb.device_ptr(), vb.device_ptr(), n)
-            G.synchronize()
+            assert hip.hipDeviceSynchronize() == 0  # (every stream: a fault may have moved work off the library queue)
             host = np.empty(cnt, dtype=np.uint32)
             h = ctypes.c_uint32(0)
             if cnt:
                 G.check(G.lib().glu_buffer_wrap(ctypes.c_void_p(kp), cnt * 4, ctypes.byref(h)))
                 G.check(G.lib().glu_buffer_read(h, host.ctypes.data_as(ctypes.c_void_p), cnt * 4, 0))
                 G.check(G.lib().glu_buffer_destroy(h))
-            verdicts.append(("sorted" if (host[1:] >= host[:-1]).all() else "unsorted", int(cnt)))
+            verdicts.append(("sorted" if (host[1:] >= host[:-1]).all() else "unsorted", int(cnt), int(host.astype(np.uint64).sum()),
+                             int(host[0]) if cnt else -1, int(host[-1]) if cnt else -1, int(keys.astype(np.uint64).sum())))
         except G.GluError as e:
             verdicts.append(("error", str(e)))
             break  # (the ranks may no longer agree on what comes next)
@@ -542,12 +549,17 @@ def _mock_fault_worker(rank, world, unique_id, mock_lib, mock_dir, q, fault):
     os._exit(0)  # (after a fault the object may be unusable: no orderly destroy)
 
 
-@pytest.mark.parametrize("fault", [None, "no_hist_wait"])
-def test_async_transport_catches_a_missing_stream_dependency(built, fault, tmp_path):
-    """Negative control of the asynchronous test double: GLU_HIP_DIST_TEST_FAULT=no_hist_wait leaves out the one
-    hipStreamWaitEvent that orders the histogram all-gather (side stream) behind the partition's count + scan kernels.  With
-    a transport that only enqueues, the gather then reads the histogram before it exists: the rows do not add up to the slice
-    sizes (every rank refuses) or the shards come out wrong.  Without the fault the same three sorts are right."""
+@pytest.mark.parametrize("fault,mock_async,expect_clean", [(None, True, True), ("no_hist_wait", True, False),
+                                                           ("local_sort_unordered", True, False), ("local_sort_unordered", False, True)],
+                         ids=["no-fault-async", "no_hist_wait-async", "local_sort_unordered-async", "local_sort_unordered-sync"])
+def test_async_transport_catches_a_missing_stream_dependency(built, fault, mock_async, expect_clean, tmp_path):
+    """Negative controls of the test double (GLU_HIP_DIST_TEST_FAULT leaves a stream dependency out of the product on purpose).
+    no_hist_wait: the histogram all-gather (side stream) is not ordered behind the partition's count + scan kernels; with
+    half a millisecond of other work queued in front of the sort the gather reads the histogram of the sort BEFORE: the plan is
+    made from it and elements are lost and duplicated.  local_sort_unordered: the local sort runs on the side stream instead of
+    behind the exchange.  With a transport that has moved the bytes by the time the call returns (the synchronous double) that
+    is still RIGHT -- the blind spot the asynchronous double was built for; with one that only enqueues (the asynchronous
+    double, RCCL) the sort reads landing arrays nothing has arrived in.  Without a fault the same three sorts are right."""
     import queue
 
     import torch.multiprocessing as mp
@@ -558,19 +570,27 @@ def test_async_transport_catches_a_missing_stream_dependency(built, fault, tmp_p
     unique_id = os.urandom(128)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_mock_fault_worker, args=(r, world, unique_id, mock_lib, str(tmp_path), q, fault)) for r in range(world)]
+    procs = [ctx.Process(target=_mock_fault_worker, args=(r, world, unique_id, mock_lib, str(tmp_path), q, fault, mock_async)) for r in range(world)]
     for p in procs:
         p.start()
     results = _collect(q, procs, world, 300)
     for p in procs:
         p.join(timeout=60)
     total = sum(3 * (1 << 20) + 1000 * r for r in range(world))
-    clean = all(len(v) == 3 and all(x[0] == "sorted" for x in v) for v in results.values()) and \
-        all(sum(results[r][i][1] for r in range(world)) == total for i in range(3))
-    if fault is None:
+    # clean = every shard ascending, the shards in rank order ascending across their borders, and together exactly the keys
+    # that went in (count and sum): a plan made from a stale histogram loses and duplicates elements
+    clean = all(len(v) == 3 and all(x[0] == "sorted" for x in v) for v in results.values())
+    for i in range(3):
+        if not clean:
+            break
+        shards = [results[r][i] for r in range(world)]
+        clean = sum(x[1] for x in shards) == total and sum(x[2] for x in shards) == sum(x[5] for x in shards)
+        filled = [x for x in shards if x[1]]
+        clean = clean and all(a[4] <= b[3] for a, b in zip(filled, filled[1:]))
+    if expect_clean:
         assert clean, results
     else:
-        assert not clean, "the asynchronous transport did not notice the missing hipStreamWaitEvent: %r" % (results,)
+        assert not clean, "the %s transport did not notice the fault %s: %r" % ("asynchronous" if mock_async else "synchronous", fault, results)
 
 
 def _mock_failure_worker(rank, world, unique_id, mock_lib, mock_dir, q, env, mock_async=False):
