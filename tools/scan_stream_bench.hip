@@ -351,6 +351,96 @@ __global__ __launch_bounds__(THREADS, MINW) void exp_chained_kernel(U* __restric
     }
 }
 
+// Persistent, SINGLE-buffered: a workgroup stays and takes chunk after chunk in ticket order; the ticket of the next chunk is
+// requested at the start of a chunk and collected behind its look-back, and the next chunk's loads go out right behind the
+// current chunk's stores, into the same registers (a store has read its registers when it is issued).  Against one workgroup
+// per chunk this saves the workgroup's exit, the dispatch of the next one and the exposed ticket round trip, and keeps whole
+// 8-group chunks in flight (two workgroups per CU as before).
+template<int GROUPS, int THREADS, int MINW = 1>
+__global__ __launch_bounds__(THREADS, MINW) void persist_chained_kernel(U* __restrict__ data, uint64_t count, uint32_t chunks,
+                                                                         unsigned long long* __restrict__ chain, uint32_t* __restrict__ ticket,
+                                                                         uint32_t epoch)
+{
+    using T = U;
+    using C = ScanCfg<T, GROUPS, THREADS>;
+    __shared__ T wsum[2][C::WAVES];
+    __shared__ uint32_t s_ticket[2];
+    __shared__ T s_prefix;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_ticket[1] = atomicAdd(ticket, 1u);
+    __syncthreads();
+    uint32_t chunk = s_ticket[1];
+    uint32_t parity = 0;
+    while (chunk < chunks)
+    {
+        uint32_t requested = 0;
+        if (tid == 0) requested = atomicAdd(ticket, 1u);
+        const uint64_t cbeg = (uint64_t) chunk * C::CHUNK;
+        const uint32_t valid = (count - cbeg) < (uint64_t) C::CHUNK ? (uint32_t) (count - cbeg) : (uint32_t) C::CHUNK;
+        T* base = data + cbeg;
+        T x[GROUPS][C::VEC];
+        scan_load<uint32_t, 1, true, GROUPS>(base, valid, wave, lane, x);
+        T gexcl[GROUPS], gtot[GROUPS];
+#pragma unroll
+        for (int g = 0; g < GROUPS; g++)
+        {
+            T lsum = x[g][0];
+#pragma unroll
+            for (int k = 1; k < C::VEC; k++) lsum = combine<OP_SUM>(lsum, x[g][k]);
+            T incl = lsum;
+#pragma unroll
+            for (int off = 1; off < kW; off <<= 1)
+            {
+                T t = shfl_up_t(incl, off);
+                if (lane >= (uint32_t) off) incl = combine<OP_SUM>(t, incl);
+            }
+            gtot[g] = shfl_t(incl, kW - 1);
+            T up = shfl_up_t(incl, 1);
+            gexcl[g] = lane == 0 ? zero_elem<uint32_t, 1>() : up;
+        }
+        T wave_total = gtot[0];
+#pragma unroll
+        for (int g = 1; g < GROUPS; g++) wave_total = combine<OP_SUM>(wave_total, gtot[g]);
+        if (lane == 0) wsum[parity][wave] = wave_total;
+        __syncthreads();
+        if (wave == 0)
+        {
+            T total = wsum[parity][0];
+#pragma unroll
+            for (int w = 1; w < C::WAVES; w++) total = combine<OP_SUM>(total, wsum[parity][w]);
+            const T prefix = chain_resolve<T>(chain, chunk, epoch, total, lane);
+            if (lane == 0)
+            {
+                s_prefix = prefix;
+                s_ticket[parity] = requested;
+            }
+        }
+        __syncthreads();
+        T run = s_prefix;
+        const uint32_t next = s_ticket[parity];
+#pragma unroll
+        for (int w = 0; w < C::WAVES; w++)
+            if ((uint32_t) w < wave) run = combine<OP_SUM>(run, wsum[parity][w]);
+#pragma unroll
+        for (int g = 0; g < GROUPS; g++)
+        {
+            T acc = combine<OP_SUM>(run, gexcl[g]);
+            Pack<T, C::VEC> p;
+#pragma unroll
+            for (int k = 0; k < C::VEC; k++)
+            {
+                p.v[k] = acc;
+                acc = combine<OP_SUM>(acc, x[g][k]);
+            }
+            const uint32_t e0 = wave * C::WAVE_ELEMS + (g * kW + lane) * C::VEC;
+            if (e0 + C::VEC <= valid) *reinterpret_cast<Pack<T, C::VEC>*>(base + e0) = p;
+            run = combine<OP_SUM>(run, gtot[g]);
+        }
+        chunk = next;
+        parity ^= 1u;
+    }
+}
+
 __global__ void fill(uint32_t* p, size_t n)
 {
     for (size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x; i < n; i += (size_t) gridDim.x * blockDim.x)
@@ -460,6 +550,44 @@ int main(int argc, char** argv)
             hipLaunchKernelGGL((exp_chained_kernel<G, TH, MODE>), dim3(ch), dim3(TH), 0, 0, (U*) work, (uint64_t) n, ch, chain, ticket, epoch); \
         });                                                                                                                      \
     }
+#define PERSIST(G, TH, MINW, WGS)                                                                                                 \
+    {                                                                                                                            \
+        using CE = ScanCfg<U, G, TH>;                                                                                            \
+        const uint32_t ch = (uint32_t) ((n + CE::CHUNK - 1) / CE::CHUNK);                                                        \
+        char name[96];                                                                                                           \
+        snprintf(name, sizeof name, "persistent single-buffered: %d x %d groups, min waves/EU %d, %d workgroups/CU", TH, G, MINW, WGS); \
+        run(name, [&] {                                                                                                          \
+            hipLaunchKernelGGL((persist_chained_kernel<G, TH, MINW>), dim3(std::min<uint32_t>(ch, cus* WGS)), dim3(TH), 0, 0, (U*) work, \
+                               (uint64_t) n, ch, chain, ticket, epoch);                                                          \
+        });                                                                                                                      \
+    }
+    PERSIST(8, 1024, 8, 2)
+    PERSIST(8, 1024, 4, 2)
+    PERSIST(8, 1024, 4, 1)
+    PERSIST(16, 1024, 4, 1)
+    PERSIST(4, 1024, 8, 2)
+    PERSIST(8, 512, 8, 4)
+    PERSIST(16, 512, 4, 2)
+#define EXPW(G, TH, MODE, MINW, NOTE)                                                                                             \
+    {                                                                                                                            \
+        using CE = ScanCfg<U, G, TH>;                                                                                            \
+        const uint32_t ch = (uint32_t) ((n + CE::CHUNK - 1) / CE::CHUNK);                                                        \
+        char name[96];                                                                                                           \
+        snprintf(name, sizeof name, "%d threads x %d groups, mode %d, min waves/EU %d %s", TH, G, MODE, MINW, NOTE);              \
+        run(name, [&] {                                                                                                          \
+            hipLaunchKernelGGL((exp_chained_kernel<G, TH, MODE, MINW>), dim3(ch), dim3(TH), 0, 0, (U*) work, (uint64_t) n, ch, chain, ticket, epoch); \
+        });                                                                                                                      \
+    }
+    EXPW(8, 1024, 0, 8, "(64 VGPRs: two workgroups per CU)")
+    EXPW(8, 1024, 0, 4, "")
+    EXPW(6, 1024, 0, 8, "")
+    EXPW(7, 1024, 0, 8, "")
+    EXPW(10, 1024, 0, 4, "")
+    EXPW(12, 1024, 0, 4, "")
+    EXPW(8, 512, 0, 8, "(64 VGPRs: four workgroups per CU)")
+    EXPW(12, 512, 0, 6, "")
+    EXPW(16, 512, 0, 4, "")
+    if (getenv("SSB_ONLY_PERSIST")) return 0;
     EXP(8, 1024, 0, "(replica of the library kernel)")
     EXP(8, 1024, 1, "(NO look-back: wrong result, upper bound)")
     EXP(8, 1024, 2, "(total published before the scans)")
