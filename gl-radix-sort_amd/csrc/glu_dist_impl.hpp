@@ -155,6 +155,45 @@ bool dist_single_bucket(const uint32_t* all_hist, int world)
     return used < 2;
 }
 
+// The buckets of every rank cut into `rounds` contiguous GROUPS of about equal element counts (a bucket is never split; groups
+// may be empty): cut[q * (rounds + 1) + j] = first bucket of group j of rank q, cut[... + rounds] = one past its last bucket.
+// A pure function of what every rank knows after the histogram all-gather, so sender and receiver agree on every message.
+void dist_plan_groups(const uint32_t* all_hist, int world, const int* owner, int rounds, int* cut)
+{
+    for (int q = 0; q < world; q++)
+    {
+        int g0 = kDistBuckets, g1 = 0;
+        for (int b = 0; b < kDistBuckets; b++)
+            if (owner[b] == q) g0 = std::min(g0, b), g1 = std::max(g1, b + 1);
+        int* c = cut + (size_t) q * (rounds + 1);
+        if (g1 <= g0)
+        {
+            for (int j = 0; j <= rounds; j++) c[j] = 0;
+            continue;
+        }
+        uint64_t total = 0;
+        for (int b = g0; b < g1; b++)
+            for (int s = 0; s < world; s++) total += all_hist[(size_t) s * kDistBuckets + b];
+        c[0] = g0;
+        uint64_t before = 0; // elements in buckets [g0, b)
+        int b = g0;
+        for (int j = 1; j < rounds; j++)
+        {
+            const uint64_t target = total * (uint64_t) j / (uint64_t) rounds;
+            while (b < g1)
+            {
+                uint64_t in_b = 0;
+                for (int s = 0; s < world; s++) in_b += all_hist[(size_t) s * kDistBuckets + b];
+                if (before + in_b / 2 > target) break; // the boundary nearer to the target
+                before += in_b;
+                b++;
+            }
+            c[j] = b;
+        }
+        c[rounds] = g1;
+    }
+}
+
 // send[d] = elements of `rank` whose bucket belongs to rank d; recv[s] = elements of rank s whose bucket belongs to `rank`
 void dist_plan_counts(const uint32_t* all_hist, int world, int rank, const int* owner, uint64_t* send, uint64_t* recv)
 {
@@ -175,6 +214,13 @@ struct glu_dist_s
     glu_radix_sort_s* sorter = nullptr; // partition pass + local sort (its scratch is sized for the receive side)
     hipStream_t aux = nullptr;          // histogram all-gather + copy to the host, beside the partition's scatter kernel
     hipEvent_t ev_hist = nullptr, ev_plan = nullptr;
+    // the exchange in ROUNDS (world > 1, large shards): round j carries the j-th group of every rank's buckets on the side
+    // stream while the local sort of group j - 1 runs on the sort's stream (dist_sort_finish)
+    static constexpr int kMaxRounds = 8;
+    int rounds = 4;                     // GLU_HIP_DIST_ROUNDS (1 .. kMaxRounds)
+    size_t rounds_min = (size_t) 1 << 24; // GLU_HIP_DIST_ROUNDS_MIN: pairs per rank (global count / world) from which rounds are used
+    hipEvent_t ev_part = nullptr, ev_round[kMaxRounds] = {};
+    uint32_t last_rounds = 1;           // rounds of the last sort's exchange (glu_dist_last_rounds)
     // profiling: one set of events per sort since the last glu_dist_phase_times (start, after partition, after exchange,
     // after local sort on the sort's stream; begin / end of the histogram exchange on the side stream); nothing waits
     // for them before glu_dist_phase_times does
@@ -267,6 +313,9 @@ glu_status glu_dist_create(const void* unique_id, size_t id_bytes, int world_siz
         if (atoll(e) > 0) d->shard_limit = (uint64_t) atoll(e);
     if (const char* e = getenv("GLU_HIP_DIST_SEG_MIN")) d->seg_min = (size_t) atoll(e);
     if (const char* e = getenv("GLU_HIP_DIST_SEG")) d->seg_enabled = atoi(e) != 0, d->seg_forced = atoi(e) == 2;
+    if (const char* e = getenv("GLU_HIP_DIST_ROUNDS"))
+        if (atoi(e) >= 1 && atoi(e) <= glu_dist_s::kMaxRounds) d->rounds = atoi(e);
+    if (const char* e = getenv("GLU_HIP_DIST_ROUNDS_MIN")) d->rounds_min = (size_t) atoll(e);
     if (const char* e = getenv("GLU_HIP_DIST_TEST_FAULT"))
         d->test_fault = strcmp(e, "no_hist_wait") == 0 ? 1 : (strcmp(e, "local_sort_unordered") == 0 ? 2 : 0);
     if (const char* e = getenv("GLU_HIP_DIST_TEST_FAIL"))
@@ -292,6 +341,8 @@ glu_status glu_dist_create(const void* unique_id, size_t id_bytes, int world_siz
     hipError_t e = hipStreamCreateWithFlags(&d->aux, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&d->ev_hist, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&d->ev_plan, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&d->ev_part, hipEventDisableTiming);
+    for (int j = 0; j < glu_dist_s::kMaxRounds && e == hipSuccess; j++) e = hipEventCreateWithFlags(&d->ev_round[j], hipEventDisableTiming);
     if (e == hipSuccess) e = hipHostMalloc((void**) &d->all_hist_host, ((size_t) world_size * kDistRow + 8 + 4 + world_size) * sizeof(uint32_t));
     if (e != hipSuccess) return cleanup(fail(GLU_ERROR_DEVICE, "glu_dist_create: %s", hipGetErrorString(e)));
     if (glu_status st = d->hist.reserve(((size_t) (world_size + 1) * kDistRow + 4 + world_size) * sizeof(uint32_t)); st != GLU_OK) return cleanup(st);
@@ -309,6 +360,9 @@ glu_status glu_dist_destroy(glu_dist d)
     if (d->aux) (void) hipStreamDestroy(d->aux);
     if (d->ev_hist) (void) hipEventDestroy(d->ev_hist);
     if (d->ev_plan) (void) hipEventDestroy(d->ev_plan);
+    if (d->ev_part) (void) hipEventDestroy(d->ev_part);
+    for (hipEvent_t e : d->ev_round)
+        if (e) (void) hipEventDestroy(e);
     for (glu_dist_s::Marks& m : d->marks)
         for (hipEvent_t e : m.e)
             if (e) (void) hipEventDestroy(e);
@@ -656,49 +710,159 @@ glu_status dist_sort_finish(glu_dist_s* d, uint32_t* recv_keys, uint32_t* recv_v
     uint32_t* land_k = segmented ? (uint32_t*) d->sorter->keys.ptr : recv_keys;
     uint32_t* land_v = segmented ? (uint32_t*) d->sorter->vals.ptr : recv_vals;
 
-    // 4. one grouped exchange: keys and values to and from every peer; receive segments in source-rank order
-    std::vector<uint64_t> soff(d->world + 1, 0), roff(d->world + 1, 0);
-    for (int r = 0; r < d->world; r++) soff[r + 1] = soff[r] + d->send_counts[r], roff[r + 1] = roff[r] + d->recv_counts[r];
-    bool any_peer = false;
-    for (int r = 0; r < d->world; r++) any_peer = any_peer || (r != d->rank && (d->send_counts[r] || d->recv_counts[r]));
-    if (any_peer)
+    // 4. the exchange.  One grouped exchange (ncclSend / ncclRecv to and from every peer between ncclGroupStart / End) per
+    // ROUND.  With one round a rank's message to a peer is all of the peer's buckets and everything runs on `st`: partition
+    // -> exchange -> local sort in series.  With several rounds (world > 1, large shards: `rounds` is a function of what
+    // every rank knows, so all ranks post the same sequence) round j carries GROUP j of every destination's buckets
+    // (dist_plan_groups) on the side stream, behind the partition, and the local sort of group j runs on `st` behind round j
+    // only: the exchange of the later groups travels while the earlier ones are sorted.  A group of buckets is a contiguous
+    // key range of the shard, sorted on its own by the same segmented passes; what lands is group-major, then source rank,
+    // then bucket (one sort at a time at eight GPUs: partition + one round + max(rest of the exchange, sorts) instead of
+    // partition + exchange + sort).  A rank whose local sort is the ordinary one posts the same rounds
+    // into the usual source-major layout and sorts when the last round has landed.
+    const int R = d->world;
+    uint64_t per_rank = 0;
+    for (int q = 0; q < R; q++)
+        for (int b = 0; b < kDistBuckets; b++) per_rank += d->hist_dense[(size_t) q * kDistBuckets + b];
+    per_rank /= (uint64_t) R;
+    const int rounds = ((R > 1 || d->repartition_at_world_1) && d->partition_shift == 32 - kDistTopBits && per_rank >= d->rounds_min) ? d->rounds : 1;
+    // (repartition_at_world_1, GLU_HIP_DIST_TEST_REPARTITION=1: a single rank takes the multi-rank code paths too, for tests
+    // and for measuring what the rounds cost a rank without a fabric: bench.py --force-dist)
+    d->last_rounds = (uint32_t) rounds;
+    std::vector<int> cut((size_t) R * (rounds + 1));
+    dist_plan_groups(d->hist_dense.data(), R, d->owner.data(), rounds, cut.data());
+    // prefix[q][b] = elements of rank q's slice in buckets below b (its partitioned slice is bucket-major)
+    auto hist_of = [&](int q, int b) { return (uint64_t) d->hist_dense[(size_t) q * kDistBuckets + b]; };
+    auto count_in = [&](int q, int b0, int b1) {
+        uint64_t c = 0;
+        for (int b = b0; b < b1; b++) c += hist_of(q, b);
+        return c;
+    };
+    const int me = d->rank;
+    const int* my_cut = cut.data() + (size_t) me * (rounds + 1);
+    // landing offsets: group_off[j] = where group j of this rank's shard starts (also in the sorted result)
+    std::vector<uint64_t> group_off(rounds + 1, 0);
+    for (int j = 0; j < rounds; j++)
     {
-        NCCL_TRY(rccl().GroupStart());
-        ncclResult_t res = ncclSuccess;
-        for (int peer = 0; peer < d->world && res == ncclSuccess; peer++)
-        {
-            if (peer == d->rank) continue;
-            if (d->send_counts[peer])
-            {
-                res = rccl().Send(part_k + soff[peer], (size_t) d->send_counts[peer], ncclUint32, peer, d->comm, st);
-                if (res == ncclSuccess) res = rccl().Send(part_v + soff[peer], (size_t) d->send_counts[peer], ncclUint32, peer, d->comm, st);
-            }
-            if (d->recv_counts[peer] && res == ncclSuccess)
-            {
-                res = rccl().Recv(land_k + roff[peer], (size_t) d->recv_counts[peer], ncclUint32, peer, d->comm, st);
-                if (res == ncclSuccess) res = rccl().Recv(land_v + roff[peer], (size_t) d->recv_counts[peer], ncclUint32, peer, d->comm, st);
-            }
-        }
-        ncclResult_t end = rccl().GroupEnd();
-        NCCL_TRY(res);
-        NCCL_TRY(end);
+        uint64_t c = 0;
+        for (int src = 0; src < R; src++) c += count_in(src, my_cut[j], my_cut[j + 1]);
+        group_off[j + 1] = group_off[j] + c;
     }
-    // (fault injection, glu_dist_s::test_fault == 2: what follows the exchange runs on the side stream, not behind it)
-    hipStream_t sort_stream = d->test_fault == 2 ? d->aux : st;
-    if (d->send_counts[d->rank])
+    std::vector<uint64_t> roff(R + 1, 0); // ordinary local sort: source-major, as with one round
+    for (int r = 0; r < R; r++) roff[r + 1] = roff[r] + d->recv_counts[r];
+    hipStream_t xs = rounds > 1 ? d->aux : st;
+    if (rounds > 1)
     {
-        const size_t bytes = (size_t) d->send_counts[d->rank] * sizeof(uint32_t);
-        HIP_TRY(hipMemcpyAsync(land_k + roff[d->rank], part_k + soff[d->rank], bytes, hipMemcpyDeviceToDevice, sort_stream));
-        HIP_TRY(hipMemcpyAsync(land_v + roff[d->rank], part_v + soff[d->rank], bytes, hipMemcpyDeviceToDevice, sort_stream));
+        HIP_TRY(hipEventRecord(d->ev_part, st)); // the partitioned slice is complete
+        HIP_TRY(hipStreamWaitEvent(d->aux, d->ev_part, 0));
+    }
+    for (int j = 0; j < rounds; j++)
+    {
+        bool any_peer = false;
+        for (int peer = 0; peer < R && !any_peer; peer++)
+        {
+            if (peer == me) continue;
+            const int* pc = cut.data() + (size_t) peer * (rounds + 1);
+            any_peer = count_in(me, pc[j], pc[j + 1]) != 0 || count_in(peer, my_cut[j], my_cut[j + 1]) != 0;
+        }
+        // where source `src`'s part of group j lands
+        auto land_at = [&](int src) {
+            uint64_t at;
+            if (segmented)
+            {
+                at = group_off[j];
+                for (int q = 0; q < src; q++) at += count_in(q, my_cut[j], my_cut[j + 1]);
+            }
+            else
+            {
+                at = roff[src];
+                for (int jj = 0; jj < j; jj++) at += count_in(src, my_cut[jj], my_cut[jj + 1]);
+            }
+            return at;
+        };
+        if (any_peer)
+        {
+            NCCL_TRY(rccl().GroupStart());
+            ncclResult_t res = ncclSuccess;
+            for (int peer = 0; peer < R && res == ncclSuccess; peer++)
+            {
+                if (peer == me) continue;
+                const int* pc = cut.data() + (size_t) peer * (rounds + 1);
+                const uint64_t n_send = count_in(me, pc[j], pc[j + 1]), send_at = count_in(me, 0, pc[j]);
+                const uint64_t n_get = count_in(peer, my_cut[j], my_cut[j + 1]), get_at = land_at(peer);
+                if (n_send)
+                {
+                    res = rccl().Send(part_k + send_at, (size_t) n_send, ncclUint32, peer, d->comm, xs);
+                    if (res == ncclSuccess) res = rccl().Send(part_v + send_at, (size_t) n_send, ncclUint32, peer, d->comm, xs);
+                }
+                if (n_get && res == ncclSuccess)
+                {
+                    res = rccl().Recv(land_k + get_at, (size_t) n_get, ncclUint32, peer, d->comm, xs);
+                    if (res == ncclSuccess) res = rccl().Recv(land_v + get_at, (size_t) n_get, ncclUint32, peer, d->comm, xs);
+                }
+            }
+            ncclResult_t end = rccl().GroupEnd();
+            NCCL_TRY(res);
+            NCCL_TRY(end);
+        }
+        // (fault injection, glu_dist_s::test_fault == 2: what follows the exchange runs on the side stream, not behind it)
+        hipStream_t self_stream = (d->test_fault == 2 && rounds == 1) ? d->aux : xs;
+        if (const uint64_t n_self = count_in(me, my_cut[j], my_cut[j + 1]))
+        {
+            const uint64_t from = count_in(me, 0, my_cut[j]), to = land_at(me);
+            HIP_TRY(hipMemcpyAsync(land_k + to, part_k + from, (size_t) n_self * sizeof(uint32_t), hipMemcpyDeviceToDevice, self_stream));
+            HIP_TRY(hipMemcpyAsync(land_v + to, part_v + from, (size_t) n_self * sizeof(uint32_t), hipMemcpyDeviceToDevice, self_stream));
+        }
+        if (rounds > 1) HIP_TRY(hipEventRecord(d->ev_round[j], xs));
     }
     glu_dist_s::Marks* marks = dist_marks(d, false);
-    if (marks) HIP_TRY(hipEventRecord(marks->e[2], st));
+    if (marks) HIP_TRY(hipEventRecord(marks->e[2], xs)); // (with rounds: the end of the last round, on the side stream)
 
     // 5. local stable sort of the received pairs
-    if (segmented)
+    hipStream_t sort_stream = (d->test_fault == 2 && rounds == 1) ? d->aux : st;
+    if (segmented && rounds == 1)
         GLU_TRY(seg_run_plan(d->sorter, plan, land_k, land_v, recv_keys, recv_vals, sort_stream));
-    else if (n_recv > 1)
-        GLU_TRY(sort_run<uint32_t>(d->sorter, recv_keys, recv_vals, n_recv, 0, sort_stream));
+    else if (segmented)
+    {
+        // group by group, each behind its own round: the pieces of group j are (source, bucket) in source order per bucket,
+        // at their places in the (16-byte aligned) landing arrays; its segments occupy [group_off[j], group_off[j + 1]) of the
+        // result.  The sort kernels leave a few CUs to the RCCL kernels of the rounds still travelling (as the partition does
+        // for the histogram exchange).
+        const uint32_t saved_reserved = d->sorter->reserved_cus;
+        const int leave = std::max(d->reserved_cus, 8);
+        if (g_dev.num_cus > 4 * leave) d->sorter->reserved_cus = (uint32_t) leave;
+        glu_status sorted = GLU_OK;
+        for (int j = 0; j < rounds && sorted == GLU_OK; j++)
+        {
+            if (hipError_t e = hipStreamWaitEvent(st, d->ev_round[j], 0); e != hipSuccess)
+            {
+                sorted = fail(GLU_ERROR_DEVICE, "hipStreamWaitEvent failed: %s", hipGetErrorString(e));
+                break;
+            }
+            const uint64_t count_j = group_off[j + 1] - group_off[j];
+            if (count_j == 0) continue;
+            std::vector<SegPiece> pieces;
+            uint64_t at = group_off[j];
+            for (int src = 0; src < R; src++)
+                for (int bk = my_cut[j]; bk < my_cut[j + 1]; bk++)
+                {
+                    const uint64_t len = hist_of(src, bk);
+                    if (len) pieces.push_back(SegPiece{at, len, (uint32_t) (bk - my_cut[j])});
+                    at += len;
+                }
+            SegPlan gplan;
+            seg_make_plan(d->sorter, std::move(pieces), (uint32_t) (my_cut[j + 1] - my_cut[j]), (size_t) count_j, 32 - kDistTopBits, true, gplan,
+                          group_off[j]);
+            sorted = seg_run_plan(d->sorter, gplan, land_k, land_v, recv_keys, recv_vals, st);
+        }
+        d->sorter->reserved_cus = saved_reserved;
+        GLU_TRY(sorted);
+    }
+    else
+    {
+        if (rounds > 1) HIP_TRY(hipStreamWaitEvent(st, d->ev_round[rounds - 1], 0));
+        if (n_recv > 1) GLU_TRY(sort_run<uint32_t>(d->sorter, recv_keys, recv_vals, n_recv, 0, sort_stream));
+    }
     if (marks) HIP_TRY(hipEventRecord(marks->e[3], st));
     return GLU_OK;
 }
@@ -736,6 +900,13 @@ glu_status glu_dist_sort_ptr(glu_dist d, const uint32_t* keys, const uint32_t* v
     if (out_keys) *out_keys = (uint32_t*) d->recv_k.ptr;
     if (out_vals) *out_vals = (uint32_t*) d->recv_v.ptr;
     if (out_count) *out_count = n_recv;
+    return GLU_OK;
+}
+
+glu_status glu_dist_last_rounds(glu_dist d, uint32_t* rounds)
+{
+    if (!d || !rounds) return fail(GLU_ERROR_INVALID_ARGUMENT, "NULL argument");
+    *rounds = d->last_rounds;
     return GLU_OK;
 }
 

@@ -1302,8 +1302,11 @@ struct SegPlan
     uint32_t max_subs_per_wg() const { return std::max(first.max_subs_per_wg, later.max_subs_per_wg); }
 };
 
+// `origin`: where the first segment starts in the output (and in the arrays of the intermediate passes): the segments of a
+// plan occupy [origin, origin + count) there, so several plans can share one set of (aligned) arrays -- the groups of a
+// sharded sort's exchange in rounds, glu_dist_impl.hpp.
 void seg_make_plan(glu_radix_sort_s* s, std::vector<SegPiece>&& pieces, uint32_t nseg, size_t count, uint32_t bits, bool aligned,
-                   SegPlan& plan)
+                   SegPlan& plan, uint64_t origin = 0)
 {
     plan.pieces = std::move(pieces);
     std::stable_sort(plan.pieces.begin(), plan.pieces.end(), [](const SegPiece& a, const SegPiece& b) { return a.seg < b.seg; });
@@ -1313,6 +1316,7 @@ void seg_make_plan(glu_radix_sort_s* s, std::vector<SegPiece>&& pieces, uint32_t
     plan.passes = bits / 8;
     plan.seg_start.assign((size_t) nseg + 1, 0);
     for (const SegPiece& pc : plan.pieces) plan.seg_start[pc.seg + 1] += pc.len;
+    plan.seg_start[0] = origin;
     for (uint32_t g = 0; g < nseg; g++) plan.seg_start[g + 1] += plan.seg_start[g];
     plan.by_copies = count < kSegMinCount || !aligned || plan.passes == 0;
     if (plan.by_copies) return;
@@ -1337,7 +1341,7 @@ glu_status seg_run_plan(glu_radix_sort_s* s, const SegPlan& plan, uint32_t* in_k
     if (plan.by_copies)
     {
         // small (or unaligned, or nothing to sort by): lay the segments out with copies, then one sort per segment
-        uint64_t at = 0;
+        uint64_t at = plan.seg_start.empty() ? 0 : plan.seg_start[0];
         for (const SegPiece& pc : plan.pieces)
         {
             if (pc.len == 0) continue;

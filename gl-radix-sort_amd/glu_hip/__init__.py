@@ -91,6 +91,7 @@ SYMBOLS = [
     ("glu_dist_sort_finish", _int, [_vp, _vp, _vp, _sz, _vp]),
     ("glu_dist_sort_ptr", _int, [_vp, _vp, _vp, _sz, _vp, _P(_vp), _P(_vp), _P(_sz)]),
     ("glu_dist_last_local_sort", _int, [_vp, _P(_u32)]),
+    ("glu_dist_last_rounds", _int, [_vp, _P(_u32)]),
     ("glu_dist_set_reserved_cus", _int, [_vp, _int]),
     ("glu_dist_set_profiling", _int, [_vp, _int]),
     ("glu_dist_phase_times", _int, [_vp, _P(ctypes.c_double), _P(_u64)]),
@@ -503,6 +504,12 @@ class Dist:
         v = _u32(0)
         check(lib().glu_dist_last_local_sort(self._h, ctypes.byref(v)))
         return "segmented" if v.value else "ordinary"
+
+    def last_rounds(self):
+        """In how many rounds the last sort's exchange was posted (glu_dist_last_rounds)."""
+        v = _u32(0)
+        check(lib().glu_dist_last_rounds(self._h, ctypes.byref(v)))
+        return int(v.value)
 
     def set_reserved_cus(self, cus):
         check(lib().glu_dist_set_reserved_cus(self._h, cus))

@@ -369,9 +369,13 @@ def _mock_cases(world):
     return cases
 
 
-def _mock_rank_worker(rank, world, unique_id, mock_lib, mock_dir, q, seg_mode=None, mock_async=False):
+def _mock_rank_worker(rank, world, unique_id, mock_lib, mock_dir, q, seg_mode=None, mock_async=False, rounds=None):
     import os
     import sys
+
+    if rounds:  # the exchange in `rounds` rounds (groups of buckets), whatever the shard size
+        os.environ["GLU_HIP_DIST_ROUNDS"] = str(rounds)
+        os.environ["GLU_HIP_DIST_ROUNDS_MIN"] = "1"
 
     if mock_async:  # the test double only enqueues, like RCCL (tests/cpp/mock_rccl.cpp): stream-order bugs become wrong data
         os.environ["GLU_MOCK_RCCL_ASYNC"] = "1"
@@ -445,21 +449,27 @@ def _mock_rank_worker(rank, world, unique_id, mock_lib, mock_dir, q, seg_mode=No
             same = same and bool((read_back(ptr, cnt) == ref).all())
         if keys.size:  # the input is untouched
             same = same and bool((kb.get_data(np.uint32) == keys).all()) and bool((vb.get_data(np.uint32) == vals).all())
-        out.append((name, first.partition_shift(), gk, gv, same, first.last_local_sort()))
+        out.append((name, first.partition_shift(), gk, gv, same, first.last_local_sort(), first.last_rounds()))
     first.destroy()
     second.destroy()
     q.put((rank, out))
 
 
-@pytest.mark.parametrize("seg_mode,mock_async", [("2", False), ("0", False), (None, False), ("2", True), (None, True)],
-                         ids=["seg-sync", "noseg-sync", "default-sync", "seg-async", "default-async"])
+@pytest.mark.parametrize("seg_mode,mock_async,rounds",
+                         [("2", False, None), ("0", False, None), (None, False, None), ("2", True, None), (None, True, None),
+                          ("2", True, 3), ("2", False, 4), ("0", True, 2)],
+                         ids=["seg-sync", "noseg-sync", "default-sync", "seg-async", "default-async", "seg-async-3rounds", "seg-sync-4rounds",
+                              "noseg-async-2rounds"])
 @pytest.mark.parametrize("world", [2, 3, 8])
-def test_native_multi_rank_sort_over_mock_transport(built, world, seg_mode, mock_async, tmp_path):
+def test_native_multi_rank_sort_over_mock_transport(built, world, seg_mode, mock_async, rounds, tmp_path):
     """seg_mode "2": every shard of 2^16 pairs or more takes the segmented local sort (the exchange then lands in the
     sorter's scratch and the first pass regroups the source-major shard by bucket), "0": never, None: the library's rule
     (these shards are below its 2^24 threshold).  mock_async: the test double only ENQUEUES its collectives on the caller's
     stream and returns (GLU_MOCK_RCCL_ASYNC, like the real library), so a missing stream dependency shows as wrong data;
-    the synchronous mode proves offsets and the plan only."""
+    the synchronous mode proves offsets and the plan only.  rounds: the exchange is posted in that many rounds, one group of
+    every rank's buckets each, on the side stream, and the local sort of a group runs behind its own round (what sorts of 2^24
+    pairs per rank do by themselves); every round's messages, the group-major landing layout and the per-group segmented sorts
+    at their places in the shard are then what the comparison with the oracle checks."""
     import torch.multiprocessing as mp
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -468,7 +478,7 @@ def test_native_multi_rank_sort_over_mock_transport(built, world, seg_mode, mock
     unique_id = os.urandom(128)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_mock_rank_worker, args=(r, world, unique_id, mock_lib, str(tmp_path), q, seg_mode, mock_async))
+    procs = [ctx.Process(target=_mock_rank_worker, args=(r, world, unique_id, mock_lib, str(tmp_path), q, seg_mode, mock_async, rounds))
              for r in range(world)]
     for p in procs:
         p.start()
@@ -492,6 +502,8 @@ def test_native_multi_rank_sort_over_mock_transport(built, world, seg_mode, mock
         for g in got:  # which local sort ran: the segmented one exactly when forced and the shard is large enough for it
             want = "segmented" if (seg_mode == "2" and g[2].size >= (1 << 16) and g[1] == 24) else "ordinary"
             assert g[5] == want, (name, g[2].size, g[1], g[5])
+            # rounds are used on the top-byte partition only (a lower byte means tiny or degenerate inputs)
+            assert g[6] == (rounds if rounds and g[1] == 24 else 1), (name, g[6])
         if name == "uniform":  # the plan balances: a shard exceeds its share by less than the hottest (unsplittable) bucket
             sizes = [g[2].size for g in got]
             hottest = int(np.bincount(all_keys >> 24, minlength=256).max())
