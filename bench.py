@@ -515,12 +515,13 @@ def main():
             hang = os.environ.get("GLU_BENCH_TEST_NATIVE_HANG")  # tests of the watchdog below: this rank never arrives
             if native and hang is not None and int(hang) == rank:
                 time.sleep(1e6)
-            def run_depth(depth):
+            def run_depth(depth, rounds=None):
                 """W warm-up sorts, then K timed sorts with `depth` sorts in flight (depth 1 = strictly one after the other, the
                 same regime as the N = 1 line; depth 2 = consecutive independent sorts on two streams / buffer sets /
-                communicators, so that the exchange of sort i+1 can run under the local sort of sort i)."""
+                communicators, so that the exchange of sort i+1 can run under the local sort of sort i).  rounds: rounds of
+                the exchange (None = the library's choice: 3 at depth 1 for shards of 2^24 pairs and more, 1 at depth 2)."""
                 dsort = D.DistributedRadixSort(slots=depth, profile=not args.no_kernel_events,
-                                               native=native)
+                                               native=native, rounds=rounds)
                 if args.digit_bits is not None:
                     for srt in dsort.local_sorters():
                         srt.set_digit_bits(args.digit_bits)
@@ -560,6 +561,18 @@ def main():
             elapsed1 = max_over_ranks(r1["elapsed"])
             res["value_depth1"] = round(n * world * K / elapsed1 / 1e6, 1)
             res["ms_per_step_depth1"] = round(elapsed1 / K * 1e3, 4)
+            if r1["dsort"].native:
+                # how the exchange was posted: in rounds (groups of buckets travel while the groups that have arrived are sorted:
+                # the library's default for one sort at a time on more than one rank) -- and, beside it, the same K sorts with
+                # ONE grouped exchange, then the local sort (what rounds 2 and 3 measured)
+                res["exchange_rounds"] = r1["dsort"]._slots[0]["native"].last_rounds()
+                if res["exchange_rounds"] > 1:
+                    r1b = run_depth(1, rounds=1)
+                    e1b = max_over_ranks(r1b["elapsed"])
+                    res["value_depth1_one_round"] = round(n * world * K / e1b / 1e6, 1)
+                    res["ms_per_step_depth1_one_round"] = round(e1b / K * 1e3, 4)
+                    res["phases_ms_rank0_one_round"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in r1b["phases"].items()}
+                    del r1b
             depth = max(1, args.pipeline_depth)
             elapsed = r1["elapsed"]
             if depth > 1:

@@ -217,7 +217,7 @@ struct glu_dist_s
     // the exchange in ROUNDS (world > 1, large shards): round j carries the j-th group of every rank's buckets on the side
     // stream while the local sort of group j - 1 runs on the sort's stream (dist_sort_finish)
     static constexpr int kMaxRounds = 8;
-    int rounds = 4;                     // GLU_HIP_DIST_ROUNDS (1 .. kMaxRounds)
+    int rounds = 3;                     // glu_dist_set_rounds / GLU_HIP_DIST_ROUNDS (1 .. kMaxRounds)
     size_t rounds_min = (size_t) 1 << 24; // GLU_HIP_DIST_ROUNDS_MIN: pairs per rank (global count / world) from which rounds are used
     hipEvent_t ev_part = nullptr, ev_round[kMaxRounds] = {};
     uint32_t last_rounds = 1;           // rounds of the last sort's exchange (glu_dist_last_rounds)
@@ -900,6 +900,14 @@ glu_status glu_dist_sort_ptr(glu_dist d, const uint32_t* keys, const uint32_t* v
     if (out_keys) *out_keys = (uint32_t*) d->recv_k.ptr;
     if (out_vals) *out_vals = (uint32_t*) d->recv_v.ptr;
     if (out_count) *out_count = n_recv;
+    return GLU_OK;
+}
+
+glu_status glu_dist_set_rounds(glu_dist d, int rounds)
+{
+    if (!d) return fail(GLU_ERROR_INVALID_ARGUMENT, "dist is NULL");
+    if (rounds < 1 || rounds > glu_dist_s::kMaxRounds) return fail(GLU_ERROR_INVALID_ARGUMENT, "rounds must be 1 .. %d (got %d)", glu_dist_s::kMaxRounds, rounds);
+    d->rounds = rounds; // (every rank must set the same value: the rounds are part of the message sequence)
     return GLU_OK;
 }
 

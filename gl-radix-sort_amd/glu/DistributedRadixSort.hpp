@@ -83,6 +83,17 @@ namespace glu
             return seg != 0;
         }
 
+        /// Rounds of the exchange (glu_dist_set_rounds): groups of every rank's buckets travel one after the other while the
+        /// groups that have arrived are sorted -- the default (3) for one sort at a time; 1 for callers that keep several sorts
+        /// in flight on several objects.  The same value on every rank.
+        void set_exchange_rounds(int rounds) { GLU_CHECK_STATUS(glu_dist_set_rounds(m_impl, rounds)); }
+        [[nodiscard]] int last_exchange_rounds() const
+        {
+            uint32_t r = 0;
+            GLU_CHECK_STATUS(glu_dist_last_rounds(m_impl, &r));
+            return (int) r;
+        }
+
         [[nodiscard]] int world_size() const
         {
             int w = 0;

@@ -91,6 +91,7 @@ SYMBOLS = [
     ("glu_dist_sort_finish", _int, [_vp, _vp, _vp, _sz, _vp]),
     ("glu_dist_sort_ptr", _int, [_vp, _vp, _vp, _sz, _vp, _P(_vp), _P(_vp), _P(_sz)]),
     ("glu_dist_last_local_sort", _int, [_vp, _P(_u32)]),
+    ("glu_dist_set_rounds", _int, [_vp, _int]),
     ("glu_dist_last_rounds", _int, [_vp, _P(_u32)]),
     ("glu_dist_set_reserved_cus", _int, [_vp, _int]),
     ("glu_dist_set_profiling", _int, [_vp, _int]),
@@ -504,6 +505,10 @@ class Dist:
         v = _u32(0)
         check(lib().glu_dist_last_local_sort(self._h, ctypes.byref(v)))
         return "segmented" if v.value else "ordinary"
+
+    def set_rounds(self, rounds):
+        """Rounds of the exchange (glu_dist_set_rounds; the same value on every rank)."""
+        check(lib().glu_dist_set_rounds(self._h, int(rounds)))
 
     def last_rounds(self):
         """In how many rounds the last sort's exchange was posted (glu_dist_last_rounds)."""

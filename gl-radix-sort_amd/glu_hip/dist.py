@@ -160,7 +160,7 @@ class DistributedRadixSort:
     of collectives is the call order on every rank, so ranks must issue the same sequence of sorts."""
 
     def __init__(self, group=None, local_ops=None, capacity_factor=1.25, slots=1, local_ops_factory=None, profile=False,
-                 native=None):
+                 native=None, rounds=None):
         import torch
         import torch.distributed as dist
 
@@ -188,6 +188,14 @@ class DistributedRadixSort:
                 made.append(nd)
             if len(made) == max(1, slots):
                 self._slots = [{"ops": None, "native": nd, "bufs": None, "stream": None} for nd in made]
+                # The exchange in rounds (groups of buckets travel while the groups that have arrived are sorted) shortens ONE
+                # sort and costs compute; with several sorts in flight the exchange of one hides under the local sort of
+                # another anyway, so those take one round.  (The same on every rank: part of the message sequence.)
+                if rounds is None and slots > 1:
+                    rounds = 1
+                if rounds is not None:
+                    for nd in made:
+                        nd.set_rounds(rounds)
             else:
                 import warnings
 

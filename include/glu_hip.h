@@ -347,11 +347,17 @@ GLU_API glu_status glu_dist_sort_ptr(glu_dist dist, const uint32_t* keys, const 
  * one message per source rank, each grouped by bucket; glu_radix_sort_run_segments_ptr), 0 if it was the ordinary sort of
  * all 32 bits (small shards, shards made of very many tiny pieces, a partition on a lower byte). */
 GLU_API glu_status glu_dist_last_local_sort(glu_dist dist, uint32_t* segmented);
-/* In how many ROUNDS the last sort's exchange was posted.  With more than one rank and large shards (2^24 pairs per rank by
- * default; GLU_HIP_DIST_ROUNDS = 1 .. 8, default 4; GLU_HIP_DIST_ROUNDS_MIN) every rank's buckets are cut into that many
- * groups of about equal size, round j carries group j of every rank on a side stream, and the local sort of group j runs on
- * the sort's stream behind round j only: the later groups travel while the earlier ones are sorted.  1 = one grouped
- * exchange, then the local sort. */
+/* The exchange in ROUNDS.  With more than one rank and large shards (2^24 pairs per rank and more; GLU_HIP_DIST_ROUNDS_MIN)
+ * every rank's buckets are cut into `rounds` groups of about equal size (1 .. 8, default 3, GLU_HIP_DIST_ROUNDS), round j
+ * carries group j of every rank on a side stream, and the local sort of group j runs on the sort's stream behind round j
+ * only: the later groups travel while the earlier ones are sorted, so ONE sort takes about partition + one round +
+ * max(the other rounds, the sorts) instead of partition + exchange + sort.  The price is compute: a group is sorted by its
+ * own three passes, and four sorts of a quarter cost about a third more than one sort of the whole (measured without a
+ * fabric: 2.70 -> 3.2 ms per 2^27 pairs at 4 rounds).  A caller that keeps several sorts in flight on several objects, where
+ * the exchange of one hides under the local sort of another anyway, sets 1 = one grouped exchange, then the local sort.
+ * Every rank must use the same value (the rounds are part of the message sequence).  glu_dist_last_rounds: what the last
+ * sort used. */
+GLU_API glu_status glu_dist_set_rounds(glu_dist dist, int rounds);
 GLU_API glu_status glu_dist_last_rounds(glu_dist dist, uint32_t* rounds);
 /* CUs that the sort kernels of `dist` leave free (for RCCL kernels of another sort in flight; the partition pass always
  * leaves 8, one per XCD, for the histogram all-gather that runs beside its scatter kernel). */

@@ -724,6 +724,8 @@ def test_bench_multi_gpu_command_line_rehearsal(built, mock_async):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, GRAFT_REPO_ROOT=root, GLU_MOCK_RCCL_ASYNC=mock_async)  # (async: the depth-2 pair of communicators
     #                                                                                  really has two exchanges in flight)
+    if mock_async == "1":
+        env["GLU_HIP_DIST_ROUNDS_MIN"] = "1"  # ... and the one-at-a-time sorts post their exchange in rounds, as large shards do
     p = subprocess.run(["bash", os.path.join(root, "tools", "rehearse_multi_gpu.sh"), "2", "20"], capture_output=True, text=True,
                        env=env, timeout=900)
     assert p.returncode == 0, p.stderr[-2000:]
@@ -734,6 +736,10 @@ def test_bench_multi_gpu_command_line_rehearsal(built, mock_async):
     # the line's value is the one-sort-at-a-time figure, like the N = 1 line; the two-in-flight throughput stands beside it
     assert line["pipeline_depth"] == 2 and line["value"] == line["value_depth1"] and line["value_depth2"] > 0 and "rehearsal" in line
     # ... and so do this run's own single-GPU figures, taken the same way, with the speed-ups against them
+    if mock_async == "1":  # depth 1: three rounds (and the one-round figure beside it); depth 2: one round per sort
+        assert line["exchange_rounds"] == 3 and line["value_depth1_one_round"] > 0
+    else:
+        assert line["exchange_rounds"] == 1 and "value_depth1_one_round" not in line
     one = line["one_gpu"]
     assert one["verified"] is True and one["value_depth1"] > 0 and one["value_depth2"] > 0
     for d in (1, 2):
