@@ -478,6 +478,16 @@ glu_status glu_dist_plan_counts(const uint32_t* all_hist, int world_size, int ra
     return GLU_OK;
 }
 
+glu_status glu_dist_plan_groups(const uint32_t* all_hist, int world_size, const int* bucket_owner, int rounds, int* group_cut)
+{
+    if (!all_hist || !bucket_owner || !group_cut || world_size < 1 || rounds < 1 || rounds > glu_dist_s::kMaxRounds)
+        return fail(GLU_ERROR_INVALID_ARGUMENT, "bad arguments");
+    for (int b = 0; b < kDistBuckets; b++)
+        if (bucket_owner[b] < 0 || bucket_owner[b] >= world_size) return fail(GLU_ERROR_INVALID_ARGUMENT, "bucket %d has owner %d", b, bucket_owner[b]);
+    dist_plan_groups(all_hist, world_size, bucket_owner, rounds, group_cut);
+    return GLU_OK;
+}
+
 // Steps 1-3: partition the local slice, exchange the histograms, plan.  The partition is enqueued on `stream`; the call
 // returns when the host has the plan (it waited for the histogram exchange on the side stream, not for the partition's
 // scatter kernel).  *recv_count = number of pairs this rank will receive: the caller sizes its receive arrays with it.

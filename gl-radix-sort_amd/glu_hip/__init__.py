@@ -98,6 +98,7 @@ SYMBOLS = [
     ("glu_dist_phase_times", _int, [_vp, _P(ctypes.c_double), _P(_u64)]),
     ("glu_dist_plan_buckets", _int, [_P(_u32), _int, _P(_int)]),
     ("glu_dist_plan_counts", _int, [_P(_u32), _int, _int, _P(_int), _P(_u64), _P(_u64)]),
+    ("glu_dist_plan_groups", _int, [_P(_u32), _int, _P(_int), _int, _P(_int)]),
     ("glu_timer_begin", _int, [_P(_vp)]),
     ("glu_timer_end", _int, [_vp, _P(_u64)]),
 ]
@@ -457,6 +458,16 @@ def dist_plan(all_hist, world_size, rank):
     send, recv = (_u64 * world_size)(), (_u64 * world_size)()
     check(lib().glu_dist_plan_counts(h, world_size, rank, owner, send, recv))
     return list(owner), list(send), list(recv)
+
+
+def dist_plan_groups(all_hist, world_size, owner, rounds):
+    """glu_dist_plan_groups (host only): [world][rounds + 1] bucket boundaries of every rank's groups."""
+    flat = [int(x) for row in all_hist for x in row]
+    h = (_u32 * len(flat))(*flat)
+    own = (_int * DIST_BUCKETS)(*[int(x) for x in owner])
+    cut = (_int * (world_size * (rounds + 1)))()
+    check(lib().glu_dist_plan_groups(h, world_size, own, rounds, cut))
+    return [list(cut[q * (rounds + 1):(q + 1) * (rounds + 1)]) for q in range(world_size)]
 
 
 class Dist:

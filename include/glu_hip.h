@@ -372,6 +372,11 @@ GLU_API glu_status glu_dist_phase_times(glu_dist dist, double* ms4, uint64_t* so
 GLU_API glu_status glu_dist_plan_buckets(const uint32_t* all_hist, int world_size, int* bucket_owner);
 GLU_API glu_status glu_dist_plan_counts(const uint32_t* all_hist, int world_size, int rank, const int* bucket_owner,
                                         uint64_t* send_counts, uint64_t* recv_counts);
+/* The groups of the exchange in rounds (glu_dist_set_rounds): group_cut: [world_size][rounds + 1], group j of rank q =
+ * the buckets [group_cut[q][j], group_cut[q][j + 1]) -- contiguous, in order, together exactly q's buckets, cut on the bucket
+ * boundaries nearest to j / rounds of what q receives (a bucket is never split; groups may be empty). */
+GLU_API glu_status glu_dist_plan_groups(const uint32_t* all_hist, int world_size, const int* bucket_owner, int rounds,
+                                        int* group_cut);
 
 /* ---- timing: replaces glu::measure_gl_elapsed_time (glu/gl_utils.hpp:249-265) ---------------------- */
 

@@ -110,6 +110,41 @@ def test_c_abi_plan_equals_the_python_plan(world):
             assert c_send == [int(x) for x in send] and c_recv == [int(x) for x in recv]
 
 
+@pytest.mark.parametrize("rounds", [1, 2, 3, 4, 8])
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_c_abi_groups_of_the_exchange_in_rounds(world, rounds):
+    """glu_dist_plan_groups (host only): every rank's buckets cut into `rounds` contiguous groups -- in order, together exactly
+    the rank's buckets, never splitting a bucket, and balanced to within the largest bucket of the rank."""
+    import glu_hip as G
+
+    rng = np.random.default_rng(100 * world + rounds)
+    for trial in range(10):
+        h = rng.integers(0, 5000, (world, 256))
+        if trial % 4 == 1:
+            h[:, rng.integers(0, 256)] += 3000000
+        if trial % 4 == 2:
+            h[:, 7:] = 0
+        if trial == 9:
+            h[:] = 0
+        owner = D.plan_bucket_to_rank(h.sum(axis=0), world)
+        cuts = G.dist_plan_groups(h, world, owner, rounds)
+        tot = h.sum(axis=0)
+        for q in range(world):
+            mine = np.nonzero(owner == q)[0]
+            c = cuts[q]
+            assert len(c) == rounds + 1 and all(a <= b for a, b in zip(c, c[1:]))
+            if mine.size == 0:
+                assert c[0] == c[-1]
+                continue
+            assert c[0] == mine[0] and c[-1] == mine[-1] + 1
+            sizes = [int(tot[c[j]:c[j + 1]].sum()) for j in range(rounds)]
+            total, biggest = int(tot[mine].sum()), int(tot[mine].max())
+            assert sum(sizes) == total
+            # every boundary lies within one bucket of its target
+            for j in range(1, rounds):
+                assert abs(sum(sizes[:j]) - total * j // rounds) <= biggest
+
+
 def test_plan_skew_never_splits_a_bucket():
     totals = np.zeros(256, dtype=np.int64)
     totals[77] = 10**6
