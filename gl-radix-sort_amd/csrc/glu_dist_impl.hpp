@@ -402,15 +402,14 @@ glu_status glu_dist_prepare(glu_dist d, size_t local_count, size_t recv_capacity
 {
     GLU_TRY(enter());
     if (!d) return fail(GLU_ERROR_INVALID_ARGUMENT, "dist is NULL");
-    GLU_TRY(d->part_k.reserve(std::max<size_t>(local_count, 1) * sizeof(uint32_t)));
-    GLU_TRY(d->part_v.reserve(std::max<size_t>(local_count, 1) * sizeof(uint32_t)));
-    if (recv_capacity)
-    {
-        GLU_TRY(d->recv_k.reserve(recv_capacity * sizeof(uint32_t)));
-        GLU_TRY(d->recv_v.reserve(recv_capacity * sizeof(uint32_t)));
-    }
-    // partition pass: table only; local sort: scratch for the receive side
+    // the local sorter first: partition pass: table only; local sort: scratch for the receive side (the landing arrays of the
+    // exchange), placed by measurement
     GLU_TRY(sort_prepare(d->sorter, std::max(local_count, recv_capacity), sizeof(uint32_t), true, /*may_place=*/true));
+    // then the send-side pair (the partitioned slice) and the receive-side pair of glu_dist_sort_ptr, each placed by
+    // measurement against the sorter: every scatter pass of a rank's sort but the first one's source then runs between pairs
+    // of arrays that were chosen, not drawn (place_pair_by_measurement; plain allocations for small arrays)
+    GLU_TRY(place_pair_by_measurement(d->sorter, std::max<size_t>(local_count, 1), d->part_k, d->part_v));
+    if (recv_capacity) GLU_TRY(place_pair_by_measurement(d->sorter, recv_capacity, d->recv_k, d->recv_v));
     // segmented local sort: one table row per sub-block (at most pieces + workgroups: world x buckets owned + CUs) and the
     // descriptor image of its two pass shapes
     const size_t rows = (size_t) kDistBuckets * (size_t) std::min(d->world, 16) + (size_t) g_dev.num_cus;

@@ -1179,6 +1179,119 @@ glu_status tune_scratch_placement(glu_radix_sort_s* s, size_t count, size_t key_
     return cleanup(GLU_OK);
 }
 
+// A PAIR of arrays for the caller's side of a sort, placed by measurement against a sorter whose own scratch is in place:
+// the same search as tune_scratch_placement with the roles turned round -- the candidates (keys, values; the value array
+// behind spacers of 0, 0.5 ... 7.5 GiB) are the arrays that are sorted, the sorter's scratch is what it is.  A pair of arrays
+// is fast or slow whatever it is paired with, so a pair that sorts fast here is a good source and a good
+// destination of any pass.  glu_dist_prepare places the sharded sort's send-side and receive-side arrays with it: of the four
+// scatter passes of a rank's sort only the first one's source, the caller's slice, is then left to luck.  `keys` / `vals` are
+// (re)allocated: `count` 4-byte elements each.  Explicit prepare calls only; silently the plain allocation when the search is
+// switched off, the arrays are small or memory is short.
+glu_status place_pair_by_measurement(glu_radix_sort_s* s, size_t count, Scratch& keys, Scratch& vals)
+{
+    const size_t bytes = count * sizeof(uint32_t);
+    auto plain = [&]() -> glu_status {
+        GLU_TRY(keys.reserve(bytes));
+        return vals.reserve(bytes);
+    };
+    if (keys.size >= bytes && vals.size >= bytes) return GLU_OK;
+    if (!s->tune_scratch || bytes < kTuneMinKeyBytes || s->keys.size < bytes || s->vals.size < bytes) return plain();
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return plain();
+    keys.release();
+    vals.release();
+    const size_t step_mib = 512, candidates = 16;
+    if (free_b < 2 * (2 * bytes + ((candidates - 1) * step_mib << 20)) + ((size_t) 1 << 30))
+    {
+        if (getenv("GLU_VERBOSE")) fprintf(stderr, "[glu_hip] pair placement skipped: %zu MiB free; plain allocation\n", free_b >> 20);
+        return plain();
+    }
+    if (hipDeviceSynchronize() != hipSuccess) return fail(GLU_ERROR_DEVICE, "hipDeviceSynchronize failed before the pair placement");
+    hipStream_t st = g_dev.queue;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
+    {
+        if (e0) (void) hipEventDestroy(e0);
+        return plain();
+    }
+    struct Cand { void* k = nullptr; void* v = nullptr; double ms = 1e30; } best;
+    double worst = 0;
+    uint32_t tried = 0;
+    const auto t_begin = std::chrono::steady_clock::now();
+    const bool was_profiling = s->profiling;
+    s->profiling = false;
+    s->tuning = true; // (the sorts below must not start a search of their own)
+    glu_status status = GLU_OK;
+    for (size_t i = 0; i < candidates && status == GLU_OK; i++)
+    {
+        void *k = nullptr, *sp = nullptr, *v = nullptr;
+        if (hipMalloc(&k, bytes) != hipSuccess)
+        {
+            (void) hipGetLastError();
+            break;
+        }
+        if (i && hipMalloc(&sp, i * step_mib << 20) != hipSuccess)
+        {
+            (void) hipGetLastError();
+            (void) hipFree(k);
+            continue;
+        }
+        if (hipMalloc(&v, bytes) != hipSuccess)
+        {
+            (void) hipGetLastError();
+            (void) hipFree(k);
+            if (sp) (void) hipFree(sp);
+            continue;
+        }
+        if (sp) (void) hipFree(sp);
+        double ms = 1e30;
+        for (int rep = 0; rep < 3 && status == GLU_OK; rep++) // the first run is a warm-up
+        {
+            hipLaunchKernelGGL(tune_fill_kernel, dim3(g_dev.num_cus * 8), dim3(256), 0, st, (uint32_t*) k, bytes / 4, 0x5EEDu + rep);
+            hipLaunchKernelGGL(tune_fill_kernel, dim3(g_dev.num_cus * 8), dim3(256), 0, st, (uint32_t*) v, bytes / 4, 77u);
+            (void) hipEventRecord(e0, st);
+            status = sort_run<uint32_t>(s, (uint32_t*) k, (uint32_t*) v, count, 0, st);
+            (void) hipEventRecord(e1, st);
+            if (status == GLU_OK && hipEventSynchronize(e1) == hipSuccess && rep > 0)
+            {
+                float t = 0;
+                if (hipEventElapsedTime(&t, e0, e1) == hipSuccess) ms = std::min(ms, (double) t);
+            }
+        }
+        (void) hipStreamSynchronize(st);
+        if (getenv("GLU_VERBOSE")) fprintf(stderr, "[glu_hip]   pair candidate: keys %p values %p (spacer %zu MiB): %.3f ms\n", k, v, i * step_mib, ms);
+        if (ms < 1e29) worst = std::max(worst, ms);
+        if (status == GLU_OK && ms < best.ms)
+        {
+            if (best.k) (void) hipFree(best.k);
+            if (best.v) (void) hipFree(best.v);
+            best.k = k, best.v = v, best.ms = ms;
+        }
+        else
+        {
+            (void) hipFree(k);
+            (void) hipFree(v);
+        }
+        tried++;
+        if (tried >= 8 && best.ms <= 0.93 * worst) break;
+        if (std::chrono::steady_clock::now() - t_begin > std::chrono::milliseconds(1000)) break;
+    }
+    s->tuning = false;
+    s->profiling = was_profiling;
+    s->last_planned = false;
+    (void) hipEventDestroy(e0);
+    (void) hipEventDestroy(e1);
+    if (best.k)
+    {
+        keys.ptr = best.k, keys.size = bytes;
+        vals.ptr = best.v, vals.size = bytes;
+        if (getenv("GLU_VERBOSE"))
+            fprintf(stderr, "[glu_hip] pair placement: %u candidates, calibration sort %.3f ms (slowest %.3f ms)\n", tried, best.ms, worst);
+    }
+    if (status != GLU_OK) return status;
+    return best.k ? GLU_OK : plain();
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // segmented sort (radix_seg_passes.hpp): glu_radix_sort_run_segments_ptr
 // ------------------------------------------------------------------------------------------------------------

@@ -89,6 +89,19 @@ def shard_pieces(all_hist, bucket_to_rank, rank):
     return begin[keep].astype(np.uint64), lens[keep].astype(np.uint64), seg[keep], g1 - g0
 
 
+class _DeviceMemory:
+    """`count` int32 words of device memory that somebody else owns, for torch.as_tensor (no copy)."""
+
+    def __init__(self, ptr, count):
+        self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<i4", "data": (ptr, False), "version": 2}
+
+
+def _device_array(torch, ptr, count, device):
+    if count == 0 or not ptr:
+        return torch.empty(0, dtype=torch.int32, device=device)
+    return torch.as_tensor(_DeviceMemory(ptr, count), device=device)
+
+
 class HipLocalOps:
     """Device work of one rank on torch tensors (int32 views of the uint32 data) through libglu_hip.so."""
 
@@ -367,8 +380,11 @@ class DistributedRadixSort:
         return {"sorts": count, **{n: (sums[i] / count if count else 0.0) for i, n in enumerate(names)}}
 
     def _sort_native(self, slot, keys, vals):
-        """The sort inside libglu_hip.so: partition + histogram exchange + plan, then (receive arrays sized by the plan)
-        the grouped exchange and the local sort.  Only the receive arrays are torch's."""
+        """The sort inside libglu_hip.so (glu_dist_sort_ptr): partition + histogram exchange + plan, the exchange (in rounds
+        for large shards) and the local sort, into the receive arrays of the glu_dist object -- which glu_dist_prepare has
+        PLACED by measurement together with the send-side arrays and the sorter's scratch (where large arrays lie to each other
+        decides between discrete speeds of every pass on this memory system; arrays from torch's allocator cannot be chosen).
+        The returned tensors alias those arrays (valid until the slot is used again)."""
         t = self.torch
         nd = slot["native"]
         n_local = keys.numel()
@@ -376,38 +392,12 @@ class DistributedRadixSort:
         b = slot["bufs"]
         if b is None or b["n_local"] < n_local:
             try:
-                cap = int(n_local * self.capacity_factor) + 4096
-                b = {"n_local": n_local, "cap": cap,
-                     "recv_k": t.empty(cap, dtype=t.int32, device=keys.device),
-                     "recv_v": t.empty(cap, dtype=t.int32, device=keys.device)}
-                nd.prepare(n_local, cap)
-                slot["bufs"] = b
+                nd.prepare(n_local, int(n_local * self.capacity_factor) + 4096)
             except Exception:
-                # the other ranks are on their way into the histogram exchange: take part in it, reporting a failure
-                # (a slice without arrays), so that every rank's begin returns it
-                try:
-                    nd.sort_begin(0, 0, max(n_local, 1), stream)
-                except Exception:
-                    pass
-                raise
-        n_recv = nd.sort_begin(keys.data_ptr() if n_local else 0, vals.data_ptr() if n_local else 0, n_local, stream)
-        if n_recv > b["cap"]:  # a skewed plan: this rank owns more than its share (buckets are never split)
-            try:
-                cap = int(n_recv * 1.1) + 4096
-                rk = t.empty(cap, dtype=t.int32, device=keys.device)
-                rv = t.empty(cap, dtype=t.int32, device=keys.device)
-                nd.prepare(n_local, cap)
-                b["cap"], b["recv_k"], b["recv_v"] = cap, rk, rv
-            except Exception:
-                # this rank cannot take its shard: the others are about to enter the exchange, so it still calls finish --
-                # with no room, which makes every rank's finish return the failure instead of leaving them waiting
-                try:
-                    nd.sort_finish(0, 0, 0, stream)
-                except Exception:
-                    pass
-                raise
-        nd.sort_finish(b["recv_k"].data_ptr(), b["recv_v"].data_ptr(), b["cap"], stream)
-        return b["recv_k"][:n_recv], b["recv_v"][:n_recv], n_recv
+                pass  # (a rank that cannot allocate says so inside the sort, to every rank: the failure is collective there)
+            slot["bufs"] = {"n_local": n_local}
+        k_ptr, v_ptr, n_recv = nd.sort_ptr(keys.data_ptr() if n_local else 0, vals.data_ptr() if n_local else 0, n_local, stream)
+        return (_device_array(t, k_ptr, n_recv, keys.device), _device_array(t, v_ptr, n_recv, keys.device), n_recv)
 
     def _sort(self, slot, keys, vals):
         if self.native and keys.is_cuda:

@@ -329,7 +329,13 @@ GLU_API glu_status glu_dist_partition_shift(glu_dist dist, uint32_t* shift);
  * glu_radix_sort_set_digit_bits / set_profiling / read_profile. */
 GLU_API glu_status glu_dist_local_sorter(glu_dist dist, glu_radix_sort* out);
 /* Grow-only buffers for slices of `local_count` pairs and (for glu_dist_sort_ptr) shards of `recv_capacity` pairs: after
- * it a sort whose slice / shard fit allocates nothing (the analogue of RadixSort::prepare_internal_buffers, :237-271). */
+ * it a sort whose slice / shard fit allocates nothing (the analogue of RadixSort::prepare_internal_buffers, :237-271).
+ * Like glu_radix_sort_prepare it PLACES large arrays by measurement -- the local sorter's scratch, and against it the
+ * send-side pair (the partitioned slice) and the receive-side pair of glu_dist_sort_ptr, three searches of 0.13-1 s each from
+ * 2^27 pairs up (skipped when memory is short or GLU_HIP_SCRATCH_TUNE=0): every scatter pass of a rank's sort except the
+ * first one's source, the caller's slice, then runs between pairs of arrays that were chosen, not drawn (2.33 -> 2.19 ms of
+ * compute per 2^27 pairs in an alternating same-box comparison with the search switched off).  Receive arrays that a caller
+ * hands to glu_dist_sort_finish are the caller's and are not placed. */
 GLU_API glu_status glu_dist_prepare(glu_dist dist, size_t local_count, size_t recv_capacity);
 /* First half of a sort: partition + histogram exchange + plan.  The partition is enqueued on `stream`; the call returns
  * when the host has the plan (it waits for the histogram exchange, which runs on a side stream beside the partition's
