@@ -60,6 +60,75 @@ def test_single_rank_nccl_distributed_sort(built):
         dist.destroy_process_group()
 
 
+def _placement_worker(q):
+    """Own process (a fresh device heap and GLU_VERBOSE read at start): glu_dist_prepare for 2^27 pairs places the sorter's
+    scratch, the send-side pair and the receive-side pair by measurement; a sort into them is right; everything the searches
+    allocated on the way is gone."""
+    import ctypes
+    import io
+    import os
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (os.path.join(root, "gl-radix-sort_amd"), os.path.join(root, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["GLU_VERBOSE"] = "1"
+    err_path = os.path.join(os.environ.get("TMPDIR", "/tmp"), "glu_placement_%d.err" % os.getpid())
+    saved = os.dup(2)
+    fd = os.open(err_path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC)
+    os.dup2(fd, 2)
+    try:
+        import numpy as np
+        import glu_hip as G
+
+        G.set_device(0)
+        hip = ctypes.CDLL("libamdhip64.so")
+        free0, total = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        d = G.Dist(G.dist_unique_id(), 1, 0)
+        n = 1 << 27
+        keys = np.random.default_rng(5).integers(0, 2**32, n, dtype=np.uint32)
+        vals = np.arange(n, dtype=np.uint32)
+        kb, vb = G.ShaderStorageBuffer(keys), G.ShaderStorageBuffer(vals)
+        G.synchronize()
+        assert hip.hipMemGetInfo(ctypes.byref(free0), ctypes.byref(total)) == 0
+        d.prepare(n, n + 4096)
+        free1 = ctypes.c_size_t(0)
+        assert hip.hipMemGetInfo(ctypes.byref(free1), ctypes.byref(total)) == 0
+        kp, vp, cnt = d.sort_ptr(kb.device_ptr(), vb.device_ptr(), n)
+        G.synchronize()
+        out = np.empty(cnt, dtype=np.uint32)
+        h = ctypes.c_uint32(0)
+        G.check(G.lib().glu_buffer_wrap(ctypes.c_void_p(kp), cnt * 4, ctypes.byref(h)))
+        G.check(G.lib().glu_buffer_read(h, out.ctypes.data_as(ctypes.c_void_p), cnt * 4, 0))
+        G.check(G.lib().glu_buffer_destroy(h))
+        ok = cnt == n and bool((out[1:] >= out[:-1]).all()) and int(out.astype(np.uint64).sum()) == int(keys.astype(np.uint64).sum())
+        d.destroy()
+    finally:
+        os.dup2(saved, 2)
+        os.close(fd)
+    log = open(err_path).read()
+    os.unlink(err_path)
+    q.put((ok, free0.value - free1.value, log.count("scratch placement:"), log.count("pair placement:"), log.count("candidate")))
+
+
+def test_prepare_places_every_array_of_the_sharded_sort(built):
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_placement_worker, args=(q,))
+    p.start()
+    ok, held, scratch_searches, pair_searches, candidates = q.get(timeout=600)
+    p.join(timeout=60)
+    assert ok
+    assert scratch_searches == 1 and pair_searches == 2 and candidates >= 3 * 8  # three searches, at least eight candidates each
+    # what prepare holds afterwards: 3 pairs of 2^27 (+ 4096) 4-byte words, tables, the communicator's buffers (0.7 GiB) and what
+    # the HIP allocator keeps of freed blocks (about 1 GiB, reused by later allocations: tools/place_probe_dist.py) -- not the
+    # 24+ candidates, their spacers or the calibration arrays
+    assert held < 6 * ((1 << 27) + 4096) * 4 + (3 << 30), held
+
+
 def _repartition_worker(q):
     """Own process: GLU_HIP_DIST_TEST_REPARTITION makes a one-rank glu_dist take the lower-byte fallback that a multi-rank
     sort takes when all keys share the top byte."""
