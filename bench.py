@@ -635,7 +635,10 @@ def main():
             res["shard_pairs_rank0"] = int(cnt)
             workload = ("2^%d uint32 key+val pairs per GPU (%d GPUs, 2^%.2f total), uniform-random keys; top-8-bit bucket "
                         "partition + one RCCL all-to-all over xGMI + local sort") % (log2n, world, log2n + __import__("math").log2(world))
-            parallelism = "bucket-sharded x%d (1 grouped RCCL exchange per sort), one sort at a time" % world
+            rounds_used = res.get("exchange_rounds", 1)
+            parallelism = "bucket-sharded x%d (%s per sort), one sort at a time" % (
+                world, "1 grouped RCCL exchange" if rounds_used <= 1 else "the exchange in %d rounds of grouped RCCL sends / receives, "
+                "each group of buckets sorted behind its own round" % rounds_used)
             if depth > 1:
                 parallelism += " (value_depth%d: %d independent sorts in flight)" % (depth, depth)
 
