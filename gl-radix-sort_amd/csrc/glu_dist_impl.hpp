@@ -6,11 +6,13 @@
 //   1. stable partition of the local slice by the bucket key >> 24 with the sort's own count / scan / scatter kernels
 //      (the 256-bin bucket histogram falls out of the row scan, before the scatter runs);
 //   2. ncclAllGather of the R x 256 histograms and the copy to the host run on a side stream while the partition's
-//      scatter kernel is still running (it leaves two CUs free for the RCCL kernel): the host has the plan by the time
+//      scatter kernel is still running (it leaves eight CUs free, one per XCD, for the RCCL kernel): the host has the plan by the time
 //      the partition is done and posts the exchange right behind it, the sort's stream never waits for the host;
 //   3. every rank derives the same contiguous bucket -> rank map (a bucket is never split) and its send / receive counts;
-//   4. ONE grouped exchange (ncclGroupStart .. ncclGroupEnd) carries keys and values to and from every peer, receive
-//      segments in source-rank order; the part that stays on the rank is a device copy;
+//   4. one grouped exchange (ncclGroupStart .. ncclGroupEnd) carries keys and values to and from every peer, receive
+//      segments in source-rank order; the part that stays on the rank is a device copy.  Large shards on more than one rank
+//      post it in ROUNDS (round 4): every rank's buckets are cut into a few groups, round j is the grouped exchange of
+//      group j of every destination, on the side stream, and step 5 runs group by group, each behind its own round;
 //   5. local stable sort of what was received: the shard arrives as one message per source rank, each grouped by bucket,
 //      and is sorted by its low 24 bits per bucket with three SEGMENTED passes (radix_seg_passes.hpp; the first one reads
 //      the messages where they lie, so regrouping them by bucket costs no pass).  Shards that are small, made of very many
@@ -740,7 +742,7 @@ glu_status dist_sort_finish(glu_dist_s* d, uint32_t* recv_keys, uint32_t* recv_v
     d->last_rounds = (uint32_t) rounds;
     std::vector<int> cut((size_t) R * (rounds + 1));
     dist_plan_groups(d->hist_dense.data(), R, d->owner.data(), rounds, cut.data());
-    // prefix[q][b] = elements of rank q's slice in buckets below b (its partitioned slice is bucket-major)
+    // (a rank's partitioned slice is bucket-major: its elements of the buckets [b0, b1) start count_in(rank, 0, b0) in)
     auto hist_of = [&](int q, int b) { return (uint64_t) d->hist_dense[(size_t) q * kDistBuckets + b]; };
     auto count_in = [&](int q, int b0, int b1) {
         uint64_t c = 0;
