@@ -579,6 +579,74 @@ def test_native_multi_rank_sort_over_mock_transport(built, world, seg_mode, mock
             assert max(sizes) <= ek.size / world + hottest, (sizes, hottest)
 
 
+def _default_settings_worker(rank, world, unique_id, mock_lib, mock_dir, q, n):
+    import os
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (os.path.join(root, "gl-radix-sort_amd"), os.path.join(root, "oracle"), os.path.join(root, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(GLU_HIP_RCCL_LIB=mock_lib, GLU_MOCK_RCCL_DIR=mock_dir, GLU_MOCK_RCCL_ASYNC="1")
+    import ctypes
+
+    import numpy as np
+    import glu_hip as G
+
+    G.set_device(0)
+    d = G.Dist(unique_id, world, rank)
+    keys = np.random.default_rng(900 + rank).integers(0, 2**32, n, dtype=np.uint32)
+    keys[::13] = np.uint32(0x40000000 + rank)  # duplicates inside and across the ranks
+    vals = np.arange(rank * n, (rank + 1) * n, dtype=np.uint32)
+    kb, vb = G.ShaderStorageBuffer(keys), G.ShaderStorageBuffer(vals)
+    d.prepare(n, n + n // 4)
+    kp, vp, cnt = d.sort_ptr(kb.device_ptr(), vb.device_ptr(), n)
+    G.synchronize()
+    out = []
+    for ptr in (kp, vp):
+        host = np.empty(cnt, dtype=np.uint32)
+        h = ctypes.c_uint32(0)
+        G.check(G.lib().glu_buffer_wrap(ctypes.c_void_p(ptr), cnt * 4, ctypes.byref(h)))
+        G.check(G.lib().glu_buffer_read(h, host.ctypes.data_as(ctypes.c_void_p), cnt * 4, 0))
+        G.check(G.lib().glu_buffer_destroy(h))
+        out.append(host)
+    q.put((rank, (out[0], out[1], d.last_local_sort(), d.last_rounds())))
+    d.destroy()
+
+
+def test_native_two_ranks_with_the_library_defaults_at_production_size(built, tmp_path):
+    """Two ranks of 2^24 pairs each with NOTHING overridden: the sizes from which the library by itself posts the exchange in
+    rounds (three) and sorts the shard group by group with segmented passes, after a prepare that placed every array by
+    measurement -- over the asynchronous test double, against the oracle."""
+    import torch.multiprocessing as mp
+
+    world, n = 2, 1 << 24
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    mock_lib = os.path.join(root, "tests", "cpp", "bin", "libmock_rccl.so")
+    unique_id = os.urandom(128)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_default_settings_worker, args=(r, world, unique_id, mock_lib, str(tmp_path), q, n)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = _collect(q, procs, world, 600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    all_keys = np.concatenate([np.random.default_rng(900 + r).integers(0, 2**32, n, dtype=np.uint32) for r in range(world)])
+    for r in range(world):
+        all_keys[r * n:(r + 1) * n:13] = np.uint32(0x40000000 + r)
+    ek, ev = O.stable_sort_pairs(all_keys, np.arange(world * n, dtype=np.uint32))
+    gk = np.concatenate([results[r][0] for r in range(world)])
+    gv = np.concatenate([results[r][1] for r in range(world)])
+    assert gk.size == ek.size and (gk == ek).all() and (gv == ev).all()
+    # three rounds everywhere; a rank's local sort is the segmented one from 2^24 pairs up (the split is not exactly even, so the
+    # two ranks may well differ: one posts its rounds into the group-major layout, the other into the source-major one)
+    for r in range(world):
+        assert results[r][3] == 3, results[r][2:]
+        assert results[r][2] == ("segmented" if results[r][0].size >= (1 << 24) else "ordinary"), (results[r][0].size, results[r][2])
+
+
 def _mock_fault_worker(rank, world, unique_id, mock_lib, mock_dir, q, fault, mock_async=True):
     import os
     import sys
