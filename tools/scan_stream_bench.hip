@@ -441,6 +441,141 @@ __global__ __launch_bounds__(THREADS, MINW) void persist_chained_kernel(U* __res
     }
 }
 
+// LDS-DMA prefetch (round 4, the last idea of DESIGN.md section 8): persistent workgroups, one per CU; the NEXT chunk streams
+// into LDS with global_load_lds_dwordx4 (no registers) -- issued by waves 1 .. 15 at the start of a step, so that wave 0's
+// look-back loads never queue behind them -- while the current chunk is scanned in registers, its carry-in is looked up and its
+// stores go out; then the next chunk moves LDS -> registers (ds_read_b128).  Loads and stores of a CU overlap all the time, the
+// look-back is off the memory pipe's critical path.  Raw s_barrier + lgkmcnt(0) (a __syncthreads() would drain the DMA).
+// count must be a multiple of the chunk (tuning harness).
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// STATIC: no tickets -- workgroup b takes the chunks b, b + grid, b + 2 grid, ... (all workgroups must be resident: an experiment)
+template<int GROUPS, int PREFETCH_WAVES = 15, bool STATIC = false>
+__global__ __launch_bounds__(1024) void lds_chained_kernel(U* __restrict__ data, uint64_t count, uint32_t chunks,
+                                                           unsigned long long* __restrict__ chain, uint32_t* __restrict__ ticket,
+                                                           uint32_t epoch)
+{
+    using T = U;
+    using C = ScanCfg<T, GROUPS, 1024>;
+    constexpr int PIECES = GROUPS * 16; // 1 KiB each: one wave-instruction of global_load_lds_dwordx4
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[]; // the next chunk: PIECES KiB
+    __shared__ T wsum[2][C::WAVES];
+    __shared__ uint32_t s_ticket[2];
+    __shared__ T s_prefix;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+    auto prefetch = [&](uint32_t t) {
+        if (wave == 0 || wave > (uint32_t) PREFETCH_WAVES) return; // wave 0 keeps its memory queue for the look-back
+        const unsigned char* gbase = reinterpret_cast<const unsigned char*>(data + (uint64_t) t * C::CHUNK) + lane * 16;
+        for (int p = (int) wave - 1; p < PIECES; p += PREFETCH_WAVES)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*) (gbase + (size_t) p * 1024),
+                                             (__attribute__((address_space(3))) void*) (lds + p * 1024), 16, 0, 0);
+    };
+    T x[GROUPS][C::VEC];
+    auto read_chunk = [&]() {
+#pragma unroll
+        for (int g = 0; g < GROUPS; g++)
+        {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(lds + (wave * GROUPS + g) * 1024 + lane * 16);
+            x[g][0].c[0] = v.x, x[g][1].c[0] = v.y, x[g][2].c[0] = v.z, x[g][3].c[0] = v.w;
+        }
+    };
+
+    if (!STATIC && tid == 0)
+    {
+        s_ticket[0] = atomicAdd(ticket, 1u);
+        s_ticket[1] = atomicAdd(ticket, 1u);
+    }
+    __syncthreads();
+    uint32_t t_cur = STATIC ? blockIdx.x : s_ticket[0], t_next = STATIC ? blockIdx.x + gridDim.x : s_ticket[1];
+    if (t_cur >= chunks) return;
+    prefetch(t_cur);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
+    read_chunk();
+    lds_barrier(); // the LDS buffer is free
+    uint32_t parity = 0;
+    for (;;)
+    {
+        if (t_next < chunks) prefetch(t_next);
+        uint32_t requested = 0;
+        if (!STATIC && tid == 0) requested = atomicAdd(ticket, 1u);
+        T* base = data + (uint64_t) t_cur * C::CHUNK;
+        T gexcl[GROUPS], gtot[GROUPS];
+#pragma unroll
+        for (int g = 0; g < GROUPS; g++)
+        {
+            T lsum = x[g][0];
+#pragma unroll
+            for (int k = 1; k < C::VEC; k++) lsum = combine<OP_SUM>(lsum, x[g][k]);
+            T incl = lsum;
+#pragma unroll
+            for (int off = 1; off < kW; off <<= 1)
+            {
+                T t = shfl_up_t(incl, off);
+                if (lane >= (uint32_t) off) incl = combine<OP_SUM>(t, incl);
+            }
+            gtot[g] = shfl_t(incl, kW - 1);
+            T up = shfl_up_t(incl, 1);
+            gexcl[g] = lane == 0 ? zero_elem<uint32_t, 1>() : up;
+        }
+        T wave_total = gtot[0];
+#pragma unroll
+        for (int g = 1; g < GROUPS; g++) wave_total = combine<OP_SUM>(wave_total, gtot[g]);
+        if (lane == 0) wsum[parity][wave] = wave_total;
+        lds_barrier();
+        if (wave == 0)
+        {
+            T total = wsum[parity][0];
+#pragma unroll
+            for (int w = 1; w < C::WAVES; w++) total = combine<OP_SUM>(total, wsum[parity][w]);
+            const T prefix = chain_resolve<T>(chain, t_cur, epoch, total, lane);
+            if (lane == 0)
+            {
+                s_prefix = prefix;
+                s_ticket[parity] = requested;
+            }
+        }
+        lds_barrier();
+        T run = s_prefix;
+        const uint32_t t_after = STATIC ? t_next + gridDim.x : s_ticket[parity];
+#pragma unroll
+        for (int w = 0; w < C::WAVES; w++)
+            if ((uint32_t) w < wave) run = combine<OP_SUM>(run, wsum[parity][w]);
+        // the next chunk has landed in LDS (issued a scan and a look-back ago); the stores of the chunk before have long been
+        // acknowledged: nothing to wait for in the common case
+        if (wave != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int g = 0; g < GROUPS; g++)
+        {
+            T acc = combine<OP_SUM>(run, gexcl[g]);
+            Pack<T, C::VEC> p;
+#pragma unroll
+            for (int k = 0; k < C::VEC; k++)
+            {
+                p.v[k] = acc;
+                acc = combine<OP_SUM>(acc, x[g][k]);
+            }
+            const uint32_t e0 = wave * C::WAVE_ELEMS + (g * kW + lane) * C::VEC;
+            *reinterpret_cast<Pack<T, C::VEC>*>(base + e0) = p;
+            run = combine<OP_SUM>(run, gtot[g]);
+        }
+        t_cur = t_next;
+        t_next = t_after;
+        parity ^= 1u;
+        if (t_cur >= chunks) break;
+        lds_barrier(); // every wave's share of the prefetch has landed
+        read_chunk();
+        lds_barrier(); // the LDS buffer is free for the next prefetch
+    }
+}
+
 __global__ void fill(uint32_t* p, size_t n)
 {
     for (size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x; i < n; i += (size_t) gridDim.x * blockDim.x)
@@ -561,6 +696,46 @@ int main(int argc, char** argv)
                                (uint64_t) n, ch, chain, ticket, epoch);                                                          \
         });                                                                                                                      \
     }
+#define LDSV2(G, PW, WGS)                                                                                                         \
+    {                                                                                                                            \
+        using CE = ScanCfg<U, G, 1024>;                                                                                          \
+        const uint32_t ch = (uint32_t) (n / CE::CHUNK);                                                                          \
+        auto kern = lds_chained_kernel<G, PW>;                                                                                   \
+        CK(hipFuncSetAttribute((const void*) kern, hipFuncAttributeMaxDynamicSharedMemorySize, G * 16 * 1024));                  \
+        char name[96];                                                                                                           \
+        snprintf(name, sizeof name, "LDS-DMA prefetch: 1024 x %d groups, %d prefetching waves, %d workgroups/CU", G, PW, WGS);    \
+        run(name, [&] {                                                                                                          \
+            hipLaunchKernelGGL(kern, dim3(std::min<uint32_t>(ch, cus * WGS)), dim3(1024), G * 16 * 1024, 0, (U*) work, (uint64_t) n, ch, chain, ticket, epoch); \
+        });                                                                                                                      \
+    }
+#define LDSV(G, PW)                                                                                                               \
+    {                                                                                                                            \
+        using CE = ScanCfg<U, G, 1024>;                                                                                          \
+        const uint32_t ch = (uint32_t) (n / CE::CHUNK);                                                                          \
+        auto kern = lds_chained_kernel<G, PW>;                                                                                   \
+        CK(hipFuncSetAttribute((const void*) kern, hipFuncAttributeMaxDynamicSharedMemorySize, G * 16 * 1024));                  \
+        char name[96];                                                                                                           \
+        snprintf(name, sizeof name, "LDS-DMA prefetch: 1024 x %d groups, %d prefetching waves, 1 workgroup/CU", G, PW);           \
+        run(name, [&] {                                                                                                          \
+            hipLaunchKernelGGL(kern, dim3(std::min<uint32_t>(ch, cus)), dim3(1024), G * 16 * 1024, 0, (U*) work, (uint64_t) n, ch, chain, ticket, epoch); \
+        });                                                                                                                      \
+    }
+    LDSV(8, 15)
+    LDSV(8, 8)
+    LDSV(9, 15)
+    LDSV(4, 15)
+    LDSV(6, 15)
+    LDSV2(4, 15, 2)
+    {
+        using CE = ScanCfg<U, 8, 1024>;
+        const uint32_t ch = (uint32_t) (n / CE::CHUNK);
+        auto kern = lds_chained_kernel<8, 15, true>;
+        CK(hipFuncSetAttribute((const void*) kern, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 16 * 1024));
+        run("LDS-DMA prefetch, STATIC chunk assignment (no tickets), 1024 x 8, 1 workgroup/CU", [&] {
+            hipLaunchKernelGGL(kern, dim3(std::min<uint32_t>(ch, cus)), dim3(1024), 8 * 16 * 1024, 0, (U*) work, (uint64_t) n, ch, chain, ticket, epoch);
+        });
+    }
+    if (getenv("SSB_ONLY_LDS")) return 0;
     PERSIST(8, 1024, 8, 2)
     PERSIST(8, 1024, 4, 2)
     PERSIST(8, 1024, 4, 1)
