@@ -58,8 +58,7 @@ def parse_args():
                    help="N>1: consecutive independent sorts in flight in the line's timed region (own stream, buffers and "
                         "communicator each; the one-at-a-time figure is reported beside it as value_depth1); 1 = one at a time only")
     p.add_argument("--reserved-cus", type=int, default=8,
-                   help="N>1: CUs the sort kernels leave to RCCL kernels that run beside them (the other sort in flight at depth 2; this "
-                        "sort's own later rounds at depth 1)")
+                   help="N>1, pipelined measurement: CUs the sort kernels leave to the RCCL kernels of the other sort in flight")
     p.add_argument("--transport", default="native", choices=["native", "torch"],
                    help="N>1: native = the whole sharded sort inside libglu_hip.so (glu_dist_*: its own RCCL communicator, one grouped "
                         "exchange); torch = torch.distributed collectives around the same C-ABI device work")
@@ -526,11 +525,8 @@ def main():
                 if args.digit_bits is not None:
                     for srt in dsort.local_sorters():
                         srt.set_digit_bits(args.digit_bits)
-                if dsort.native and args.reserved_cus:
-                    # CUs the sort kernels leave free: for the RCCL kernels of the other sort in flight (depth 2), or of this sort's
-                    # own later rounds (depth 1 with the exchange in rounds); a sort with one round and nothing beside it never
-                    # has both kinds of kernel at once, and its partition leaves 8 for the histogram exchange anyway
-                    for slot in dsort._slots:
+                if dsort.native and depth > 1 and args.reserved_cus:
+                    for slot in dsort._slots:  # leave CUs to the RCCL kernels of the other sort in flight
                         slot["native"].set_reserved_cus(args.reserved_cus)
                 for i in range(W):
                     dsort.sort_async(keys0, vals0)
