@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -18,6 +19,7 @@
 #include "radix_scatter_lines.hpp"
 #include "radix_pair_passes.hpp"
 #include "radix_seg_passes.hpp"
+#include "radix_lds_finish.hpp"
 #include "scan_reduce_kernels.hpp"
 
 using namespace glu_hip;
@@ -477,6 +479,13 @@ struct glu_radix_sort_s
                                   // than 1 / this of a workgroup's share (0 = never: tests reach the counter-overflow check that way)
     hipEvent_t after_histogram_event = nullptr; // partition passes: recorded once the digit histogram has been copied out
                                                 // (after the row scan, before the scatter): glu_dist uses it
+    // a sort that ends in LDS (radix_lds_finish.hpp): large sorts of 32-bit keys try two top-bit passes + one in-LDS pass
+    Scratch finish_lengths;       // [65536] run lengths,
+    Scratch finish_starts;        // [65537] run starts
+    bool lds_finish = true;       // GLU_HIP_SORT_LDS_FINISH=0: always the four passes of the ordinary sort (tests / tuning)
+    size_t finish_min = 0;        // GLU_HIP_SORT_FINISH_MIN=N: element count from which the attempt is made (tests / tuning)
+    bool last_finish_attempted = false; // the last sort enqueued both sequences (glu_radix_sort_read_finish)
+    uint32_t last_finish_capacity = 0;  // and the longest run its last pass would take
     size_t large_min = 0;         // GLU_HIP_SORT_LARGE_MIN=N: element count from which the large geometry is used (tuning)
     // optional per-kernel timing: 4 events per pass (before count, after count, after scan, after scatter)
     bool profiling = false;
@@ -547,6 +556,11 @@ glu_status sort_prepare(glu_radix_sort_s* s, size_t count, size_t key_size, bool
         GLU_TRY(s->pair_table.reserve(((size_t) kPairRadix * nb + kPairRadix) * sizeof(uint32_t)));
         GLU_TRY(s->pair_ranges.reserve(nb * sizeof(uint2)));
         GLU_TRY(s->pair_sub.reserve((size_t) kPair4Radix * nb * kPairSub * sizeof(uint32_t)));
+        if (key_size == 4 && s->lds_finish)
+        {
+            GLU_TRY(s->finish_lengths.reserve((size_t) kFinishRuns * sizeof(uint32_t)));
+            GLU_TRY(s->finish_starts.reserve(((size_t) kFinishRuns + 1) * sizeof(uint32_t)));
+        }
     }
     return GLU_OK;
 }
@@ -564,6 +578,10 @@ struct PlanArgs
     int pair_role = 0;
     uint32_t shift2 = 0, bits2 = 0;
     uint32_t flags = 0; // kPlanCollectBits / kPlanShortcut for the pass's count kernel
+    // the first top-bit pass of a sort that tries to end in LDS (radix_lds_finish.hpp): between its row scan and its scatter
+    // the run lengths are summed from the two-digit table and the device decides which sequence of passes runs
+    uint32_t finish_capacity = 0; // 0: not such a pass
+    uint32_t finish_first_ordinary = 0, finish_num_ordinary = 0;
 };
 
 // XF: this pass encodes keys on load and / or decodes them on store (first / last pass of a typed sort); every other
@@ -759,6 +777,16 @@ glu_status launch_pass_lines(glu_radix_sort_s* s, const KeyT* src_k, const uint3
                            pa.plan);
     }
     HIP_TRY(hipGetLastError());
+    if (pa.finish_capacity)
+    {
+        hipLaunchKernelGGL(radix_finish_lengths_kernel, dim3(kPairRadix), dim3(1024), 0, stream, (const uint32_t*) s->pair_t2.ptr, nb,
+                           (uint32_t*) s->finish_lengths.ptr, (const PassPlan*) pa.plan, pa.pass);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(radix_finish_plan_kernel, dim3(kFinishPlanBlocks), dim3(1024), 0, stream, (const uint32_t*) s->finish_lengths.ptr,
+                           (uint32_t*) s->finish_starts.ptr, (uint32_t) count, pa.finish_capacity, pa.plan, pa.pass,
+                           pa.finish_first_ordinary, pa.finish_num_ordinary);
+        HIP_TRY(hipGetLastError());
+    }
     s->mark(stream);
     if (histogram_out)
     {
@@ -880,6 +908,34 @@ glu_status sort_single_block(KeyT* keys, uint32_t* vals, size_t count, uint32_t 
 }
 
 
+// A sort that ends in LDS (radix_lds_finish.hpp): the geometry of its last pass by the mean run length.  The longest of
+// 65536 runs of uniformly drawn keys stays below mean + 6 sigma; a workgroup takes capacity = 256 x KPT pairs.
+// 0: no geometry holds such runs (more than about 2^28 pairs): the ordinary sort.
+inline uint32_t finish_capacity_of(int kpt) { return 256u * (uint32_t) kpt; }
+inline int finish_kpt_for(size_t count)
+{
+    const double mean = (double) count / kFinishRuns;
+    const double need = mean + 6.0 * std::sqrt(mean) + 8.0;
+    for (int kpt : {6, 10, 18})
+        if (need <= (double) finish_capacity_of(kpt)) return kpt;
+    return 0;
+}
+
+template<bool VALS>
+glu_status launch_finish(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, const uint32_t* starts, int kpt,
+                         const PassPlan* plan, uint32_t pass, hipStream_t stream)
+{
+#define GLU_FINISH(KPT_)                                                                                                         \
+    hipLaunchKernelGGL((radix_finish_sort_kernel<256, KPT_, VALS>), dim3(kFinishRuns), dim3(256), sizeof(FinishSmem<256, KPT_, VALS>), \
+                       stream, keys_a, vals_a, keys_b, vals_b, starts, 16u, plan, pass)
+    if (kpt == 6) GLU_FINISH(6);
+    else if (kpt == 10) GLU_FINISH(10);
+    else GLU_FINISH(18);
+#undef GLU_FINISH
+    HIP_TRY(hipGetLastError());
+    return GLU_OK;
+}
+
 // vals == nullptr: keys-only sort (no value traffic, no value scratch)
 template<typename KeyT>
 glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t count, uint32_t first_bit, uint32_t end_bit,
@@ -929,6 +985,23 @@ glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t cou
     // line kernel of the same digit width (wider than 4 bits: the 8-bit kernels, else the 4-bit ones).
     const bool pairs_ok = planned && s->pairs && s->pair_t2.ptr &&
                           count >= (s->pair_min ? s->pair_min : kPairMinKeyBytes / sizeof(KeyT));
+    // Whole 32-bit keys, 8-bit digits, paired line passes: the sort first tries to end in LDS (radix_lds_finish.hpp) -- the two
+    // top-bit passes and the in-LDS pass are enqueued in front of the four ordinary passes, and the device runs one of the
+    // two sequences.
+    int finish_kpt = 0;
+    if (sizeof(KeyT) == 4 && pairs_ok && s->lds_finish && s->finish_starts.ptr && key_xf == KEY_XF_NONE && first_bit == 0 &&
+        end_bit == 32 && s->digit_bits == 8 && num_passes == 4 && count >= (s->finish_min ? s->finish_min : (size_t) 1 << 26) &&
+        lines_applicable<KeyT, 8>(s, kbuf[0], vbuf[0], kbuf[1], vbuf[1], count))
+        finish_kpt = finish_kpt_for(count);
+    if (finish_kpt)
+    {
+        for (uint32_t i = num_passes; i-- > 0;) passes[i + 2] = passes[i];
+        passes[0] = PassDesc{16u, 8u, 0u, 0};
+        passes[1] = PassDesc{24u, 8u, 0u, 0};
+        num_passes += 2;
+    }
+    s->last_finish_attempted = finish_kpt != 0;
+    s->last_finish_capacity = finish_kpt ? finish_capacity_of(finish_kpt) : 0u;
     if (pairs_ok)
     {
         const bool lines8 = lines_applicable<KeyT, 8>(s, kbuf[0], vbuf[0], kbuf[1], vbuf[1], count);
@@ -974,7 +1047,31 @@ glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t cou
                 pa.shift2 = passes[pass + 1].shift;
                 pa.bits2 = passes[pass + 1].bits;
             }
+            if (finish_kpt && pass == 0)
+            {
+                pa.finish_capacity = finish_capacity_of(finish_kpt);
+                pa.finish_first_ordinary = 2;
+                pa.finish_num_ordinary = num_passes - 2;
+            }
             GLU_TRY(dispatch_pass<KeyT>(s, kbuf[0], vbuf[0], kbuf[1], vbuf[1], count, shift, bits, nullptr, stream, xform, pa));
+            if constexpr (sizeof(KeyT) == 4)
+            {
+                if (finish_kpt && pass == 1)
+                {
+                    // the in-LDS pass, in place on whichever pair of arrays holds the data now (returns at once if the
+                    // device chose the ordinary passes, which follow)
+                    s->mark(stream);
+                    s->mark(stream);
+                    s->mark(stream);
+                    if (vals)
+                        GLU_TRY(launch_finish<true>((uint32_t*) kbuf[0], vbuf[0], (uint32_t*) kbuf[1], vbuf[1],
+                                                    (const uint32_t*) s->finish_starts.ptr, finish_kpt, pa.plan, 2u, stream));
+                    else
+                        GLU_TRY(launch_finish<false>((uint32_t*) kbuf[0], nullptr, (uint32_t*) kbuf[1], nullptr,
+                                                     (const uint32_t*) s->finish_starts.ptr, finish_kpt, pa.plan, 2u, stream));
+                    s->mark(stream);
+                }
+            }
         }
         else
         {
@@ -1542,6 +1639,8 @@ glu_status glu_radix_sort_create(glu_radix_sort* out)
     if (const char* e = getenv("GLU_HIP_SORT_EQUAL_SHARES")) s->equal_shares = atoi(e) != 0;
     if (const char* e = getenv("GLU_HIP_SORT_NO_BIT_SHORTCUT")) s->no_bit_shortcut = atoi(e) != 0;
     if (const char* e = getenv("GLU_HIP_SORT_PAIR_MIN")) s->pair_min = (size_t) atoll(e);
+    if (const char* e = getenv("GLU_HIP_SORT_LDS_FINISH")) s->lds_finish = atoi(e) != 0;
+    if (const char* e = getenv("GLU_HIP_SORT_FINISH_MIN")) s->finish_min = (size_t) atoll(e);
     if (const char* e = getenv("GLU_HIP_SORT_PAIR_UNIT_DIV"))
     {
         int v = atoi(e); // 0: no limit
@@ -1861,12 +1960,33 @@ glu_status glu_radix_sort_read_plan(glu_radix_sort sort, uint32_t* skipped, uint
     memset(&host, 0, sizeof(host));
     // a sort below 2^22 elements runs without a device-side plan: every pass ran, none was paired
     if (sort->last_planned) HIP_TRY(hipMemcpy(&host, sort->plan.ptr, sizeof(host), hipMemcpyDeviceToHost));
+    // a sort that tried to end in LDS has its two top-bit passes in front of the ordinary ones, which are what this call
+    // reports (glu_radix_sort_read_finish tells which of the two sequences ran)
+    const size_t first = sort->last_planned && sort->last_finish_attempted ? 2 : 0;
     for (size_t p = 0; p < passes; p++)
     {
-        if (skipped) skipped[p] = host.skip[p];
-        if (counted_alone) counted_alone[p] = host.pair_fallback[p];
-        if (pair_role) pair_role[p] = sort->last_planned ? sort->last_pair_roles[p] : 0u;
+        const bool have = first + p < (size_t) kPlanMaxPasses;
+        if (skipped) skipped[p] = have ? host.skip[first + p] : 0u;
+        if (counted_alone) counted_alone[p] = have ? host.pair_fallback[first + p] : 0u;
+        if (pair_role) pair_role[p] = sort->last_planned && have ? sort->last_pair_roles[first + p] : 0u;
     }
+    return GLU_OK;
+}
+
+glu_status glu_radix_sort_read_finish(glu_radix_sort sort, uint32_t* attempted, uint32_t* accepted, uint32_t* longest_run,
+                                      uint32_t* capacity)
+{
+    GLU_TRY(enter());
+    if (!sort) return fail(GLU_ERROR_INVALID_ARGUMENT, "sort is NULL");
+    if (!sort->plan.ptr) return fail(GLU_ERROR_INVALID_STATE, "no sort has run on this object");
+    const bool tried = sort->last_planned && sort->last_finish_attempted;
+    PassPlan host;
+    memset(&host, 0, sizeof(host));
+    if (tried) HIP_TRY(hipMemcpy(&host, sort->plan.ptr, sizeof(host), hipMemcpyDeviceToHost));
+    if (attempted) *attempted = tried ? 1u : 0u;
+    if (accepted) *accepted = tried ? host.finish : 0u;
+    if (longest_run) *longest_run = tried ? host.finish_longest : 0u;
+    if (capacity) *capacity = tried ? sort->last_finish_capacity : 0u;
     return GLU_OK;
 }
 

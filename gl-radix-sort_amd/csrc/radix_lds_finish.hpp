@@ -1,0 +1,289 @@
+// radix_lds_finish.hpp -- a large sort of 32-bit keys that ENDS IN LDS: two counting passes instead of four.
+//
+// The reference sorts least significant digit first, every pass a full permutation of the array in memory
+// (k_radix_sort_counting_shader + BlellochScan + k_radix_sort_reordering_shader per 4-bit step, glu/RadixSort.hpp:289-345);
+// this library's large sort does the same with four 8-bit passes: 4 x (16 B of scatter + its share of a key read) = 72.5 B
+// per pair.  The result of a stable sort does not depend on how it is reached, and the memory system prices bytes, not
+// passes:
+//
+//   1. the two counting passes on the TOP 16 key bits first (digit [16, 24), then [24, 32): an ordinary pair of passes,
+//      radix_pair_passes.hpp).  After them the array is a sequence of 65536 RUNS, run r = the pairs whose key's top 16 bits
+//      are r, in input order.  The leader's two-digit histogram T2 already holds every run's length:
+//      len[r] = sum over blocks b of T2[r & 255][b][r >> 8].
+//   2. if no run is longer than what one workgroup sorts in LDS, ONE pass finishes the sort in place: a workgroup per run
+//      orders it by the low 16 bits (two rank / scan / re-stage rounds of 8 bits, as in radix_sort_single_block_kernel) and
+//      writes it back where it was.  16 B per pair instead of the 2 x 20.5 of two more passes: 52.5 B per pair in all.
+//   3. otherwise (keys that crowd into few runs: small value ranges, heavy duplicates) the top-bit passes are not run at
+//      all and the four passes of the ordinary sort follow.  The decision is made on the device, after the leader's count
+//      kernel and before its scatter, from exact run lengths; the launch sequence is the same either way and the kernels
+//      of the path not taken return at once (PassPlan::off, PassPlan::skip).  A refused attempt costs one read of the
+//      keys (the leader's count kernel: 4 of 72.5 B per pair).
+//
+//   radix_finish_lengths_kernel   len[r] from T2                                  (32 MiB of table, once per sort)
+//   radix_finish_plan_kernel      run starts, the longest run, the decision       (64 workgroups)
+//   radix_finish_sort_kernel      step 2                                         (one 256-thread workgroup per run)
+#pragma once
+
+#include "radix_pair_passes.hpp"
+
+namespace glu_hip
+{
+constexpr uint32_t kFinishRuns = 65536; // runs = values of the top 16 key bits
+
+// lengths[e * 256 + d] = #keys with digit [16, 24) = d and digit [24, 32) = e: T2 rows (d, b) summed over the leader's nb
+// blocks.  One workgroup per d; thread (g, q) adds word q (counters e = 2q, 2q + 1) of the rows b = g, g + 8, ...
+__global__ __launch_bounds__(1024) void radix_finish_lengths_kernel(const uint32_t* __restrict__ t2, uint32_t nb,
+                                                                    uint32_t* __restrict__ lengths, const PassPlan* plan,
+                                                                    uint32_t pass)
+{
+    if (plan->off[pass] || plan->skip[pass] == kSkipWithoutCounting) return; // no tables (kernel-uniform)
+    __shared__ uint32_t part[8][kPairRadix];
+    const uint32_t tid = threadIdx.x, g = tid >> 7, q = tid & 127u, d = blockIdx.x;
+    uint32_t lo = 0, hi = 0;
+#pragma unroll 4
+    for (uint32_t b = g; b < nb; b += 8)
+    {
+        const uint32_t w = t2[((size_t) d * nb + b) * kPairRowWords + q];
+        lo += w & 0xFFFFu;
+        hi += w >> 16;
+    }
+    part[g][2 * q] = lo;
+    part[g][2 * q + 1] = hi;
+    __syncthreads();
+    if (tid < kPairRadix)
+    {
+        uint32_t c = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) c += part[k][tid];
+        lengths[tid * kPairRadix + d] = c;
+    }
+}
+
+// starts[r] = exclusive scan of lengths (starts[65536] = n), and the decision: the sort ends in LDS if the lengths are
+// exact (they add up to n: a 16-bit counter of T2 that overflowed loses 65536) and no run is longer than `cap`.
+//   accepted: finish = 1, the ordinary passes [first_ordinary, first_ordinary + num_ordinary) are switched off;
+//   refused:  the two top-bit passes `pass`, `pass + 1` are switched off (the leader has counted already: its scatter
+//             sees skip = kSkipWithoutCounting, which leaves the arrays' roles as they are).
+// 64 workgroups, each scans 1024 runs; every workgroup reads all 65536 lengths (256 KiB, from L2) for the sum in front of
+// its runs, the total and the longest run, so each reaches the same decision without a second launch.
+constexpr uint32_t kFinishPlanBlocks = kFinishRuns / 1024;
+__global__ __launch_bounds__(1024) void radix_finish_plan_kernel(const uint32_t* __restrict__ lengths, uint32_t* __restrict__ starts,
+                                                                 uint32_t n, uint32_t cap, PassPlan* plan, uint32_t pass,
+                                                                 uint32_t first_ordinary, uint32_t num_ordinary)
+{
+    __shared__ uint32_t tmp[3][16];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
+    const bool tables = !(plan->off[pass] || plan->skip[pass] == kSkipWithoutCounting); // (kernel-uniform)
+    uint32_t before = 0, all = 0, longest = 0, mine = 0;
+    if (tables)
+    {
+#pragma unroll 8
+        for (uint32_t j = 0; j < kFinishPlanBlocks; j++)
+        {
+            const uint32_t v = lengths[j * 1024u + tid];
+            all += v;
+            before += j < b ? v : 0u;
+            longest = max(longest, v);
+            mine = j == b ? v : mine;
+        }
+    }
+    uint32_t wtotal;
+    uint32_t excl = wave_exclusive_sum(mine, lane, wtotal);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+    {
+        before += __shfl_xor(before, o);
+        all += __shfl_xor(all, o);
+        longest = max(longest, (uint32_t) __shfl_xor(longest, o));
+    }
+    if (lane == 0) tmp[0][wave] = before, tmp[1][wave] = all, tmp[2][wave] = longest;
+    __shared__ uint32_t wsum[16];
+    if (lane == 0) wsum[wave] = wtotal;
+    __syncthreads();
+    before = all = longest = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++)
+    {
+        before += tmp[0][w];
+        all += tmp[1][w];
+        longest = max(longest, tmp[2][w]);
+        if ((uint32_t) w < wave) excl += wsum[w];
+    }
+    const bool accept = tables && all == n && longest <= cap;
+    if (accept)
+    {
+        starts[b * 1024u + tid] = before + excl;
+        if (b == 0 && tid == 0) starts[kFinishRuns] = n;
+    }
+    if (b == 0 && tid == 0)
+    {
+        plan->finish = accept ? 1u : 0u;
+        plan->finish_longest = tables ? longest : 0xFFFFFFFFu;
+        if (!accept)
+        {
+            plan->skip[pass] = kSkipWithoutCounting;
+            plan->off[pass + 1] = 1;
+        }
+    }
+    if (b == 0 && accept && tid < num_ordinary) plan->off[first_ordinary + tid] = 1;
+}
+
+template<int THREADS, int KPT, bool VALS>
+struct FinishSmem
+{
+    static constexpr int RADIX = 256;
+    static constexpr int WAVES = THREADS / kWave;
+    static constexpr int TILE = THREADS * KPT;
+    PairArray<uint32_t, TILE, VALS> stage;
+    // wave-private running digit counters, 16-bit (a tile has fewer than 65536 slots): with 256 x 18 pairs the workgroup
+    // stays below 40 KiB and four of them share a CU (tools/lds_final_pass_bench.hip: 1.06 -> 0.99 ms for 2^28 pairs)
+    uint16_t wcnt[WAVES][RADIX];
+    uint32_t scan_tmp[WAVES];
+};
+static_assert(sizeof(FinishSmem<256, 18, true>) <= 40 * 1024, "four workgroups per CU");
+
+// the longest run a workgroup of this geometry takes
+template<int THREADS, int KPT>
+constexpr uint32_t finish_capacity() { return (uint32_t) (THREADS * KPT); }
+
+// One workgroup per run r = blockIdx.x: pairs [starts[r], starts[r + 1]) of the arrays that hold the data after pass `pass`
+// - 1 (PassPlan::flip[pass]) are ordered by key bits [0, low_bits), stably, in place.  Wave-striped items, wave-private
+// running digit counters, one scan over (digit, wave), staging in ranked order: the body of radix_sort_single_block_kernel.
+// Every wave takes an equal share of the run (a multiple of 64 slots) and ranks only the items its share has -- a run of
+// 4096 pairs costs 16 items per lane, not the 18 the longest run needs.  Slots past the run's end hold the key ~0 (largest
+// digit in every round, behind every real pair in input order); their loads read the run's last element instead of being
+// predicated, so that all loads of a lane are in flight at once.
+template<int THREADS, int KPT, bool VALS>
+__global__ __launch_bounds__(THREADS) void radix_finish_sort_kernel(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b,
+                                                                    uint32_t* vals_b, const uint32_t* __restrict__ starts,
+                                                                    uint32_t low_bits, const PassPlan* plan, uint32_t pass)
+{
+    if (!plan->finish) return; // (kernel-uniform)
+    using Smem = FinishSmem<THREADS, KPT, VALS>;
+    constexpr int RADIX = Smem::RADIX;
+    constexpr int WAVES = Smem::WAVES;
+    constexpr int WQ = WAVES / 4;
+    constexpr int SCAN_THREADS = RADIX * WQ;
+    constexpr int SCAN_WAVES = (SCAN_THREADS + kWave - 1) / kWave;
+    static_assert(WAVES % 4 == 0 && SCAN_THREADS <= THREADS, "offset scan geometry");
+
+    const uint32_t begin = starts[blockIdx.x], end = starts[blockIdx.x + 1];
+    const uint32_t len = end - begin;
+    if (len <= 1) return; // (workgroup-uniform)
+    uint32_t* keys = plan->flip[pass] ? keys_b : keys_a;
+    uint32_t* vals = plan->flip[pass] ? vals_b : vals_a;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    Smem& s = *reinterpret_cast<Smem*>(smem_raw);
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t share = ((len + WAVES * kWave - 1) / (WAVES * kWave)) * kWave; // slots per wave: <= kWave * KPT
+    const uint32_t items = share / kWave;
+    const uint32_t wave_off = wave * share + lane;
+
+    uint32_t key[KPT], val[KPT];
+#pragma unroll
+    for (int i = 0; i < KPT; i++)
+    {
+        const uint32_t p = wave_off + i * kWave;
+        const bool ok = p < len;
+        const uint32_t pc = ok ? p : len - 1;
+        const uint32_t k = keys[begin + pc];
+        const uint32_t v = VALS ? vals[begin + pc] : 0u;
+        key[i] = ok ? k : ~0u;
+        val[i] = ok ? v : 0u;
+    }
+
+    uint16_t* my_cnt = s.wcnt[wave];
+    for (uint32_t shift = 0; shift < low_bits; shift += 8)
+    {
+        constexpr uint32_t MASK = 255u;
+        for (int i = tid; i < WAVES * RADIX / 2; i += THREADS) reinterpret_cast<uint32_t*>(&s.wcnt[0][0])[i] = 0;
+        __syncthreads();
+
+        uint32_t rank[KPT];
+#pragma unroll
+        for (int i = 0; i < KPT; i++)
+        {
+            if ((uint32_t) i >= items) continue; // (workgroup-uniform)
+            const uint32_t d = (key[i] >> shift) & MASK;
+            uint16_t* const cnt = my_cnt + d;
+            const uint32_t prev = *cnt;
+            uint32_t plo = ~0u, phi = ~0u;
+#pragma unroll
+            for (int bit = 0; bit < 8; bit++)
+            {
+                int32_t sel; // (as in radix_sort_single_block_kernel)
+                asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(sel) : "v"(d), "n"(bit));
+                const uint64_t m = __ballot(sel < 0);
+                plo = __builtin_amdgcn_bitop3_b32(plo, (uint32_t) m, (uint32_t) sel, 0x90);
+                phi = __builtin_amdgcn_bitop3_b32(phi, (uint32_t) (m >> 32), (uint32_t) sel, 0x90);
+            }
+            const uint32_t lower = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
+            const uint32_t total = (uint32_t) __popc(plo) + (uint32_t) __popc(phi);
+            rank[i] = prev + lower;
+            asm volatile("" : "+v"(rank[i]));
+            *cnt = (uint16_t) (prev + total);
+        }
+        __syncthreads();
+
+        {
+            const uint32_t sd = tid / WQ, sw = (tid % WQ) * 4;
+            uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+            if (tid < SCAN_THREADS)
+            {
+                c0 = s.wcnt[sw + 0][sd];
+                c1 = s.wcnt[sw + 1][sd];
+                c2 = s.wcnt[sw + 2][sd];
+                c3 = s.wcnt[sw + 3][sd];
+            }
+            uint32_t excl = 0;
+            if (wave < SCAN_WAVES)
+            {
+                uint32_t wtotal;
+                excl = wave_exclusive_sum(c0 + c1 + c2 + c3, lane, wtotal);
+                if (SCAN_WAVES > 1 && lane == 0) s.scan_tmp[wave] = wtotal;
+            }
+            if (SCAN_WAVES > 1)
+            {
+                __syncthreads();
+                excl += sum_of_preceding_waves(s.scan_tmp, SCAN_WAVES, wave, lane);
+            }
+            if (tid < SCAN_THREADS)
+            {
+                s.wcnt[sw + 0][sd] = (uint16_t) excl;
+                s.wcnt[sw + 1][sd] = (uint16_t) (excl + c0);
+                s.wcnt[sw + 2][sd] = (uint16_t) (excl + c0 + c1);
+                s.wcnt[sw + 3][sd] = (uint16_t) (excl + c0 + c1 + c2);
+            }
+        }
+        __syncthreads();
+
+#pragma unroll
+        for (int i = 0; i < KPT; i++)
+        {
+            if ((uint32_t) i >= items) continue;
+            s.stage.put((uint32_t) my_cnt[(key[i] >> shift) & MASK] + rank[i], key[i], val[i]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < KPT; i++)
+        {
+            if ((uint32_t) i >= items) continue;
+            s.stage.get(wave_off + i * kWave, key[i], val[i]);
+        }
+        if (shift + 8 < low_bits) __syncthreads();
+    }
+
+#pragma unroll
+    for (int i = 0; i < KPT; i++)
+    {
+        const uint32_t p = wave_off + i * kWave;
+        if ((uint32_t) i < items && p < len)
+        {
+            __builtin_nontemporal_store(key[i], &keys[begin + p]);
+            if (VALS) __builtin_nontemporal_store(val[i], &vals[begin + p]);
+        }
+    }
+}
+
+} // namespace glu_hip

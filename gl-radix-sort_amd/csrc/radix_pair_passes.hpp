@@ -64,7 +64,7 @@ __global__ __launch_bounds__(1024) void radix_pair_count_kernel(const KeyT* __re
     {
         // this pass's digit lies in key bits that do not vary: an identity, known without counting -- no tables either, so
         // the follower counts for itself (or finds its own digit constant)
-        if ((plan_flags & kPlanShortcut) && plan_digit_is_constant(plan, shift, mask)) // (kernel-uniform)
+        if (plan->off[pass] || ((plan_flags & kPlanShortcut) && plan_digit_is_constant(plan, shift, mask))) // (kernel-uniform; off: radix_lds_finish.hpp)
         {
             if (blockIdx.x == 0 && tid == 0)
             {
@@ -258,6 +258,11 @@ __global__ __launch_bounds__(1024) void radix_pair_unitsum_kernel(const uint32_t
                                                                   uint32_t n, PassPlan* plan, uint32_t pass,
                                                                   uint32_t shift = 0, uint32_t mask = 0, uint32_t plan_flags = 0)
 {
+    if (plan->off[pass]) // a pass of the sequence not taken (radix_lds_finish.hpp)
+    {
+        if (blockIdx.x == 0 && threadIdx.x == 0) plan->skip[pass] = kSkipWithoutCounting;
+        return;
+    }
     if (plan->pair_fallback[pass]) return; // (kernel-uniform)
     if ((plan_flags & kPlanShortcut) && plan_digit_is_constant(plan, shift, mask)) // an identity, known without any table
     {

@@ -159,6 +159,12 @@ struct PassPlan
     // paired passes (radix_pair_passes.hpp): 1 = pass p counts for itself although its table was to come from the
     // two-digit histogram of pass p - 1; zeroed at the start of every sort, set by kernels that run before pass p
     uint32_t pair_fallback[kPlanMaxPasses + 1];
+    // A sort that tries to end in LDS (radix_lds_finish.hpp) enqueues two alternative sequences of passes; off[p] = 1: pass
+    // p belongs to the sequence not taken -- its count kernels return at once and report it as skipped without counting.
+    // finish = 1: the top-bit passes ran and the last pass orders every run in LDS; finish_longest: the longest run seen
+    // (~0: never counted).  Zeroed with pair_fallback, set by radix_finish_plan_kernel.
+    uint32_t off[kPlanMaxPasses];
+    uint32_t finish, finish_longest;
     // Which key bits vary over the input: collected by the count kernel of the first pass of an untyped sort (the OR of
     // all keys and the OR of all complemented keys, low / high word).  A later pass whose digit lies in bits that do not
     // vary is an identity: its count kernel says so (skip[p] = 1) without reading the keys.  Zeroed with pair_fallback.
@@ -368,8 +374,9 @@ __global__ __launch_bounds__(THREADS) void radix_count_kernel(const KeyT* __rest
     const KeyT* __restrict__ keys = keys_a;
     if (plan)
     {
-        // a digit in key bits that do not vary (the first pass's count kernel collected them): an identity pass
-        if ((plan_flags & kPlanShortcut) && plan_digit_is_constant(plan, shift, MASK)) // (kernel-uniform)
+        // a pass of the sequence not taken (PassPlan::off), or a digit in key bits that do not vary (the first pass's count
+        // kernel collected them): an identity pass
+        if (plan->off[pass] || ((plan_flags & kPlanShortcut) && plan_digit_is_constant(plan, shift, MASK))) // (kernel-uniform)
         {
             if (blockIdx.x == 0 && tid == 0) plan->skip[pass] = kSkipWithoutCounting;
             return;

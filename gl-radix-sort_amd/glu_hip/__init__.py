@@ -70,6 +70,7 @@ SYMBOLS = [
     ("glu_radix_sort_set_profiling", _int, [_vp, _int]),
     ("glu_radix_sort_read_profile", _int, [_vp, _P(ctypes.c_double), _P(ctypes.c_double), _P(ctypes.c_double), _P(_u64)]),
     ("glu_radix_sort_read_plan", _int, [_vp, _P(_u32), _P(_u32), _P(_u32), _sz]),
+    ("glu_radix_sort_read_finish", _int, [_vp, _P(_u32), _P(_u32), _P(_u32), _P(_u32)]),
     ("glu_scan_create", _int, [_int, _P(_vp)]),
     ("glu_scan_destroy", _int, [_vp]),
     ("glu_scan_prepare", _int, [_vp, _sz, _sz]),
@@ -285,6 +286,13 @@ class RadixSort:
         sk, ca, ro = (_u32 * passes)(), (_u32 * passes)(), (_u32 * passes)()
         check(lib().glu_radix_sort_read_plan(self._h, sk, ca, ro, passes))
         return (list(sk), list(ca), list(ro)) if roles else (list(sk), list(ca))
+
+    def read_finish(self):
+        """{attempted, accepted, longest_run, capacity} of the last sort: did it try to / did it end in LDS
+        (glu_radix_sort_read_finish); synchronise first."""
+        a, b, c, d = _u32(0), _u32(0), _u32(0), _u32(0)
+        check(lib().glu_radix_sort_read_finish(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c), ctypes.byref(d)))
+        return {"attempted": a.value, "accepted": b.value, "longest_run": c.value, "capacity": d.value}
 
     def __call__(self, key_buffer, val_buffer, count, num_steps=0, key_bytes=4):
         kb = key_buffer.handle() if isinstance(key_buffer, ShaderStorageBuffer) else key_buffer
