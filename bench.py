@@ -403,12 +403,25 @@ def main():
         # once more in its count kernel unless it is the second pass of a pair that took its count table from the first
         # pass's two-digit histogram (then the pair moves that table instead: 256 x workgroups x 512 B written and read)
         # (skipped[p]: 1 = an identity pass found by its count kernel, 2 = known before counting: no key read at all)
-        skipped, alone, roles = sorter.read_plan(passes_per_sort, roles=True)
-        from_table = sum(1 for p in range(passes_per_sort) if roles[p] == 2 and not alone[p] and skipped[p] != 2)
-        key_reads = sum(1 for p in range(passes_per_sort) if skipped[p] != 2) - from_table
-        scatters = sum(1 for p in range(passes_per_sort) if not skipped[p])
-        pair_table_bytes = sum(1 for p in range(passes_per_sort) if roles[p] == 1 and skipped[p] != 2) * 2 * 256 * 256 * 512
-        bytes_per_pair_moved = round(scatters * 2 * (KEY_BYTES + VAL_BYTES) + key_reads * KEY_BYTES + pair_table_bytes / n, 2)
+        # A sort that ended in LDS (include/glu_hip.h, glu_radix_sort_read_finish): two counting passes on the top 16 key bits
+        # (one read of the keys for both tables) and one pass that orders every run of equal top bits inside LDS, reading and
+        # writing each pair once; the profile above then holds those two passes, and the in-LDS pass on its own.
+        fin = sorter.read_finish()
+        ended_in_lds = bool(fin["accepted"])
+        finish_ms = prof["finish_ms"] / max(int(prof["finish_passes"]), 1)
+        if ended_in_lds:
+            key_reads, scatters = 1, 2
+            pair_table_bytes = 2 * 256 * 256 * 512 + 2 * 65536 * 4
+            bytes_per_pair_moved = round(scatters * 2 * (KEY_BYTES + VAL_BYTES) + key_reads * KEY_BYTES + pair_table_bytes / n +
+                                         2 * (KEY_BYTES + VAL_BYTES), 2)
+        else:
+            npl = 4 if fin["attempted"] else passes_per_sort  # (the plan describes the ordinary passes)
+            skipped, alone, roles = sorter.read_plan(npl, roles=True)
+            from_table = sum(1 for p in range(npl) if roles[p] == 2 and not alone[p] and skipped[p] != 2)
+            key_reads = sum(1 for p in range(npl) if skipped[p] != 2) - from_table + (1 if fin["attempted"] else 0)
+            scatters = sum(1 for p in range(npl) if not skipped[p])
+            pair_table_bytes = sum(1 for p in range(npl) if roles[p] == 1 and skipped[p] != 2) * 2 * 256 * 256 * 512
+            bytes_per_pair_moved = round(scatters * 2 * (KEY_BYTES + VAL_BYTES) + key_reads * KEY_BYTES + pair_table_bytes / n, 2)
         result.update({
             "roofline": {
                 "bound": "hbm", "kernel": "radix_scatter_lines_kernel<u32,%d>" % bits,
@@ -427,6 +440,13 @@ def main():
             "whole_sort": {
                 "passes": passes_per_sort, "digit_bits": bits,
                 "count_kernels_reading_keys": key_reads, "scatter_passes_run": scatters,
+                "ended_in_lds": ended_in_lds,
+                "in_lds_pass": ({
+                    "kernel": "radix_finish_sort_kernel", "avg_launch_ms": round(finish_ms, 4),
+                    "algorithmic_bytes_per_launch": alg_bytes,
+                    "achieved_GBps": round(alg_bytes / (finish_ms * 1e-3) / 1e9, 1) if finish_ms > 0 else None,
+                    "frac_of_peak": round(alg_bytes / (finish_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if finish_ms > 0 else None,
+                    "longest_run": fin["longest_run"], "capacity": fin["capacity"]} if ended_in_lds else None),
                 "bytes_per_pair_moved": bytes_per_pair_moved,
                 "achieved_GBps_own_bytes": round(units * bytes_per_pair_moved / elapsed / 1e9, 1),
                 "frac_of_peak_own_bytes": round(units * bytes_per_pair_moved / elapsed / 1e9 / HBM_PEAK_GBPS, 4),
@@ -440,6 +460,41 @@ def main():
             # the spread is the physical placement of each copy's arrays in HBM, not noise
             result["step_device_ms"] = {"min": round(step_ms[0], 4), "median": round(step_ms[len(step_ms) // 2], 4),
                                         "max": round(step_ms[-1], 4)}
+        # the same sort by the four ordinary passes (the attempt to end in LDS switched off), measured like the legs below:
+        # warm-ups, then steps on restored inputs, device time per sort.  Reported next to the headline, not part of `value`.
+        if ended_in_lds and not args.no_alt:
+            os.environ["GLU_HIP_SORT_LDS_FINISH"] = "0"
+            try:
+                four = G.RadixSort(digit_bits=args.digit_bits)
+            finally:
+                del os.environ["GLU_HIP_SORT_LDS_FINISH"]
+            four.prepare_internal_buffers(n)
+            f_warm, f_steps = max(W, 3), max(K, 10)
+            f_events = []
+            for i in range(f_warm + f_steps):
+                sets[i % copies][0].copy_(keys0)
+                sets[i % copies][1].copy_(vals0)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(work_stream)
+                four.run_ptr(sets[i % copies][0].data_ptr(), sets[i % copies][1].data_ptr(), n, 0, stream)
+                e1.record(work_stream)
+                if i >= f_warm:
+                    f_events.append((e0, e1))
+            barrier()
+            f_ms = sorted(a.elapsed_time(b) for a, b in f_events)
+            f_verified = None
+            if not args.no_verify:
+                k, v = sets[(f_warm + f_steps - 1) % copies]
+                f_verified = verify_sorted(torch, keys0, k, v, True)
+            result["four_pass_sort"] = {
+                "what": "the same sort with GLU_HIP_SORT_LDS_FINISH=0: four 8-bit counting passes, 72.5 B/pair",
+                "steps": f_steps, "warmup": f_warm, "ms_per_step": round(f_ms[len(f_ms) // 2], 4), "ms_per_step_min": round(f_ms[0], 4),
+                "timing": "device time per sort (HIP events), median and min",
+                "value": round(n / (f_ms[len(f_ms) // 2] * 1e-3) / 1e6, 1), "unit": "Mkeys/s",
+                "scratch_placement": four.scratch_placement(), "verified": f_verified,
+            }
+            four.destroy()
+            del four
         # the same sort with the reference's pass structure (8 x 4-bit digits, 160 B/pair), measured like the headline:
         # warm-ups, then K timed steps on restored inputs (restores outside the per-step device timing), median + min.
         # Reported next to the headline, not part of `value`.
@@ -500,7 +555,7 @@ def main():
                 "count_kernel_avg_ms": round(ap["count_ms"] / max(int(ap["passes"]), 1), 4),
                 "verified": alt_verified,
             }
-        workload = "2^%d uint32 key + uint32 val pairs, %s keys, vals=iota, in-place stable LSD radix sort, 1x MI355X" % (
+        workload = "2^%d uint32 key + uint32 val pairs, %s keys, vals=iota, in-place stable radix sort, 1x MI355X" % (
             log2n, "uniform-random full-range" if args.keys == "uniform" else "all-zero")
         parallelism = "single"
     else:

@@ -484,6 +484,13 @@ struct glu_radix_sort_s
     Scratch finish_starts;        // [65537] run starts
     bool lds_finish = true;       // GLU_HIP_SORT_LDS_FINISH=0: always the four passes of the ordinary sort (tests / tuning)
     size_t finish_min = 0;        // GLU_HIP_SORT_FINISH_MIN=N: element count from which the attempt is made (tests / tuning)
+    // A refused attempt costs one read of the keys.  The plan kernel notes each attempt's outcome in a pinned host word
+    // (attempt number << 1 | accepted); a later sort call that finds its LAST attempt refused skips the next
+    // `finish_backoff` attempts (no synchronisation: an outcome that is not there yet counts as unknown and the attempt is
+    // made).  Inputs that never fit thus pay for one count kernel in finish_backoff + 1 sorts.
+    uint32_t* finish_hint = nullptr;
+    uint32_t finish_seq = 0, finish_seq_acted_on = 0, finish_wait = 0;
+    uint32_t finish_backoff = 8;  // GLU_HIP_SORT_FINISH_BACKOFF=N (0: every sort attempts: tests)
     bool last_finish_attempted = false; // the last sort enqueued both sequences (glu_radix_sort_read_finish)
     uint32_t last_finish_capacity = 0;  // and the longest run its last pass would take
     size_t large_min = 0;         // GLU_HIP_SORT_LARGE_MIN=N: element count from which the large geometry is used (tuning)
@@ -501,9 +508,14 @@ struct glu_radix_sort_s
         }
         return events[events_used++];
     }
+    // what the four events of a pass belong to: 0 = a pass of the ordinary sort, 1 = a top-bit pass of a sort that tries to
+    // end in LDS, 2 = its in-LDS pass (glu_radix_sort_read_profile books them by which of the two sequences ran)
+    std::vector<uint8_t> pass_kinds;
+    uint8_t cur_kind = 0;
     void mark(hipStream_t stream)
     {
         if (!profiling) return;
+        if (events_used % 4 == 0) pass_kinds.push_back(cur_kind);
         if (hipEvent_t e = next_event()) (void) hipEventRecord(e, stream);
     }
 };
@@ -560,6 +572,11 @@ glu_status sort_prepare(glu_radix_sort_s* s, size_t count, size_t key_size, bool
         {
             GLU_TRY(s->finish_lengths.reserve((size_t) kFinishRuns * sizeof(uint32_t)));
             GLU_TRY(s->finish_starts.reserve(((size_t) kFinishRuns + 1) * sizeof(uint32_t)));
+            if (!s->finish_hint)
+            {
+                HIP_TRY(hipHostMalloc((void**) &s->finish_hint, 64));
+                *s->finish_hint = 0;
+            }
         }
     }
     return GLU_OK;
@@ -580,8 +597,10 @@ struct PlanArgs
     uint32_t flags = 0; // kPlanCollectBits / kPlanShortcut for the pass's count kernel
     // the first top-bit pass of a sort that tries to end in LDS (radix_lds_finish.hpp): between its row scan and its scatter
     // the run lengths are summed from the two-digit table and the device decides which sequence of passes runs
+    bool behind_attempt = false;  // an ordinary pass enqueued behind such an attempt (runs only if the attempt was refused)
     uint32_t finish_capacity = 0; // 0: not such a pass
     uint32_t finish_first_ordinary = 0, finish_num_ordinary = 0;
+    uint32_t finish_seq = 0;
 };
 
 // XF: this pass encodes keys on load and / or decodes them on store (first / last pass of a typed sort); every other
@@ -683,15 +702,25 @@ glu_status launch_pass_lines(glu_radix_sort_s* s, const KeyT* src_k, const uint3
     constexpr int RS = (G::KPT + 2) / 3;
     auto scatter_nt = radix_scatter_lines_kernel<KeyT, BITS, G::THREADS, G::KPT, XF, VALS, 0, false, RS, true, true>;
     auto scatter_plain = radix_scatter_lines_kernel<KeyT, BITS, G::THREADS, G::KPT, XF, VALS, 0, false, RS, true, false>;
+    // the same kernel under another name for the ordinary passes enqueued behind an attempt to end in LDS: they return at
+    // once when the attempt was accepted, and a kernel trace's per-name statistics of the scatter stay those of launches
+    // that moved data
+    auto scatter_behind = scatter_nt;
+    constexpr bool kHasBehind = BITS == 8 && !XF && sizeof(KeyT) == 4; // (the sorts that make such attempts)
+    if constexpr (kHasBehind)
+        scatter_behind = radix_scatter_lines_kernel<KeyT, BITS, G::THREADS, G::KPT, XF, VALS, 0, false, RS, true, true, 0, false, false, true>;
     static std::once_flag lds_opt_in; // per instantiation: allow > 64 KiB of dynamic LDS
     static hipError_t lds_opt_in_result = hipSuccess;
     std::call_once(lds_opt_in, [&] {
         lds_opt_in_result = hipFuncSetAttribute((const void*) scatter_nt, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sizeof(Smem));
         if (lds_opt_in_result == hipSuccess)
             lds_opt_in_result = hipFuncSetAttribute((const void*) scatter_plain, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sizeof(Smem));
+        if (lds_opt_in_result == hipSuccess && kHasBehind)
+            lds_opt_in_result = hipFuncSetAttribute((const void*) scatter_behind, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sizeof(Smem));
     });
     HIP_TRY(lds_opt_in_result);
     auto scatter = s->nt_stores ? scatter_nt : scatter_plain;
+    if (pa.behind_attempt && kHasBehind && s->nt_stores) scatter = scatter_behind;
 
     const uint2* ranges = nullptr;
     s->mark(stream);
@@ -784,7 +813,7 @@ glu_status launch_pass_lines(glu_radix_sort_s* s, const KeyT* src_k, const uint3
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(radix_finish_plan_kernel, dim3(kFinishPlanBlocks), dim3(1024), 0, stream, (const uint32_t*) s->finish_lengths.ptr,
                            (uint32_t*) s->finish_starts.ptr, (uint32_t) count, pa.finish_capacity, pa.plan, pa.pass,
-                           pa.finish_first_ordinary, pa.finish_num_ordinary);
+                           pa.finish_first_ordinary, pa.finish_num_ordinary, s->finish_hint, pa.finish_seq);
         HIP_TRY(hipGetLastError());
     }
     s->mark(stream);
@@ -946,6 +975,8 @@ glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t cou
     if (((uintptr_t) keys % sizeof(KeyT)) != 0 || (vals && ((uintptr_t) vals % sizeof(uint32_t)) != 0))
         return fail(GLU_ERROR_INVALID_ARGUMENT, "key/value arrays must be aligned to their element size");
     GLU_TRY(sort_prepare(s, count, sizeof(KeyT), vals != nullptr)); // RadixSort.hpp:281 (no-op when prepared)
+    s->last_planned = false; // (what glu_radix_sort_read_plan / read_finish report is about THIS sort)
+    s->last_finish_attempted = false;
 
     if (count <= single_block_limit<KeyT>() && !s->no_single_block)
     {
@@ -960,6 +991,7 @@ glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t cou
     KeyT* kbuf[2] = {keys, (KeyT*) s->keys.ptr};
     uint32_t* vbuf[2] = {vals, vals ? (uint32_t*) s->vals.ptr : nullptr};
     int cur = 0;
+    s->cur_kind = 0;
     // large sorts: device-side pass plan (constant-digit passes are skipped, the arrays' roles follow on the device)
     const bool planned = count >= kPlanMinCount && !s->no_plan;
     s->last_planned = planned;
@@ -993,8 +1025,26 @@ glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t cou
         end_bit == 32 && s->digit_bits == 8 && num_passes == 4 && count >= (s->finish_min ? s->finish_min : (size_t) 1 << 26) &&
         lines_applicable<KeyT, 8>(s, kbuf[0], vbuf[0], kbuf[1], vbuf[1], count))
         finish_kpt = finish_kpt_for(count);
+    if (finish_kpt && s->finish_backoff && s->finish_hint)
+    {
+        if (s->finish_wait == 0 && s->finish_seq)
+        {
+            const uint32_t seen = __atomic_load_n(s->finish_hint, __ATOMIC_RELAXED);
+            if ((seen >> 1) == s->finish_seq && s->finish_seq != s->finish_seq_acted_on && !(seen & 1u))
+            {
+                s->finish_wait = s->finish_backoff; // the last attempt was refused (acted on once)
+                s->finish_seq_acted_on = s->finish_seq;
+            }
+        }
+        if (s->finish_wait)
+        {
+            s->finish_wait--;
+            finish_kpt = 0;
+        }
+    }
     if (finish_kpt)
     {
+        s->finish_seq = s->finish_seq >= 0x7FFFFFFFu ? 1u : s->finish_seq + 1;
         for (uint32_t i = num_passes; i-- > 0;) passes[i + 2] = passes[i];
         passes[0] = PassDesc{16u, 8u, 0u, 0};
         passes[1] = PassDesc{24u, 8u, 0u, 0};
@@ -1047,11 +1097,14 @@ glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t cou
                 pa.shift2 = passes[pass + 1].shift;
                 pa.bits2 = passes[pass + 1].bits;
             }
+            s->cur_kind = finish_kpt && pass < 2 ? 1 : 0;
+            pa.behind_attempt = finish_kpt && pass >= 2;
             if (finish_kpt && pass == 0)
             {
                 pa.finish_capacity = finish_capacity_of(finish_kpt);
                 pa.finish_first_ordinary = 2;
                 pa.finish_num_ordinary = num_passes - 2;
+                pa.finish_seq = s->finish_seq;
             }
             GLU_TRY(dispatch_pass<KeyT>(s, kbuf[0], vbuf[0], kbuf[1], vbuf[1], count, shift, bits, nullptr, stream, xform, pa));
             if constexpr (sizeof(KeyT) == 4)
@@ -1060,6 +1113,7 @@ glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t cou
                 {
                     // the in-LDS pass, in place on whichever pair of arrays holds the data now (returns at once if the
                     // device chose the ordinary passes, which follow)
+                    s->cur_kind = 2;
                     s->mark(stream);
                     s->mark(stream);
                     s->mark(stream);
@@ -1641,6 +1695,7 @@ glu_status glu_radix_sort_create(glu_radix_sort* out)
     if (const char* e = getenv("GLU_HIP_SORT_PAIR_MIN")) s->pair_min = (size_t) atoll(e);
     if (const char* e = getenv("GLU_HIP_SORT_LDS_FINISH")) s->lds_finish = atoi(e) != 0;
     if (const char* e = getenv("GLU_HIP_SORT_FINISH_MIN")) s->finish_min = (size_t) atoll(e);
+    if (const char* e = getenv("GLU_HIP_SORT_FINISH_BACKOFF")) s->finish_backoff = (uint32_t) std::max(0, atoi(e));
     if (const char* e = getenv("GLU_HIP_SORT_PAIR_UNIT_DIV"))
     {
         int v = atoi(e); // 0: no limit
@@ -1660,8 +1715,9 @@ glu_status glu_radix_sort_destroy(glu_radix_sort sort)
     // library queue, before its scratch goes away (RAII of the reference: RadixSort.hpp:194-200, gl_utils.hpp:184-188)
     (void) hipDeviceSynchronize();
     for (Scratch* sc : {&sort->keys, &sort->vals, &sort->table, &sort->plan, &sort->pair_t2, &sort->pair_table, &sort->pair_ranges,
-                        &sort->pair_sub, &sort->seg_desc, &sort->seg_zero})
+                        &sort->pair_sub, &sort->seg_desc, &sort->seg_zero, &sort->finish_lengths, &sort->finish_starts})
         sc->release();
+    if (sort->finish_hint) (void) hipHostFree(sort->finish_hint);
     for (hipEvent_t e : sort->events) (void) hipEventDestroy(e);
     for (glu_radix_sort_s::SegStage& st : sort->seg_stage)
     {
@@ -1978,8 +2034,7 @@ glu_status glu_radix_sort_read_finish(glu_radix_sort sort, uint32_t* attempted, 
 {
     GLU_TRY(enter());
     if (!sort) return fail(GLU_ERROR_INVALID_ARGUMENT, "sort is NULL");
-    if (!sort->plan.ptr) return fail(GLU_ERROR_INVALID_STATE, "no sort has run on this object");
-    const bool tried = sort->last_planned && sort->last_finish_attempted;
+    const bool tried = sort->plan.ptr && sort->last_planned && sort->last_finish_attempted; // (no plan yet: nothing was tried)
     PassPlan host;
     memset(&host, 0, sizeof(host));
     if (tried) HIP_TRY(hipMemcpy(&host, sort->plan.ptr, sizeof(host), hipMemcpyDeviceToHost));
@@ -1990,27 +2045,69 @@ glu_status glu_radix_sort_read_finish(glu_radix_sort sort, uint32_t* attempted, 
     return GLU_OK;
 }
 
-glu_status glu_radix_sort_read_profile(glu_radix_sort sort, double* count_ms, double* scan_ms, double* scatter_ms,
-                                       uint64_t* passes)
+namespace
+{
+// Sums the recorded intervals.  Sorts that tried to end in LDS (radix_lds_finish.hpp) enqueue two sequences of passes, one of
+// which returns at once; which one is read from the plan of the LAST sort and assumed for every sort since the previous
+// read.  Booked are the passes that did the work: accepted -- the two top-bit passes (count / scan / scatter) and the in-LDS
+// pass (finish_ms); refused -- the ordinary passes, plus the count interval of the first top-bit pass (the price of asking).
+glu_status read_profile_impl(glu_radix_sort sort, double* count_ms, double* scan_ms, double* scatter_ms, uint64_t* passes,
+                             double* finish_ms, uint64_t* finish_passes)
 {
     GLU_TRY(enter());
     if (!sort) return fail(GLU_ERROR_INVALID_ARGUMENT, "sort is NULL");
-    double acc[3] = {0, 0, 0};
+    double acc[3] = {0, 0, 0}, fin = 0;
+    uint64_t live = 0, fin_n = 0;
     const size_t n = sort->events_used / 4;
     if (n > 0) HIP_TRY(hipEventSynchronize(sort->events[n * 4 - 1]));
+    bool accepted = false;
+    if (sort->last_planned && sort->last_finish_attempted && sort->plan.ptr)
+    {
+        PassPlan host;
+        HIP_TRY(hipMemcpy(&host, sort->plan.ptr, sizeof(host), hipMemcpyDeviceToHost));
+        accepted = host.finish != 0;
+    }
     for (size_t p = 0; p < n; p++)
-        for (int k = 0; k < 3; k++)
+    {
+        float ms[3] = {0.f, 0.f, 0.f};
+        for (int k = 0; k < 3; k++) HIP_TRY(hipEventElapsedTime(&ms[k], sort->events[p * 4 + k], sort->events[p * 4 + k + 1]));
+        const uint8_t kind = p < sort->pass_kinds.size() ? sort->pass_kinds[p] : 0;
+        if (kind == 2)
         {
-            float ms = 0.f;
-            HIP_TRY(hipEventElapsedTime(&ms, sort->events[p * 4 + k], sort->events[p * 4 + k + 1]));
-            acc[k] += ms;
+            if (accepted) fin += ms[2], fin_n++;
+            continue;
         }
+        if (kind == 1 && !accepted)
+        {
+            acc[0] += ms[0]; // the leader's count kernel ran before the device said no
+            continue;
+        }
+        if (kind == 0 && accepted && sort->last_finish_attempted) continue; // the sequence not taken
+        for (int k = 0; k < 3; k++) acc[k] += ms[k];
+        live++;
+    }
     sort->events_used = 0;
+    sort->pass_kinds.clear();
     if (count_ms) *count_ms = acc[0];
     if (scan_ms) *scan_ms = acc[1];
     if (scatter_ms) *scatter_ms = acc[2];
-    if (passes) *passes = n;
+    if (passes) *passes = live;
+    if (finish_ms) *finish_ms = fin;
+    if (finish_passes) *finish_passes = fin_n;
     return GLU_OK;
+}
+}
+
+glu_status glu_radix_sort_read_profile(glu_radix_sort sort, double* count_ms, double* scan_ms, double* scatter_ms,
+                                       uint64_t* passes)
+{
+    return read_profile_impl(sort, count_ms, scan_ms, scatter_ms, passes, nullptr, nullptr);
+}
+
+glu_status glu_radix_sort_read_profile_finish(glu_radix_sort sort, double* count_ms, double* scan_ms, double* scatter_ms,
+                                              uint64_t* passes, double* finish_ms, uint64_t* finish_passes)
+{
+    return read_profile_impl(sort, count_ms, scan_ms, scatter_ms, passes, finish_ms, finish_passes);
 }
 
 glu_status glu_radix_sort_scratch_placement(glu_radix_sort sort, uint32_t* candidates, double* chosen_ms, double* slowest_ms)
@@ -2027,7 +2124,8 @@ glu_status glu_radix_sort_scratch_size(glu_radix_sort sort, size_t* bytes)
     GLU_TRY(enter());
     if (!sort || !bytes) return fail(GLU_ERROR_INVALID_ARGUMENT, "NULL argument");
     *bytes = sort->keys.size + sort->vals.size + sort->table.size + sort->plan.size + sort->pair_t2.size + sort->pair_table.size +
-             sort->pair_ranges.size + sort->pair_sub.size + sort->seg_desc.size + sort->seg_zero.size;
+             sort->pair_ranges.size + sort->pair_sub.size + sort->seg_desc.size + sort->seg_zero.size + sort->finish_lengths.size +
+             sort->finish_starts.size;
     return GLU_OK;
 }
 

@@ -64,12 +64,13 @@ __global__ __launch_bounds__(1024) void radix_finish_lengths_kernel(const uint32
 //   accepted: finish = 1, the ordinary passes [first_ordinary, first_ordinary + num_ordinary) are switched off;
 //   refused:  the two top-bit passes `pass`, `pass + 1` are switched off (the leader has counted already: its scatter
 //             sees skip = kSkipWithoutCounting, which leaves the arrays' roles as they are).
-// 64 workgroups, each scans 1024 runs; every workgroup reads all 65536 lengths (256 KiB, from L2) for the sum in front of
+// hint: see glu_radix_sort_s::finish_hint.  64 workgroups, each scans 1024 runs; every workgroup reads all 65536 lengths (256 KiB, from L2) for the sum in front of
 // its runs, the total and the longest run, so each reaches the same decision without a second launch.
 constexpr uint32_t kFinishPlanBlocks = kFinishRuns / 1024;
 __global__ __launch_bounds__(1024) void radix_finish_plan_kernel(const uint32_t* __restrict__ lengths, uint32_t* __restrict__ starts,
                                                                  uint32_t n, uint32_t cap, PassPlan* plan, uint32_t pass,
-                                                                 uint32_t first_ordinary, uint32_t num_ordinary)
+                                                                 uint32_t first_ordinary, uint32_t num_ordinary,
+                                                                 uint32_t* hint, uint32_t attempt)
 {
     __shared__ uint32_t tmp[3][16];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
@@ -119,6 +120,8 @@ __global__ __launch_bounds__(1024) void radix_finish_plan_kernel(const uint32_t*
     {
         plan->finish = accept ? 1u : 0u;
         plan->finish_longest = tables ? longest : 0xFFFFFFFFu;
+        // for the host, which reads it without synchronising: the outcome of attempt number `attempt` (pinned host memory)
+        if (hint) __hip_atomic_store(hint, (attempt << 1) | (accept ? 1u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if (!accept)
         {
             plan->skip[pass] = kSkipWithoutCounting;

@@ -74,6 +74,8 @@ struct LineSmem
 // tuning only (s_setprio around the LDS-bound phases: measured, no effect).  STAMPS: s_memtime per phase of the first and
 // the last wave into stamps[0..15] (tools/scatter_bench.hip).
 //
+// BEHIND_ATTEMPT changes nothing but the kernel's name: the ordinary passes enqueued behind an attempt to end the sort in LDS
+// (radix_lds_finish.hpp), which return at once when the attempt was accepted.
 // RANK_ATOMIC (measured in round 3, NOT used by the library; tools/scatter_bench.hip SB_RA=1): an item's rank inside its wave
 // from ONE returning LDS atomic add on the wave's counter row (two 16-bit counters per word) instead of eight ballots.  A
 // stable pass needs the lanes of one instruction that add to the same counter served in lane order: gfx950 does that
@@ -90,7 +92,7 @@ struct LineSmem
 // (sub-block, digit) range -- is the pass as above; `totals`, `plan`, `share` are not used.
 template<typename KeyT, int BITS, int THREADS, int KPT, bool XF = false, bool VALS = true, int ABLATE = 0, bool STAMPS = false,
          int RANK_SPLIT = (KPT + 2) / 3, bool STAGGER = true, bool NT_STORES = false, int PRIO = 0, bool SEG = false,
-         bool RANK_ATOMIC = false>
+         bool RANK_ATOMIC = false, bool BEHIND_ATTEMPT = false>
 __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
     const KeyT* __restrict__ keys_a, const uint32_t* __restrict__ vals_a, KeyT* __restrict__ keys_b,
     uint32_t* __restrict__ vals_b, const uint32_t* __restrict__ table, const uint32_t* __restrict__ totals, uint32_t n,

@@ -70,6 +70,8 @@ SYMBOLS = [
     ("glu_radix_sort_set_profiling", _int, [_vp, _int]),
     ("glu_radix_sort_read_profile", _int, [_vp, _P(ctypes.c_double), _P(ctypes.c_double), _P(ctypes.c_double), _P(_u64)]),
     ("glu_radix_sort_read_plan", _int, [_vp, _P(_u32), _P(_u32), _P(_u32), _sz]),
+    ("glu_radix_sort_read_profile_finish", _int, [_vp, _P(ctypes.c_double), _P(ctypes.c_double), _P(ctypes.c_double), _P(_u64),
+                                                  _P(ctypes.c_double), _P(_u64)]),
     ("glu_radix_sort_read_finish", _int, [_vp, _P(_u32), _P(_u32), _P(_u32), _P(_u32)]),
     ("glu_scan_create", _int, [_int, _P(_vp)]),
     ("glu_scan_destroy", _int, [_vp]),
@@ -276,9 +278,11 @@ class RadixSort:
         """{count_ms, scan_ms, scatter_ms, passes}: summed device time per kernel class since the last read."""
         c, s, x = ctypes.c_double(0), ctypes.c_double(0), ctypes.c_double(0)
         n = _u64(0)
-        check(lib().glu_radix_sort_read_profile(self._h, ctypes.byref(c), ctypes.byref(s), ctypes.byref(x),
-                                                ctypes.byref(n)))
-        return {"count_ms": c.value, "scan_ms": s.value, "scatter_ms": x.value, "passes": n.value}
+        f, fn = ctypes.c_double(0), _u64(0)
+        check(lib().glu_radix_sort_read_profile_finish(self._h, ctypes.byref(c), ctypes.byref(s), ctypes.byref(x),
+                                                       ctypes.byref(n), ctypes.byref(f), ctypes.byref(fn)))
+        return {"count_ms": c.value, "scan_ms": s.value, "scatter_ms": x.value, "passes": n.value,
+                "finish_ms": f.value, "finish_passes": fn.value}
 
     def read_plan(self, passes, roles=False):
         """(skipped[passes], counted_alone[passes]) -- with roles=True also pair_role[passes] -- of the last planned sort

@@ -255,6 +255,14 @@ GLU_API glu_status glu_radix_sort_scratch_size(glu_radix_sort sort, size_t* byte
 GLU_API glu_status glu_radix_sort_set_profiling(glu_radix_sort sort, int enable);
 GLU_API glu_status glu_radix_sort_read_profile(glu_radix_sort sort, double* count_ms, double* scan_ms,
                                                double* scatter_ms, uint64_t* passes);
+/* The same with the in-LDS pass of sorts that ended in LDS (glu_radix_sort_read_finish below): finish_ms = its summed
+ * device milliseconds, finish_passes = how many ran.  Such a sort enqueues two sequences of passes of which one returns at
+ * once; both calls book the passes that did the work (which sequence that was is read from the last sort and assumed for
+ * every sort since the previous read): the two top-bit passes when the sort ended in LDS, else the ordinary passes plus the
+ * count kernel the refused attempt cost. */
+GLU_API glu_status glu_radix_sort_read_profile_finish(glu_radix_sort sort, double* count_ms, double* scan_ms,
+                                                      double* scatter_ms, uint64_t* passes, double* finish_ms,
+                                                      uint64_t* finish_passes);
 /* Diagnostics of the last sort of >= 2^22 elements on this object, whose passes are planned on the device (the caller has
  * synchronised the sort's stream): for pass p < passes, skipped[p] != 0 if the pass was an identity (every key had the same
  * digit value: its scatter did not run) -- 1 if its count kernel found that out, 2 if it was known before counting (the

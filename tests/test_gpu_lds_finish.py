@@ -1,0 +1,287 @@
+"""GPU parity tests of the sort that ends in LDS (radix_lds_finish.hpp): a large sort of whole 32-bit keys first tries the two
+counting passes on the TOP 16 key bits and one pass that orders every run of equal top bits inside LDS; the device accepts
+that only if no run is longer than a workgroup's tile, else the four ordinary passes run.  Either way the result is the
+stable sort of glu::RadixSort::operator() (reference glu/RadixSort.hpp:273-334) -- compared bit for bit with the oracle,
+through the C ABI."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def G(built):
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return built
+
+
+def _sorter(G, **env):
+    """A sort object created under the given GLU_HIP_* switches (they are read by glu_radix_sort_create)."""
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update({k: str(v) for k, v in env.items()})
+    try:
+        return G.RadixSort()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+# small sizes: pair the passes and make the attempt from the smallest planned sort up (defaults: 2^26 elements)
+SMALL = dict(GLU_HIP_SORT_PAIR_MIN=1, GLU_HIP_SORT_FINISH_MIN=1)
+CAP_SMALL = 1536  # the smallest geometry of the in-LDS pass: 256 threads x 6 pairs
+
+
+def _run(G, sorter, keys, vals):
+    kb = G.ShaderStorageBuffer(keys)
+    if vals is None:
+        sorter.sort_keys_ptr(kb.device_ptr(), keys.size)
+        G.synchronize()
+        return kb.get_data(np.uint32), None, sorter.read_finish()
+    vb = G.ShaderStorageBuffer(vals)
+    sorter(kb, vb, keys.size)
+    G.synchronize()
+    return kb.get_data(np.uint32), vb.get_data(np.uint32), sorter.read_finish()
+
+
+def _check(keys, vals, gk, gv):
+    if vals is None:
+        assert (gk == np.sort(keys, kind="stable")).all()
+        return
+    ek, ev = O.stable_sort_pairs(keys, vals)
+    assert (gk == ek).all(), "keys differ from the oracle at %s" % np.flatnonzero(gk != ek)[:5]
+    assert (gv == ev).all(), "values differ from the oracle at %s" % np.flatnonzero(gv != ev)[:5]
+
+
+N_SMALL = (1 << 22) + 54321
+
+
+def _uniform(n, seed):
+    return np.random.default_rng(seed).integers(0, 2**32, n, dtype=np.uint32)
+
+
+def test_uniform_keys_end_in_lds(G):
+    keys, vals = _uniform(N_SMALL, 1), np.arange(N_SMALL, dtype=np.uint32)
+    s = _sorter(G, **SMALL)
+    gk, gv, fin = _run(G, s, keys, vals)
+    _check(keys, vals, gk, gv)
+    assert fin["attempted"] == 1 and fin["accepted"] == 1 and fin["capacity"] == CAP_SMALL
+    top = np.bincount(keys >> 16, minlength=65536)
+    assert fin["longest_run"] == top.max()
+    # the ordinary passes were the sequence not taken: all four known to be skipped before counting
+    skipped, alone, roles = s.read_plan(4, roles=True)
+    assert skipped == [2, 2, 2, 2] and roles == [1, 2, 1, 2]
+    # same object, switch off: the same result from the four ordinary passes
+    off = _sorter(G, GLU_HIP_SORT_LDS_FINISH=0, **SMALL)
+    gk2, gv2, fin2 = _run(G, off, keys, vals)
+    assert (gk2 == gk).all() and (gv2 == gv).all() and fin2["attempted"] == 0
+
+
+def test_keys_only_end_in_lds(G):
+    keys = _uniform((1 << 23) + 4321, 2)  # (the keys-only line kernel starts at 6.3 M keys)
+    s = _sorter(G, **SMALL)
+    gk, _, fin = _run(G, s, keys, None)
+    _check(keys, None, gk, None)
+    assert fin["attempted"] == 1 and fin["accepted"] == 1
+
+
+def test_duplicate_keys_inside_runs_keep_their_order(G):
+    """Few distinct low 16 bits: every run is full of equal keys; the values must come out in input order."""
+    rng = np.random.default_rng(3)
+    keys = (rng.integers(0, 65536, N_SMALL, dtype=np.uint32) << 16) | rng.integers(0, 3, N_SMALL, dtype=np.uint32) * np.uint32(0x0101)
+    vals = np.arange(N_SMALL, dtype=np.uint32)
+    gk, gv, fin = _run(G, _sorter(G, **SMALL), keys, vals)
+    _check(keys, vals, gk, gv)
+    assert fin["accepted"] == 1
+
+
+def test_small_key_range_is_refused_and_sorted_by_the_ordinary_passes(G):
+    """Keys below 2^20: sixteen runs hold everything -- the device says no after the first count kernel, the top-bit passes
+    move nothing, the ordinary passes follow (their two top-byte passes skipped as usual)."""
+    rng = np.random.default_rng(4)
+    keys = rng.integers(0, 1 << 20, N_SMALL, dtype=np.uint32)
+    vals = np.arange(N_SMALL, dtype=np.uint32)
+    s = _sorter(G, **SMALL)
+    gk, gv, fin = _run(G, s, keys, vals)
+    _check(keys, vals, gk, gv)
+    assert fin["attempted"] == 1 and fin["accepted"] == 0 and fin["longest_run"] > CAP_SMALL
+    skipped, alone, roles = s.read_plan(4, roles=True)
+    assert skipped[:3] == [0, 0, 0] and skipped[3] != 0 and roles == [1, 2, 1, 2]
+
+
+def test_all_keys_equal_is_refused(G):
+    """One run of n keys: the 16-bit counters of the two-digit table overflow, the lengths do not add up, refused."""
+    keys = np.full(N_SMALL, 0xDEADBEEF, dtype=np.uint32)
+    vals = np.arange(N_SMALL, dtype=np.uint32)
+    gk, gv, fin = _run(G, _sorter(G, **SMALL), keys, vals)
+    _check(keys, vals, gk, gv)
+    assert fin["attempted"] == 1 and fin["accepted"] == 0
+
+
+def _with_one_run_of(n, length, seed, run=0x1234):
+    """Uniform keys, except that exactly `length` of them (at random positions) have the top 16 bits `run`."""
+    rng = np.random.default_rng(seed)
+    keys = rng.integers(0, 2**32, n, dtype=np.uint32)
+    clash = (keys >> 16) == run
+    keys[clash] ^= np.uint32(0x80000000)  # out of the run
+    pos = rng.choice(n, size=length, replace=False)
+    keys[pos] = (np.uint32(run) << 16) | rng.integers(0, 65536, length, dtype=np.uint32)
+    return keys
+
+
+@pytest.mark.parametrize("length,accepted", [(CAP_SMALL, 1), (CAP_SMALL + 1, 0), (CAP_SMALL - 1, 1), (CAP_SMALL + 5000, 0)])
+def test_the_longest_run_decides(G, length, accepted):
+    """A run of exactly the tile's capacity is sorted in LDS; one pair more and the ordinary passes run."""
+    keys = _with_one_run_of(N_SMALL, length, 5)
+    vals = np.arange(N_SMALL, dtype=np.uint32)
+    gk, gv, fin = _run(G, _sorter(G, **SMALL), keys, vals)
+    _check(keys, vals, gk, gv)
+    assert fin["attempted"] == 1 and fin["accepted"] == accepted and fin["longest_run"] == length
+
+
+def test_empty_runs_and_runs_of_one(G):
+    """Top 16 bits only even, and a handful of runs with a single pair."""
+    rng = np.random.default_rng(6)
+    keys = rng.integers(0, 2**32, N_SMALL, dtype=np.uint32) & np.uint32(0xFFFEFFFF)
+    keys[keys >> 16 == 0x0002] |= np.uint32(0x00040000)  # empty run 2 ...
+    keys[7] = 0x00020007                                  # ... but for one pair
+    keys[N_SMALL - 1] = 0x00030001                        # an odd run with one pair (the last element)
+    vals = np.arange(N_SMALL, dtype=np.uint32)
+    gk, gv, fin = _run(G, _sorter(G, **SMALL), keys, vals)
+    _check(keys, vals, gk, gv)
+    assert fin["accepted"] == 1
+
+
+@pytest.mark.parametrize("shape", ["sorted", "reversed", "sorted_runs_reversed_inside"])
+def test_presorted_inputs(G, shape):
+    keys = np.sort(_uniform(N_SMALL, 7))
+    if shape == "reversed":
+        keys = keys[::-1].copy()
+    elif shape == "sorted_runs_reversed_inside":
+        keys = (keys & np.uint32(0xFFFF0000)) | (~keys & np.uint32(0xFFFF))
+    vals = np.arange(N_SMALL, dtype=np.uint32)
+    gk, gv, fin = _run(G, _sorter(G, **SMALL), keys, vals)
+    _check(keys, vals, gk, gv)
+    assert fin["accepted"] == 1
+
+
+def test_one_object_alternates_between_the_two_sequences(G):
+    """The plan is per sort: accepted, refused, accepted on the same object, and a small sort (no plan) in between."""
+    s = _sorter(G, GLU_HIP_SORT_FINISH_BACKOFF=0, **SMALL)  # (by default a refusal makes the next sorts skip the attempt)
+    vals = np.arange(N_SMALL, dtype=np.uint32)
+    for seed, small_range in [(8, False), (9, True), (10, False)]:
+        keys = _uniform(N_SMALL, seed)
+        if small_range:
+            keys >>= np.uint32(14)
+        gk, gv, fin = _run(G, s, keys, vals)
+        _check(keys, vals, gk, gv)
+        assert fin["attempted"] == 1 and fin["accepted"] == (0 if small_range else 1)
+        k2 = _uniform(5000, seed)
+        gk2, gv2, fin2 = _run(G, s, k2, np.arange(5000, dtype=np.uint32))
+        _check(k2, np.arange(5000, dtype=np.uint32), gk2, gv2)
+        assert fin2["attempted"] == 0
+
+
+def test_after_a_refusal_the_next_sorts_do_not_ask_again(G):
+    """A refused attempt costs a read of the keys; an object whose last attempt was refused skips the next eight attempts, then
+    asks again (inputs that fit are taken up again, inputs that never fit pay once in nine sorts)."""
+    s = _sorter(G, **SMALL)
+    vals = np.arange(N_SMALL, dtype=np.uint32)
+    narrow = _uniform(N_SMALL, 13) >> np.uint32(12)
+    wide = _uniform(N_SMALL, 14)
+    seen = []
+    for i in range(11):
+        keys = narrow if i < 10 else wide
+        gk, gv, fin = _run(G, s, keys, vals)
+        if i in (0, 1, 9, 10):
+            _check(keys, vals, gk, gv)
+        seen.append((fin["attempted"], fin["accepted"]))
+    assert seen == [(1, 0)] + [(0, 0)] * 8 + [(1, 0)] + [(0, 0)], seen
+    # eight more sorts and the object asks again -- this time the keys fit
+    for i in range(7):
+        _run(G, s, wide, vals)
+    gk, gv, fin = _run(G, s, wide, vals)
+    _check(wide, vals, gk, gv)
+    assert fin["attempted"] == 1 and fin["accepted"] == 1
+
+
+def test_sizes_around_the_geometries_of_the_in_lds_pass(G):
+    """Sizes whose mean run length falls into each tile geometry (6 / 10 / 18 pairs per thread), keys-only to keep the host
+    side short; sortedness + the multiset (a checksum) instead of a full oracle sort at the largest."""
+    import torch
+
+    s = _sorter(G, GLU_HIP_SORT_PAIR_MIN=1, GLU_HIP_SORT_FINISH_MIN=1)
+    for n, cap in [((1 << 26) - 77, 1536), ((1 << 27) + 4099, 2560), ((1 << 28) - 3, 4608)]:
+        g = torch.Generator(device="cuda:0")
+        g.manual_seed(n)
+        keys = torch.randint(-2**31, 2**31, (n,), dtype=torch.int32, device="cuda:0", generator=g)
+        vals = torch.arange(n, dtype=torch.int32, device="cuda:0")
+        k0 = keys.clone()
+        torch.cuda.synchronize()
+        s.run_ptr(keys.data_ptr(), vals.data_ptr(), n)
+        G.synchronize()
+        fin = s.read_finish()
+        assert fin["attempted"] == 1 and fin["accepted"] == 1 and fin["capacity"] == cap, fin
+        # unsigned order == order of (key ^ 0x80000000) as int32
+        flipped = keys ^ torch.tensor(-2**31, dtype=torch.int32, device="cuda:0")
+        assert bool((flipped[1:] >= flipped[:-1]).all()), "not sorted"
+        # the permutation is a permutation, and carries each key with its value
+        assert bool((k0[vals.long()] == keys).all()), "a value does not point at its key"
+        # stability: equal neighbours keep ascending values
+        eq = keys[1:] == keys[:-1]
+        assert bool((vals[1:][eq] > vals[:-1][eq]).all()), "equal keys out of input order"
+        del keys, vals, k0, flipped, eq
+        torch.cuda.empty_cache()
+
+
+def test_beyond_the_largest_geometry_no_attempt_is_made(G):
+    import torch
+
+    n = (1 << 28) + (1 << 25)
+    s = _sorter(G)
+    keys = torch.randint(-2**31, 2**31, (n,), dtype=torch.int32, device="cuda:0")
+    vals = torch.arange(n, dtype=torch.int32, device="cuda:0")
+    s.run_ptr(keys.data_ptr(), vals.data_ptr(), n)
+    G.synchronize()
+    assert s.read_finish()["attempted"] == 0
+    flipped = keys ^ torch.tensor(-2**31, dtype=torch.int32, device="cuda:0")
+    assert bool((flipped[1:] >= flipped[:-1]).all())
+
+
+def test_profile_books_the_sequence_that_ran(G):
+    """read_profile counts the passes that did the work: two counting passes + the in-LDS pass when accepted, the four
+    ordinary passes (three here: the top byte is constant) when refused."""
+    s = _sorter(G, **SMALL)
+    s.set_profiling(True)
+    vals = np.arange(N_SMALL, dtype=np.uint32)
+    _run(G, s, _uniform(N_SMALL, 11), vals)
+    prof = s.read_profile()
+    assert prof["passes"] == 2 and prof["finish_passes"] == 1 and prof["finish_ms"] > 0 and prof["scatter_ms"] > 0
+    _run(G, s, _uniform(N_SMALL, 12) >> np.uint32(8), vals)
+    prof = s.read_profile()
+    assert prof["passes"] == 4 and prof["finish_passes"] == 0 and prof["finish_ms"] == 0
+
+
+def test_typed_and_partial_sorts_do_not_attempt(G):
+    """Key transforms (int32 / float32) and sorts of fewer than 32 bits keep the ordinary passes."""
+    import torch
+
+    s = _sorter(G, **SMALL)
+    n = N_SMALL
+    keys = torch.randint(-2**31, 2**31, (n,), dtype=torch.int32, device="cuda:0")
+    vals = torch.arange(n, dtype=torch.int32, device="cuda:0")
+    s.sort_typed_ptr(keys.data_ptr(), vals.data_ptr(), n, "int32")
+    G.synchronize()
+    assert s.read_finish()["attempted"] == 0
+    assert bool((keys[1:] >= keys[:-1]).all())
+    s.run_ptr(keys.data_ptr(), vals.data_ptr(), n, num_steps=6)
+    G.synchronize()
+    assert s.read_finish()["attempted"] == 0

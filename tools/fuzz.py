@@ -22,6 +22,8 @@ SWITCH = [1024, 4096, 8192, 12288, 256 * 4096, 768 * 4096, 256 * 12288, 256 * 20
 LARGE = os.environ.get("FUZZ_LARGE") == "1"  # most sizes in [2^22, 2^23], passes paired from 2^22 elements up
 if LARGE:
     os.environ["GLU_HIP_SORT_PAIR_MIN"] = "1"  # (default: from 2^28 bytes of keys)
+    os.environ["GLU_HIP_SORT_FINISH_MIN"] = "1"     # and every whole-key u32 sort of that size tries to end in LDS (default: from 2^26)
+    os.environ["GLU_HIP_SORT_FINISH_BACKOFF"] = "0" # ... whatever the sort before it on the same object was told
 
 
 def draw_n(limit=1 << 23):
@@ -36,8 +38,14 @@ def draw_n(limit=1 << 23):
 
 def draw_keys(n, bits):
     dt = np.uint32 if bits == 32 else np.uint64
-    kind = rng.integers(0, 11)
+    kind = rng.integers(0, 12)
     full = rng.integers(0, 2 ** bits, n, dtype=dt)
+    if kind == 11:  # the top 16 bits take few enough values that the runs of equal top bits are about as long as the in-LDS
+        # pass's tile (1536 pairs at these sizes): sorts that end in LDS, sorts that are refused, and the border between them
+        m = max(1, n // int(rng.integers(700, 2200)))
+        tops = rng.choice(1 << 16, size=min(m, 1 << 16), replace=False).astype(dt)
+        pick = tops[rng.integers(0, tops.size, n)]
+        return ((full & dt(0xFFFF)) | (pick << dt(bits - 16))).astype(dt)
     if kind == 8:  # one byte takes one value in a tenth to a half of the keys (paired passes: units too long to balance)
         b = dt(8 * int(rng.integers(0, bits // 8)))
         hot = rng.random(n) < rng.uniform(0.05, 0.5)
@@ -73,6 +81,7 @@ def draw_keys(n, bits):
 
 
 cases = fails = 0
+finish_attempts = finish_accepted = 0  # sorts that tried to / did end in LDS (glu_radix_sort_read_finish)
 t_end = time.time() + budget
 while time.time() < t_end:
     api = str(rng.choice(["pairs", "keys", "u64", "typed", "bits", "scan", "reduce", "steps"]))
@@ -97,6 +106,9 @@ while time.time() < t_end:
                 vb = G.ShaderStorageBuffer(vals)
                 s(kb, vb, n, steps)
                 ok = (kb.get_data(np.uint32) == keys[order]).all() and (vb.get_data(np.uint32) == vals[order]).all()
+            fin = s.read_finish()  # (the reads above waited for the sort)
+            finish_attempts += fin["attempted"]
+            finish_accepted += fin["accepted"]
         elif api == "u64":
             n = draw_n(1 << 23)
             keys = draw_keys(n, 64)
@@ -173,5 +185,5 @@ while time.time() < t_end:
     if not ok:
         fails += 1
         print("FAIL", desc, flush=True)
-print("cases %d, failures %d" % (cases, fails))
+print("cases %d, failures %d; sorts that tried to end in LDS %d, that did %d" % (cases, fails, finish_attempts, finish_accepted))
 sys.exit(1 if fails else 0)
