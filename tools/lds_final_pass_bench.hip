@@ -7,7 +7,13 @@
 // 16 bits, values = position.  Every geometry's output is compared with std::stable_sort on sampled tiles.
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -I gl-radix-sort_amd/csrc -o tools/lds_final_pass_bench tools/lds_final_pass_bench.hip
 //   tools/lds_final_pass_bench [log2 pairs = 28]
-// Not part of the product.
+// Second half: the pass in the product's form (runs of any length from an array of run starts) and what was tried on it --
+// stores aligned to the run's first 128-byte line (slower: 1.05-1.09 against 1.02-1.06 ms), an equal share of the run per wave
+// instead of 18 items whatever the length (slower alone, faster together with 16-bit counters, which bring the workgroup
+// below 40 KiB and a fourth workgroup onto the CU: 0.96-0.99 ms, adopted), 6-byte stage slots for a fifth workgroup (level,
+// measured in place only: its output check does not apply to this harness's keys), persistent workgroups that load the next
+// run's bounds early (slower: 1.05-1.16 ms -- a workgroup per run lets the next one start while this one drains its stores).
+// Records: profiles/r04/lds_final_pass_*.txt.  Not part of the product.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -153,9 +159,10 @@ struct RunsSmemCnt
 {
     CntT wcnt[WAVES][RADIX];
 };
-template<int THREADS, int KPT, bool ALIGN_STORES, bool DYN, typename CntT>
+// PACK: the stage holds the low 16 key bits (the top 16 are the run's) and the value, 6 instead of 8 bytes per slot.
+template<int THREADS, int KPT, bool ALIGN_STORES, bool DYN, typename CntT, bool PACK = false>
 __global__ __launch_bounds__(THREADS) void lds_runs_kernel(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out,
-                                                           uint32_t* vals_out, const uint32_t* __restrict__ starts)
+                                                           uint32_t* vals_out, const uint32_t* __restrict__ starts, uint32_t num_runs)
 {
     constexpr int RADIX = 256;
     constexpr int WAVES = THREADS / kWave;
@@ -164,11 +171,20 @@ __global__ __launch_bounds__(THREADS) void lds_runs_kernel(const uint32_t* keys_
     constexpr int SCAN_THREADS = RADIX * WQ;
     constexpr int SCAN_WAVES = (SCAN_THREADS + kWave - 1) / kWave;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr size_t SLOT = PACK ? 6 : 8;
     uint2* stage = reinterpret_cast<uint2*>(smem_raw);
-    CntT(*wcnt)[RADIX] = reinterpret_cast<CntT(*)[RADIX]>(smem_raw + (size_t) TILE * 8);
-    uint32_t* scan_tmp = reinterpret_cast<uint32_t*>(smem_raw + (size_t) TILE * 8 + sizeof(CntT) * WAVES * RADIX);
+    uint32_t* stage_v = reinterpret_cast<uint32_t*>(smem_raw);
+    uint16_t* stage_k = reinterpret_cast<uint16_t*>(smem_raw + (size_t) TILE * 4);
+    CntT(*wcnt)[RADIX] = reinterpret_cast<CntT(*)[RADIX]>(smem_raw + (size_t) TILE * SLOT);
+    uint32_t* scan_tmp = reinterpret_cast<uint32_t*>(smem_raw + (size_t) TILE * SLOT + sizeof(CntT) * WAVES * RADIX);
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t begin = starts[blockIdx.x], len = starts[blockIdx.x + 1] - begin;
+    // (a launch with fewer workgroups than runs: every workgroup takes runs blockIdx.x, + gridDim.x, ...; the next run's
+    // bounds are loaded while this one is sorted)
+    uint32_t nbegin = starts[blockIdx.x], nend = starts[blockIdx.x + 1];
+    for (uint32_t run = blockIdx.x; run < num_runs; run += gridDim.x)
+    {
+    const uint32_t begin = nbegin, len = nend - nbegin;
+    if (run + gridDim.x < num_runs) nbegin = starts[run + gridDim.x], nend = starts[run + gridDim.x + 1];
     const uint32_t chunk = DYN ? ((len + WAVES * 64 - 1) / (WAVES * 64)) * 64 : (uint32_t) (kWave * KPT);
     const uint32_t items = chunk >> 6;
     const uint32_t wave_off = wave * chunk + lane;
@@ -248,7 +264,11 @@ __global__ __launch_bounds__(THREADS) void lds_runs_kernel(const uint32_t* keys_
         for (int i = 0; i < KPT; i++)
         {
             if (DYN && i >= items) continue;
-            stage[(uint32_t) my_cnt[(key[i] >> shift) & 255u] + rank[i]] = make_uint2(key[i], val[i]);
+            const uint32_t pos = (uint32_t) my_cnt[(key[i] >> shift) & 255u] + rank[i];
+            if (PACK)
+                stage_k[pos] = (uint16_t) key[i], stage_v[pos] = val[i];
+            else
+                stage[pos] = make_uint2(key[i], val[i]);
         }
         __syncthreads();
         if (shift == 0 || !ALIGN_STORES)
@@ -257,8 +277,13 @@ __global__ __launch_bounds__(THREADS) void lds_runs_kernel(const uint32_t* keys_
             for (int i = 0; i < KPT; i++)
             {
                 if (DYN && i >= items) continue;
-                const uint2 e = stage[wave_off + i * kWave];
-                key[i] = e.x, val[i] = e.y;
+                if (PACK)
+                    key[i] = (key[i] & 0xFFFF0000u) | stage_k[wave_off + i * kWave], val[i] = stage_v[wave_off + i * kWave];
+                else
+                {
+                    const uint2 e = stage[wave_off + i * kWave];
+                    key[i] = e.x, val[i] = e.y;
+                }
             }
             if (shift == 0) __syncthreads();
         }
@@ -291,6 +316,8 @@ __global__ __launch_bounds__(THREADS) void lds_runs_kernel(const uint32_t* keys_
                 __builtin_nontemporal_store(val[i], &vals_out[begin + p]);
             }
         }
+    }
+    __syncthreads(); // (the stage and the counters are reused)
     }
 }
 
@@ -378,12 +405,13 @@ static void run(const char* name, Buffers& b, bool copy_only = false)
 }
 
 
-template<int THREADS, int KPT, bool ALIGN_STORES, bool DYN, typename CntT>
-static void run_runs(const char* name, Buffers& b, const uint32_t* d_starts, const std::vector<uint32_t>& h_starts, bool in_place)
+template<int THREADS, int KPT, bool ALIGN_STORES, bool DYN, typename CntT, bool PACK = false>
+static void run_runs(const char* name, Buffers& b, const uint32_t* d_starts, const std::vector<uint32_t>& h_starts, bool in_place,
+                     uint32_t grid = 0)
 {
     const uint32_t runs = (uint32_t) h_starts.size() - 1;
-    const size_t lds = (size_t) THREADS * KPT * 8 + sizeof(CntT) * (THREADS / 64) * 256 + 64;
-    auto kern = lds_runs_kernel<THREADS, KPT, ALIGN_STORES, DYN, CntT>;
+    const size_t lds = (size_t) THREADS * KPT * (PACK ? 6 : 8) + sizeof(CntT) * (THREADS / 64) * 256 + 64;
+    auto kern = lds_runs_kernel<THREADS, KPT, ALIGN_STORES, DYN, CntT, PACK>;
     CK(hipFuncSetAttribute((const void*) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
     if (in_place) CK(hipMemcpy(b.ki, b.host_keys.data(), b.n * 4, hipMemcpyHostToDevice)); // (sorted runs sort as fast as random ones)
     hipEvent_t e0, e1;
@@ -393,7 +421,7 @@ static void run_runs(const char* name, Buffers& b, const uint32_t* d_starts, con
     for (int rep = 0; rep < 12; rep++)
     {
         CK(hipEventRecord(e0, 0));
-        hipLaunchKernelGGL(kern, dim3(runs), dim3(THREADS), lds, 0, b.ki, b.vi, in_place ? b.ki : b.ko, in_place ? b.vi : b.vo, d_starts);
+        hipLaunchKernelGGL(kern, dim3(grid ? grid : runs), dim3(THREADS), lds, 0, b.ki, b.vi, in_place ? b.ki : b.ko, in_place ? b.vi : b.vo, d_starts, runs);
         CK(hipEventRecord(e1, 0));
         CK(hipEventSynchronize(e1));
         float t;
@@ -415,7 +443,7 @@ static void run_runs(const char* name, Buffers& b, const uint32_t* d_starts, con
             const uint32_t* hk = b.host_keys.data() + lo;
             std::stable_sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) { return (hk[x] & 0xffffu) < (hk[y] & 0xffffu); });
             for (uint32_t i = 0; i < S; i++)
-                if (ok[i] != hk[idx[i]] || ov[i] != lo + idx[i]) bad++;
+                if ((ok[i] & 0xFFFFu) != (hk[idx[i]] & 0xFFFFu) || ov[i] != lo + idx[i]) bad++; // (PACK: the top bits are the run's first key's)
         }
     }
     printf("%-72s LDS %6zu B  median %.3f ms  min %.3f ms  %s\n", name, lds, ms[ms.size() / 2], ms.front(),
@@ -473,6 +501,11 @@ int main(int argc, char** argv)
         run_runs<256, 18, false, true, uint32_t>("ragged runs, 256 x 18, equal shares per wave", b, d_ragged, ragged, false);
         run_runs<256, 18, false, true, uint16_t>("ragged runs, 256 x 18, equal shares per wave, 16-bit counters", b, d_ragged, ragged, false);
         run_runs<256, 18, false, true, uint16_t>("ragged runs, 256 x 18, equal shares per wave, 16-bit counters, in place", b, d_ragged, ragged, true);
+        run_runs<256, 18, false, true, uint16_t>("ragged runs, 256 x 18, equal shares, 16-bit counters, 1024 persistent workgroups", b, d_ragged, ragged, false, 1024);
+        run_runs<256, 18, false, true, uint16_t>("ragged runs, 256 x 18, equal shares, 16-bit counters, 2048 persistent workgroups", b, d_ragged, ragged, false, 2048);
+        run_runs<256, 18, false, true, uint16_t>("ragged runs, 256 x 18, equal shares, 16-bit counters, 8192 workgroups x 8 runs", b, d_ragged, ragged, false, 8192);
+        run_runs<256, 18, false, true, uint16_t>("ragged runs, 256 x 18, equal shares, 16-bit counters, 1024 persistent workgroups, in place", b, d_ragged, ragged, true, 1024);
+        run_runs<256, 18, false, true, uint16_t, true>("ragged runs, 256 x 18, equal shares, 16-bit counters, 6-byte slots (time only)", b, d_ragged, ragged, true);
         run_runs<512, 9, false, false, uint32_t>("ragged runs, 512 x 9", b, d_ragged, ragged, false);
         run_runs<512, 9, false, true, uint32_t>("ragged runs, 512 x 9, equal shares per wave", b, d_ragged, ragged, false);
         run_runs<512, 9, false, true, uint16_t>("ragged runs, 512 x 9, equal shares per wave, 16-bit counters", b, d_ragged, ragged, false);

@@ -22,7 +22,8 @@ def parse(path):
 
 def find(d, *subs):
     for k, v in d.items():
-        if all(s in k for s in subs):
+        # (not the copy of the line scatter that only differs in name: the passes enqueued behind an attempt to end in LDS)
+        if all(s in k for s in subs) and not k.split("(")[0].rstrip().endswith("false, false, true>"):
             return k, v
     raise KeyError(subs)
 
@@ -60,6 +61,7 @@ all_k = {
     "source": src, "corrections": corr,
     "kernels": [
         e8, e4,
+        entry(bench_f, bench_w, ("radix_finish_sort_kernel<256, 18, true>",), N * 16, "in-LDS pass of the headline sort (a workgroup per run of equal top 16 key bits; reads and writes every pair once)"),
         entry(bench_f, bench_w, ("radix_pair_count_kernel<unsigned int",), N * 4 + T2, "count kernel of a pair of passes of the headline sort (reads the keys, writes the two-digit table)"),
         entry(bench_f, bench_w, ("radix_pair_unitsum_kernel",), T2, "count table of the second pass of a pair (reads the two-digit table)"),
         entry(bench_f, bench_w, ("radix_pair4_count_kernel<unsigned int",), N * 4 + T2_4, "count kernel of a pair of passes of the 4-bit sort (reads the keys -- the calibration of the FETCH_SIZE factor -- and writes 4.25 MiB of tables)"),

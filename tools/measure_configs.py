@@ -53,6 +53,12 @@ def time_sort(keys, vals, bits, key_bytes=4, reps=5):
         leaders = sum(1 for p in range(passes) if roles[p] == 1)
         tables = 2 * 256 * 256 * 512 if bits == 8 else 2 * (256 * 16 * 1024 + 16 * 256 * 16 * 4)  # written and read once
         moved = passes * 2 * (key_bytes + 4) + (passes - from_table) * key_bytes + leaders * tables / n
+        fin = s.read_finish()
+        if fin["accepted"]:
+            # the sort ended in LDS (glu_radix_sort_read_finish): two counting passes on the top 16 bits with one read of the
+            # keys and one two-digit table, then one pass that reads and writes every pair once
+            time_sort.key_reads = 1
+            moved = 2 * 2 * (key_bytes + 4) + key_bytes + (2 * 256 * 256 * 512 + 2 * 65536 * 4) / n + 2 * (key_bytes + 4)
     return best * 1e-9, moved
 
 

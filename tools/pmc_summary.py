@@ -1,4 +1,6 @@
 """Summarise rocprofv3 --pmc CSV output: per kernel name, average counter value per dispatch.
+Dispatches whose value is below 1 % of the kernel's largest are left out of the average and counted separately: a sort that
+tries to end in LDS enqueues two sequences of passes and the kernels of the one not taken return at once (radix_lds_finish.hpp).
 usage: python tools/pmc_summary.py <dir> [substring]"""
 import csv, glob, os, sys, collections
 d = sys.argv[1]
@@ -11,6 +13,9 @@ for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=T
             continue
         acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k, cs in acc.items():
-    print(k[:150])
+    print(k)
     for c, v in sorted(cs.items()):
-        print("   %-24s n=%3d avg=%.6g" % (c, len(v), sum(v) / len(v)))
+        top = max(v)
+        kept = [x for x in v if x >= 0.01 * top] if top > 0 else v
+        note = "" if len(kept) == len(v) else "   (+ %d dispatches that returned at once, not averaged)" % (len(v) - len(kept))
+        print("   %-24s n=%3d avg=%.6g%s" % (c, len(kept), sum(kept) / len(kept), note))

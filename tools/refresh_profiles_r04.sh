@@ -43,20 +43,9 @@ PY
 python tools/measure_configs.py > $OUT/configs_single_gpu.txt 2>&1
 python bench.py --force-dist --log2-keys 27 --no-cpu-baseline > $OUT/bench_force_dist_2p27.json 2> $OUT/bench_force_dist.err
 find $OUT/prof_bench -name "*kernel_stats.csv" -exec cp {} $OUT/bench_n1_bits8_kernel_stats.csv \;
-# the stats above average over the WHOLE process, which since the scratch placement by measurement includes the 48 calibration
-# sorts of prepare (16 placements x 3) and those of the 4-bit sorter: the timed region of the bench is the last steps x 4
-# launches of the 8-bit line scatter -- their average from the kernel trace of the same run
-python - > $OUT/bench_n1_bits8_timed_region_from_trace.txt <<PY
-import csv, glob
-f = glob.glob("$OUT/prof_bench/**/*kernel_trace.csv", recursive=True)[0]
-rows = [r for r in csv.DictReader(open(f)) if "radix_scatter_lines_kernel<unsigned int, 8" in r["Kernel_Name"]]
-rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1000.0 for r in rows]
-timed = d[-40:]
-print("radix_scatter_lines_kernel<u32, 8>: %d launches in the process (calibration sorts of prepare + warm-up + timed steps)" % len(d))
-print("all launches:        average %.1f us" % (sum(d) / len(d)))
-print("last 40 (10 timed steps x 4 passes): average %.1f us  min %.1f  max %.1f" % (sum(timed) / len(timed), min(timed), max(timed)))
-PY
+# the stats above average over the WHOLE process (the calibration sorts of prepare, the four-pass and the 4-bit comparison legs);
+# the timed region of the bench is the last 10 sorts that ended in LDS: their launches from the kernel trace of the same run
+python tools/trace_summary.py $(find $OUT/prof_bench -name "*kernel_trace.csv" | head -1) --bench 10 > $OUT/bench_n1_bits8_timed_region_from_trace.txt
 find $OUT/prof_dist -name "*kernel_stats.csv" -exec cp {} $OUT/force_dist_2p27_kernel_stats.csv \;
 rm -rf $OUT/prof_bench $OUT/prof_dist $OUT/pmc_bench_fetch $OUT/pmc_bench_write $OUT/pmc_cfg_fetch $OUT/pmc_cfg_write $OUT/pmc_sb_fetch
 ls -la $OUT

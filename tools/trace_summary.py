@@ -1,11 +1,19 @@
-"""Per-sort kernel durations from a rocprofv3 --kernel-trace CSV: for every sort (ended by radix_finalize_kernel) the durations
-(us) of its scatter launches that moved data (S), of the in-LDS pass (F), and of everything else summed (o).
-   python tools/trace_summary.py <kernel_trace.csv> [last N sorts]"""
+"""Per-sort kernel durations from a rocprofv3 --kernel-trace CSV.
+   python tools/trace_summary.py <kernel_trace.csv> [last N sorts]
+       one line per sort (a sort ends with radix_finalize_kernel): C = leader count kernels that read keys, S = scatter launches
+       that moved data, F = the in-LDS pass (us), the other kernels summed, and first start to last end
+   python tools/trace_summary.py <kernel_trace.csv> --bench K
+       what bench.py's timed region looks like in the trace: the last K sorts that ended in LDS (bench.py's K timed steps are
+       the last sorts of its headline sort object; the comparison legs that follow use other pass structures) -- average,
+       min and max of their scatter launches and of their in-LDS pass, to set beside bench.py's roofline object"""
 import csv, sys
+
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-last = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+bench = "--bench" in sys.argv
+last = int(sys.argv[sys.argv.index("--bench") + 1]) if bench else (int(sys.argv[2]) if len(sys.argv) > 2 else 20)
 sorts, cur, other, t0 = [], [], 0.0, None
+all_scatter8 = []
 for r in rows:
     n = r["Kernel_Name"]
     if "glu_hip::" not in n:
@@ -13,16 +21,40 @@ for r in rows:
     d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     if t0 is None:
         t0 = int(r["Start_Timestamp"])
+    if "radix_scatter_lines_kernel<unsigned int, 8" in n:
+        all_scatter8.append((n, d))
     if "radix_finalize" in n:
-        sorts.append((cur, round(other), round((int(r["End_Timestamp"]) - t0) / 1e3)))
+        sorts.append((cur, other, (int(r["End_Timestamp"]) - t0) / 1e3))
         cur, other, t0 = [], 0.0, None
     elif "radix_scatter_lines" in n and d > 100:
-        cur.append("S%d" % round(d))
-    elif "radix_finish_sort" in n:
-        cur.append("F%d" % round(d))
+        cur.append(("S", d))
+    elif "radix_finish_sort" in n and d > 100:
+        cur.append(("F", d))
     elif "pair_count" in n and d > 100:
-        cur.append("C%d" % round(d))
+        cur.append(("C", d))
     else:
         other += d
-for cur, other, span in sorts[-last:]:
-    print(" ".join(cur), " other kernels %d us, first start to last end %d us" % (other, span))
+if not bench:
+    for cur, other, span in sorts[-last:]:
+        print(" ".join("%s%d" % (k, round(d)) for k, d in cur), " other kernels %d us, first start to last end %d us" % (other, span))
+    sys.exit(0)
+
+
+def stat(v):
+    return "n %d  average %.1f us  min %.1f  max %.1f" % (len(v), sum(v) / len(v), min(v), max(v)) if v else "none"
+
+
+ended = [s for s in sorts if any(k == "F" for k, _ in s[0])]
+timed = ended[-last:]
+plain = [d for n, d in all_scatter8 if not n.rstrip().split("(")[0].rstrip().endswith("true>")]
+behind = [d for n, d in all_scatter8 if n.rstrip().split("(")[0].rstrip().endswith("true>")]
+print("radix_scatter_lines_kernel<u32, 8, ...> launches in the whole process (calibration sorts of prepare, warm-up, timed steps, the")
+print("four-pass comparison leg):  under its plain name %s" % stat(plain))
+print("  under the name of the passes enqueued behind an attempt to end in LDS (BEHIND_ATTEMPT = true; they return at once when the")
+print("  attempt was accepted): %s" % stat(behind))
+print("sorts that ended in LDS: %d; the last %d of them (bench.py's timed steps):" % (len(ended), len(timed)))
+print("  scatter launches (two per sort):  %s" % stat([d for s in timed for k, d in s[0] if k == "S"]))
+print("  in-LDS pass (one per sort):       %s" % stat([d for s in timed for k, d in s[0] if k == "F"]))
+print("  leader count kernel (one):        %s" % stat([d for s in timed for k, d in s[0] if k == "C"]))
+print("  every other kernel of the sort, summed per sort: %s" % stat([s[1] for s in timed]))
+print("  first kernel start to last kernel end per sort:  %s" % stat([s[2] for s in timed]))
