@@ -598,7 +598,7 @@ struct PlanArgs
     // the first top-bit pass of a sort that tries to end in LDS (radix_lds_finish.hpp): between its row scan and its scatter
     // the run lengths are summed from the two-digit table and the device decides which sequence of passes runs
     bool behind_attempt = false;  // an ordinary pass enqueued behind such an attempt (runs only if the attempt was refused)
-    uint32_t finish_capacity = 0; // 0: not such a pass
+    uint32_t finish_geo_first = 0, finish_geo_last = 0; // tile geometries of the in-LDS pass that are enqueued (0: not such a pass)
     uint32_t finish_first_ordinary = 0, finish_num_ordinary = 0;
     uint32_t finish_seq = 0;
 };
@@ -806,13 +806,13 @@ glu_status launch_pass_lines(glu_radix_sort_s* s, const KeyT* src_k, const uint3
                            pa.plan);
     }
     HIP_TRY(hipGetLastError());
-    if (pa.finish_capacity)
+    if (pa.finish_geo_first)
     {
         hipLaunchKernelGGL(radix_finish_lengths_kernel, dim3(kPairRadix), dim3(1024), 0, stream, (const uint32_t*) s->pair_t2.ptr, nb,
                            (uint32_t*) s->finish_lengths.ptr, (const PassPlan*) pa.plan, pa.pass);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(radix_finish_plan_kernel, dim3(kFinishPlanBlocks), dim3(1024), 0, stream, (const uint32_t*) s->finish_lengths.ptr,
-                           (uint32_t*) s->finish_starts.ptr, (uint32_t) count, pa.finish_capacity, pa.plan, pa.pass,
+                           (uint32_t*) s->finish_starts.ptr, (uint32_t) count, pa.finish_geo_first, pa.finish_geo_last, pa.plan, pa.pass,
                            pa.finish_first_ordinary, pa.finish_num_ordinary, s->finish_hint, pa.finish_seq);
         HIP_TRY(hipGetLastError());
     }
@@ -937,31 +937,43 @@ glu_status sort_single_block(KeyT* keys, uint32_t* vals, size_t count, uint32_t 
 }
 
 
-// A sort that ends in LDS (radix_lds_finish.hpp): the geometry of its last pass by the mean run length.  The longest of
-// 65536 runs of uniformly drawn keys stays below mean + 6 sigma; a workgroup takes capacity = 256 x KPT pairs.
-// 0: no geometry holds such runs (more than about 2^28 pairs): the ordinary sort.
-inline uint32_t finish_capacity_of(int kpt) { return 256u * (uint32_t) kpt; }
-inline int finish_kpt_for(size_t count)
+// A sort that ends in LDS (radix_lds_finish.hpp): the tile geometry of its last pass that suits uniformly drawn keys -- the
+// longest of 65536 runs stays below mean + 6 sigma.  The launches of that geometry and of the next larger ones are enqueued
+// and the device picks by the longest run it counted.  0: no geometry holds such runs (more than about 2^29 pairs).
+inline uint32_t finish_geometry_for(size_t count)
 {
     const double mean = (double) count / kFinishRuns;
     const double need = mean + 6.0 * std::sqrt(mean) + 8.0;
-    for (int kpt : {6, 10, 18})
-        if (need <= (double) finish_capacity_of(kpt)) return kpt;
+    for (uint32_t g = 1; g <= kFinishGeometries; g++)
+        if (need <= (double) finish_geometry_capacity(g)) return g;
     return 0;
 }
 
 template<bool VALS>
-glu_status launch_finish(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, const uint32_t* starts, int kpt,
-                         const PassPlan* plan, uint32_t pass, hipStream_t stream)
+glu_status launch_finish(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, const uint32_t* starts,
+                         uint32_t geo_first, uint32_t geo_last, const PassPlan* plan, uint32_t pass, hipStream_t stream)
 {
-#define GLU_FINISH(KPT_)                                                                                                         \
-    hipLaunchKernelGGL((radix_finish_sort_kernel<256, KPT_, VALS>), dim3(kFinishRuns), dim3(256), sizeof(FinishSmem<256, KPT_, VALS>), \
-                       stream, keys_a, vals_a, keys_b, vals_b, starts, 16u, plan, pass)
-    if (kpt == 6) GLU_FINISH(6);
-    else if (kpt == 10) GLU_FINISH(10);
-    else GLU_FINISH(18);
+#define GLU_FINISH(GEO_, THREADS_, KPT_)                                                                                          \
+    if (geo_first <= GEO_ && GEO_ <= geo_last)                                                                                    \
+    {                                                                                                                             \
+        static_assert(finish_geometry_capacity(GEO_) == THREADS_ * KPT_, "geometry table");                                       \
+        auto kern = radix_finish_sort_kernel<THREADS_, KPT_, VALS>;                                                               \
+        static std::once_flag lds_opt_in;                                                                                         \
+        static hipError_t lds_opt_in_result = hipSuccess;                                                                         \
+        std::call_once(lds_opt_in, [&] {                                                                                          \
+            lds_opt_in_result = hipFuncSetAttribute((const void*) kern, hipFuncAttributeMaxDynamicSharedMemorySize,               \
+                                                    (int) sizeof(FinishSmem<THREADS_, KPT_, VALS>));                              \
+        });                                                                                                                       \
+        HIP_TRY(lds_opt_in_result);                                                                                               \
+        hipLaunchKernelGGL(kern, dim3(kFinishRuns), dim3(THREADS_), sizeof(FinishSmem<THREADS_, KPT_, VALS>), stream, keys_a,     \
+                           vals_a, keys_b, vals_b, starts, 16u, plan, pass, (uint32_t) GEO_);                                     \
+        HIP_TRY(hipGetLastError());                                                                                               \
+    }
+    GLU_FINISH(1, 256, 6)
+    GLU_FINISH(2, 256, 10)
+    GLU_FINISH(3, 256, 18)
+    GLU_FINISH(4, 512, 18)
 #undef GLU_FINISH
-    HIP_TRY(hipGetLastError());
     return GLU_OK;
 }
 
@@ -1020,11 +1032,11 @@ glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t cou
     // Whole 32-bit keys, 8-bit digits, paired line passes: the sort first tries to end in LDS (radix_lds_finish.hpp) -- the two
     // top-bit passes and the in-LDS pass are enqueued in front of the four ordinary passes, and the device runs one of the
     // two sequences.
-    int finish_kpt = 0;
+    uint32_t finish_kpt = 0; // (the geometry that suits uniform keys; 0: no attempt)
     if (sizeof(KeyT) == 4 && pairs_ok && s->lds_finish && s->finish_starts.ptr && key_xf == KEY_XF_NONE && first_bit == 0 &&
         end_bit == 32 && s->digit_bits == 8 && num_passes == 4 && count >= (s->finish_min ? s->finish_min : (size_t) 1 << 26) &&
         lines_applicable<KeyT, 8>(s, kbuf[0], vbuf[0], kbuf[1], vbuf[1], count))
-        finish_kpt = finish_kpt_for(count);
+        finish_kpt = finish_geometry_for(count);
     if (finish_kpt && s->finish_backoff && s->finish_hint)
     {
         if (s->finish_wait == 0 && s->finish_seq)
@@ -1051,7 +1063,8 @@ glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t cou
         num_passes += 2;
     }
     s->last_finish_attempted = finish_kpt != 0;
-    s->last_finish_capacity = finish_kpt ? finish_capacity_of(finish_kpt) : 0u;
+    const uint32_t finish_last = std::min<uint32_t>(finish_kpt + 2, kFinishGeometries); // the larger tiles enqueued behind it
+    s->last_finish_capacity = finish_kpt ? finish_geometry_capacity(finish_last) : 0u;
     if (pairs_ok)
     {
         const bool lines8 = lines_applicable<KeyT, 8>(s, kbuf[0], vbuf[0], kbuf[1], vbuf[1], count);
@@ -1101,7 +1114,8 @@ glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t cou
             pa.behind_attempt = finish_kpt && pass >= 2;
             if (finish_kpt && pass == 0)
             {
-                pa.finish_capacity = finish_capacity_of(finish_kpt);
+                pa.finish_geo_first = finish_kpt;
+                pa.finish_geo_last = finish_last;
                 pa.finish_first_ordinary = 2;
                 pa.finish_num_ordinary = num_passes - 2;
                 pa.finish_seq = s->finish_seq;
@@ -1119,10 +1133,10 @@ glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t cou
                     s->mark(stream);
                     if (vals)
                         GLU_TRY(launch_finish<true>((uint32_t*) kbuf[0], vbuf[0], (uint32_t*) kbuf[1], vbuf[1],
-                                                    (const uint32_t*) s->finish_starts.ptr, finish_kpt, pa.plan, 2u, stream));
+                                                    (const uint32_t*) s->finish_starts.ptr, finish_kpt, finish_last, pa.plan, 2u, stream));
                     else
                         GLU_TRY(launch_finish<false>((uint32_t*) kbuf[0], nullptr, (uint32_t*) kbuf[1], nullptr,
-                                                     (const uint32_t*) s->finish_starts.ptr, finish_kpt, pa.plan, 2u, stream));
+                                                     (const uint32_t*) s->finish_starts.ptr, finish_kpt, finish_last, pa.plan, 2u, stream));
                     s->mark(stream);
                 }
             }
@@ -2039,9 +2053,10 @@ glu_status glu_radix_sort_read_finish(glu_radix_sort sort, uint32_t* attempted, 
     memset(&host, 0, sizeof(host));
     if (tried) HIP_TRY(hipMemcpy(&host, sort->plan.ptr, sizeof(host), hipMemcpyDeviceToHost));
     if (attempted) *attempted = tried ? 1u : 0u;
-    if (accepted) *accepted = tried ? host.finish : 0u;
+    if (accepted) *accepted = tried && host.finish ? 1u : 0u;
     if (longest_run) *longest_run = tried ? host.finish_longest : 0u;
-    if (capacity) *capacity = tried ? sort->last_finish_capacity : 0u;
+    // the tile the device chose; refused: the largest one that was enqueued
+    if (capacity) *capacity = !tried ? 0u : host.finish ? finish_geometry_capacity(host.finish) : sort->last_finish_capacity;
     return GLU_OK;
 }
 

@@ -10,7 +10,8 @@
 //      radix_pair_passes.hpp).  After them the array is a sequence of 65536 RUNS, run r = the pairs whose key's top 16 bits
 //      are r, in input order.  The leader's two-digit histogram T2 already holds every run's length:
 //      len[r] = sum over blocks b of T2[r & 255][b][r >> 8].
-//   2. if no run is longer than what one workgroup sorts in LDS, ONE pass finishes the sort in place: a workgroup per run
+//   2. if no run is longer than what one workgroup sorts in LDS (tiles of 1536 .. 9216 pairs: the device picks the smallest of
+//      the enqueued geometries that holds the longest run), ONE pass finishes the sort in place: a workgroup per run
 //      orders it by the low 16 bits (two rank / scan / re-stage rounds of 8 bits, as in radix_sort_single_block_kernel) and
 //      writes it back where it was.  16 B per pair instead of the 2 x 20.5 of two more passes: 52.5 B per pair in all.
 //   3. otherwise (keys that crowd into few runs: small value ranges, heavy duplicates) the top-bit passes are not run at
@@ -21,7 +22,7 @@
 //
 //   radix_finish_lengths_kernel   len[r] from T2                                  (32 MiB of table, once per sort)
 //   radix_finish_plan_kernel      run starts, the longest run, the decision       (64 workgroups)
-//   radix_finish_sort_kernel      step 2                                         (one 256-thread workgroup per run)
+//   radix_finish_sort_kernel      step 2                                         (one workgroup of 256 / 512 threads per run)
 #pragma once
 
 #include "radix_pair_passes.hpp"
@@ -60,15 +61,26 @@ __global__ __launch_bounds__(1024) void radix_finish_lengths_kernel(const uint32
 }
 
 // starts[r] = exclusive scan of lengths (starts[65536] = n), and the decision: the sort ends in LDS if the lengths are
-// exact (they add up to n: a 16-bit counter of T2 that overflowed loses 65536) and no run is longer than `cap`.
+// exact (they add up to n: a 16-bit counter of T2 that overflowed loses 65536) and the longest run fits the tile of one of the
+// in-LDS pass's geometries whose launches follow (numbered geo_first .. geo_last, finish_geometry_capacity; the host enqueues the
+// one that suits uniformly drawn keys of this count and the next larger ones: keys that leave some runs empty and the others
+// longer -- 31-bit keys, mild skew -- still end in LDS, in a larger tile).  PassPlan::finish = the geometry chosen.
 //   accepted: finish = 1, the ordinary passes [first_ordinary, first_ordinary + num_ordinary) are switched off;
 //   refused:  the two top-bit passes `pass`, `pass + 1` are switched off (the leader has counted already: its scatter
 //             sees skip = kSkipWithoutCounting, which leaves the arrays' roles as they are).
 // hint: see glu_radix_sort_s::finish_hint.  64 workgroups, each scans 1024 runs; every workgroup reads all 65536 lengths (256 KiB, from L2) for the sum in front of
 // its runs, the total and the longest run, so each reaches the same decision without a second launch.
 constexpr uint32_t kFinishPlanBlocks = kFinishRuns / 1024;
+// tile geometries of the in-LDS pass: 1 = 256 threads x 6 pairs, 2 = 256 x 10, 3 = 256 x 18 (39 KiB of LDS: four workgroups per
+// CU), 4 = 512 x 18 (78 KiB: two per CU, the largest that still overlaps one run's memory time with another's ranking)
+constexpr uint32_t kFinishGeometries = 4;
+__host__ __device__ constexpr uint32_t finish_geometry_capacity(uint32_t g)
+{
+    return g == 1 ? 256u * 6u : g == 2 ? 256u * 10u : g == 3 ? 256u * 18u : g == 4 ? 512u * 18u : 0u;
+}
 __global__ __launch_bounds__(1024) void radix_finish_plan_kernel(const uint32_t* __restrict__ lengths, uint32_t* __restrict__ starts,
-                                                                 uint32_t n, uint32_t cap, PassPlan* plan, uint32_t pass,
+                                                                 uint32_t n, uint32_t geo_first, uint32_t geo_last, PassPlan* plan,
+                                                                 uint32_t pass,
                                                                  uint32_t first_ordinary, uint32_t num_ordinary,
                                                                  uint32_t* hint, uint32_t attempt)
 {
@@ -110,7 +122,11 @@ __global__ __launch_bounds__(1024) void radix_finish_plan_kernel(const uint32_t*
         longest = max(longest, tmp[2][w]);
         if ((uint32_t) w < wave) excl += wsum[w];
     }
-    const bool accept = tables && all == n && longest <= cap;
+    // the smallest of the enqueued tile geometries [geo_first, geo_last] that holds the longest run (0: none does)
+    uint32_t geo = 0;
+    for (uint32_t g = geo_last; g >= geo_first && g >= 1; g--)
+        if (longest <= finish_geometry_capacity(g)) geo = g;
+    const bool accept = tables && all == n && geo != 0;
     if (accept)
     {
         starts[b * 1024u + tid] = before + excl;
@@ -118,7 +134,7 @@ __global__ __launch_bounds__(1024) void radix_finish_plan_kernel(const uint32_t*
     }
     if (b == 0 && tid == 0)
     {
-        plan->finish = accept ? 1u : 0u;
+        plan->finish = accept ? geo : 0u;
         plan->finish_longest = tables ? longest : 0xFFFFFFFFu;
         // for the host, which reads it without synchronising: the outcome of attempt number `attempt` (pinned host memory)
         if (hint) __hip_atomic_store(hint, (attempt << 1) | (accept ? 1u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -144,6 +160,7 @@ struct FinishSmem
     uint32_t scan_tmp[WAVES];
 };
 static_assert(sizeof(FinishSmem<256, 18, true>) <= 40 * 1024, "four workgroups per CU");
+static_assert(sizeof(FinishSmem<512, 18, true>) <= 80 * 1024, "two workgroups per CU");
 
 // the longest run a workgroup of this geometry takes
 template<int THREADS, int KPT>
@@ -159,9 +176,10 @@ constexpr uint32_t finish_capacity() { return (uint32_t) (THREADS * KPT); }
 template<int THREADS, int KPT, bool VALS>
 __global__ __launch_bounds__(THREADS) void radix_finish_sort_kernel(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b,
                                                                     uint32_t* vals_b, const uint32_t* __restrict__ starts,
-                                                                    uint32_t low_bits, const PassPlan* plan, uint32_t pass)
+                                                                    uint32_t low_bits, const PassPlan* plan, uint32_t pass,
+                                                                    uint32_t geometry)
 {
-    if (!plan->finish) return; // (kernel-uniform)
+    if (plan->finish != geometry) return; // (kernel-uniform: the device chose another geometry, or the ordinary passes)
     using Smem = FinishSmem<THREADS, KPT, VALS>;
     constexpr int RADIX = Smem::RADIX;
     constexpr int WAVES = Smem::WAVES;

@@ -274,16 +274,19 @@ GLU_API glu_status glu_radix_sort_read_profile_finish(glu_radix_sort sort, doubl
  * passes <= 32. */
 GLU_API glu_status glu_radix_sort_read_plan(glu_radix_sort sort, uint32_t* skipped, uint32_t* counted_alone,
                                             uint32_t* pair_role, size_t passes);
-/* A sort that ends in LDS.  A sort of whole 32-bit keys (no key transform) of 2^26 .. about 2^28 elements with 8-bit digits
+/* A sort that ends in LDS.  A sort of whole 32-bit keys (no key transform) of 2^26 .. about 2^29 elements with 8-bit digits
  * first tries a shorter way to the same result: the two counting passes on the TOP 16 key bits, after which the array is
  * 65536 runs of keys that share those bits, and one pass in which a workgroup per run orders the run by the low 16 bits
- * inside LDS, in place -- 52.5 instead of 72.5 bytes of memory traffic per pair.  That works if no run is longer than a
- * workgroup's LDS tile (`capacity`), which the device checks from exact run lengths before anything is moved; otherwise
- * (keys crowded into few runs: small value ranges, heavy duplicates) the four ordinary passes run, at the cost of one extra
- * read of the keys.  The launch sequence is the same either way (the kernels of the sequence not taken return at once), so
+ * inside LDS, in place -- 52.25 instead of 72.5 bytes of memory traffic per pair.  That works if no run is longer than a
+ * workgroup's LDS tile, which the device checks from exact run lengths before anything is moved: the in-LDS pass is enqueued
+ * in the tile geometry that suits uniformly drawn keys of this count (1536 / 2560 / 4608 / 9216 pairs) and in the next
+ * larger ones, and the device runs the smallest that holds the longest run (`capacity`) -- so keys that leave some runs empty
+ * and make the others longer (31-bit keys, mild skew) still end in LDS.  Otherwise (keys crowded into few runs: small value
+ * ranges, heavy duplicates) the four ordinary passes run, at the cost of one extra read of the keys; an object whose last
+ * attempt was refused skips the next eight attempts.  The launch sequence is the same either way (the kernels of the sequence not taken return at once), so
  * the sort stays asynchronous and capturable.  This reports, for the last sort on the object (the caller has synchronised
  * its stream): attempted = 1 if both sequences were enqueued, accepted = 1 if the sort ended in LDS, longest_run = the
- * longest run counted (0xFFFFFFFF: not counted), capacity = the longest run the last pass would have taken.
+ * longest run counted (0xFFFFFFFF: not counted), capacity = the tile the device chose (refused: the largest one enqueued).
  * glu_radix_sort_read_plan describes the ordinary passes (all "skipped without counting" when accepted = 1).
  * GLU_HIP_SORT_LDS_FINISH=0 in the environment of glu_radix_sort_create switches the attempt off.  Any pointer may be NULL. */
 GLU_API glu_status glu_radix_sort_read_finish(glu_radix_sort sort, uint32_t* attempted, uint32_t* accepted,

@@ -137,14 +137,19 @@ def _with_one_run_of(n, length, seed, run=0x1234):
     return keys
 
 
-@pytest.mark.parametrize("length,accepted", [(CAP_SMALL, 1), (CAP_SMALL + 1, 0), (CAP_SMALL - 1, 1), (CAP_SMALL + 5000, 0)])
-def test_the_longest_run_decides(G, length, accepted):
-    """A run of exactly the tile's capacity is sorted in LDS; one pair more and the ordinary passes run."""
+@pytest.mark.parametrize("length,accepted,capacity", [(CAP_SMALL - 1, 1, 1536), (CAP_SMALL, 1, 1536), (CAP_SMALL + 1, 1, 2560),
+                                                      (2560, 1, 2560), (2561, 1, 4608), (4608, 1, 4608), (4609, 0, 4608),
+                                                      (4608 + 5000, 0, 4608)])
+def test_the_longest_run_decides(G, length, accepted, capacity):
+    """The in-LDS pass is enqueued in the tile geometry that suits uniform keys of this count (here 256 x 6 = 1536 pairs) and in
+    the next two larger ones; the device runs the smallest whose tile holds the longest run.  A run of exactly a tile's
+    capacity is sorted in that tile, one pair more takes the next, and one pair more than the largest enqueued tile sends
+    the sort to the ordinary passes."""
     keys = _with_one_run_of(N_SMALL, length, 5)
     vals = np.arange(N_SMALL, dtype=np.uint32)
     gk, gv, fin = _run(G, _sorter(G, **SMALL), keys, vals)
     _check(keys, vals, gk, gv)
-    assert fin["attempted"] == 1 and fin["accepted"] == accepted and fin["longest_run"] == length
+    assert fin["attempted"] == 1 and fin["accepted"] == accepted and fin["longest_run"] == length and fin["capacity"] == capacity
 
 
 def test_empty_runs_and_runs_of_one(G):
@@ -242,10 +247,38 @@ def test_sizes_around_the_geometries_of_the_in_lds_pass(G):
         torch.cuda.empty_cache()
 
 
+def test_keys_that_leave_runs_empty_take_a_larger_tile(G):
+    """31-bit keys (what the reference's test generator draws) fill half of the runs, each twice as long as uniform keys of the
+    same count would: the device takes the next tile geometry; 2^28 of them (runs of 8192) and 2^29 full-range keys end in
+    the largest tile, 512 threads x 18."""
+    import torch
+
+    s = _sorter(G)
+    for n, shift, cap in [((1 << 27) + 333, 1, 4608), ((1 << 28) - 5, 1, 9216), (1 << 29, 0, 9216)]:
+        keys = torch.randint(-2**31, 2**31, (n,), dtype=torch.int32, device="cuda:0")
+        if shift:
+            keys = (keys >> 1) & torch.tensor(0x7FFFFFFF, dtype=torch.int32, device="cuda:0")
+        vals = torch.arange(n, dtype=torch.int32, device="cuda:0")
+        k0 = keys.clone()
+        torch.cuda.synchronize()
+        s.run_ptr(keys.data_ptr(), vals.data_ptr(), n)
+        G.synchronize()
+        fin = s.read_finish()
+        assert fin["attempted"] == 1 and fin["accepted"] == 1 and fin["capacity"] == cap, (n, fin)
+        flipped = keys ^ torch.tensor(-2**31, dtype=torch.int32, device="cuda:0")
+        assert bool((flipped[1:] >= flipped[:-1]).all()), "not sorted"
+        del flipped
+        assert bool((k0[vals.long()] == keys).all()), "a value does not point at its key"
+        eq = keys[1:] == keys[:-1]
+        assert bool((vals[1:][eq] > vals[:-1][eq]).all()), "equal keys out of input order"
+        del keys, vals, k0, eq
+        torch.cuda.empty_cache()
+
+
 def test_beyond_the_largest_geometry_no_attempt_is_made(G):
     import torch
 
-    n = (1 << 28) + (1 << 25)
+    n = (1 << 29) + (1 << 26)
     s = _sorter(G)
     keys = torch.randint(-2**31, 2**31, (n,), dtype=torch.int32, device="cuda:0")
     vals = torch.arange(n, dtype=torch.int32, device="cuda:0")

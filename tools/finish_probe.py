@@ -31,12 +31,20 @@ def timed(srt, k0, v0, n, reps=7):
 
 
 def main():
-    sizes = [int(a) for a in sys.argv[1:]] or [26, 27, 28]
+    # arguments: log2 sizes; "b31" / "b30" before a size: keys of that many bits (the top bits zero) from there on
     dev = torch.device("cuda:0")
-    for lg in sizes:
+    cases, bits = [], 32
+    for a in sys.argv[1:] or ["26", "27", "28"]:
+        if a.startswith("b"):
+            bits = int(a[1:])
+        else:
+            cases.append((int(a), bits))
+    for lg, bits in cases:
         for n in ((1 << lg), (1 << lg) - 12345):
             g = torch.Generator(device=dev); g.manual_seed(lg)
             k0 = torch.randint(-2**31, 2**31, (n,), dtype=torch.int32, device=dev, generator=g)
+            if bits < 32:
+                k0 = (k0 >> (32 - bits)) & torch.tensor((1 << bits) - 1, dtype=torch.int32, device=dev)
             v0 = torch.arange(n, dtype=torch.int32, device=dev)
             a, b = sorter(False), sorter(True)
             for s in (a, b):
@@ -44,8 +52,8 @@ def main():
             ka, va, ta = timed(a, k0, v0, n)
             kb, vb, tb = timed(b, k0, v0, n)
             same = bool((ka == kb).all()) and bool((va == vb).all())
-            print("2^%d%s pairs: ordinary median %.3f min %.3f ms | LDS finish median %.3f min %.3f ms  %s  same result: %s" % (
-                lg, "" if n == 1 << lg else "-12345", ta[len(ta) // 2], ta[0], tb[len(tb) // 2], tb[0], b.read_finish(), same), flush=True)
+            print("2^%d%s pairs%s: ordinary median %.3f min %.3f ms | LDS finish median %.3f min %.3f ms  %s  same result: %s" % (
+                lg, "" if n == 1 << lg else "-12345", "" if bits == 32 else " of %d-bit keys" % bits, ta[len(ta) // 2], ta[0], tb[len(tb) // 2], tb[0], b.read_finish(), same), flush=True)
             if not same:
                 bad = (ka != kb).nonzero()
                 print("  first differing positions", bad[:8].flatten().tolist(), "of", int(bad.numel()))
