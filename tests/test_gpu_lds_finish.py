@@ -318,3 +318,35 @@ def test_typed_and_partial_sorts_do_not_attempt(G):
     s.run_ptr(keys.data_ptr(), vals.data_ptr(), n, num_steps=6)
     G.synchronize()
     assert s.read_finish()["attempted"] == 0
+
+
+def test_one_captured_graph_serves_every_outcome(G):
+    """Which sequence of passes runs, and in which tile the in-LDS pass, is decided on the device: one captured graph of a
+    sort replays correctly on keys that end in LDS in the smallest tile, in a larger one, and on keys that are refused."""
+    import torch
+
+    n = N_SMALL
+    sorter = _sorter(G, GLU_HIP_SORT_FINISH_BACKOFF=0, **SMALL)
+    sorter.prepare_internal_buffers(n)
+    kt = torch.empty(n, dtype=torch.int32, device="cuda")
+    vt = torch.empty(n, dtype=torch.int32, device="cuda")
+    side = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    vals = np.arange(n, dtype=np.uint32)
+    inputs = [(_uniform(n, 21), 1, 1536), (_with_one_run_of(n, 3000, 22), 1, 4608), (_uniform(n, 23) >> np.uint32(10), 0, 4608),
+              (np.full(n, 5, dtype=np.uint32), 0, 4608), (_with_one_run_of(n, 2000, 24), 1, 2560), (_uniform(n, 25), 1, 1536)]
+    with torch.cuda.stream(side):
+        kt.copy_(torch.from_numpy(inputs[0][0].view(np.int32)))
+        vt.copy_(torch.from_numpy(vals.view(np.int32)))
+        sorter.run_ptr(kt.data_ptr(), vt.data_ptr(), n, 0, side.cuda_stream)  # warm-up outside the capture
+        side.synchronize()
+        with torch.cuda.graph(graph, stream=side):
+            sorter.run_ptr(kt.data_ptr(), vt.data_ptr(), n, 0, torch.cuda.current_stream().cuda_stream)
+        for keys, accepted, capacity in inputs:
+            kt.copy_(torch.from_numpy(keys.view(np.int32)))
+            vt.copy_(torch.from_numpy(vals.view(np.int32)))
+            graph.replay()
+            side.synchronize()
+            _check(keys, vals, kt.cpu().numpy().view(np.uint32), vt.cpu().numpy().view(np.uint32))
+            fin = sorter.read_finish()
+            assert fin["attempted"] == 1 and fin["accepted"] == accepted and fin["capacity"] == capacity, fin
