@@ -568,7 +568,7 @@ glu_status sort_prepare(glu_radix_sort_s* s, size_t count, size_t key_size, bool
         GLU_TRY(s->pair_table.reserve(((size_t) kPairRadix * nb + kPairRadix) * sizeof(uint32_t)));
         GLU_TRY(s->pair_ranges.reserve(nb * sizeof(uint2)));
         GLU_TRY(s->pair_sub.reserve((size_t) kPair4Radix * nb * kPairSub * sizeof(uint32_t)));
-        if (key_size == 4 && s->lds_finish)
+        if (s->lds_finish)
         {
             GLU_TRY(s->finish_lengths.reserve((size_t) kFinishRuns * sizeof(uint32_t)));
             GLU_TRY(s->finish_starts.reserve(((size_t) kFinishRuns + 1) * sizeof(uint32_t)));
@@ -706,7 +706,7 @@ glu_status launch_pass_lines(glu_radix_sort_s* s, const KeyT* src_k, const uint3
     // once when the attempt was accepted, and a kernel trace's per-name statistics of the scatter stay those of launches
     // that moved data
     auto scatter_behind = scatter_nt;
-    constexpr bool kHasBehind = BITS == 8 && !XF && sizeof(KeyT) == 4; // (the sorts that make such attempts)
+    constexpr bool kHasBehind = BITS == 8 && !XF; // (the sorts that make such attempts)
     if constexpr (kHasBehind)
         scatter_behind = radix_scatter_lines_kernel<KeyT, BITS, G::THREADS, G::KPT, XF, VALS, 0, false, RS, true, true, 0, false, false, true>;
     static std::once_flag lds_opt_in; // per instantiation: allow > 64 KiB of dynamic LDS
@@ -949,30 +949,41 @@ inline uint32_t finish_geometry_for(size_t count)
     return 0;
 }
 
-template<bool VALS>
-glu_status launch_finish(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, const uint32_t* starts,
-                         uint32_t geo_first, uint32_t geo_last, const PassPlan* plan, uint32_t pass, hipStream_t stream)
+template<typename KeyT, bool VALS>
+glu_status launch_finish(KeyT* keys_a, uint32_t* vals_a, KeyT* keys_b, uint32_t* vals_b, const uint32_t* starts,
+                         uint32_t geo_first, uint32_t geo_last, uint32_t low_bits, const PassPlan* plan, uint32_t pass,
+                         hipStream_t stream)
 {
 #define GLU_FINISH(GEO_, THREADS_, KPT_)                                                                                          \
     if (geo_first <= GEO_ && GEO_ <= geo_last)                                                                                    \
     {                                                                                                                             \
         static_assert(finish_geometry_capacity(GEO_) == THREADS_ * KPT_, "geometry table");                                       \
-        auto kern = radix_finish_sort_kernel<THREADS_, KPT_, VALS>;                                                               \
+        auto kern = radix_finish_sort_kernel<KeyT, THREADS_, KPT_, VALS>;                                                         \
         static std::once_flag lds_opt_in;                                                                                         \
         static hipError_t lds_opt_in_result = hipSuccess;                                                                         \
         std::call_once(lds_opt_in, [&] {                                                                                          \
             lds_opt_in_result = hipFuncSetAttribute((const void*) kern, hipFuncAttributeMaxDynamicSharedMemorySize,               \
-                                                    (int) sizeof(FinishSmem<THREADS_, KPT_, VALS>));                              \
+                                                    (int) sizeof(FinishSmem<KeyT, THREADS_, KPT_, VALS>));                        \
         });                                                                                                                       \
         HIP_TRY(lds_opt_in_result);                                                                                               \
-        hipLaunchKernelGGL(kern, dim3(kFinishRuns), dim3(THREADS_), sizeof(FinishSmem<THREADS_, KPT_, VALS>), stream, keys_a,     \
-                           vals_a, keys_b, vals_b, starts, 16u, plan, pass, (uint32_t) GEO_);                                     \
+        hipLaunchKernelGGL(kern, dim3(kFinishRuns), dim3(THREADS_), sizeof(FinishSmem<KeyT, THREADS_, KPT_, VALS>), stream,       \
+                           keys_a, vals_a, keys_b, vals_b, starts, low_bits, plan, pass, (uint32_t) GEO_);                        \
         HIP_TRY(hipGetLastError());                                                                                               \
     }
     GLU_FINISH(1, 256, 6)
     GLU_FINISH(2, 256, 10)
-    GLU_FINISH(3, 256, 18)
-    GLU_FINISH(4, 512, 18)
+    if constexpr (sizeof(KeyT) == 4)
+    {
+        GLU_FINISH(3, 256, 18)
+        GLU_FINISH(4, 512, 18)
+    }
+    else
+    {
+        // 8-byte keys: 12 bytes per slot leave two workgroups per CU (one for the largest tile) whatever their shape, and six
+        // ranking rounds make the pass compute-bound: twice the waves per workgroup (256 x 18: 3.8 ms for 2^28 pairs)
+        GLU_FINISH(3, 512, 9)
+        GLU_FINISH(4, 1024, 9)
+    }
 #undef GLU_FINISH
     return GLU_OK;
 }
@@ -1033,8 +1044,8 @@ glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t cou
     // top-bit passes and the in-LDS pass are enqueued in front of the four ordinary passes, and the device runs one of the
     // two sequences.
     uint32_t finish_kpt = 0; // (the geometry that suits uniform keys; 0: no attempt)
-    if (sizeof(KeyT) == 4 && pairs_ok && s->lds_finish && s->finish_starts.ptr && key_xf == KEY_XF_NONE && first_bit == 0 &&
-        end_bit == 32 && s->digit_bits == 8 && num_passes == 4 && count >= (s->finish_min ? s->finish_min : (size_t) 1 << 26) &&
+    if (pairs_ok && s->lds_finish && s->finish_starts.ptr && key_xf == KEY_XF_NONE && first_bit == 0 &&
+        end_bit == 8 * sizeof(KeyT) && s->digit_bits == 8 && num_passes == sizeof(KeyT) && count >= (s->finish_min ? s->finish_min : (size_t) 1 << 26) &&
         lines_applicable<KeyT, 8>(s, kbuf[0], vbuf[0], kbuf[1], vbuf[1], count))
         finish_kpt = finish_geometry_for(count);
     if (finish_kpt && s->finish_backoff && s->finish_hint)
@@ -1058,8 +1069,8 @@ glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t cou
     {
         s->finish_seq = s->finish_seq >= 0x7FFFFFFFu ? 1u : s->finish_seq + 1;
         for (uint32_t i = num_passes; i-- > 0;) passes[i + 2] = passes[i];
-        passes[0] = PassDesc{16u, 8u, 0u, 0};
-        passes[1] = PassDesc{24u, 8u, 0u, 0};
+        passes[0] = PassDesc{end_bit - 16u, 8u, 0u, 0};
+        passes[1] = PassDesc{end_bit - 8u, 8u, 0u, 0};
         num_passes += 2;
     }
     s->last_finish_attempted = finish_kpt != 0;
@@ -1121,7 +1132,6 @@ glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t cou
                 pa.finish_seq = s->finish_seq;
             }
             GLU_TRY(dispatch_pass<KeyT>(s, kbuf[0], vbuf[0], kbuf[1], vbuf[1], count, shift, bits, nullptr, stream, xform, pa));
-            if constexpr (sizeof(KeyT) == 4)
             {
                 if (finish_kpt && pass == 1)
                 {
@@ -1132,11 +1142,11 @@ glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t cou
                     s->mark(stream);
                     s->mark(stream);
                     if (vals)
-                        GLU_TRY(launch_finish<true>((uint32_t*) kbuf[0], vbuf[0], (uint32_t*) kbuf[1], vbuf[1],
-                                                    (const uint32_t*) s->finish_starts.ptr, finish_kpt, finish_last, pa.plan, 2u, stream));
+                        GLU_TRY((launch_finish<KeyT, true>(kbuf[0], vbuf[0], kbuf[1], vbuf[1], (const uint32_t*) s->finish_starts.ptr,
+                                                           finish_kpt, finish_last, end_bit - 16u, pa.plan, 2u, stream)));
                     else
-                        GLU_TRY(launch_finish<false>((uint32_t*) kbuf[0], nullptr, (uint32_t*) kbuf[1], nullptr,
-                                                     (const uint32_t*) s->finish_starts.ptr, finish_kpt, finish_last, pa.plan, 2u, stream));
+                        GLU_TRY((launch_finish<KeyT, false>(kbuf[0], nullptr, kbuf[1], nullptr, (const uint32_t*) s->finish_starts.ptr,
+                                                            finish_kpt, finish_last, end_bit - 16u, pa.plan, 2u, stream)));
                     s->mark(stream);
                 }
             }

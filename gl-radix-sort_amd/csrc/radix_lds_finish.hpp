@@ -147,20 +147,21 @@ __global__ __launch_bounds__(1024) void radix_finish_plan_kernel(const uint32_t*
     if (b == 0 && accept && tid < num_ordinary) plan->off[first_ordinary + tid] = 1;
 }
 
-template<int THREADS, int KPT, bool VALS>
+template<typename KeyT, int THREADS, int KPT, bool VALS>
 struct FinishSmem
 {
     static constexpr int RADIX = 256;
     static constexpr int WAVES = THREADS / kWave;
     static constexpr int TILE = THREADS * KPT;
-    PairArray<uint32_t, TILE, VALS> stage;
+    PairArray<KeyT, TILE, VALS> stage;
     // wave-private running digit counters, 16-bit (a tile has fewer than 65536 slots): with 256 x 18 pairs the workgroup
     // stays below 40 KiB and four of them share a CU (tools/lds_final_pass_bench.hip: 1.06 -> 0.99 ms for 2^28 pairs)
     uint16_t wcnt[WAVES][RADIX];
     uint32_t scan_tmp[WAVES];
 };
-static_assert(sizeof(FinishSmem<256, 18, true>) <= 40 * 1024, "four workgroups per CU");
-static_assert(sizeof(FinishSmem<512, 18, true>) <= 80 * 1024, "two workgroups per CU");
+static_assert(sizeof(FinishSmem<uint32_t, 256, 18, true>) <= 40 * 1024, "four workgroups per CU");
+static_assert(sizeof(FinishSmem<uint32_t, 512, 18, true>) <= 80 * 1024, "two workgroups per CU");
+static_assert(sizeof(FinishSmem<uint64_t, 512, 9, true>) <= 80 * 1024, "64-bit keys: two workgroups per CU");
 
 // the longest run a workgroup of this geometry takes
 template<int THREADS, int KPT>
@@ -173,14 +174,15 @@ constexpr uint32_t finish_capacity() { return (uint32_t) (THREADS * KPT); }
 // 4096 pairs costs 16 items per lane, not the 18 the longest run needs.  Slots past the run's end hold the key ~0 (largest
 // digit in every round, behind every real pair in input order); their loads read the run's last element instead of being
 // predicated, so that all loads of a lane are in flight at once.
-template<int THREADS, int KPT, bool VALS>
-__global__ __launch_bounds__(THREADS) void radix_finish_sort_kernel(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b,
+// 64-bit keys: the same with 8-byte keys in registers and LDS and six rounds for the low 48 bits (low_bits = 48).
+template<typename KeyT, int THREADS, int KPT, bool VALS>
+__global__ __launch_bounds__(THREADS) void radix_finish_sort_kernel(KeyT* keys_a, uint32_t* vals_a, KeyT* keys_b,
                                                                     uint32_t* vals_b, const uint32_t* __restrict__ starts,
                                                                     uint32_t low_bits, const PassPlan* plan, uint32_t pass,
                                                                     uint32_t geometry)
 {
     if (plan->finish != geometry) return; // (kernel-uniform: the device chose another geometry, or the ordinary passes)
-    using Smem = FinishSmem<THREADS, KPT, VALS>;
+    using Smem = FinishSmem<KeyT, THREADS, KPT, VALS>;
     constexpr int RADIX = Smem::RADIX;
     constexpr int WAVES = Smem::WAVES;
     constexpr int WQ = WAVES / 4;
@@ -191,7 +193,7 @@ __global__ __launch_bounds__(THREADS) void radix_finish_sort_kernel(uint32_t* ke
     const uint32_t begin = starts[blockIdx.x], end = starts[blockIdx.x + 1];
     const uint32_t len = end - begin;
     if (len <= 1) return; // (workgroup-uniform)
-    uint32_t* keys = plan->flip[pass] ? keys_b : keys_a;
+    KeyT* keys = plan->flip[pass] ? keys_b : keys_a;
     uint32_t* vals = plan->flip[pass] ? vals_b : vals_a;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -201,16 +203,17 @@ __global__ __launch_bounds__(THREADS) void radix_finish_sort_kernel(uint32_t* ke
     const uint32_t items = share / kWave;
     const uint32_t wave_off = wave * share + lane;
 
-    uint32_t key[KPT], val[KPT];
+    KeyT key[KPT];
+    uint32_t val[KPT];
 #pragma unroll
     for (int i = 0; i < KPT; i++)
     {
         const uint32_t p = wave_off + i * kWave;
         const bool ok = p < len;
         const uint32_t pc = ok ? p : len - 1;
-        const uint32_t k = keys[begin + pc];
+        const KeyT k = keys[begin + pc];
         const uint32_t v = VALS ? vals[begin + pc] : 0u;
-        key[i] = ok ? k : ~0u;
+        key[i] = ok ? k : (KeyT) ~(KeyT) 0;
         val[i] = ok ? v : 0u;
     }
 
@@ -226,7 +229,7 @@ __global__ __launch_bounds__(THREADS) void radix_finish_sort_kernel(uint32_t* ke
         for (int i = 0; i < KPT; i++)
         {
             if ((uint32_t) i >= items) continue; // (workgroup-uniform)
-            const uint32_t d = (key[i] >> shift) & MASK;
+            const uint32_t d = digit_of<KeyT>(key[i], shift, MASK);
             uint16_t* const cnt = my_cnt + d;
             const uint32_t prev = *cnt;
             uint32_t plo = ~0u, phi = ~0u;
@@ -283,7 +286,7 @@ __global__ __launch_bounds__(THREADS) void radix_finish_sort_kernel(uint32_t* ke
         for (int i = 0; i < KPT; i++)
         {
             if ((uint32_t) i >= items) continue;
-            s.stage.put((uint32_t) my_cnt[(key[i] >> shift) & MASK] + rank[i], key[i], val[i]);
+            s.stage.put((uint32_t) my_cnt[digit_of<KeyT>(key[i], shift, MASK)] + rank[i], key[i], val[i]);
         }
         __syncthreads();
 #pragma unroll

@@ -274,10 +274,11 @@ GLU_API glu_status glu_radix_sort_read_profile_finish(glu_radix_sort sort, doubl
  * passes <= 32. */
 GLU_API glu_status glu_radix_sort_read_plan(glu_radix_sort sort, uint32_t* skipped, uint32_t* counted_alone,
                                             uint32_t* pair_role, size_t passes);
-/* A sort that ends in LDS.  A sort of whole 32-bit keys (no key transform) of 2^26 .. about 2^29 elements with 8-bit digits
- * first tries a shorter way to the same result: the two counting passes on the TOP 16 key bits, after which the array is
- * 65536 runs of keys that share those bits, and one pass in which a workgroup per run orders the run by the low 16 bits
- * inside LDS, in place -- 52.25 instead of 72.5 bytes of memory traffic per pair.  That works if no run is longer than a
+/* A sort that ends in LDS.  A sort of whole 32-bit or 64-bit keys (no key transform) of 2^26 .. about 2^29 elements with 8-bit
+ * digits first tries a shorter way to the same result: the two counting passes on the TOP 16 key bits, after which the array
+ * is 65536 runs of keys that share those bits, and one pass in which a workgroup per run orders the run by the remaining low
+ * bits inside LDS (two rounds of 8 bits for 32-bit keys, six for 64-bit keys), in place -- 52.25 instead of 72.5 bytes of
+ * memory traffic per pair with 32-bit keys, 80.5 instead of 225 with 64-bit keys.  That works if no run is longer than a
  * workgroup's LDS tile, which the device checks from exact run lengths before anything is moved: the in-LDS pass is enqueued
  * in the tile geometry that suits uniformly drawn keys of this count (1536 / 2560 / 4608 / 9216 pairs) and in the next
  * larger ones, and the device runs the smallest that holds the longest run (`capacity`) -- so keys that leave some runs empty

@@ -350,3 +350,98 @@ def test_one_captured_graph_serves_every_outcome(G):
             _check(keys, vals, kt.cpu().numpy().view(np.uint32), vt.cpu().numpy().view(np.uint32))
             fin = sorter.read_finish()
             assert fin["attempted"] == 1 and fin["accepted"] == accepted and fin["capacity"] == capacity, fin
+
+
+# ---- 64-bit keys: two counting passes on key bits [48, 64), then six rounds inside LDS on the low 48 bits ---------------------
+
+def _run64(G, sorter, keys, vals):
+    kb = G.ShaderStorageBuffer(keys)
+    if vals is None:
+        sorter.sort_keys_ptr(kb.device_ptr(), keys.size, key_bytes=8)
+        G.synchronize()
+        return kb.get_data(np.uint64), None, sorter.read_finish()
+    vb = G.ShaderStorageBuffer(vals)
+    sorter(kb, vb, keys.size, 0, key_bytes=8)
+    G.synchronize()
+    return kb.get_data(np.uint64), vb.get_data(np.uint32), sorter.read_finish()
+
+
+def _uniform64(n, seed):
+    return np.random.default_rng(seed).integers(0, 2**64, n, dtype=np.uint64)
+
+
+def test_u64_uniform_keys_end_in_lds(G):
+    keys, vals = _uniform64(N_SMALL, 31), np.arange(N_SMALL, dtype=np.uint32)
+    s = _sorter(G, **SMALL)
+    gk, gv, fin = _run64(G, s, keys, vals)
+    ek, ev = O.stable_sort_pairs(keys, vals)
+    assert (gk == ek).all() and (gv == ev).all()
+    assert fin["attempted"] == 1 and fin["accepted"] == 1 and fin["capacity"] == CAP_SMALL
+    assert fin["longest_run"] == np.bincount((keys >> np.uint64(48)).astype(np.int64), minlength=65536).max()
+    skipped, alone, roles = s.read_plan(8, roles=True)
+    assert skipped == [2] * 8  # the eight ordinary passes were the sequence not taken
+
+
+def test_u64_keys_only_and_duplicates(G):
+    rng = np.random.default_rng(32)
+    n = (1 << 23) + 99
+    keys = (rng.integers(0, 65536, n, dtype=np.uint64) << np.uint64(48)) | (rng.integers(0, 3, n, dtype=np.uint64) * np.uint64(0x010000010001))
+    gk, _, fin = _run64(G, _sorter(G, **SMALL), keys, None)
+    assert (gk == np.sort(keys, kind="stable")).all() and fin["accepted"] == 1
+    vals = np.arange(N_SMALL, dtype=np.uint32)
+    gk, gv, fin = _run64(G, _sorter(G, **SMALL), keys[:N_SMALL], vals)
+    ek, ev = O.stable_sort_pairs(keys[:N_SMALL], vals)
+    assert (gk == ek).all() and (gv == ev).all() and fin["accepted"] == 1
+
+
+def test_u64_small_range_is_refused(G):
+    keys = _uniform64(N_SMALL, 33) >> np.uint64(20)
+    vals = np.arange(N_SMALL, dtype=np.uint32)
+    s = _sorter(G, **SMALL)
+    gk, gv, fin = _run64(G, s, keys, vals)
+    ek, ev = O.stable_sort_pairs(keys, vals)
+    assert (gk == ek).all() and (gv == ev).all()
+    assert fin["attempted"] == 1 and fin["accepted"] == 0
+
+
+@pytest.mark.parametrize("length,accepted,capacity", [(1536, 1, 1536), (1537, 1, 2560), (4608, 1, 4608), (4609, 0, 4608)])
+def test_u64_the_longest_run_decides(G, length, accepted, capacity):
+    rng = np.random.default_rng(34)
+    keys = rng.integers(0, 2**64, N_SMALL, dtype=np.uint64)
+    run = np.uint64(0xBEEF)
+    keys[(keys >> np.uint64(48)) == run] ^= np.uint64(1 << 63)
+    pos = rng.choice(N_SMALL, size=length, replace=False)
+    keys[pos] = (run << np.uint64(48)) | rng.integers(0, 2**48, length, dtype=np.uint64)
+    vals = np.arange(N_SMALL, dtype=np.uint32)
+    gk, gv, fin = _run64(G, _sorter(G, **SMALL), keys, vals)
+    ek, ev = O.stable_sort_pairs(keys, vals)
+    assert (gk == ek).all() and (gv == ev).all()
+    assert fin["attempted"] == 1 and fin["accepted"] == accepted and fin["longest_run"] == length and fin["capacity"] == capacity
+
+
+def test_u64_large_sizes_and_the_largest_tile(G):
+    """2^27 full-range keys (tile of 2560), 2^27 keys with the top two bits clear (a quarter of the runs, four times as long:
+    the largest tile, 1024 threads x 9) and BASELINE.json's configs[4], 2^28 keys (tile of 4608): sortedness, the value of
+    every pair still points at its key, equal keys in input order."""
+    import torch
+
+    s = _sorter(G)
+    for n, clear, cap in [((1 << 27) + 77, 0, 2560), ((1 << 27) - 9, 2, 9216), (1 << 28, 0, 4608)]:
+        keys = torch.randint(-2**63, 2**63 - 1, (n,), dtype=torch.int64, device="cuda:0")
+        if clear:
+            keys = (keys >> clear) & torch.tensor((1 << (64 - clear)) - 1, dtype=torch.int64, device="cuda:0")
+        vals = torch.arange(n, dtype=torch.int32, device="cuda:0")
+        k0 = keys.clone()
+        torch.cuda.synchronize()
+        s.run_ptr(keys.data_ptr(), vals.data_ptr(), n, key_bytes=8)
+        G.synchronize()
+        fin = s.read_finish()
+        assert fin["attempted"] == 1 and fin["accepted"] == 1 and fin["capacity"] == cap, (n, fin)
+        flipped = keys ^ torch.tensor(-2**63, dtype=torch.int64, device="cuda:0")
+        assert bool((flipped[1:] >= flipped[:-1]).all()), "not sorted"
+        del flipped
+        assert bool((k0[vals.long()] == keys).all()), "a value does not point at its key"
+        eq = keys[1:] == keys[:-1]
+        assert bool((vals[1:][eq] > vals[:-1][eq]).all()), "equal keys out of input order"
+        del keys, vals, k0, eq
+        torch.cuda.empty_cache()
