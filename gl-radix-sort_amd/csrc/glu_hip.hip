@@ -490,6 +490,7 @@ struct glu_radix_sort_s
     // made).  Inputs that never fit thus pay for one count kernel in finish_backoff + 1 sorts.
     uint32_t* finish_hint = nullptr;
     uint32_t finish_seq = 0, finish_seq_acted_on = 0, finish_wait = 0;
+    uint32_t finish_last_geo = 0; // the tile geometry the device chose for the last sort whose outcome is known (0: none yet)
     uint32_t finish_backoff = 8;  // GLU_HIP_SORT_FINISH_BACKOFF=N (0: every sort attempts: tests)
     bool last_finish_attempted = false; // the last sort enqueued both sequences (glu_radix_sort_read_finish)
     uint32_t last_finish_capacity = 0;  // and the longest run its last pass would take
@@ -951,22 +952,28 @@ inline uint32_t finish_geometry_for(size_t count)
 
 template<typename KeyT, bool VALS>
 glu_status launch_finish(KeyT* keys_a, uint32_t* vals_a, KeyT* keys_b, uint32_t* vals_b, const uint32_t* starts,
-                         uint32_t geo_first, uint32_t geo_last, uint32_t low_bits, const PassPlan* plan, uint32_t pass,
-                         hipStream_t stream)
+                         uint32_t geo_first, uint32_t geo_last, uint32_t geo_expected, uint32_t low_bits, const PassPlan* plan,
+                         uint32_t pass, hipStream_t stream)
 {
+    // the geometry the sort is expected to take gets a workgroup per run, the others 8192 workgroups that loop
 #define GLU_FINISH(GEO_, THREADS_, KPT_)                                                                                          \
     if (geo_first <= GEO_ && GEO_ <= geo_last)                                                                                    \
     {                                                                                                                             \
         static_assert(finish_geometry_capacity(GEO_) == THREADS_ * KPT_, "geometry table");                                       \
-        auto kern = radix_finish_sort_kernel<KeyT, THREADS_, KPT_, VALS>;                                                         \
+        auto kern = GEO_ == geo_expected ? radix_finish_sort_kernel<KeyT, THREADS_, KPT_, VALS, false>                            \
+                                         : radix_finish_sort_kernel<KeyT, THREADS_, KPT_, VALS, true>;                            \
         static std::once_flag lds_opt_in;                                                                                         \
         static hipError_t lds_opt_in_result = hipSuccess;                                                                         \
         std::call_once(lds_opt_in, [&] {                                                                                          \
-            lds_opt_in_result = hipFuncSetAttribute((const void*) kern, hipFuncAttributeMaxDynamicSharedMemorySize,               \
-                                                    (int) sizeof(FinishSmem<KeyT, THREADS_, KPT_, VALS>));                        \
+            for (const void* k : {(const void*) radix_finish_sort_kernel<KeyT, THREADS_, KPT_, VALS, false>,                      \
+                                  (const void*) radix_finish_sort_kernel<KeyT, THREADS_, KPT_, VALS, true>})                      \
+                if (lds_opt_in_result == hipSuccess)                                                                              \
+                    lds_opt_in_result = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize,                        \
+                                                            (int) sizeof(FinishSmem<KeyT, THREADS_, KPT_, VALS>));                \
         });                                                                                                                       \
         HIP_TRY(lds_opt_in_result);                                                                                               \
-        hipLaunchKernelGGL(kern, dim3(kFinishRuns), dim3(THREADS_), sizeof(FinishSmem<KeyT, THREADS_, KPT_, VALS>), stream,       \
+        hipLaunchKernelGGL(kern, dim3(GEO_ == geo_expected ? kFinishRuns : 8192u), dim3(THREADS_),                                \
+                           sizeof(FinishSmem<KeyT, THREADS_, KPT_, VALS>), stream,                                                \
                            keys_a, vals_a, keys_b, vals_b, starts, low_bits, plan, pass, (uint32_t) GEO_);                        \
         HIP_TRY(hipGetLastError());                                                                                               \
     }
@@ -1048,12 +1055,13 @@ glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t cou
         end_bit == 8 * sizeof(KeyT) && s->digit_bits == 8 && num_passes == sizeof(KeyT) && count >= (s->finish_min ? s->finish_min : (size_t) 1 << 26) &&
         lines_applicable<KeyT, 8>(s, kbuf[0], vbuf[0], kbuf[1], vbuf[1], count))
         finish_kpt = finish_geometry_for(count);
-    if (finish_kpt && s->finish_backoff && s->finish_hint)
+    if (finish_kpt && s->finish_hint)
     {
         if (s->finish_wait == 0 && s->finish_seq)
         {
             const uint32_t seen = __atomic_load_n(s->finish_hint, __ATOMIC_RELAXED);
-            if ((seen >> 1) == s->finish_seq && s->finish_seq != s->finish_seq_acted_on && !(seen & 1u))
+            if ((seen >> 3) == s->finish_seq && (seen & 7u)) s->finish_last_geo = seen & 7u; // the tile the last sort took
+            if ((seen >> 3) == s->finish_seq && s->finish_seq != s->finish_seq_acted_on && !(seen & 7u) && s->finish_backoff)
             {
                 s->finish_wait = s->finish_backoff; // the last attempt was refused (acted on once)
                 s->finish_seq_acted_on = s->finish_seq;
@@ -1067,7 +1075,7 @@ glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t cou
     }
     if (finish_kpt)
     {
-        s->finish_seq = s->finish_seq >= 0x7FFFFFFFu ? 1u : s->finish_seq + 1;
+        s->finish_seq = s->finish_seq >= 0x0FFFFFFFu ? 1u : s->finish_seq + 1;
         for (uint32_t i = num_passes; i-- > 0;) passes[i + 2] = passes[i];
         passes[0] = PassDesc{end_bit - 16u, 8u, 0u, 0};
         passes[1] = PassDesc{end_bit - 8u, 8u, 0u, 0};
@@ -1075,6 +1083,8 @@ glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t cou
     }
     s->last_finish_attempted = finish_kpt != 0;
     const uint32_t finish_last = std::min<uint32_t>(finish_kpt + 2, kFinishGeometries); // the larger tiles enqueued behind it
+    // the one that gets a workgroup per run: what this object's last sort took if that is among them, else the uniform-keys one
+    const uint32_t finish_expected = s->finish_last_geo >= finish_kpt && s->finish_last_geo <= finish_last ? s->finish_last_geo : finish_kpt;
     s->last_finish_capacity = finish_kpt ? finish_geometry_capacity(finish_last) : 0u;
     if (pairs_ok)
     {
@@ -1143,10 +1153,10 @@ glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t cou
                     s->mark(stream);
                     if (vals)
                         GLU_TRY((launch_finish<KeyT, true>(kbuf[0], vbuf[0], kbuf[1], vbuf[1], (const uint32_t*) s->finish_starts.ptr,
-                                                           finish_kpt, finish_last, end_bit - 16u, pa.plan, 2u, stream)));
+                                                           finish_kpt, finish_last, finish_expected, end_bit - 16u, pa.plan, 2u, stream)));
                     else
                         GLU_TRY((launch_finish<KeyT, false>(kbuf[0], nullptr, kbuf[1], nullptr, (const uint32_t*) s->finish_starts.ptr,
-                                                            finish_kpt, finish_last, end_bit - 16u, pa.plan, 2u, stream)));
+                                                            finish_kpt, finish_last, finish_expected, end_bit - 16u, pa.plan, 2u, stream)));
                     s->mark(stream);
                 }
             }

@@ -137,7 +137,8 @@ __global__ __launch_bounds__(1024) void radix_finish_plan_kernel(const uint32_t*
         plan->finish = accept ? geo : 0u;
         plan->finish_longest = tables ? longest : 0xFFFFFFFFu;
         // for the host, which reads it without synchronising: the outcome of attempt number `attempt` (pinned host memory)
-        if (hint) __hip_atomic_store(hint, (attempt << 1) | (accept ? 1u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        // (attempt << 3 | the geometry chosen, 0 = refused)
+        if (hint) __hip_atomic_store(hint, (attempt << 3) | (accept ? geo : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if (!accept)
         {
             plan->skip[pass] = kSkipWithoutCounting;
@@ -167,7 +168,7 @@ static_assert(sizeof(FinishSmem<uint64_t, 512, 9, true>) <= 80 * 1024, "64-bit k
 template<int THREADS, int KPT>
 constexpr uint32_t finish_capacity() { return (uint32_t) (THREADS * KPT); }
 
-// One workgroup per run r = blockIdx.x: pairs [starts[r], starts[r + 1]) of the arrays that hold the data after pass `pass`
+// A workgroup per run r: pairs [starts[r], starts[r + 1]) of the arrays that hold the data after pass `pass`
 // - 1 (PassPlan::flip[pass]) are ordered by key bits [0, low_bits), stably, in place.  Wave-striped items, wave-private
 // running digit counters, one scan over (digit, wave), staging in ranked order: the body of radix_sort_single_block_kernel.
 // Every wave takes an equal share of the run (a multiple of 64 slots) and ranks only the items its share has -- a run of
@@ -175,7 +176,11 @@ constexpr uint32_t finish_capacity() { return (uint32_t) (THREADS * KPT); }
 // digit in every round, behind every real pair in input order); their loads read the run's last element instead of being
 // predicated, so that all loads of a lane are in flight at once.
 // 64-bit keys: the same with 8-byte keys in registers and LDS and six rounds for the low 48 bits (low_bits = 48).
-template<typename KeyT, int THREADS, int KPT, bool VALS>
+// LOOP = false: launched with a workgroup per run (the hardware's dispatcher is the loop over the runs, and the next workgroup
+// starts while this one drains its stores: 0.96-0.99 ms for 2^28 pairs where a loop inside the kernel takes 1.05-1.16).  LOOP =
+// true: fewer workgroups, each takes every gridDim.x-th run -- for the geometries that are enqueued besides the expected one:
+// 65536 workgroups that return at once cost 15-29 us, 8192 cost 5.
+template<typename KeyT, int THREADS, int KPT, bool VALS, bool LOOP>
 __global__ __launch_bounds__(THREADS) void radix_finish_sort_kernel(KeyT* keys_a, uint32_t* vals_a, KeyT* keys_b,
                                                                     uint32_t* vals_b, const uint32_t* __restrict__ starts,
                                                                     uint32_t low_bits, const PassPlan* plan, uint32_t pass,
@@ -190,15 +195,16 @@ __global__ __launch_bounds__(THREADS) void radix_finish_sort_kernel(KeyT* keys_a
     constexpr int SCAN_WAVES = (SCAN_THREADS + kWave - 1) / kWave;
     static_assert(WAVES % 4 == 0 && SCAN_THREADS <= THREADS, "offset scan geometry");
 
-    const uint32_t begin = starts[blockIdx.x], end = starts[blockIdx.x + 1];
-    const uint32_t len = end - begin;
-    if (len <= 1) return; // (workgroup-uniform)
     KeyT* keys = plan->flip[pass] ? keys_b : keys_a;
     uint32_t* vals = plan->flip[pass] ? vals_b : vals_a;
-
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Smem& s = *reinterpret_cast<Smem*>(smem_raw);
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (uint32_t run = blockIdx.x; run < kFinishRuns; run += LOOP ? gridDim.x : kFinishRuns)
+    {
+    const uint32_t begin = starts[run], end = starts[run + 1];
+    const uint32_t len = end - begin;
+    if (len <= 1) continue; // (workgroup-uniform)
     const uint32_t share = ((len + WAVES * kWave - 1) / (WAVES * kWave)) * kWave; // slots per wave: <= kWave * KPT
     const uint32_t items = share / kWave;
     const uint32_t wave_off = wave * share + lane;
@@ -307,6 +313,8 @@ __global__ __launch_bounds__(THREADS) void radix_finish_sort_kernel(KeyT* keys_a
             __builtin_nontemporal_store(key[i], &keys[begin + p]);
             if (VALS) __builtin_nontemporal_store(val[i], &vals[begin + p]);
         }
+    }
+    if (LOOP) __syncthreads(); // (the stage and the counters are reused)
     }
 }
 
