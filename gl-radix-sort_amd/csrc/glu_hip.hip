@@ -527,6 +527,10 @@ namespace
 // of passes whatever the input size: below this many bytes of keys a second read of the keys is cheaper
 // (tools/pairs_ladder.py; GLU_HIP_SORT_PAIR_MIN=elements overrides: tests, tuning)
 constexpr size_t kPairMinKeyBytes = (size_t) 1 << 28;
+// a sort that tries to end in LDS (radix_lds_finish.hpp) pairs its two top-bit passes and pays the same tables, but replaces
+// more: it is faster from about 2^24.5 pairs up (tools/finish_midsize_probe.py: 2^25 0.637 -> 0.586 ms, 2^25.5 0.907 -> 0.736)
+// (64-bit keys, where it replaces six passes, not two: from about 2^23: 2^24 1.01 -> 0.74 ms, 2^25 1.81 -> 1.07)
+constexpr size_t finish_min_count(size_t key_size) { return key_size == 8 ? (size_t) 3 << 22 : (size_t) 1 << 25; }
 constexpr size_t kPlanMinCount = (size_t) 1 << 22; // planned sorts: see PlanArgs below
 
 // CUs the pass kernels of `s` may fill (glu_dist reserves some for RCCL kernels that run beside them)
@@ -561,7 +565,9 @@ glu_status sort_prepare(glu_radix_sort_s* s, size_t count, size_t key_size, bool
         HIP_TRY(hipMemset(s->plan.ptr, 0, sizeof(PassPlan))); // never read uninitialised (glu_radix_sort_read_plan)
         HIP_TRY(hipDeviceSynchronize());                       // (the sort's stream does not wait for the null stream)
     }
-    if (count >= kPlanMinCount && count >= (s->pair_min ? s->pair_min : kPairMinKeyBytes / key_size) && s->pairs && !s->no_plan &&
+    const size_t pair_from = std::min<size_t>(s->pair_min ? s->pair_min : kPairMinKeyBytes / key_size,
+                                              s->lds_finish ? (s->finish_min ? s->finish_min : finish_min_count(key_size)) : (size_t) -1);
+    if (count >= kPlanMinCount && count >= pair_from && s->pairs && !s->no_plan &&
         !s->no_lines && !s->force_small)
     {
         const size_t nb = (size_t) g_dev.num_cus;
@@ -1045,14 +1051,14 @@ glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t cou
     }
     // A leader is a pass of the line kernel that does not encode keys on load; its follower is the pass after it, of the
     // line kernel of the same digit width (wider than 4 bits: the 8-bit kernels, else the 4-bit ones).
-    const bool pairs_ok = planned && s->pairs && s->pair_t2.ptr &&
-                          count >= (s->pair_min ? s->pair_min : kPairMinKeyBytes / sizeof(KeyT));
+    const bool pair_tables = planned && s->pairs && s->pair_t2.ptr;
+    const bool pairs_ok = pair_tables && count >= (s->pair_min ? s->pair_min : kPairMinKeyBytes / sizeof(KeyT));
     // Whole 32-bit keys, 8-bit digits, paired line passes: the sort first tries to end in LDS (radix_lds_finish.hpp) -- the two
     // top-bit passes and the in-LDS pass are enqueued in front of the four ordinary passes, and the device runs one of the
     // two sequences.
     uint32_t finish_kpt = 0; // (the geometry that suits uniform keys; 0: no attempt)
-    if (pairs_ok && s->lds_finish && s->finish_starts.ptr && key_xf == KEY_XF_NONE && first_bit == 0 &&
-        end_bit == 8 * sizeof(KeyT) && s->digit_bits == 8 && num_passes == sizeof(KeyT) && count >= (s->finish_min ? s->finish_min : (size_t) 1 << 26) &&
+    if (pair_tables && s->lds_finish && s->finish_starts.ptr && key_xf == KEY_XF_NONE && first_bit == 0 &&
+        end_bit == 8 * sizeof(KeyT) && s->digit_bits == 8 && num_passes == sizeof(KeyT) && count >= (s->finish_min ? s->finish_min : finish_min_count(sizeof(KeyT))) &&
         lines_applicable<KeyT, 8>(s, kbuf[0], vbuf[0], kbuf[1], vbuf[1], count))
         finish_kpt = finish_geometry_for(count);
     if (finish_kpt && s->finish_hint)
@@ -1086,14 +1092,15 @@ glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t cou
     // the one that gets a workgroup per run: what this object's last sort took if that is among them, else the uniform-keys one
     const uint32_t finish_expected = s->finish_last_geo >= finish_kpt && s->finish_last_geo <= finish_last ? s->finish_last_geo : finish_kpt;
     s->last_finish_capacity = finish_kpt ? finish_geometry_capacity(finish_last) : 0u;
-    if (pairs_ok)
+    if (pairs_ok || finish_kpt)
     {
         const bool lines8 = lines_applicable<KeyT, 8>(s, kbuf[0], vbuf[0], kbuf[1], vbuf[1], count);
         const bool lines4 = lines_applicable<KeyT, 4>(s, kbuf[0], vbuf[0], kbuf[1], vbuf[1], count);
         for (uint32_t i = 0; i + 1 < num_passes;)
         {
             const bool wide = passes[i].bits > 4;
-            if (wide == (passes[i + 1].bits > 4) && (wide ? lines8 : lines4) && (passes[i].xform & 3u) == 0)
+            // (below the size from which ordinary passes pair, only the two top-bit passes of an attempt to end in LDS do)
+            if ((pairs_ok || (finish_kpt && i == 0)) && wide == (passes[i + 1].bits > 4) && (wide ? lines8 : lines4) && (passes[i].xform & 3u) == 0)
             {
                 passes[i].pair_role = 1;
                 passes[i + 1].pair_role = 2;
