@@ -732,15 +732,16 @@ glu_status launch_pass_lines(glu_radix_sort_s* s, const KeyT* src_k, const uint3
     const uint2* ranges = nullptr;
     s->mark(stream);
     uint32_t* const sub_table = (uint32_t*) s->pair_sub.ptr; // 4-bit digits: the leader's table per sub-block
-    if constexpr (!XF)
+    if constexpr (!XF || BITS == 8)
     {
         if (pa.pair_role == 1)
         {
             // leader: one read of the keys for this pass's table and the two-digit table the follower's comes from
             if constexpr (BITS == 8)
             {
-                auto count2_plain = radix_pair_count_kernel<KeyT, G::TILE, false, false>;
-                auto count2_collect = radix_pair_count_kernel<KeyT, G::TILE, false, true>; // first pass: also notes which key bits vary
+                // (XF: the first top-bit pass of a typed sort that tries to end in LDS encodes on load; it never collects key bits)
+                auto count2_plain = radix_pair_count_kernel<KeyT, G::TILE, XF, false>;
+                auto count2_collect = radix_pair_count_kernel<KeyT, G::TILE, XF, !XF>; // first pass: also notes which key bits vary
                 static std::once_flag count2_opt_in;
                 static hipError_t count2_opt_in_result = hipSuccess;
                 std::call_once(count2_opt_in, [&] {
@@ -956,23 +957,23 @@ inline uint32_t finish_geometry_for(size_t count)
     return 0;
 }
 
-template<typename KeyT, bool VALS>
+template<typename KeyT, bool VALS, bool XF>
 glu_status launch_finish(KeyT* keys_a, uint32_t* vals_a, KeyT* keys_b, uint32_t* vals_b, const uint32_t* starts,
                          uint32_t geo_first, uint32_t geo_last, uint32_t geo_expected, uint32_t low_bits, const PassPlan* plan,
-                         uint32_t pass, hipStream_t stream)
+                         uint32_t pass, uint32_t key_xf, hipStream_t stream)
 {
     // the geometry the sort is expected to take gets a workgroup per run, the others 8192 workgroups that loop
 #define GLU_FINISH(GEO_, THREADS_, KPT_)                                                                                          \
     if (geo_first <= GEO_ && GEO_ <= geo_last)                                                                                    \
     {                                                                                                                             \
         static_assert(finish_geometry_capacity(GEO_) == THREADS_ * KPT_, "geometry table");                                       \
-        auto kern = GEO_ == geo_expected ? radix_finish_sort_kernel<KeyT, THREADS_, KPT_, VALS, false>                            \
-                                         : radix_finish_sort_kernel<KeyT, THREADS_, KPT_, VALS, true>;                            \
+        auto kern = GEO_ == geo_expected ? radix_finish_sort_kernel<KeyT, THREADS_, KPT_, VALS, false, XF>                        \
+                                         : radix_finish_sort_kernel<KeyT, THREADS_, KPT_, VALS, true, XF>;                        \
         static std::once_flag lds_opt_in;                                                                                         \
         static hipError_t lds_opt_in_result = hipSuccess;                                                                         \
         std::call_once(lds_opt_in, [&] {                                                                                          \
-            for (const void* k : {(const void*) radix_finish_sort_kernel<KeyT, THREADS_, KPT_, VALS, false>,                      \
-                                  (const void*) radix_finish_sort_kernel<KeyT, THREADS_, KPT_, VALS, true>})                      \
+            for (const void* k : {(const void*) radix_finish_sort_kernel<KeyT, THREADS_, KPT_, VALS, false, XF>,                  \
+                                  (const void*) radix_finish_sort_kernel<KeyT, THREADS_, KPT_, VALS, true, XF>})                  \
                 if (lds_opt_in_result == hipSuccess)                                                                              \
                     lds_opt_in_result = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize,                        \
                                                             (int) sizeof(FinishSmem<KeyT, THREADS_, KPT_, VALS>));                \
@@ -980,7 +981,7 @@ glu_status launch_finish(KeyT* keys_a, uint32_t* vals_a, KeyT* keys_b, uint32_t*
         HIP_TRY(lds_opt_in_result);                                                                                               \
         hipLaunchKernelGGL(kern, dim3(GEO_ == geo_expected ? kFinishRuns : 8192u), dim3(THREADS_),                                \
                            sizeof(FinishSmem<KeyT, THREADS_, KPT_, VALS>), stream,                                                \
-                           keys_a, vals_a, keys_b, vals_b, starts, low_bits, plan, pass, (uint32_t) GEO_);                        \
+                           keys_a, vals_a, keys_b, vals_b, starts, low_bits, plan, pass, (uint32_t) GEO_, key_xf);                \
         HIP_TRY(hipGetLastError());                                                                                               \
     }
     GLU_FINISH(1, 256, 6)
@@ -1057,7 +1058,7 @@ glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t cou
     // top-bit passes and the in-LDS pass are enqueued in front of the four ordinary passes, and the device runs one of the
     // two sequences.
     uint32_t finish_kpt = 0; // (the geometry that suits uniform keys; 0: no attempt)
-    if (pair_tables && s->lds_finish && s->finish_starts.ptr && key_xf == KEY_XF_NONE && first_bit == 0 &&
+    if (pair_tables && s->lds_finish && s->finish_starts.ptr && first_bit == 0 &&
         end_bit == 8 * sizeof(KeyT) && s->digit_bits == 8 && num_passes == sizeof(KeyT) && count >= (s->finish_min ? s->finish_min : finish_min_count(sizeof(KeyT))) &&
         lines_applicable<KeyT, 8>(s, kbuf[0], vbuf[0], kbuf[1], vbuf[1], count))
         finish_kpt = finish_geometry_for(count);
@@ -1083,7 +1084,7 @@ glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t cou
     {
         s->finish_seq = s->finish_seq >= 0x0FFFFFFFu ? 1u : s->finish_seq + 1;
         for (uint32_t i = num_passes; i-- > 0;) passes[i + 2] = passes[i];
-        passes[0] = PassDesc{end_bit - 16u, 8u, 0u, 0};
+        passes[0] = PassDesc{end_bit - 16u, 8u, key_xf, 0}; // (typed keys: encoded on load here, decoded on store by the in-LDS pass)
         passes[1] = PassDesc{end_bit - 8u, 8u, 0u, 0};
         num_passes += 2;
     }
@@ -1100,7 +1101,10 @@ glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t cou
         {
             const bool wide = passes[i].bits > 4;
             // (below the size from which ordinary passes pair, only the two top-bit passes of an attempt to end in LDS do)
-            if ((pairs_ok || (finish_kpt && i == 0)) && wide == (passes[i + 1].bits > 4) && (wide ? lines8 : lines4) && (passes[i].xform & 3u) == 0)
+            // (a leader does not encode keys on load -- except the first top-bit pass of an attempt, whose 8-bit pair-count
+            // kernel has the encoding instantiation)
+            if ((pairs_ok || (finish_kpt && i == 0)) && wide == (passes[i + 1].bits > 4) && (wide ? lines8 : lines4) &&
+                ((passes[i].xform & 3u) == 0 || (finish_kpt && i == 0)))
             {
                 passes[i].pair_role = 1;
                 passes[i + 1].pair_role = 2;
@@ -1158,12 +1162,21 @@ glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t cou
                     s->mark(stream);
                     s->mark(stream);
                     s->mark(stream);
+#define GLU_LAUNCH_FINISH(VALS_, XF_)                                                                                             \
+    GLU_TRY((launch_finish<KeyT, VALS_, XF_>(kbuf[0], VALS_ ? vbuf[0] : nullptr, kbuf[1], VALS_ ? vbuf[1] : nullptr,              \
+                                             (const uint32_t*) s->finish_starts.ptr, finish_kpt, finish_last, finish_expected,    \
+                                             end_bit - 16u, pa.plan, 2u, key_xf, stream)))
                     if (vals)
-                        GLU_TRY((launch_finish<KeyT, true>(kbuf[0], vbuf[0], kbuf[1], vbuf[1], (const uint32_t*) s->finish_starts.ptr,
-                                                           finish_kpt, finish_last, finish_expected, end_bit - 16u, pa.plan, 2u, stream)));
+                    {
+                        if (key_xf != KEY_XF_NONE) GLU_LAUNCH_FINISH(true, true);
+                        else GLU_LAUNCH_FINISH(true, false);
+                    }
                     else
-                        GLU_TRY((launch_finish<KeyT, false>(kbuf[0], nullptr, kbuf[1], nullptr, (const uint32_t*) s->finish_starts.ptr,
-                                                            finish_kpt, finish_last, finish_expected, end_bit - 16u, pa.plan, 2u, stream)));
+                    {
+                        if (key_xf != KEY_XF_NONE) GLU_LAUNCH_FINISH(false, true);
+                        else GLU_LAUNCH_FINISH(false, false);
+                    }
+#undef GLU_LAUNCH_FINISH
                     s->mark(stream);
                 }
             }

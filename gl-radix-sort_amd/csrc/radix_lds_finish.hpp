@@ -180,12 +180,14 @@ constexpr uint32_t finish_capacity() { return (uint32_t) (THREADS * KPT); }
 // starts while this one drains its stores: 0.96-0.99 ms for 2^28 pairs where a loop inside the kernel takes 1.05-1.16).  LOOP =
 // true: fewer workgroups, each takes every gridDim.x-th run -- for the geometries that are enqueued besides the expected one:
 // 65536 workgroups that return at once cost 15-29 us, 8192 cost 5.
-template<typename KeyT, int THREADS, int KPT, bool VALS, bool LOOP>
+// XF: typed keys (signed integers, floats): the first top-bit pass encoded them on load, this pass decodes them on store.
+template<typename KeyT, int THREADS, int KPT, bool VALS, bool LOOP, bool XF = false>
 __global__ __launch_bounds__(THREADS) void radix_finish_sort_kernel(KeyT* keys_a, uint32_t* vals_a, KeyT* keys_b,
                                                                     uint32_t* vals_b, const uint32_t* __restrict__ starts,
                                                                     uint32_t low_bits, const PassPlan* plan, uint32_t pass,
-                                                                    uint32_t geometry)
+                                                                    uint32_t geometry, uint32_t key_xf = 0)
 {
+    const KeyCodec<KeyT, XF> codec_out(key_xf);
     if (plan->finish != geometry) return; // (kernel-uniform: the device chose another geometry, or the ordinary passes)
     using Smem = FinishSmem<KeyT, THREADS, KPT, VALS>;
     constexpr int RADIX = Smem::RADIX;
@@ -310,7 +312,7 @@ __global__ __launch_bounds__(THREADS) void radix_finish_sort_kernel(KeyT* keys_a
         const uint32_t p = wave_off + i * kWave;
         if ((uint32_t) i < items && p < len)
         {
-            __builtin_nontemporal_store(key[i], &keys[begin + p]);
+            __builtin_nontemporal_store(codec_out.decode(key[i]), &keys[begin + p]);
             if (VALS) __builtin_nontemporal_store(val[i], &vals[begin + p]);
         }
     }

@@ -274,7 +274,7 @@ GLU_API glu_status glu_radix_sort_read_profile_finish(glu_radix_sort sort, doubl
  * passes <= 32. */
 GLU_API glu_status glu_radix_sort_read_plan(glu_radix_sort sort, uint32_t* skipped, uint32_t* counted_alone,
                                             uint32_t* pair_role, size_t passes);
-/* A sort that ends in LDS.  A sort of whole 32-bit or 64-bit keys (no key transform) of 2^25 (64-bit keys: 1.26e7) .. about 2^29 elements with 8-bit
+/* A sort that ends in LDS.  A sort of whole 32-bit or 64-bit keys (any key type) of 2^25 (64-bit keys: 1.26e7) .. about 2^29 elements with 8-bit
  * digits first tries a shorter way to the same result: the two counting passes on the TOP 16 key bits, after which the array
  * is 65536 runs of keys that share those bits, and one pass in which a workgroup per run orders the run by the remaining low
  * bits inside LDS (two rounds of 8 bits for 32-bit keys, six for 64-bit keys), in place -- 52.25 instead of 72.5 bytes of

@@ -303,18 +303,14 @@ def test_profile_books_the_sequence_that_ran(G):
     assert prof["passes"] == 4 and prof["finish_passes"] == 0 and prof["finish_ms"] == 0
 
 
-def test_typed_and_partial_sorts_do_not_attempt(G):
-    """Key transforms (int32 / float32) and sorts of fewer than 32 bits keep the ordinary passes."""
+def test_partial_sorts_do_not_attempt(G):
+    """Sorts of fewer than all key bits keep the ordinary passes."""
     import torch
 
     s = _sorter(G, **SMALL)
     n = N_SMALL
     keys = torch.randint(-2**31, 2**31, (n,), dtype=torch.int32, device="cuda:0")
     vals = torch.arange(n, dtype=torch.int32, device="cuda:0")
-    s.sort_typed_ptr(keys.data_ptr(), vals.data_ptr(), n, "int32")
-    G.synchronize()
-    assert s.read_finish()["attempted"] == 0
-    assert bool((keys[1:] >= keys[:-1]).all())
     s.run_ptr(keys.data_ptr(), vals.data_ptr(), n, num_steps=6)
     G.synchronize()
     assert s.read_finish()["attempted"] == 0
@@ -445,3 +441,53 @@ def test_u64_large_sizes_and_the_largest_tile(G):
         assert bool((vals[1:][eq] > vals[:-1][eq]).all()), "equal keys out of input order"
         del keys, vals, k0, eq
         torch.cuda.empty_cache()
+
+
+# ---- typed keys: the first top-bit pass encodes on load, the in-LDS pass decodes on store -------------------------------------
+
+@pytest.mark.parametrize("name", ["int32", "float32", "int64", "float64"])
+@pytest.mark.parametrize("with_vals", [True, False])
+def test_typed_keys_end_in_lds(G, name, with_vals):
+    """Signed integers and floats in their natural order (negative zero before positive zero, as the order-preserving integer
+    code of the bit patterns has it), with values and keys only."""
+    dt = np.dtype(name)
+    n = (1 << 23) + 1234 if not with_vals else N_SMALL
+    rng = np.random.default_rng(41)
+    u = rng.integers(0, 2 ** (8 * dt.itemsize), n, dtype=np.uint32 if dt.itemsize == 4 else np.uint64)
+    keys = u.view(dt)
+    if dt.kind == "f":
+        # no NaNs (they have no place in an order): clear the lowest exponent bit of every NaN pattern; a few zeros of both signs
+        mant = 23 if dt.itemsize == 4 else 52
+        u = np.where(np.isnan(keys), u & ~(u.dtype.type(1) << u.dtype.type(mant)), u)
+        keys = u.view(dt).copy()
+        keys[::100000] = dt.type(-0.0)
+        keys[1::100000] = dt.type(0.0)
+    vals = np.arange(n, dtype=np.uint32)
+    s = _sorter(G, **SMALL)
+    kb = G.ShaderStorageBuffer(keys)
+    vb = G.ShaderStorageBuffer(vals) if with_vals else None
+    s.sort_typed_ptr(kb.device_ptr(), vb.device_ptr() if with_vals else None, n, name)
+    G.synchronize()
+    fin = s.read_finish()
+    assert fin["attempted"] == 1 and fin["accepted"] == 1, fin
+    bits = keys.view(np.uint32 if dt.itemsize == 4 else np.uint64)
+    top = bits.dtype.type(1) << bits.dtype.type(dt.itemsize * 8 - 1)
+    code = (bits ^ top) if dt.kind == "i" else np.where(bits & top, ~bits, bits ^ top)
+    order = np.argsort(code, kind="stable")
+    assert (kb.get_data(dt).view(bits.dtype) == bits[order]).all()
+    if with_vals:
+        assert (vb.get_data(np.uint32) == vals[order]).all()
+
+
+def test_typed_keys_of_a_small_range_are_refused(G):
+    n = N_SMALL
+    keys = np.random.default_rng(42).integers(-5000, 5000, n, dtype=np.int32)
+    vals = np.arange(n, dtype=np.uint32)
+    s = _sorter(G, **SMALL)
+    kb, vb = G.ShaderStorageBuffer(keys), G.ShaderStorageBuffer(vals)
+    s.sort_typed_ptr(kb.device_ptr(), vb.device_ptr(), n, "int32")
+    G.synchronize()
+    fin = s.read_finish()
+    assert fin["attempted"] == 1 and fin["accepted"] == 0
+    order = np.argsort(keys, kind="stable")
+    assert (kb.get_data(np.int32) == keys[order]).all() and (vb.get_data(np.uint32) == vals[order]).all()
