@@ -13,6 +13,7 @@
 // below 40 KiB and a fourth workgroup onto the CU: 0.96-0.99 ms, adopted), 6-byte stage slots for a fifth workgroup (level,
 // measured in place only: its output check does not apply to this harness's keys), persistent workgroups that load the next
 // run's bounds early (slower: 1.05-1.16 ms -- a workgroup per run lets the next one start while this one drains its stores).
+// -DLFB_NT_LOADS: non-temporal loads of the run (level: 0.93 / 0.99 ms either way).
 // Records: profiles/r04/lds_final_pass_*.txt.  Not part of the product.
 #include <hip/hip_runtime.h>
 
@@ -195,7 +196,11 @@ __global__ __launch_bounds__(THREADS) void lds_runs_kernel(const uint32_t* keys_
         const uint32_t p = wave_off + i * kWave;
         const bool ok = p < len;
         const uint32_t pc = ok ? p : len - 1; // unconditional loads of an element of the run; slots past its end become pads
+#ifdef LFB_NT_LOADS
+        const uint32_t k = __builtin_nontemporal_load(&keys_in[begin + pc]), v = __builtin_nontemporal_load(&vals_in[begin + pc]);
+#else
         const uint32_t k = keys_in[begin + pc], v = vals_in[begin + pc];
+#endif
         key[i] = ok ? k : ~0u;
         val[i] = ok ? v : 0u;
     }

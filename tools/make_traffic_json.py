@@ -61,7 +61,7 @@ all_k = {
     "source": src, "corrections": corr,
     "kernels": [
         e8, e4,
-        entry(bench_f, bench_w, ("radix_finish_sort_kernel<unsigned int, 256, 18, true, false>",), N * 16, "in-LDS pass of the headline sort (a workgroup per run of equal top 16 key bits; reads and writes every pair once)"),
+        entry(bench_f, bench_w, ("radix_finish_sort_kernel<unsigned int, 256, 18, true, false",), N * 16, "in-LDS pass of the headline sort (a workgroup per run of equal top 16 key bits; reads and writes every pair once)"),
         entry(bench_f, bench_w, ("radix_pair_count_kernel<unsigned int",), N * 4 + T2, "count kernel of a pair of passes of the headline sort (reads the keys, writes the two-digit table)"),
         entry(bench_f, bench_w, ("radix_pair_unitsum_kernel",), T2, "count table of the second pass of a pair (reads the two-digit table)"),
         entry(bench_f, bench_w, ("radix_pair4_count_kernel<unsigned int",), N * 4 + T2_4, "count kernel of a pair of passes of the 4-bit sort (reads the keys -- the calibration of the FETCH_SIZE factor -- and writes 4.25 MiB of tables)"),
@@ -70,7 +70,7 @@ all_k = {
         entry(cfg_f, cfg_w, ("radix_scatter_lines_kernel<unsigned long, 4",), N * 24, "same, 4-bit digits"),
         entry(cfg_f, cfg_w, ("radix_pair_count_kernel<unsigned long",), N * 8 + T2, "count kernel of a pair of passes, 64-bit keys"),
         entry(cfg_f, cfg_w, ("radix_pair4_count_kernel<unsigned long",), N * 8 + T2_4, "count kernel of a pair of passes, 64-bit keys, 4-bit digits"),
-        entry(cfg_f, cfg_w, ("radix_finish_sort_kernel<unsigned long, 512, 9, true, false>",), N * 24, "in-LDS pass of BASELINE.json configs[4] (2^28 u64 keys + u32 vals: six rounds on the low 48 bits)"),
+        entry(cfg_f, cfg_w, ("radix_finish_sort_kernel<unsigned long, 512, 9, true, false",), N * 24, "in-LDS pass of BASELINE.json configs[4] (2^28 u64 keys + u32 vals: six rounds on the low 48 bits)"),
         entry(cfg_f, cfg_w, ("scan_chunks_kernel",), N * 8, "glu::BlellochScan 2^28 u32 (chained single pass)"),
     ],
 }
