@@ -491,6 +491,11 @@ struct glu_radix_sort_s
     uint32_t* finish_hint = nullptr;
     uint32_t finish_seq = 0, finish_seq_acted_on = 0, finish_wait = 0;
     uint32_t finish_last_geo = 0; // the tile geometry the device chose for the last sort whose outcome is known (0: none yet)
+    // The runs of a sort that ends in LDS are the values of the 16 key bits below `top`: the whole key's top 16 by default,
+    // the top 16 of the bits that VARIED in this object's last attempt once that is known (keys below 2^28 make 4096 runs of the
+    // whole key's top bits and 65536 of bits [12, 28)).  A guess: the plan kernel refuses if a bit from `top` up varies after all.
+    uint32_t finish_top = 0;      // 0: the key's width
+    uint32_t last_finish_top = 0; // what the last sort assumed (glu_radix_sort_read_finish)
     uint32_t finish_backoff = 8;  // GLU_HIP_SORT_FINISH_BACKOFF=N (0: every sort attempts: tests)
     bool last_finish_attempted = false; // the last sort enqueued both sequences (glu_radix_sort_read_finish)
     uint32_t last_finish_capacity = 0;  // and the longest run its last pass would take
@@ -582,7 +587,7 @@ glu_status sort_prepare(glu_radix_sort_s* s, size_t count, size_t key_size, bool
             if (!s->finish_hint)
             {
                 HIP_TRY(hipHostMalloc((void**) &s->finish_hint, 64));
-                *s->finish_hint = 0;
+                memset(s->finish_hint, 0, 64);
             }
         }
     }
@@ -607,7 +612,7 @@ struct PlanArgs
     bool behind_attempt = false;  // an ordinary pass enqueued behind such an attempt (runs only if the attempt was refused)
     uint32_t finish_geo_first = 0, finish_geo_last = 0; // tile geometries of the in-LDS pass that are enqueued (0: not such a pass)
     uint32_t finish_first_ordinary = 0, finish_num_ordinary = 0;
-    uint32_t finish_seq = 0;
+    uint32_t finish_seq = 0, finish_top_bit = 0, finish_key_bits = 0;
 };
 
 // XF: this pass encodes keys on load and / or decodes them on store (first / last pass of a typed sort); every other
@@ -821,7 +826,8 @@ glu_status launch_pass_lines(glu_radix_sort_s* s, const KeyT* src_k, const uint3
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(radix_finish_plan_kernel, dim3(kFinishPlanBlocks), dim3(1024), 0, stream, (const uint32_t*) s->finish_lengths.ptr,
                            (uint32_t*) s->finish_starts.ptr, (uint32_t) count, pa.finish_geo_first, pa.finish_geo_last, pa.plan, pa.pass,
-                           pa.finish_first_ordinary, pa.finish_num_ordinary, s->finish_hint, pa.finish_seq);
+                           pa.finish_first_ordinary, pa.finish_num_ordinary, s->finish_hint, pa.finish_seq, pa.finish_top_bit,
+                           pa.finish_key_bits);
         HIP_TRY(hipGetLastError());
     }
     s->mark(stream);
@@ -1058,20 +1064,34 @@ glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t cou
     // top-bit passes and the in-LDS pass are enqueued in front of the four ordinary passes, and the device runs one of the
     // two sequences.
     uint32_t finish_kpt = 0; // (the geometry that suits uniform keys; 0: no attempt)
+    uint32_t finish_top_bit = end_bit;
     if (pair_tables && s->lds_finish && s->finish_starts.ptr && first_bit == 0 &&
         end_bit == 8 * sizeof(KeyT) && s->digit_bits == 8 && num_passes == sizeof(KeyT) && count >= (s->finish_min ? s->finish_min : finish_min_count(sizeof(KeyT))) &&
         lines_applicable<KeyT, 8>(s, kbuf[0], vbuf[0], kbuf[1], vbuf[1], count))
         finish_kpt = finish_geometry_for(count);
     if (finish_kpt && s->finish_hint)
     {
-        if (s->finish_wait == 0 && s->finish_seq)
+        const uint32_t seen = s->finish_seq ? __atomic_load_n(s->finish_hint, __ATOMIC_ACQUIRE) : 0u;
+        if (s->finish_wait == 0 && s->finish_seq && (seen >> 3) == s->finish_seq) // the last attempt's outcome has arrived
         {
-            const uint32_t seen = __atomic_load_n(s->finish_hint, __ATOMIC_RELAXED);
-            if ((seen >> 3) == s->finish_seq && (seen & 7u)) s->finish_last_geo = seen & 7u; // the tile the last sort took
-            if ((seen >> 3) == s->finish_seq && s->finish_seq != s->finish_seq_acted_on && !(seen & 7u) && s->finish_backoff)
+            if (seen & 7u) s->finish_last_geo = seen & 7u; // the tile it took
+            if (s->finish_seq != s->finish_seq_acted_on)    // (acted on once)
             {
-                s->finish_wait = s->finish_backoff; // the last attempt was refused (acted on once)
                 s->finish_seq_acted_on = s->finish_seq;
+                const uint32_t was = s->finish_top ? s->finish_top : end_bit;
+                uint32_t top = was;
+                if (__atomic_load_n(s->finish_hint + 3, __ATOMIC_ACQUIRE) == s->finish_seq)
+                {
+                    // which key bits varied: the runs of the next attempt are the values of the top 16 of those
+                    const uint64_t varying = (uint64_t) s->finish_hint[1] | ((uint64_t) s->finish_hint[2] << 32);
+                    top = varying ? 64u - (uint32_t) __builtin_clzll(varying) : 16u;
+                    top = std::min<uint32_t>(std::max<uint32_t>(top, 16u), end_bit);
+                    if (sizeof(KeyT) == 8 && top > 32 && top < 48 && top != 40) top = top < 40 ? 40 : 48; // a digit stays inside one key word
+                }
+                if (top != was)
+                    s->finish_top = top; // the assumption changes: what the last attempt was told says nothing about the next
+                else if (!(seen & 7u) && s->finish_backoff)
+                    s->finish_wait = s->finish_backoff; // refused under the same assumption: do not ask again for a while
             }
         }
         if (s->finish_wait)
@@ -1084,10 +1104,13 @@ glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t cou
     {
         s->finish_seq = s->finish_seq >= 0x0FFFFFFFu ? 1u : s->finish_seq + 1;
         for (uint32_t i = num_passes; i-- > 0;) passes[i + 2] = passes[i];
-        passes[0] = PassDesc{end_bit - 16u, 8u, key_xf, 0}; // (typed keys: encoded on load here, decoded on store by the in-LDS pass)
-        passes[1] = PassDesc{end_bit - 8u, 8u, 0u, 0};
+        // (typed keys and sorts that do not collect which bits vary: the whole key's top bits)
+        finish_top_bit = key_xf == KEY_XF_NONE && !s->no_bit_shortcut && s->finish_top ? std::min<uint32_t>(s->finish_top, end_bit) : end_bit;
+        passes[0] = PassDesc{finish_top_bit - 16u, 8u, key_xf, 0}; // (typed keys: encoded on load here, decoded on store by the in-LDS pass)
+        passes[1] = PassDesc{finish_top_bit - 8u, 8u, 0u, 0};
         num_passes += 2;
     }
+    s->last_finish_top = finish_kpt ? finish_top_bit : 0u;
     s->last_finish_attempted = finish_kpt != 0;
     const uint32_t finish_last = std::min<uint32_t>(finish_kpt + 2, kFinishGeometries); // the larger tiles enqueued behind it
     // the one that gets a workgroup per run: what this object's last sort took if that is among them, else the uniform-keys one
@@ -1151,6 +1174,8 @@ glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t cou
                 pa.finish_first_ordinary = 2;
                 pa.finish_num_ordinary = num_passes - 2;
                 pa.finish_seq = s->finish_seq;
+                pa.finish_top_bit = finish_top_bit;
+                pa.finish_key_bits = end_bit;
             }
             GLU_TRY(dispatch_pass<KeyT>(s, kbuf[0], vbuf[0], kbuf[1], vbuf[1], count, shift, bits, nullptr, stream, xform, pa));
             {
@@ -1165,7 +1190,7 @@ glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t cou
 #define GLU_LAUNCH_FINISH(VALS_, XF_)                                                                                             \
     GLU_TRY((launch_finish<KeyT, VALS_, XF_>(kbuf[0], VALS_ ? vbuf[0] : nullptr, kbuf[1], VALS_ ? vbuf[1] : nullptr,              \
                                              (const uint32_t*) s->finish_starts.ptr, finish_kpt, finish_last, finish_expected,    \
-                                             end_bit - 16u, pa.plan, 2u, key_xf, stream)))
+                                             finish_top_bit - 16u, pa.plan, 2u, key_xf, stream)))
                     if (vals)
                     {
                         if (key_xf != KEY_XF_NONE) GLU_LAUNCH_FINISH(true, true);
@@ -2084,7 +2109,7 @@ glu_status glu_radix_sort_read_plan(glu_radix_sort sort, uint32_t* skipped, uint
 }
 
 glu_status glu_radix_sort_read_finish(glu_radix_sort sort, uint32_t* attempted, uint32_t* accepted, uint32_t* longest_run,
-                                      uint32_t* capacity)
+                                      uint32_t* capacity, uint32_t* top_bit)
 {
     GLU_TRY(enter());
     if (!sort) return fail(GLU_ERROR_INVALID_ARGUMENT, "sort is NULL");
@@ -2097,6 +2122,7 @@ glu_status glu_radix_sort_read_finish(glu_radix_sort sort, uint32_t* attempted, 
     if (longest_run) *longest_run = tried ? host.finish_longest : 0u;
     // the tile the device chose; refused: the largest one that was enqueued
     if (capacity) *capacity = !tried ? 0u : host.finish ? finish_geometry_capacity(host.finish) : sort->last_finish_capacity;
+    if (top_bit) *top_bit = tried ? sort->last_finish_top : 0u;
     return GLU_OK;
 }
 

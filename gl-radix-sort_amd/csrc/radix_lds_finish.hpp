@@ -82,7 +82,8 @@ __global__ __launch_bounds__(1024) void radix_finish_plan_kernel(const uint32_t*
                                                                  uint32_t n, uint32_t geo_first, uint32_t geo_last, PassPlan* plan,
                                                                  uint32_t pass,
                                                                  uint32_t first_ordinary, uint32_t num_ordinary,
-                                                                 uint32_t* hint, uint32_t attempt)
+                                                                 uint32_t* hint, uint32_t attempt, uint32_t top_bit,
+                                                                 uint32_t key_bits)
 {
     __shared__ uint32_t tmp[3][16];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
@@ -126,7 +127,17 @@ __global__ __launch_bounds__(1024) void radix_finish_plan_kernel(const uint32_t*
     uint32_t geo = 0;
     for (uint32_t g = geo_last; g >= geo_first && g >= 1; g--)
         if (longest <= finish_geometry_capacity(g)) geo = g;
-    const bool accept = tables && all == n && geo != 0;
+    // The runs are the values of key bits [top_bit - 16, top_bit): that orders the keys only if no key bit from top_bit up
+    // varies -- the host assumed so from what this object's last sort saw, the count kernel of this one has looked
+    // (PassPlan::bits_or / bits_nor).  Typed keys and sorts that do not collect the bits are launched with top_bit = key_bits.
+    bool range_ok = top_bit >= key_bits;
+    uint64_t varying = ~0ull;
+    if (plan->bits_valid)
+    {
+        varying = (uint64_t) (plan->bits_or[0] & plan->bits_nor[0]) | ((uint64_t) (plan->bits_or[1] & plan->bits_nor[1]) << 32);
+        if (top_bit < key_bits) range_ok = (varying >> top_bit) == 0;
+    }
+    const bool accept = tables && all == n && geo != 0 && range_ok;
     if (accept)
     {
         starts[b * 1024u + tid] = before + excl;
@@ -137,8 +148,18 @@ __global__ __launch_bounds__(1024) void radix_finish_plan_kernel(const uint32_t*
         plan->finish = accept ? geo : 0u;
         plan->finish_longest = tables ? longest : 0xFFFFFFFFu;
         // for the host, which reads it without synchronising: the outcome of attempt number `attempt` (pinned host memory)
-        // (attempt << 3 | the geometry chosen, 0 = refused)
-        if (hint) __hip_atomic_store(hint, (attempt << 3) | (accept ? geo : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        // (attempt << 3 | the geometry chosen, 0 = refused; and which key bits vary, for the next sort's choice of top_bit:
+        // words 1, 2, valid for attempt number word 3)
+        if (hint)
+        {
+            if (plan->bits_valid)
+            {
+                __hip_atomic_store(hint + 1, (uint32_t) varying, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(hint + 2, (uint32_t) (varying >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(hint + 3, attempt, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            __hip_atomic_store(hint, (attempt << 3) | (accept ? geo : 0u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         if (!accept)
         {
             plan->skip[pass] = kSkipWithoutCounting;

@@ -72,7 +72,7 @@ SYMBOLS = [
     ("glu_radix_sort_read_plan", _int, [_vp, _P(_u32), _P(_u32), _P(_u32), _sz]),
     ("glu_radix_sort_read_profile_finish", _int, [_vp, _P(ctypes.c_double), _P(ctypes.c_double), _P(ctypes.c_double), _P(_u64),
                                                   _P(ctypes.c_double), _P(_u64)]),
-    ("glu_radix_sort_read_finish", _int, [_vp, _P(_u32), _P(_u32), _P(_u32), _P(_u32)]),
+    ("glu_radix_sort_read_finish", _int, [_vp, _P(_u32), _P(_u32), _P(_u32), _P(_u32), _P(_u32)]),
     ("glu_scan_create", _int, [_int, _P(_vp)]),
     ("glu_scan_destroy", _int, [_vp]),
     ("glu_scan_prepare", _int, [_vp, _sz, _sz]),
@@ -294,9 +294,10 @@ class RadixSort:
     def read_finish(self):
         """{attempted, accepted, longest_run, capacity} of the last sort: did it try to / did it end in LDS
         (glu_radix_sort_read_finish); synchronise first."""
-        a, b, c, d = _u32(0), _u32(0), _u32(0), _u32(0)
-        check(lib().glu_radix_sort_read_finish(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c), ctypes.byref(d)))
-        return {"attempted": a.value, "accepted": b.value, "longest_run": c.value, "capacity": d.value}
+        a, b, c, d, e = _u32(0), _u32(0), _u32(0), _u32(0), _u32(0)
+        check(lib().glu_radix_sort_read_finish(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c), ctypes.byref(d),
+                                               ctypes.byref(e)))
+        return {"attempted": a.value, "accepted": b.value, "longest_run": c.value, "capacity": d.value, "top_bit": e.value}
 
     def __call__(self, key_buffer, val_buffer, count, num_steps=0, key_bytes=4):
         kb = key_buffer.handle() if isinstance(key_buffer, ShaderStorageBuffer) else key_buffer

@@ -289,9 +289,14 @@ GLU_API glu_status glu_radix_sort_read_plan(glu_radix_sort sort, uint32_t* skipp
  * its stream): attempted = 1 if both sequences were enqueued, accepted = 1 if the sort ended in LDS, longest_run = the
  * longest run counted (0xFFFFFFFF: not counted), capacity = the tile the device chose (refused: the largest one enqueued).
  * glu_radix_sort_read_plan describes the ordinary passes (all "skipped without counting" when accepted = 1).
+ * top_bit: the runs were the values of key bits [top_bit - 16, top_bit).  That is the whole key's top 16 bits for an object's
+ * first sort; afterwards it is the top 16 of the bits that VARIED in the object's last attempt (unsigned keys; the count kernel
+ * notes them): keys below 2^28 make 4096 long runs of the whole key's top bits and are refused, and 65536 short ones of bits
+ * [12, 28) from the second sort on.  It is a guess that the device checks: if a bit from top_bit up varies after all, the
+ * ordinary passes run (and the next sort guesses better).
  * GLU_HIP_SORT_LDS_FINISH=0 in the environment of glu_radix_sort_create switches the attempt off.  Any pointer may be NULL. */
 GLU_API glu_status glu_radix_sort_read_finish(glu_radix_sort sort, uint32_t* attempted, uint32_t* accepted,
-                                              uint32_t* longest_run, uint32_t* capacity);
+                                              uint32_t* longest_run, uint32_t* capacity, uint32_t* top_bit);
 
 /* ---- exclusive scan: replaces glu::BlellochScan (glu/BlellochScan.hpp:80-191) ---------------------- */
 

@@ -179,20 +179,57 @@ def test_presorted_inputs(G, shape):
 
 
 def test_one_object_alternates_between_the_two_sequences(G):
-    """The plan is per sort: accepted, refused, accepted on the same object, and a small sort (no plan) in between."""
-    s = _sorter(G, GLU_HIP_SORT_FINISH_BACKOFF=0, **SMALL)  # (by default a refusal makes the next sorts skip the attempt)
+    """The plan is per sort.  An object's first sort takes its runs from the whole key's top 16 bits; later ones from the top 16
+    of the bits that varied in the attempt before (a guess the device checks): uniform keys end in LDS, 18-bit keys are refused
+    under the first assumption and end in LDS under the second (runs = bits [2, 18)), full-range keys are then refused once --
+    bits above 18 vary -- and end in LDS again.  A small sort (no plan) in between changes nothing."""
+    s = _sorter(G, GLU_HIP_SORT_FINISH_BACKOFF=0, **SMALL)
     vals = np.arange(N_SMALL, dtype=np.uint32)
-    for seed, small_range in [(8, False), (9, True), (10, False)]:
+    steps = [(8, False, 1, 32), (9, True, 0, 32), (10, True, 1, 18), (11, False, 0, 18), (12, False, 1, 32), (13, False, 1, 32)]
+    for seed, small_range, accepted, top in steps:
         keys = _uniform(N_SMALL, seed)
         if small_range:
             keys >>= np.uint32(14)
         gk, gv, fin = _run(G, s, keys, vals)
         _check(keys, vals, gk, gv)
-        assert fin["attempted"] == 1 and fin["accepted"] == (0 if small_range else 1)
+        assert fin["attempted"] == 1 and fin["accepted"] == accepted and fin["top_bit"] == top, (seed, fin)
         k2 = _uniform(5000, seed)
         gk2, gv2, fin2 = _run(G, s, k2, np.arange(5000, dtype=np.uint32))
         _check(k2, np.arange(5000, dtype=np.uint32), gk2, gv2)
         assert fin2["attempted"] == 0
+
+
+@pytest.mark.parametrize("bits,garbage", [(28, 0), (28, 0xA0000000), (21, 0), (17, 0x00FE0000), (16, 0), (31, 0)])
+def test_keys_of_a_smaller_range_end_in_lds_from_the_second_sort_on(G, bits, garbage):
+    """Keys below 2^bits (with or without constant bits above) crowd into few runs of the whole key's top bits: the first sort is
+    refused; it has noted which key bits vary, and the second takes its runs from the top 16 of those -- bits [bits - 16, bits)
+    -- and orders the remaining low bits (12, 5, 1, none, 15) inside LDS."""
+    s = _sorter(G, **SMALL)
+    vals = np.arange(N_SMALL, dtype=np.uint32)
+    for rep in range(3):
+        keys = (_uniform(N_SMALL, 50 + rep) >> np.uint32(32 - bits)) | np.uint32(garbage)
+        gk, gv, fin = _run(G, s, keys, vals)
+        _check(keys, vals, gk, gv)
+        if rep == 0:
+            # (at this size 28 and 31 bits still fit a tile under the first assumption: 4096 runs of 1024, 32768 of 128)
+            assert fin["attempted"] == 1 and fin["accepted"] == (1 if bits >= 28 else 0) and fin["top_bit"] == 32
+        else:
+            assert fin["attempted"] == 1 and fin["accepted"] == 1 and fin["top_bit"] == max(bits, 16), (rep, fin)
+
+
+def test_u64_keys_of_a_smaller_range(G):
+    """64-bit keys of 45 varying bits: a digit must stay inside one 32-bit key word, so the runs come from bits [32, 48); of 40
+    bits: from [24, 40)."""
+    s = _sorter(G, **SMALL)
+    vals = np.arange(N_SMALL, dtype=np.uint32)
+    for bits, top in [(45, 48), (40, 40), (64, 64)]:
+        for rep in range(2):
+            keys = _uniform64(N_SMALL, 60 + rep) >> np.uint64(64 - bits)
+            gk, gv, fin = _run64(G, s, keys, vals)
+            ek, ev = O.stable_sort_pairs(keys, vals)
+            assert (gk == ek).all() and (gv == ev).all()
+            if rep == 1:
+                assert fin["attempted"] == 1 and fin["accepted"] == 1 and fin["top_bit"] == top, (bits, fin)
 
 
 def test_after_a_refusal_the_next_sorts_do_not_ask_again(G):
@@ -200,7 +237,7 @@ def test_after_a_refusal_the_next_sorts_do_not_ask_again(G):
     asks again (inputs that fit are taken up again, inputs that never fit pay once in nine sorts)."""
     s = _sorter(G, **SMALL)
     vals = np.arange(N_SMALL, dtype=np.uint32)
-    narrow = _uniform(N_SMALL, 13) >> np.uint32(12)
+    narrow = _with_one_run_of(N_SMALL, 6000, 13)  # (full-range keys, one run too long for the largest enqueued tile)
     wide = _uniform(N_SMALL, 14)
     seen = []
     for i in range(11):
@@ -253,8 +290,8 @@ def test_keys_that_leave_runs_empty_take_a_larger_tile(G):
     the largest tile, 512 threads x 18."""
     import torch
 
-    s = _sorter(G)
     for n, shift, cap in [((1 << 27) + 333, 1, 4608), ((1 << 28) - 5, 1, 9216), (1 << 29, 0, 9216)]:
+        s = _sorter(G)  # (a fresh object: its first sort takes the runs from the whole key's top bits)
         keys = torch.randint(-2**31, 2**31, (n,), dtype=torch.int32, device="cuda:0")
         if shift:
             keys = (keys >> 1) & torch.tensor(0x7FFFFFFF, dtype=torch.int32, device="cuda:0")
@@ -275,6 +312,29 @@ def test_keys_that_leave_runs_empty_take_a_larger_tile(G):
         torch.cuda.empty_cache()
 
 
+def test_31_bit_keys_at_full_size_go_back_to_the_small_tile(G):
+    """2^28 pairs of 31-bit keys: the first sort ends in LDS in the largest tile (32768 runs of 8192 under the whole key's top
+    bits), the second in the tile for uniform keys (65536 runs of 4096 of bits [15, 31))."""
+    import torch
+
+    n = 1 << 28
+    s = _sorter(G)
+    mask = torch.tensor(0x7FFFFFFF, dtype=torch.int32, device="cuda:0")
+    for rep, (cap, top) in enumerate([(9216, 32), (4608, 31), (4608, 31)]):
+        keys = torch.randint(-2**31, 2**31, (n,), dtype=torch.int32, device="cuda:0") & mask
+        vals = torch.arange(n, dtype=torch.int32, device="cuda:0")
+        torch.cuda.synchronize()  # (the sort runs on the library's queue, not on torch's stream)
+        s.run_ptr(keys.data_ptr(), vals.data_ptr(), n)
+        G.synchronize()
+        fin = s.read_finish()
+        assert fin["accepted"] == 1 and fin["capacity"] == cap and fin["top_bit"] == top, (rep, fin)
+        assert bool((keys[1:] >= keys[:-1]).all()), "not sorted"  # (non-negative as int32)
+        eq = keys[1:] == keys[:-1]
+        assert bool((vals[1:][eq] > vals[:-1][eq]).all()), "equal keys out of input order"
+        del keys, vals, eq
+        torch.cuda.empty_cache()
+
+
 def test_beyond_the_largest_geometry_no_attempt_is_made(G):
     import torch
 
@@ -282,6 +342,7 @@ def test_beyond_the_largest_geometry_no_attempt_is_made(G):
     s = _sorter(G)
     keys = torch.randint(-2**31, 2**31, (n,), dtype=torch.int32, device="cuda:0")
     vals = torch.arange(n, dtype=torch.int32, device="cuda:0")
+    torch.cuda.synchronize()
     s.run_ptr(keys.data_ptr(), vals.data_ptr(), n)
     G.synchronize()
     assert s.read_finish()["attempted"] == 0
@@ -311,6 +372,7 @@ def test_partial_sorts_do_not_attempt(G):
     n = N_SMALL
     keys = torch.randint(-2**31, 2**31, (n,), dtype=torch.int32, device="cuda:0")
     vals = torch.arange(n, dtype=torch.int32, device="cuda:0")
+    torch.cuda.synchronize()
     s.run_ptr(keys.data_ptr(), vals.data_ptr(), n, num_steps=6)
     G.synchronize()
     assert s.read_finish()["attempted"] == 0
@@ -421,8 +483,8 @@ def test_u64_large_sizes_and_the_largest_tile(G):
     every pair still points at its key, equal keys in input order."""
     import torch
 
-    s = _sorter(G)
     for n, clear, cap in [((1 << 27) + 77, 0, 2560), ((1 << 27) - 9, 2, 9216), (1 << 28, 0, 4608)]:
+        s = _sorter(G)  # (a fresh object: its first sort takes the runs from the whole key's top bits)
         keys = torch.randint(-2**63, 2**63 - 1, (n,), dtype=torch.int64, device="cuda:0")
         if clear:
             keys = (keys >> clear) & torch.tensor((1 << (64 - clear)) - 1, dtype=torch.int64, device="cuda:0")
