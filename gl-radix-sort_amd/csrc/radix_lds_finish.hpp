@@ -227,7 +227,7 @@ __global__ __launch_bounds__(THREADS) void radix_finish_sort_kernel(KeyT* keys_a
     {
     const uint32_t begin = starts[run], end = starts[run + 1];
     const uint32_t len = end - begin;
-    if (len <= 1) continue; // (workgroup-uniform)
+    if (len == 0 || (!XF && len == 1)) continue; // (workgroup-uniform; a single typed key still has to be decoded)
     const uint32_t share = ((len + WAVES * kWave - 1) / (WAVES * kWave)) * kWave; // slots per wave: <= kWave * KPT
     const uint32_t items = share / kWave;
     const uint32_t wave_off = wave * share + lane;
