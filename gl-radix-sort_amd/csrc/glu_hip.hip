@@ -2108,6 +2108,21 @@ glu_status glu_radix_sort_read_plan(glu_radix_sort sort, uint32_t* skipped, uint
     return GLU_OK;
 }
 
+glu_status glu_radix_sort_plan_finish(size_t count, uint32_t key_bytes, uint32_t* first_capacity, uint32_t* last_capacity)
+{
+    // host only (no device needed): which tiles of the in-LDS pass a whole-key sort of `count` elements would enqueue by default
+    if (key_bytes != 4 && key_bytes != 8) return fail(GLU_ERROR_INVALID_ARGUMENT, "key_bytes must be 4 or 8 (got %u)", key_bytes);
+    uint32_t first = 0, last = 0;
+    if (count >= finish_min_count(key_bytes) && count >= kPlanMinCount && count <= 0xFFFF0000ull)
+    {
+        first = finish_geometry_for(count);
+        last = first ? std::min<uint32_t>(first + 2, kFinishGeometries) : 0u;
+    }
+    if (first_capacity) *first_capacity = finish_geometry_capacity(first);
+    if (last_capacity) *last_capacity = finish_geometry_capacity(last);
+    return GLU_OK;
+}
+
 glu_status glu_radix_sort_read_finish(glu_radix_sort sort, uint32_t* attempted, uint32_t* accepted, uint32_t* longest_run,
                                       uint32_t* capacity, uint32_t* top_bit)
 {

@@ -72,6 +72,7 @@ SYMBOLS = [
     ("glu_radix_sort_read_plan", _int, [_vp, _P(_u32), _P(_u32), _P(_u32), _sz]),
     ("glu_radix_sort_read_profile_finish", _int, [_vp, _P(ctypes.c_double), _P(ctypes.c_double), _P(ctypes.c_double), _P(_u64),
                                                   _P(ctypes.c_double), _P(_u64)]),
+    ("glu_radix_sort_plan_finish", _int, [_sz, _u32, _P(_u32), _P(_u32)]),
     ("glu_radix_sort_read_finish", _int, [_vp, _P(_u32), _P(_u32), _P(_u32), _P(_u32), _P(_u32)]),
     ("glu_scan_create", _int, [_int, _P(_vp)]),
     ("glu_scan_destroy", _int, [_vp]),
@@ -234,6 +235,14 @@ class ShaderStorageBuffer:
             self.destroy()
         except Exception:
             pass
+
+
+def plan_finish(count, key_bytes=4):
+    """(first_capacity, last_capacity) of the in-LDS pass's tiles a whole-key sort of `count` elements enqueues by default; (0, 0):
+    no attempt to end in LDS (glu_radix_sort_plan_finish; host only)."""
+    a, b = _u32(0), _u32(0)
+    check(lib().glu_radix_sort_plan_finish(count, key_bytes, ctypes.byref(a), ctypes.byref(b)))
+    return a.value, b.value
 
 
 class RadixSort:

@@ -295,6 +295,11 @@ GLU_API glu_status glu_radix_sort_read_plan(glu_radix_sort sort, uint32_t* skipp
  * [12, 28) from the second sort on.  It is a guess that the device checks: if a bit from top_bit up varies after all, the
  * ordinary passes run (and the next sort guesses better).
  * GLU_HIP_SORT_LDS_FINISH=0 in the environment of glu_radix_sort_create switches the attempt off.  Any pointer may be NULL. */
+/* Host only (no device needed): the tiles of the in-LDS pass a whole-key sort of `count` elements of 4- or 8-byte keys
+ * enqueues by default -- first_capacity: the tile that suits uniformly drawn keys, last_capacity: the largest one enqueued
+ * behind it; both 0: such a sort makes no attempt (too small, or its runs would outgrow the largest tile). */
+GLU_API glu_status glu_radix_sort_plan_finish(size_t count, uint32_t key_bytes, uint32_t* first_capacity,
+                                              uint32_t* last_capacity);
 GLU_API glu_status glu_radix_sort_read_finish(glu_radix_sort sort, uint32_t* attempted, uint32_t* accepted,
                                               uint32_t* longest_run, uint32_t* capacity, uint32_t* top_bit);
 
