@@ -1,37 +1,42 @@
-// radix_lds_finish.hpp -- a large sort of 32-bit keys that ENDS IN LDS: two counting passes instead of four.
+// radix_lds_finish.hpp -- a large whole-key sort that ENDS IN LDS: two counting passes and one in-LDS pass instead of four
+// (32-bit keys) or eight (64-bit keys) counting passes.
 //
 // The reference sorts least significant digit first, every pass a full permutation of the array in memory
 // (k_radix_sort_counting_shader + BlellochScan + k_radix_sort_reordering_shader per 4-bit step, glu/RadixSort.hpp:289-345);
-// this library's large sort does the same with four 8-bit passes: 4 x (16 B of scatter + its share of a key read) = 72.5 B
-// per pair.  The result of a stable sort does not depend on how it is reached, and the memory system prices bytes, not
-// passes:
+// this library's large sort does the same with 8-bit passes: 4 x (16 B of scatter + its share of a key read) = 72.5 B per
+// pair of 32-bit key and value.  The result of a stable sort does not depend on how it is reached, and the memory system
+// prices bytes, not passes:
 //
-//   1. the two counting passes on the TOP 16 key bits first (digit [16, 24), then [24, 32): an ordinary pair of passes,
-//      radix_pair_passes.hpp).  After them the array is a sequence of 65536 RUNS, run r = the pairs whose key's top 16 bits
-//      are r, in input order.  The leader's two-digit histogram T2 already holds every run's length:
+//   1. the two counting passes on 16 TOP key bits first -- digit [top - 16, top - 8), then [top - 8, top), an ordinary pair
+//      of passes (radix_pair_passes.hpp); `top` is the key's width, or the highest key bit that varied in the object's last
+//      attempt (a guess, checked below).  After them the array is a sequence of 65536 RUNS, run r = the pairs whose key has
+//      the value r in those bits, in input order.  The leader's two-digit histogram T2 already holds every run's length:
 //      len[r] = sum over blocks b of T2[r & 255][b][r >> 8].
-//   2. if no run is longer than what one workgroup sorts in LDS (tiles of 1536 .. 9216 pairs: the device picks the smallest of
-//      the enqueued geometries that holds the longest run), ONE pass finishes the sort in place: a workgroup per run
-//      orders it by the low 16 bits (two rank / scan / re-stage rounds of 8 bits, as in radix_sort_single_block_kernel) and
-//      writes it back where it was.  16 B per pair instead of the 2 x 20.5 of two more passes: 52.5 B per pair in all.
-//   3. otherwise (keys that crowd into few runs: small value ranges, heavy duplicates) the top-bit passes are not run at
-//      all and the four passes of the ordinary sort follow.  The decision is made on the device, after the leader's count
-//      kernel and before its scatter, from exact run lengths; the launch sequence is the same either way and the kernels
-//      of the path not taken return at once (PassPlan::off, PassPlan::skip).  A refused attempt costs one read of the
-//      keys (the leader's count kernel: 4 of 72.5 B per pair).
+//   2. if no run is longer than what one workgroup sorts in LDS (tiles of 1536 .. 9216 pairs: the device picks the smallest
+//      of the enqueued geometries that holds the longest run) and no key bit from `top` up varies, ONE pass finishes the
+//      sort in place: a workgroup per run orders it by the low top - 16 bits (rounds of 8 bits of rank / scan / re-stage, as
+//      in radix_sort_single_block_kernel: two for 32-bit keys, six for 64-bit keys) and writes it back where it was.  16 B
+//      per pair instead of the 2 x 20.5 of two more passes: 52.25 B per pair in all (64-bit keys: 80.25 instead of 225).
+//      Typed keys (signed, float) are encoded on load by the first top-bit pass and decoded on store by this one.
+//   3. otherwise (keys that crowd into few runs: small value ranges under the first guess, heavy duplicates) the top-bit
+//      passes are not run at all and the passes of the ordinary sort follow.  The decision is made on the device, after the
+//      leader's count kernel and before its scatter, from exact run lengths; the launch sequence is the same either way and
+//      the kernels of the path not taken return at once (PassPlan::off, PassPlan::skip).  A refused attempt costs one read
+//      of the keys (the leader's count kernel: 4 of 72.5 B per pair); its outcome and the key bits that varied reach the host
+//      through a pinned word that the next sort call reads without synchronising (glu_radix_sort_s::finish_hint).
 //
 //   radix_finish_lengths_kernel   len[r] from T2                                  (32 MiB of table, once per sort)
 //   radix_finish_plan_kernel      run starts, the longest run, the decision       (64 workgroups)
-//   radix_finish_sort_kernel      step 2                                         (one workgroup of 256 / 512 threads per run)
+//   radix_finish_sort_kernel      step 2                                         (a workgroup of 256 .. 1024 threads per run)
 #pragma once
 
 #include "radix_pair_passes.hpp"
 
 namespace glu_hip
 {
-constexpr uint32_t kFinishRuns = 65536; // runs = values of the top 16 key bits
+constexpr uint32_t kFinishRuns = 65536; // runs = values of the 16 top-bit key bits
 
-// lengths[e * 256 + d] = #keys with digit [16, 24) = d and digit [24, 32) = e: T2 rows (d, b) summed over the leader's nb
+// lengths[e * 256 + d] = #keys with first top-bit digit d and second top-bit digit e: T2 rows (d, b) summed over the leader's nb
 // blocks.  One workgroup per d; thread (g, q) adds word q (counters e = 2q, 2q + 1) of the rows b = g, g + 8, ...
 __global__ __launch_bounds__(1024) void radix_finish_lengths_kernel(const uint32_t* __restrict__ t2, uint32_t nb,
                                                                     uint32_t* __restrict__ lengths, const PassPlan* plan,
@@ -65,11 +70,12 @@ __global__ __launch_bounds__(1024) void radix_finish_lengths_kernel(const uint32
 // in-LDS pass's geometries whose launches follow (numbered geo_first .. geo_last, finish_geometry_capacity; the host enqueues the
 // one that suits uniformly drawn keys of this count and the next larger ones: keys that leave some runs empty and the others
 // longer -- 31-bit keys, mild skew -- still end in LDS, in a larger tile).  PassPlan::finish = the geometry chosen.
-//   accepted: finish = 1, the ordinary passes [first_ordinary, first_ordinary + num_ordinary) are switched off;
+//   accepted: the ordinary passes [first_ordinary, first_ordinary + num_ordinary) are switched off;
 //   refused:  the two top-bit passes `pass`, `pass + 1` are switched off (the leader has counted already: its scatter
 //             sees skip = kSkipWithoutCounting, which leaves the arrays' roles as they are).
-// hint: see glu_radix_sort_s::finish_hint.  64 workgroups, each scans 1024 runs; every workgroup reads all 65536 lengths (256 KiB, from L2) for the sum in front of
-// its runs, the total and the longest run, so each reaches the same decision without a second launch.
+// hint: see glu_radix_sort_s::finish_hint.  64 workgroups, each scans 1024 runs; every workgroup reads all 65536 lengths
+// (256 KiB, from L2) for the sum in front of its runs, the total and the longest run, so each reaches the same decision
+// without a second launch.
 constexpr uint32_t kFinishPlanBlocks = kFinishRuns / 1024;
 // tile geometries of the in-LDS pass: 1 = 256 threads x 6 pairs, 2 = 256 x 10, 3 = 256 x 18 (39 KiB of LDS: four workgroups per
 // CU), 4 = 512 x 18 (78 KiB: two per CU, the largest that still overlaps one run's memory time with another's ranking)
