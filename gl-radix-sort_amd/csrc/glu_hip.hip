@@ -479,7 +479,7 @@ struct glu_radix_sort_s
                                   // than 1 / this of a workgroup's share (0 = never: tests reach the counter-overflow check that way)
     hipEvent_t after_histogram_event = nullptr; // partition passes: recorded once the digit histogram has been copied out
                                                 // (after the row scan, before the scatter): glu_dist uses it
-    // a sort that ends in LDS (radix_lds_finish.hpp): large sorts of 32-bit keys try two top-bit passes + one in-LDS pass
+    // a sort that ends in LDS (radix_lds_finish.hpp): large whole-key sorts try two top-bit passes + one in-LDS pass
     Scratch finish_lengths;       // [65536] run lengths,
     Scratch finish_starts;        // [65537] run starts
     bool lds_finish = true;       // GLU_HIP_SORT_LDS_FINISH=0: always the four passes of the ordinary sort (tests / tuning)
@@ -1060,9 +1060,9 @@ glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t cou
     // line kernel of the same digit width (wider than 4 bits: the 8-bit kernels, else the 4-bit ones).
     const bool pair_tables = planned && s->pairs && s->pair_t2.ptr;
     const bool pairs_ok = pair_tables && count >= (s->pair_min ? s->pair_min : kPairMinKeyBytes / sizeof(KeyT));
-    // Whole 32-bit keys, 8-bit digits, paired line passes: the sort first tries to end in LDS (radix_lds_finish.hpp) -- the two
-    // top-bit passes and the in-LDS pass are enqueued in front of the four ordinary passes, and the device runs one of the
-    // two sequences.
+    // Whole keys, 8-bit digits, line passes, from finish_min_count elements: the sort first tries to end in LDS
+    // (radix_lds_finish.hpp) -- the two top-bit passes and the in-LDS pass are enqueued in front of the ordinary passes, and the
+    // device runs one of the two sequences.
     uint32_t finish_kpt = 0; // (the geometry that suits uniform keys; 0: no attempt)
     uint32_t finish_top_bit = end_bit;
     if (pair_tables && s->lds_finish && s->finish_starts.ptr && first_bit == 0 &&
