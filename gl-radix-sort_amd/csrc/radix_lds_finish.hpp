@@ -175,13 +175,43 @@ __global__ __launch_bounds__(1024) void radix_finish_plan_kernel(const uint32_t*
     if (b == 0 && accept && tid < num_ordinary) plan->off[first_ordinary + tid] = 1;
 }
 
+// The stage of 64-bit keys: only the low 48 key bits differ inside a run (the bits above are the run's, or constant over the
+// whole input), so a slot holds 6 + 4 bytes instead of 8 + 4: 512 x 9 pairs stay below 53 KiB and a third workgroup fits the CU.
+template<int COUNT, bool VALS>
+struct FinishStage48
+{
+    uint32_t lo[COUNT];
+    uint16_t mid[COUNT];
+    uint32_t vals[VALS ? COUNT : 1];
+    __device__ __forceinline__ void put(uint32_t pos, uint64_t k, uint32_t v)
+    {
+        lo[pos] = (uint32_t) k;
+        mid[pos] = (uint16_t) (k >> 32);
+        if (VALS) vals[pos] = v;
+    }
+    __device__ __forceinline__ void get(uint32_t pos, uint64_t& k, uint32_t& v, uint64_t run_top) const
+    {
+        k = run_top | ((uint64_t) mid[pos] << 32) | lo[pos];
+        v = VALS ? vals[pos] : 0u;
+    }
+};
+template<typename KeyT, int COUNT, bool VALS>
+struct FinishStage : PairArray<KeyT, COUNT, VALS>
+{
+    __device__ __forceinline__ void get(uint32_t pos, KeyT& k, uint32_t& v, KeyT) const { PairArray<KeyT, COUNT, VALS>::get(pos, k, v); }
+};
+template<int COUNT, bool VALS>
+struct FinishStage<uint64_t, COUNT, VALS> : FinishStage48<COUNT, VALS>
+{
+};
+
 template<typename KeyT, int THREADS, int KPT, bool VALS>
 struct FinishSmem
 {
     static constexpr int RADIX = 256;
     static constexpr int WAVES = THREADS / kWave;
     static constexpr int TILE = THREADS * KPT;
-    PairArray<KeyT, TILE, VALS> stage;
+    FinishStage<KeyT, TILE, VALS> stage;
     // wave-private running digit counters, 16-bit (a tile has fewer than 65536 slots): with 256 x 18 pairs the workgroup
     // stays below 40 KiB and four of them share a CU (tools/lds_final_pass_bench.hip: 1.06 -> 0.99 ms for 2^28 pairs)
     uint16_t wcnt[WAVES][RADIX];
@@ -189,7 +219,7 @@ struct FinishSmem
 };
 static_assert(sizeof(FinishSmem<uint32_t, 256, 18, true>) <= 40 * 1024, "four workgroups per CU");
 static_assert(sizeof(FinishSmem<uint32_t, 512, 18, true>) <= 80 * 1024, "two workgroups per CU");
-static_assert(sizeof(FinishSmem<uint64_t, 512, 9, true>) <= 80 * 1024, "64-bit keys: two workgroups per CU");
+static_assert(sizeof(FinishSmem<uint64_t, 512, 9, true>) <= 53 * 1024, "64-bit keys: three workgroups per CU");
 
 // the longest run a workgroup of this geometry takes
 template<int THREADS, int KPT>
@@ -234,6 +264,8 @@ __global__ __launch_bounds__(THREADS) void radix_finish_sort_kernel(KeyT* keys_a
     const uint32_t begin = starts[run], end = starts[run + 1];
     const uint32_t len = end - begin;
     if (len == 0 || (!XF && len == 1)) continue; // (workgroup-uniform; a single typed key still has to be decoded)
+    // (64-bit keys: the key bits from 48 up, the same for every pair of the run -- and of a pad that comes back from the stage)
+    const KeyT run_top = sizeof(KeyT) == 8 ? (KeyT) (keys[begin] & (KeyT) 0xFFFF000000000000ull) : (KeyT) 0;
     const uint32_t share = ((len + WAVES * kWave - 1) / (WAVES * kWave)) * kWave; // slots per wave: <= kWave * KPT
     const uint32_t items = share / kWave;
     const uint32_t wave_off = wave * share + lane;
@@ -328,7 +360,7 @@ __global__ __launch_bounds__(THREADS) void radix_finish_sort_kernel(KeyT* keys_a
         for (int i = 0; i < KPT; i++)
         {
             if ((uint32_t) i >= items) continue;
-            s.stage.get(wave_off + i * kWave, key[i], val[i]);
+            s.stage.get(wave_off + i * kWave, key[i], val[i], run_top);
         }
         if (shift + 8 < low_bits) __syncthreads();
     }
