@@ -117,6 +117,24 @@ namespace glu
             return bits;
         }
 
+        /// What the last sort did about ending in LDS (glu_radix_sort_read_finish in glu_hip.h; synchronise its stream first):
+        /// large whole-key sorts first try two counting passes on 16 top key bits and one pass that orders every run of
+        /// equal top bits inside LDS; the device refuses if a run outgrows an LDS tile, and the ordinary passes run.
+        struct FinishReport
+        {
+            bool attempted = false, accepted = false;
+            uint32_t longest_run = 0, capacity = 0, top_bit = 0;
+        };
+        [[nodiscard]] FinishReport last_finish() const
+        {
+            uint32_t a = 0, b = 0;
+            FinishReport r;
+            GLU_CHECK_STATUS(glu_radix_sort_read_finish(m_impl, &a, &b, &r.longest_run, &r.capacity, &r.top_bit));
+            r.attempted = a != 0;
+            r.accepted = b != 0;
+            return r;
+        }
+
     private:
         template<typename KeyT>
         static constexpr glu_key_type key_type_of()
