@@ -43,3 +43,15 @@ def test_beyond_the_largest_tile_there_is_no_attempt():
 def test_argument_checks():
     with pytest.raises(G.GluError):
         G.plan_finish(1 << 26, key_bytes=2)
+
+
+def test_the_makefile_tracks_every_header_of_the_library():
+    """A header missing from the library's prerequisites lets `make` keep a stale libglu_hip.so after an edit (it happened:
+    a fix in radix_lds_finish.hpp was 'tested' against the old binary until the fuzzer failed the same way again)."""
+    import glob
+    import os
+
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gl-radix-sort_amd", "csrc")
+    rule = next(l for l in open(os.path.join(csrc, "Makefile")) if l.startswith("$(OUT)/libglu_hip.so:"))
+    for header in glob.glob(os.path.join(csrc, "*.hpp")):
+        assert os.path.basename(header) in rule.split(), os.path.basename(header)
