@@ -455,8 +455,13 @@ struct glu_radix_sort_s
         hipEvent_t copied = nullptr;
         bool in_flight = false;
     };
-    SegStage seg_stage[4];
+    SegStage seg_stage[16]; // (a sharded sort in rounds makes one segmented sort per round, up to 8: the host never waits for its own sort)
     uint32_t seg_stage_next = 0;
+    // a segmented sort that ends in LDS (seg_run_plan): the longest run its first pass found (device word), and what the host knows
+    Scratch seg_gate;
+    bool seg_finish = true;             // GLU_HIP_SEG_LDS_FINISH=0: always the ordinary segmented passes (tests / tuning)
+    bool last_seg_finish_attempted = false;
+    uint32_t last_seg_finish_capacity = 0, last_seg_finish_runs = 0;
     uint32_t digit_bits = 8;
     uint32_t max_blocks = 0;   // GLU_HIP_SORT_BLOCKS: cap on the number of workgroups (tuning)
     uint32_t reserved_cus = 0; // CUs the pass kernels leave free (glu_dist: RCCL kernels run beside them); the grid of a pass
@@ -839,7 +844,7 @@ glu_status launch_pass_lines(glu_radix_sort_s* s, const KeyT* src_k, const uint3
     }
     hipLaunchKernelGGL(scatter, dim3(nb), dim3(G::THREADS), sizeof(Smem), stream, src_k, src_v, dst_k, dst_v,
                        (const uint32_t*) table, (const uint32_t*) totals, (uint32_t) count, shift, mask, tiles,
-                       (unsigned long long*) nullptr, xform, pa.plan, pa.pass, ranges, share, (const uint32_t*) nullptr);
+                       (unsigned long long*) nullptr, xform, pa.plan, pa.pass, ranges, share, (const uint32_t*) nullptr, (const uint32_t*) nullptr, 0u, 0u);
     s->mark(stream);
     HIP_TRY(hipGetLastError());
     return GLU_OK;
@@ -954,9 +959,9 @@ glu_status sort_single_block(KeyT* keys, uint32_t* vals, size_t count, uint32_t 
 // A sort that ends in LDS (radix_lds_finish.hpp): the tile geometry of its last pass that suits uniformly drawn keys -- the
 // longest of 65536 runs stays below mean + 6 sigma.  The launches of that geometry and of the next larger ones are enqueued
 // and the device picks by the longest run it counted.  0: no geometry holds such runs (more than about 2^29 pairs).
-inline uint32_t finish_geometry_for(size_t count)
+inline uint32_t finish_geometry_for(size_t count, size_t runs = kFinishRuns)
 {
-    const double mean = (double) count / kFinishRuns;
+    const double mean = (double) count / (double) runs;
     const double need = mean + 6.0 * std::sqrt(mean) + 8.0;
     for (uint32_t g = 1; g <= kFinishGeometries; g++)
         if (need <= (double) finish_geometry_capacity(g)) return g;
@@ -966,8 +971,15 @@ inline uint32_t finish_geometry_for(size_t count)
 template<typename KeyT, bool VALS, bool XF>
 glu_status launch_finish(KeyT* keys_a, uint32_t* vals_a, KeyT* keys_b, uint32_t* vals_b, const uint32_t* starts,
                          uint32_t geo_first, uint32_t geo_last, uint32_t geo_expected, uint32_t low_bits, const PassPlan* plan,
-                         uint32_t pass, uint32_t key_xf, hipStream_t stream)
+                         uint32_t pass, uint32_t key_xf, hipStream_t stream, uint32_t nruns = kFinishRuns, const uint32_t* gate = nullptr)
 {
+    // More than 16 bits left to order (64-bit keys; a segmented sort by 32 bits): the rounds rank the top 16 .. 23 of them and
+    // ties are repaired exactly (radix_lds_finish.hpp).  GLU_HIP_FINISH_RANK_BITS=N (tuning): rank at least N bits (48: all).
+    static const uint32_t rank_bits = [] {
+        const char* e = getenv("GLU_HIP_FINISH_RANK_BITS");
+        return e && atoi(e) >= 8 ? (uint32_t) atoi(e) : 16u;
+    }();
+    const uint32_t rank_from = low_bits > rank_bits ? ((low_bits - rank_bits) / 8u) * 8u : 0u;
     // the geometry the sort is expected to take gets a workgroup per run, the others 8192 workgroups that loop
 #define GLU_FINISH(GEO_, THREADS_, KPT_)                                                                                          \
     if (geo_first <= GEO_ && GEO_ <= geo_last)                                                                                    \
@@ -985,9 +997,10 @@ glu_status launch_finish(KeyT* keys_a, uint32_t* vals_a, KeyT* keys_b, uint32_t*
                                                             (int) sizeof(FinishSmem<KeyT, THREADS_, KPT_, VALS>));                \
         });                                                                                                                       \
         HIP_TRY(lds_opt_in_result);                                                                                               \
-        hipLaunchKernelGGL(kern, dim3(GEO_ == geo_expected ? kFinishRuns : 8192u), dim3(THREADS_),                                \
+        hipLaunchKernelGGL(kern, dim3(GEO_ == geo_expected ? nruns : std::min(nruns, 8192u)), dim3(THREADS_),                     \
                            sizeof(FinishSmem<KeyT, THREADS_, KPT_, VALS>), stream,                                                \
-                           keys_a, vals_a, keys_b, vals_b, starts, low_bits, plan, pass, (uint32_t) GEO_, key_xf);                \
+                           keys_a, vals_a, keys_b, vals_b, starts, low_bits, plan, pass, (uint32_t) GEO_, key_xf, nruns, gate,     \
+                           geo_first, geo_last, rank_from);                                                                       \
         HIP_TRY(hipGetLastError());                                                                                               \
     }
     GLU_FINISH(1, 256, 6)
@@ -1592,11 +1605,19 @@ void seg_build_image(const SegPiece* pieces, size_t npieces, uint32_t nseg, cons
 }
 
 constexpr size_t kSegMinCount = 1 << 16; // below: gather + one sort per segment (the line kernel wants whole tiles to prefetch)
+constexpr uint64_t kSegFinishMaxRuns = 1u << 18; // a segmented sort tries to end in LDS with up to this many runs (1024 segments)
 
 // One segmented pass on the 8-bit digit at `shift`: count per sub-block, scan per segment, line scatter over sub-blocks.
+// gate_mode (radix_seg_passes.hpp): kSegGateIfNot = a pass of the ordinary sequence enqueued behind an attempt to end in LDS;
+// kSegGateIfFits + runs_end != 0 = the first pass of such an attempt: its count and scan kernels always run, the runs kernel
+// behind them writes the run starts and the longest run (the gate), the scatter runs if that fits `gate_cap`.
 glu_status launch_seg_pass(glu_radix_sort_s* s, const uint32_t* src_k, const uint32_t* src_v, uint32_t* dst_k, uint32_t* dst_v,
-                           size_t count, uint32_t shift, const uint32_t* image, const SegImage& img, hipStream_t stream)
+                           size_t count, uint32_t shift, const uint32_t* image, const SegImage& img, hipStream_t stream,
+                           uint32_t gate_mode = kSegGateNone, uint32_t gate_cap = 0, uint32_t runs_end = 0)
 {
+    const uint32_t* gate = gate_mode != kSegGateNone ? (const uint32_t*) s->seg_gate.ptr : nullptr;
+    const bool attempt = gate_mode == kSegGateIfFits;
+    const uint32_t gm_count = attempt ? kSegGateNone : gate_mode; // (the attempt's count and scan make the decision)
     using G = LinesGeometry<uint32_t, 8, true>;
     constexpr int RADIX = 256;
     constexpr int RS = (G::KPT + 2) / 3;
@@ -1615,16 +1636,22 @@ glu_status launch_seg_pass(glu_radix_sort_s* s, const uint32_t* src_k, const uin
     const uint2* subs = (const uint2*) image;
     s->mark(stream);
     hipLaunchKernelGGL((radix_seg_count_kernel<8, 1024>), dim3(img.nwg), dim3(1024), 0, stream, src_k, subs, image + img.off_first, table,
-                       shift, 255u);
+                       shift, 255u, gate, gate_cap, gm_count);
     HIP_TRY(hipGetLastError());
     s->mark(stream);
     hipLaunchKernelGGL((radix_seg_scan_kernel<RADIX>), dim3(img.nseg), dim3(RADIX), 0, stream, table, image + img.off_list,
-                       image + img.off_start);
+                       image + img.off_start, gate, gate_cap, gm_count);
     HIP_TRY(hipGetLastError());
+    if (attempt)
+    {
+        hipLaunchKernelGGL((radix_seg_runs_kernel<RADIX>), dim3(1), dim3(1024), 0, stream, (const uint32_t*) table, image + img.off_list,
+                           image + img.off_start, img.nseg, runs_end, (uint32_t*) s->finish_starts.ptr, (uint32_t*) s->seg_gate.ptr);
+        HIP_TRY(hipGetLastError());
+    }
     s->mark(stream);
     hipLaunchKernelGGL(s->nt_stores ? scatter_nt : scatter_plain, dim3(img.nwg), dim3(G::THREADS), sizeof(Smem), stream, src_k, src_v,
                        dst_k, dst_v, (const uint32_t*) table, (const uint32_t*) nullptr, (uint32_t) count, shift, 255u, 0u,
-                       (unsigned long long*) nullptr, 0u, (PassPlan*) nullptr, 0u, subs, 0u, image + img.off_first);
+                       (unsigned long long*) nullptr, 0u, (PassPlan*) nullptr, 0u, subs, 0u, image + img.off_first, gate, gate_cap, gate_mode);
     HIP_TRY(hipGetLastError());
     s->mark(stream);
     return GLU_OK;
@@ -1707,8 +1734,8 @@ glu_status seg_run_plan(glu_radix_sort_s* s, const SegPlan& plan, uint32_t* in_k
     const size_t bytes = (first.words.size() + later.words.size()) * sizeof(uint32_t);
     GLU_TRY(s->seg_desc.reserve(std::max<size_t>(bytes, 1 << 16)));
     GLU_TRY(s->table.reserve((size_t) std::max(first.nsb, later.nsb) * 256 * sizeof(uint32_t)));
-    glu_radix_sort_s::SegStage& st = s->seg_stage[s->seg_stage_next++ % 4];
-    if (st.in_flight) HIP_TRY(hipEventSynchronize(st.copied)); // (four calls ago: long done)
+    glu_radix_sort_s::SegStage& st = s->seg_stage[s->seg_stage_next++ % 16];
+    if (st.in_flight) HIP_TRY(hipEventSynchronize(st.copied)); // (sixteen calls ago: long done)
     if (st.size < bytes)
     {
         if (st.host) HIP_TRY(hipHostFree(st.host));
@@ -1727,6 +1754,42 @@ glu_status seg_run_plan(glu_radix_sort_s* s, const SegPlan& plan, uint32_t* in_k
     const uint32_t* image_first = (const uint32_t*) s->seg_desc.ptr;
     const uint32_t* image_later = image_first + first.words.size();
 
+    // A segmented sort that ENDS IN LDS (radix_seg_passes.hpp, radix_lds_finish.hpp): ONE counting pass, on the top digit of the
+    // bits to sort by, straight from the caller's pieces into `out` -- after it the array is nseg x 256 runs (segment, top digit)
+    // whose starts are in the pass's scanned table -- and one pass that orders every run by the remaining low bits inside LDS, in
+    // place: 20 + 16 B per pair instead of passes x 20.  The device decides by the longest run (the gate) before the pass's
+    // scatter moves anything; the ordinary passes are enqueued behind and return at once when the attempt was accepted.  The
+    // tile geometries that are enqueued: the one that suits uniformly drawn keys (mean run + 6 sigma) and the next two larger.
+    uint32_t gate_mode = kSegGateNone, gate_cap = 0;
+    const uint64_t nruns = (uint64_t) nseg * 256u;
+    s->last_seg_finish_attempted = false;
+    if (s->seg_finish && s->lds_finish && passes >= 2 && plan.bits == passes * 8 && nruns <= kSegFinishMaxRuns)
+    {
+        const uint32_t geo = finish_geometry_for(count, (size_t) nruns);
+        if (geo)
+        {
+            const uint32_t geo_last = std::min<uint32_t>(geo + 2, kFinishGeometries);
+            GLU_TRY(s->finish_starts.reserve(((size_t) std::max<uint64_t>(nruns, kFinishRuns) + 1) * sizeof(uint32_t)));
+            GLU_TRY(s->seg_gate.reserve(64));
+            gate_cap = finish_geometry_capacity(geo_last);
+            const uint32_t end = (uint32_t) (plan.seg_start[0] + count);
+            GLU_TRY(launch_seg_pass(s, in_k, in_v, out_k, out_v, count, plan.bits - 8, image_first, first, stream, kSegGateIfFits, gate_cap, end));
+            s->cur_kind = 2;
+            s->mark(stream);
+            s->mark(stream);
+            s->mark(stream);
+            // (the expected geometry gets a workgroup per run, the others loop: launch_finish)
+            GLU_TRY((launch_finish<uint32_t, true, false>(out_k, out_v, out_k, out_v, (const uint32_t*) s->finish_starts.ptr, geo, geo_last, geo,
+                                                          plan.bits - 8, nullptr, 0u, 0u, stream, (uint32_t) nruns, (const uint32_t*) s->seg_gate.ptr)));
+            s->mark(stream);
+            s->cur_kind = 0;
+            gate_mode = kSegGateIfNot;
+            s->last_seg_finish_attempted = true;
+            s->last_seg_finish_capacity = gate_cap;
+            s->last_seg_finish_runs = (uint32_t) nruns;
+        }
+    }
+
     // the arrays of every pass: the last one writes `out`; with an odd number of passes they alternate in -> out -> in -> out,
     // with an even number the sort's own scratch stands in for `out` until the last pass (in -> tmp -> in -> tmp -> out)
     const uint32_t* src_k = in_k;
@@ -1737,7 +1800,7 @@ glu_status seg_run_plan(glu_radix_sort_s* s, const SegPlan& plan, uint32_t* in_k
         uint32_t* dst_k = last ? out_k : (src_k == in_k ? ((passes & 1u) ? out_k : tmp_k) : in_k);
         uint32_t* dst_v = last ? out_v : (src_v == in_v ? ((passes & 1u) ? out_v : tmp_v) : in_v);
         GLU_TRY(launch_seg_pass(s, src_k, src_v, dst_k, dst_v, count, p * 8, p == 0 ? image_first : image_later,
-                                p == 0 ? first : later, stream));
+                                p == 0 ? first : later, stream, gate_mode, gate_cap));
         src_k = dst_k;
         src_v = dst_v;
     }
@@ -1773,6 +1836,7 @@ glu_status glu_radix_sort_create(glu_radix_sort* out)
     if (const char* e = getenv("GLU_HIP_SORT_NO_BIT_SHORTCUT")) s->no_bit_shortcut = atoi(e) != 0;
     if (const char* e = getenv("GLU_HIP_SORT_PAIR_MIN")) s->pair_min = (size_t) atoll(e);
     if (const char* e = getenv("GLU_HIP_SORT_LDS_FINISH")) s->lds_finish = atoi(e) != 0;
+    if (const char* e = getenv("GLU_HIP_SEG_LDS_FINISH")) s->seg_finish = atoi(e) != 0;
     if (const char* e = getenv("GLU_HIP_SORT_FINISH_MIN")) s->finish_min = (size_t) atoll(e);
     if (const char* e = getenv("GLU_HIP_SORT_FINISH_BACKOFF")) s->finish_backoff = (uint32_t) std::max(0, atoi(e));
     if (const char* e = getenv("GLU_HIP_SORT_PAIR_UNIT_DIV"))
@@ -1794,7 +1858,7 @@ glu_status glu_radix_sort_destroy(glu_radix_sort sort)
     // library queue, before its scratch goes away (RAII of the reference: RadixSort.hpp:194-200, gl_utils.hpp:184-188)
     (void) hipDeviceSynchronize();
     for (Scratch* sc : {&sort->keys, &sort->vals, &sort->table, &sort->plan, &sort->pair_t2, &sort->pair_table, &sort->pair_ranges,
-                        &sort->pair_sub, &sort->seg_desc, &sort->seg_zero, &sort->finish_lengths, &sort->finish_starts})
+                        &sort->pair_sub, &sort->seg_desc, &sort->seg_zero, &sort->finish_lengths, &sort->finish_starts, &sort->seg_gate})
         sc->release();
     if (sort->finish_hint) (void) hipHostFree(sort->finish_hint);
     for (hipEvent_t e : sort->events) (void) hipEventDestroy(e);
@@ -2123,6 +2187,22 @@ glu_status glu_radix_sort_plan_finish(size_t count, uint32_t key_bytes, uint32_t
     return GLU_OK;
 }
 
+glu_status glu_radix_sort_read_seg_finish(glu_radix_sort sort, uint32_t* attempted, uint32_t* accepted, uint32_t* longest_run,
+                                          uint32_t* capacity, uint32_t* runs)
+{
+    GLU_TRY(enter());
+    if (!sort) return fail(GLU_ERROR_INVALID_ARGUMENT, "sort is NULL");
+    const bool tried = sort->last_seg_finish_attempted && sort->seg_gate.ptr;
+    uint32_t longest = 0;
+    if (tried) HIP_TRY(hipMemcpy(&longest, sort->seg_gate.ptr, sizeof(longest), hipMemcpyDeviceToHost));
+    if (attempted) *attempted = tried ? 1u : 0u;
+    if (accepted) *accepted = tried && longest <= sort->last_seg_finish_capacity ? 1u : 0u;
+    if (longest_run) *longest_run = longest;
+    if (capacity) *capacity = tried ? sort->last_seg_finish_capacity : 0u;
+    if (runs) *runs = tried ? sort->last_seg_finish_runs : 0u;
+    return GLU_OK;
+}
+
 glu_status glu_radix_sort_read_finish(glu_radix_sort sort, uint32_t* attempted, uint32_t* accepted, uint32_t* longest_run,
                                       uint32_t* capacity, uint32_t* top_bit)
 {
@@ -2221,7 +2301,7 @@ glu_status glu_radix_sort_scratch_size(glu_radix_sort sort, size_t* bytes)
     if (!sort || !bytes) return fail(GLU_ERROR_INVALID_ARGUMENT, "NULL argument");
     *bytes = sort->keys.size + sort->vals.size + sort->table.size + sort->plan.size + sort->pair_t2.size + sort->pair_table.size +
              sort->pair_ranges.size + sort->pair_sub.size + sort->seg_desc.size + sort->seg_zero.size + sort->finish_lengths.size +
-             sort->finish_starts.size;
+             sort->finish_starts.size + sort->seg_gate.size;
     return GLU_OK;
 }
 

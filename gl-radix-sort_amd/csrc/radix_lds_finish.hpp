@@ -84,6 +84,14 @@ __host__ __device__ constexpr uint32_t finish_geometry_capacity(uint32_t g)
 {
     return g == 1 ? 256u * 6u : g == 2 ? 256u * 10u : g == 3 ? 256u * 18u : g == 4 ? 512u * 18u : 0u;
 }
+// the smallest of the enqueued tile geometries [geo_first, geo_last] that holds the longest run (0: none does)
+__host__ __device__ inline uint32_t finish_geometry_choice(uint32_t longest, uint32_t geo_first, uint32_t geo_last)
+{
+    uint32_t geo = 0;
+    for (uint32_t g = geo_last; g >= geo_first && g >= 1; g--)
+        if (longest <= finish_geometry_capacity(g)) geo = g;
+    return geo;
+}
 __global__ __launch_bounds__(1024) void radix_finish_plan_kernel(const uint32_t* __restrict__ lengths, uint32_t* __restrict__ starts,
                                                                  uint32_t n, uint32_t geo_first, uint32_t geo_last, PassPlan* plan,
                                                                  uint32_t pass,
@@ -129,10 +137,7 @@ __global__ __launch_bounds__(1024) void radix_finish_plan_kernel(const uint32_t*
         longest = max(longest, tmp[2][w]);
         if ((uint32_t) w < wave) excl += wsum[w];
     }
-    // the smallest of the enqueued tile geometries [geo_first, geo_last] that holds the longest run (0: none does)
-    uint32_t geo = 0;
-    for (uint32_t g = geo_last; g >= geo_first && g >= 1; g--)
-        if (longest <= finish_geometry_capacity(g)) geo = g;
+    const uint32_t geo = finish_geometry_choice(longest, geo_first, geo_last);
     // The runs are the values of key bits [top_bit - 16, top_bit): that orders the keys only if no key bit from top_bit up
     // varies -- the host assumed so from what this object's last sort saw, the count kernel of this one has looked
     // (PassPlan::bits_or / bits_nor).  Typed keys and sorts that do not collect the bits are launched with top_bit = key_bits.
@@ -194,11 +199,20 @@ struct FinishStage48
         k = run_top | ((uint64_t) mid[pos] << 32) | lo[pos];
         v = VALS ? vals[pos] : 0u;
     }
+    // (the low 48 bits: all that differs inside a run)
+    __device__ __forceinline__ uint64_t key_at(uint32_t pos) const { return ((uint64_t) mid[pos] << 32) | lo[pos]; }
 };
 template<typename KeyT, int COUNT, bool VALS>
 struct FinishStage : PairArray<KeyT, COUNT, VALS>
 {
     __device__ __forceinline__ void get(uint32_t pos, KeyT& k, uint32_t& v, KeyT) const { PairArray<KeyT, COUNT, VALS>::get(pos, k, v); }
+    __device__ __forceinline__ KeyT key_at(uint32_t pos) const
+    {
+        KeyT k;
+        uint32_t v;
+        PairArray<KeyT, COUNT, VALS>::get(pos, k, v);
+        return k;
+    }
 };
 template<int COUNT, bool VALS>
 struct FinishStage<uint64_t, COUNT, VALS> : FinishStage48<COUNT, VALS>
@@ -216,6 +230,10 @@ struct FinishSmem
     // stays below 40 KiB and four of them share a CU (tools/lds_final_pass_bench.hip: 1.06 -> 0.99 ms for 2^28 pairs)
     uint16_t wcnt[WAVES][RADIX];
     uint32_t scan_tmp[WAVES];
+    // tie repair (see the kernel): how many tie groups want repairing (their first positions are listed in wcnt, which is idle
+    // then), and whether one of them is too long for it
+    uint32_t tie_count, tie_bad;
+    static constexpr uint32_t TIE_LIST = WAVES * RADIX;
 };
 static_assert(sizeof(FinishSmem<uint32_t, 256, 18, true>) <= 40 * 1024, "four workgroups per CU");
 static_assert(sizeof(FinishSmem<uint32_t, 512, 18, true>) <= 80 * 1024, "two workgroups per CU");
@@ -238,14 +256,33 @@ constexpr uint32_t finish_capacity() { return (uint32_t) (THREADS * KPT); }
 // true: fewer workgroups, each takes every gridDim.x-th run -- for the geometries that are enqueued besides the expected one:
 // 65536 workgroups that return at once cost 15-29 us, 8192 cost 5.
 // XF: typed keys (signed integers, floats): the first top-bit pass encoded them on load, this pass decodes them on store.
+//
+// rank_from > 0 (keys with more than 16 bits left to order: 64-bit keys, a segmented sort by 32 bits): the rounds rank only the
+// key bits [rank_from, low_bits) -- the TOP of what is left, two rounds instead of six for 64-bit keys -- which orders the run
+// except where two keys agree on those bits (a TIE: for uniformly drawn keys a run of 4096 has some 128 tied neighbours on 16
+// ranked bits).  Ties are repaired exactly: every position compares itself with its successor in LDS; where both agree on the
+// ranked bits and disagree in order on the rest, the lane walks back to the first position of its tie group (a few steps) and
+// lists it; after a barrier one lane per listed group sorts the group in place by stable insertion on the whole key.  A group
+// longer than kTieMaxGroup, a walk of more than kTieMaxBack steps or more groups than the list holds mark the run as one that
+// does not suit this (keys that crowd on the ranked bits): the workgroup then runs ALL rounds, [0, low_bits), on what is staged --
+// a stable permutation of the run, so the result is the same.  Groups of EQUAL keys of any length need no repair and cost nothing.
+//
+// Two callers.  The whole-key sort (plan != nullptr): 65536 runs, the geometry and the arrays come from the PassPlan.  The
+// segmented sort (plan == nullptr, radix_seg_passes.hpp: the local sort of the sharded sort): `nruns` runs of (segment, top
+// digit of the low bits) in keys_a / vals_a, and the geometry follows from the longest run the runs kernel found (*gate):
+// the smallest of [geo_first, geo_last] that holds it; none does: the kernel returns, the ordinary segmented passes run.
 template<typename KeyT, int THREADS, int KPT, bool VALS, bool LOOP, bool XF = false>
 __global__ __launch_bounds__(THREADS) void radix_finish_sort_kernel(KeyT* keys_a, uint32_t* vals_a, KeyT* keys_b,
                                                                     uint32_t* vals_b, const uint32_t* __restrict__ starts,
                                                                     uint32_t low_bits, const PassPlan* plan, uint32_t pass,
-                                                                    uint32_t geometry, uint32_t key_xf = 0)
+                                                                    uint32_t geometry, uint32_t key_xf = 0,
+                                                                    uint32_t nruns = kFinishRuns, const uint32_t* gate = nullptr,
+                                                                    uint32_t geo_first = 0, uint32_t geo_last = 0,
+                                                                    uint32_t rank_from = 0)
 {
     const KeyCodec<KeyT, XF> codec_out(key_xf);
-    if (plan->finish != geometry) return; // (kernel-uniform: the device chose another geometry, or the ordinary passes)
+    // (kernel-uniform: the device chose another geometry, or the ordinary passes)
+    if (plan ? plan->finish != geometry : finish_geometry_choice(*gate, geo_first, geo_last) != geometry) return;
     using Smem = FinishSmem<KeyT, THREADS, KPT, VALS>;
     constexpr int RADIX = Smem::RADIX;
     constexpr int WAVES = Smem::WAVES;
@@ -254,12 +291,12 @@ __global__ __launch_bounds__(THREADS) void radix_finish_sort_kernel(KeyT* keys_a
     constexpr int SCAN_WAVES = (SCAN_THREADS + kWave - 1) / kWave;
     static_assert(WAVES % 4 == 0 && SCAN_THREADS <= THREADS, "offset scan geometry");
 
-    KeyT* keys = plan->flip[pass] ? keys_b : keys_a;
-    uint32_t* vals = plan->flip[pass] ? vals_b : vals_a;
+    KeyT* keys = plan && plan->flip[pass] ? keys_b : keys_a;
+    uint32_t* vals = plan && plan->flip[pass] ? vals_b : vals_a;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Smem& s = *reinterpret_cast<Smem*>(smem_raw);
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (uint32_t run = blockIdx.x; run < kFinishRuns; run += LOOP ? gridDim.x : kFinishRuns)
+    for (uint32_t run = blockIdx.x; run < nruns; run += LOOP ? gridDim.x : nruns)
     {
     const uint32_t begin = starts[run], end = starts[run + 1];
     const uint32_t len = end - begin;
@@ -285,7 +322,12 @@ __global__ __launch_bounds__(THREADS) void radix_finish_sort_kernel(KeyT* keys_a
     }
 
     uint16_t* my_cnt = s.wcnt[wave];
-    for (uint32_t shift = 0; shift < low_bits; shift += 8)
+    // (workgroup-uniform) the first attempt ranks [rank_from, low_bits) and repairs ties; if the run does not suit that, the
+    // second ranks everything
+    for (uint32_t shift_begin = rank_from;; shift_begin = 0)
+    {
+    if (shift_begin != 0 && tid == 0) s.tie_count = 0, s.tie_bad = 0; // (barriers follow before either is used)
+    for (uint32_t shift = shift_begin; shift < low_bits; shift += 8)
     {
         constexpr uint32_t MASK = 255u;
         for (int i = tid; i < WAVES * RADIX / 2; i += THREADS) reinterpret_cast<uint32_t*>(&s.wcnt[0][0])[i] = 0;
@@ -363,6 +405,106 @@ __global__ __launch_bounds__(THREADS) void radix_finish_sort_kernel(KeyT* keys_a
             s.stage.get(wave_off + i * kWave, key[i], val[i], run_top);
         }
         if (shift + 8 < low_bits) __syncthreads();
+    }
+    if (shift_begin == 0) break;
+    // ---- tie repair on the stage (the registers hold a copy of it)
+    {
+        constexpr uint32_t kTieMaxBack = 16, kTieMaxGroup = 32;
+        uint16_t* const list = &s.wcnt[0][0];
+        // (only the key bits [0, low_bits) count: a segmented sort by fewer bits than the key has must not look at the others)
+        const KeyT low_mask = low_bits >= 8u * sizeof(KeyT) ? (KeyT) ~(KeyT) 0 : (KeyT) ((((KeyT) 1) << low_bits) - 1);
+        auto tied = [&](KeyT a, KeyT b) { return (((a ^ b) & low_mask) >> shift_begin) == 0; };
+        auto above = [&](KeyT a, KeyT b) { return (a & low_mask) > (b & low_mask); };
+#pragma unroll
+        for (int i = 0; i < KPT; i++)
+        {
+            if ((uint32_t) i >= items) continue;
+            const uint32_t p = wave_off + i * kWave;
+            // (positions from len on are the pads; the key of position p is in key[i], up to the bits above low_bits)
+            const bool in = p + 1 < len;
+            const KeyT kp = s.stage.key_at(in ? p : 0u), kn = s.stage.key_at(in ? p + 1 : 0u);
+            if (in && tied(kp, kn) && above(kp, kn))
+            {
+                // the first out-of-order neighbours of a tie group list the group's first position
+                uint32_t q = p, steps = 0;
+                KeyT kq = kp;
+                bool mine = true, open = true;
+                while (q > 0 && steps < kTieMaxBack)
+                {
+                    const KeyT kb = s.stage.key_at(q - 1);
+                    if (!tied(kb, kq))
+                    {
+                        open = false;
+                        break;
+                    }
+                    if (above(kb, kq))
+                    {
+                        mine = false; // (an earlier lane's)
+                        break;
+                    }
+                    kq = kb;
+                    q--;
+                    steps++;
+                }
+                if (q == 0) open = false;
+                if (mine && open)
+                    s.tie_bad = 1u; // the group begins further back than this lane may walk
+                else if (mine)
+                {
+                    const uint32_t at = atomicAdd(&s.tie_count, 1u);
+                    if (at < Smem::TIE_LIST) list[at] = (uint16_t) q;
+                    else s.tie_bad = 1u;
+                }
+            }
+        }
+        __syncthreads();
+        const uint32_t groups = s.tie_count;
+        if (!s.tie_bad)
+        {
+            for (uint32_t g = tid; g < groups; g += THREADS)
+            {
+                const uint32_t first = list[g];
+                const KeyT k0 = s.stage.key_at(first);
+                uint32_t end = first + 1;
+                while (end < len && end - first <= kTieMaxGroup && tied(k0, s.stage.key_at(end))) end++;
+                if (end - first > kTieMaxGroup)
+                {
+                    s.tie_bad = 1u;
+                    continue;
+                }
+                for (uint32_t a = first + 1; a < end; a++) // stable insertion by the whole key
+                {
+                    KeyT ka;
+                    uint32_t va;
+                    s.stage.get(a, ka, va, run_top);
+                    uint32_t b = a;
+                    while (b > first)
+                    {
+                        KeyT kb;
+                        uint32_t vb;
+                        s.stage.get(b - 1, kb, vb, run_top);
+                        if (!above(kb, ka)) break;
+                        s.stage.put(b, kb, vb);
+                        b--;
+                    }
+                    if (b != a) s.stage.put(b, ka, va);
+                }
+            }
+        }
+        __syncthreads();
+        const bool bad = s.tie_bad != 0u;
+        if (bad || groups)
+        {
+#pragma unroll
+            for (int i = 0; i < KPT; i++)
+            {
+                if ((uint32_t) i >= items) continue;
+                s.stage.get(wave_off + i * kWave, key[i], val[i], run_top);
+            }
+        }
+        if (!bad) break;
+        __syncthreads(); // (the counters -- the list -- are zeroed by the next round)
+    }
     }
 
 #pragma unroll

@@ -98,8 +98,10 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
     uint32_t* __restrict__ vals_b, const uint32_t* __restrict__ table, const uint32_t* __restrict__ totals, uint32_t n,
     uint32_t shift, uint32_t mask, uint32_t tiles_total, unsigned long long* stamps = nullptr, uint32_t xform = 0,
     PassPlan* plan = nullptr, uint32_t pass = 0, const uint2* __restrict__ ranges = nullptr, uint32_t share = 0,
-    const uint32_t* __restrict__ seg_first = nullptr)
+    const uint32_t* __restrict__ seg_first = nullptr, const uint32_t* gate = nullptr, uint32_t gate_cap = 0, uint32_t gate_mode = 0)
 {
+    // (SEG: a pass of a segmented sort that may end in LDS runs or returns by the longest run, radix_seg_passes.hpp)
+    if (SEG && gate_mode != 0 && ((*gate <= gate_cap) != (gate_mode == 1))) return; // (kernel-uniform)
     const KeyT* __restrict__ src_keys = keys_a;
     const uint32_t* __restrict__ src_vals = vals_a;
     KeyT* __restrict__ dst_keys = keys_b;

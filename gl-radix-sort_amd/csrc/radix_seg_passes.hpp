@@ -18,6 +18,55 @@
 
 namespace glu_hip
 {
+// A segmented sort that ENDS IN LDS (glu_hip.hip, seg_run_plan): its first pass is the one on the TOP digit of the bits to sort
+// by; after it the array is a sequence of runs (segment, top digit), whose starts are the first table row of every segment
+// after that pass's scan.  radix_seg_runs_kernel writes them out and notes the longest run in a device word, the GATE: when it
+// fits an LDS tile (gate_cap: the capacity of the largest tile geometry that is enqueued) the pass's scatter and the in-LDS pass
+// over the runs (radix_finish_sort_kernel, radix_lds_finish.hpp) run and the ordinary passes, enqueued behind, return at once;
+// otherwise the other way round.  One launch sequence either way, decided on the device (as in radix_lds_finish.hpp).
+constexpr uint32_t kSegGateNone = 0, kSegGateIfFits = 1, kSegGateIfNot = 2;
+__device__ __forceinline__ bool seg_gate_closed(const uint32_t* gate, uint32_t gate_cap, uint32_t gate_mode)
+{
+    if (gate_mode == kSegGateNone) return false;
+    const bool fits = *gate <= gate_cap;
+    return gate_mode == kSegGateIfFits ? !fits : fits;
+}
+
+// starts[g * RADIX + d] = where the keys of segment g with top digit d begin after the pass (table: the scanned rows of that
+// pass, seg_list / seg_start: radix_seg_scan_kernel's), starts[nseg * RADIX] = end; *gate = the longest run.  One workgroup.
+template<int RADIX>
+__global__ __launch_bounds__(1024) void radix_seg_runs_kernel(const uint32_t* __restrict__ table, const uint32_t* __restrict__ seg_list,
+                                                              const uint32_t* __restrict__ seg_start, uint32_t nseg, uint32_t end,
+                                                              uint32_t* __restrict__ starts, uint32_t* __restrict__ gate)
+{
+    __shared__ uint32_t wave_max[16];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t nruns = nseg * RADIX;
+    auto start_of = [&](uint32_t i) -> uint32_t {
+        if (i >= nruns) return end;
+        const uint32_t g = i / RADIX, d = i % RADIX;
+        const uint32_t row = seg_list[g];
+        return row == seg_list[g + 1] ? seg_start[g] : table[(size_t) row * RADIX + d]; // (a segment without elements has no rows)
+    };
+    uint32_t longest = 0;
+    for (uint32_t i = tid; i < nruns; i += 1024)
+    {
+        const uint32_t a = start_of(i), b = start_of(i + 1);
+        starts[i] = a;
+        longest = max(longest, b - a);
+    }
+    if (tid == 0) starts[nruns] = end;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) longest = max(longest, (uint32_t) __shfl_xor(longest, o));
+    if (lane == 0) wave_max[wave] = longest;
+    __syncthreads();
+    if (tid == 0)
+    {
+        for (int w = 1; w < 16; w++) longest = max(longest, wave_max[w]);
+        *gate = longest;
+    }
+}
+
 // K1 per sub-block.  Reads 4 B per key; a range may start and end at any element of a 16-byte aligned array.  Workgroup w
 // counts the sub-blocks [seg_first[w], seg_first[w + 1]) one after the other -- the same equal share of the elements that
 // workgroup w of the scatter kernel moves.  (One workgroup per sub-block, the first version, ran 125 us where the plain
@@ -27,8 +76,11 @@ template<int BITS, int THREADS>
 __global__ __launch_bounds__(THREADS) void radix_seg_count_kernel(const uint32_t* __restrict__ keys,
                                                                   const uint2* __restrict__ subs,
                                                                   const uint32_t* __restrict__ seg_first,
-                                                                  uint32_t* __restrict__ table, uint32_t shift, uint32_t mask)
+                                                                  uint32_t* __restrict__ table, uint32_t shift, uint32_t mask,
+                                                                  const uint32_t* gate = nullptr, uint32_t gate_cap = 0,
+                                                                  uint32_t gate_mode = kSegGateNone)
 {
+    if (seg_gate_closed(gate, gate_cap, gate_mode)) return; // (kernel-uniform)
     constexpr int RADIX = 1 << BITS;
     constexpr int WAVES = THREADS / kWave;
     __shared__ uint32_t hist[WAVES][RADIX];
@@ -102,8 +154,11 @@ __global__ __launch_bounds__(THREADS) void radix_seg_count_kernel(const uint32_t
 template<int RADIX>
 __global__ __launch_bounds__(RADIX) void radix_seg_scan_kernel(uint32_t* __restrict__ table,
                                                                const uint32_t* __restrict__ seg_list,
-                                                               const uint32_t* __restrict__ seg_start)
+                                                               const uint32_t* __restrict__ seg_start,
+                                                               const uint32_t* gate = nullptr, uint32_t gate_cap = 0,
+                                                               uint32_t gate_mode = kSegGateNone)
 {
+    if (seg_gate_closed(gate, gate_cap, gate_mode)) return; // (kernel-uniform)
     constexpr int WAVES = (RADIX + kWave - 1) / kWave;
     __shared__ uint32_t wave_sums[WAVES];
     const uint32_t d = threadIdx.x, lane = d & 63, wave = d >> 6;

@@ -74,6 +74,7 @@ SYMBOLS = [
                                                   _P(ctypes.c_double), _P(_u64)]),
     ("glu_radix_sort_plan_finish", _int, [_sz, _u32, _P(_u32), _P(_u32)]),
     ("glu_radix_sort_read_finish", _int, [_vp, _P(_u32), _P(_u32), _P(_u32), _P(_u32), _P(_u32)]),
+    ("glu_radix_sort_read_seg_finish", _int, [_vp, _P(_u32), _P(_u32), _P(_u32), _P(_u32), _P(_u32)]),
     ("glu_scan_create", _int, [_int, _P(_vp)]),
     ("glu_scan_destroy", _int, [_vp]),
     ("glu_scan_prepare", _int, [_vp, _sz, _sz]),
@@ -307,6 +308,14 @@ class RadixSort:
         check(lib().glu_radix_sort_read_finish(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c), ctypes.byref(d),
                                                ctypes.byref(e)))
         return {"attempted": a.value, "accepted": b.value, "longest_run": c.value, "capacity": d.value, "top_bit": e.value}
+
+    def read_seg_finish(self):
+        """{attempted, accepted, longest_run, capacity, runs} of the last SEGMENTED sort: did it try to / did it end in LDS
+        (glu_radix_sort_read_seg_finish); waits for the device."""
+        a, b, c, d, e = _u32(0), _u32(0), _u32(0), _u32(0), _u32(0)
+        check(lib().glu_radix_sort_read_seg_finish(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c), ctypes.byref(d),
+                                                   ctypes.byref(e)))
+        return {"attempted": a.value, "accepted": b.value, "longest_run": c.value, "capacity": d.value, "runs": e.value}
 
     def __call__(self, key_buffer, val_buffer, count, num_steps=0, key_bytes=4):
         kb = key_buffer.handle() if isinstance(key_buffer, ShaderStorageBuffer) else key_buffer

@@ -302,6 +302,14 @@ GLU_API glu_status glu_radix_sort_plan_finish(size_t count, uint32_t key_bytes, 
                                               uint32_t* last_capacity);
 GLU_API glu_status glu_radix_sort_read_finish(glu_radix_sort sort, uint32_t* attempted, uint32_t* accepted,
                                               uint32_t* longest_run, uint32_t* capacity, uint32_t* top_bit);
+/* The same question for the last SEGMENTED sort of the object (glu_radix_sort_run_segments_ptr; the local sort of glu_dist_*):
+ * a segmented sort by 16 key bits or more first tries ONE counting pass on the top digit of those bits and one pass that orders
+ * every run (segment, top digit) by the remaining bits inside LDS (the reference's pass, glu/RadixSort.hpp:289-333, once instead
+ * of three times for 24 bits).  attempted: both sequences were enqueued; accepted: the device found no run longer than
+ * `capacity` pairs and ended the sort in LDS (otherwise the ordinary segmented passes ran); runs = segments x 256.
+ * GLU_HIP_SEG_LDS_FINISH=0 in the environment of glu_radix_sort_create switches the attempt off.  Waits for the device. */
+GLU_API glu_status glu_radix_sort_read_seg_finish(glu_radix_sort sort, uint32_t* attempted, uint32_t* accepted,
+                                                  uint32_t* longest_run, uint32_t* capacity, uint32_t* runs);
 
 /* ---- exclusive scan: replaces glu::BlellochScan (glu/BlellochScan.hpp:80-191) ---------------------- */
 

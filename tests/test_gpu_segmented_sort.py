@@ -186,3 +186,117 @@ def test_segmented_sort_argument_checks(G):
             assert "captured" in e.value.message
     s.run_segments_ptr(k.data_ptr(), v.data_ptr(), k2.data_ptr(), v2.data_ptr(), 100, *one, 1, 24)  # and works afterwards
     torch.cuda.synchronize()
+
+
+# ---- a segmented sort that ends in LDS (round 5): one counting pass on the top digit of the bits + one in-LDS pass over the
+# runs (segment, top digit), decided on the device by the longest run; the ordinary passes behind it otherwise
+
+def _run_with_report(G, keys, vals, begin, length, seg, nseg, key_bits, env=None):
+    import os
+
+    old = {k: os.environ.get(k) for k in (env or {})}
+    os.environ.update(env or {})
+    try:
+        sorter = G.RadixSort()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+    gk, gv = run(G, keys, vals, begin, length, seg, nseg, key_bits, sorter=sorter)
+    return gk, gv, sorter.read_seg_finish()
+
+
+@pytest.mark.parametrize("key_bits", [16, 24, 32])
+@pytest.mark.parametrize("n,sources,nseg", [(700_001, 8, 32), (3_000_000, 2, 128), (2_500_000, 3, 1)])
+def test_segmented_sort_ends_in_lds(G, n, sources, nseg, key_bits):
+    """Uniform keys: the runs (segment, top digit) are short, the device accepts, and the result is the oracle's."""
+    rng = np.random.default_rng(n * 3 + key_bits)
+    keys = rng.integers(0, 2**32, n, dtype=np.uint32)
+    vals = np.arange(n, dtype=np.uint32)
+    begin, length, seg = source_major_pieces(rng, n, sources, nseg)
+    gk, gv, rep = _run_with_report(G, keys, vals, begin, length, seg, nseg, key_bits)
+    ek, ev = expected(keys, vals, begin, length, seg, nseg, key_bits)
+    assert (gk == ek).all() and (gv == ev).all()
+    if n / (nseg * 256) + 6 * (n / (nseg * 256)) ** 0.5 + 8 <= 512 * 18:
+        assert rep["attempted"] == 1 and rep["accepted"] == 1 and rep["runs"] == nseg * 256, rep
+        assert 0 < rep["longest_run"] <= rep["capacity"]
+    # and the same input by the ordinary passes (the attempt switched off) gives the same arrays
+    pk, pv, rep0 = _run_with_report(G, keys, vals, begin, length, seg, nseg, key_bits, env={"GLU_HIP_SEG_LDS_FINISH": "0"})
+    assert rep0["attempted"] == 0
+    assert (pk == ek).all() and (pv == ev).all()
+
+
+@pytest.mark.parametrize("shape", ["one_long_run", "run_of_exactly_the_capacity", "one_pair_more", "all_keys_equal", "empty_segments",
+                                   "long_run_in_last_segment"])
+def test_segmented_sort_lds_ending_decides_by_the_longest_run(G, shape):
+    """Runs longer than the largest enqueued tile send the whole segmented sort to the ordinary passes; a run of exactly the
+    capacity is still taken.  With 1 M pairs in 16 segments the uniform-keys tile holds 1536 pairs and the largest enqueued 4608."""
+    rng = np.random.default_rng(11)
+    n, nseg, sources = 1_048_576, 16, 4
+    keys = rng.integers(0, 2**32, n, dtype=np.uint32)
+    vals = np.arange(n, dtype=np.uint32)
+    skew = None
+    if shape == "empty_segments":
+        skew = [1, 0, 0, 2, 0, 1, 1, 0, 1, 1, 0, 0, 0, 1, 0, 0]
+    begin, length, seg = source_major_pieces(rng, n, sources, nseg, skew=skew)
+    # the elements of segment 5, in the segment's own order, through their indices in the input
+    def seg_indices(g):
+        return np.concatenate([np.arange(begin[i], begin[i] + length[i]) for i in range(len(seg)) if seg[i] == g]).astype(np.int64)
+    want_accept = True
+    if shape in ("one_long_run", "long_run_in_last_segment"):
+        idx = seg_indices(5 if shape == "one_long_run" else nseg - 1)
+        keys[idx[:6000]] = (keys[idx[:6000]] & np.uint32(0xFF00FFFF)) | np.uint32(0x00A50000)  # 6000 + chance pairs in run (g, 0xA5)
+        want_accept = False
+    elif shape in ("run_of_exactly_the_capacity", "one_pair_more"):
+        idx = seg_indices(5)
+        in_run = ((keys[idx] >> 16) & 0xFF) == 0xA5
+        keys[idx[in_run]] ^= np.uint32(0x00010000)  # nobody is in run (5, 0xA5) ...
+        m = 4608 + (1 if shape == "one_pair_more" else 0)
+        pick = idx[rng.choice(idx.size, m, replace=False)]
+        keys[pick] = (keys[pick] & np.uint32(0xFF00FFFF)) | np.uint32(0x00A50000)  # ... but exactly m pairs
+        want_accept = shape == "run_of_exactly_the_capacity"
+    elif shape == "all_keys_equal":
+        keys[:] = 0x12345678
+        want_accept = False
+    gk, gv, rep = _run_with_report(G, keys, vals, begin, length, seg, nseg, 24)
+    ek, ev = expected(keys, vals, begin, length, seg, nseg, 24)
+    assert (gk == ek).all() and (gv == ev).all()
+    assert rep["attempted"] == 1 and rep["capacity"] == 4608, rep
+    assert rep["accepted"] == (1 if want_accept else 0), rep
+    if shape == "run_of_exactly_the_capacity":
+        assert rep["longest_run"] == 4608
+    if shape == "one_pair_more":
+        assert rep["longest_run"] == 4609
+
+
+def test_segmented_sort_lds_ending_back_to_back_with_changing_outcomes(G):
+    """One object, one stream, no host synchronisation between the sorts: accepted, refused, accepted -- the gate word and the run
+    starts of a sort are rewritten by the next one in stream order."""
+    import torch
+
+    sorter = G.RadixSort()
+    rng = np.random.default_rng(5)
+    n, nseg = 600_000, 8
+    sorter.prepare_internal_buffers(n)
+    st = torch.cuda.Stream()
+    outs, exps = [], []
+    with torch.cuda.stream(st):
+        for it in range(6):
+            keys = rng.integers(0, 2**32, n, dtype=np.uint32)
+            if it % 2:
+                keys[: n // 3] &= np.uint32(0xFF00FFFF)  # a third of the pairs in the runs (g, 0): far beyond any tile
+            vals = np.arange(n, dtype=np.uint32)
+            begin, length, seg = source_major_pieces(rng, n, 2 + it, nseg)
+            kin = torch.from_numpy(keys.view(np.int32)).cuda()
+            vin = torch.from_numpy(vals.view(np.int32)).cuda()
+            kout, vout = torch.empty_like(kin), torch.empty_like(vin)
+            sorter.run_segments_ptr(kin.data_ptr(), vin.data_ptr(), kout.data_ptr(), vout.data_ptr(), n, begin, length, seg, nseg, 24,
+                                    st.cuda_stream)
+            outs.append((kin, vin, kout, vout))
+            exps.append(expected(keys, vals, begin, length, seg, nseg, 24))
+        st.synchronize()
+    for (_, _, kout, vout), (ek, ev) in zip(outs, exps):
+        assert (kout.cpu().numpy().view(np.uint32) == ek).all() and (vout.cpu().numpy().view(np.uint32) == ev).all()
+    assert sorter.read_seg_finish()["accepted"] == 0  # (the last one was a refused one)

@@ -5,14 +5,19 @@
    python tools/trace_summary.py <kernel_trace.csv> --bench K
        what bench.py's timed region looks like in the trace: the last K sorts that ended in LDS (bench.py's K timed steps are
        the last sorts of its headline sort object; the comparison legs that follow use other pass structures) -- average,
-       min and max of their scatter launches and of their in-LDS pass, to set beside bench.py's roofline object"""
+       min and max of their scatter launches and of their in-LDS pass, to set beside bench.py's roofline object
+   python tools/trace_summary.py <kernel_trace.csv> --sorts K
+       the same for any key type (tools/sort_loop.py): the last K sorts that ended in LDS, per kind of kernel, the other
+       kernels by name, and the time between first kernel start and last kernel end that no kernel of the sort covers"""
 import csv, sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 bench = "--bench" in sys.argv
-last = int(sys.argv[sys.argv.index("--bench") + 1]) if bench else (int(sys.argv[2]) if len(sys.argv) > 2 else 20)
+per_sorts = "--sorts" in sys.argv
+last = int(sys.argv[sys.argv.index("--bench") + 1]) if bench else int(sys.argv[sys.argv.index("--sorts") + 1]) if per_sorts else (int(sys.argv[2]) if len(sys.argv) > 2 else 20)
 sorts, cur, other, t0 = [], [], 0.0, None
+names, busy, t_end = {}, 0.0, None
 all_scatter8 = []
 for r in rows:
     n = r["Kernel_Name"]
@@ -23,9 +28,14 @@ for r in rows:
         t0 = int(r["Start_Timestamp"])
     if "radix_scatter_lines_kernel<unsigned int, 8" in n:
         all_scatter8.append((n, d))
+    # (time covered by at least one kernel of the sort: kernels of one stream run one after the other)
+    busy += (int(r["End_Timestamp"]) - max(int(r["Start_Timestamp"]), t_end or 0)) / 1e3 if (t_end or 0) < int(r["End_Timestamp"]) else 0.0
+    t_end = max(t_end or 0, int(r["End_Timestamp"]))
+    short = n.split("glu_hip::")[1].split("<")[0].split("(")[0]
     if "radix_finalize" in n:
-        sorts.append((cur, other, (int(r["End_Timestamp"]) - t0) / 1e3))
-        cur, other, t0 = [], 0.0, None
+        names[short] = names.get(short, 0.0) + d
+        sorts.append((cur, other + d, (int(r["End_Timestamp"]) - t0) / 1e3, names, busy))
+        cur, other, t0, names, busy, t_end = [], 0.0, None, {}, 0.0, None
     elif "radix_scatter_lines" in n and d > 100:
         cur.append(("S", d))
     elif "radix_finish_sort" in n and d > 100:
@@ -34,8 +44,29 @@ for r in rows:
         cur.append(("C", d))
     else:
         other += d
+        names[short] = names.get(short, 0.0) + d
+if per_sorts:
+    def st(v):
+        return "n %d  average %.1f us  min %.1f  max %.1f" % (len(v), sum(v) / len(v), min(v), max(v)) if v else "none"
+    ended = [s for s in sorts if any(k == "F" for k, _ in s[0])]
+    timed = ended[-last:]
+    print("sorts in the trace: %d, of them ended in LDS: %d; the last %d of those:" % (len(sorts), len(ended), len(timed)))
+    print("  scatter launches that moved data:   %s" % st([d for s in timed for k, d in s[0] if k == "S"]))
+    print("  in-LDS pass (one per sort):         %s" % st([d for s in timed for k, d in s[0] if k == "F"]))
+    print("  leader count kernel (one per sort): %s" % st([d for s in timed for k, d in s[0] if k == "C"]))
+    print("  every other kernel, summed per sort: %s" % st([s[1] for s in timed]))
+    print("  first kernel start to last kernel end per sort: %s" % st([s[2] for s in timed]))
+    print("  of that, covered by no kernel (launch gaps): %s" % st([s[2] - s[4] for s in timed]))
+    print("  the other kernels by name, average us per sort (launch count per sort is not shown: most return at once):")
+    agg = {}
+    for s in timed:
+        for k, d in s[3].items():
+            agg[k] = agg.get(k, 0.0) + d / len(timed)
+    for k, d in sorted(agg.items(), key=lambda kv: -kv[1]):
+        print("    %-40s %7.1f" % (k, d))
+    sys.exit(0)
 if not bench:
-    for cur, other, span in sorts[-last:]:
+    for cur, other, span, _, _ in sorts[-last:]:
         print(" ".join("%s%d" % (k, round(d)) for k, d in cur), " other kernels %d us, first start to last end %d us" % (other, span))
     sys.exit(0)
 
