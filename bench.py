@@ -71,6 +71,10 @@ def parse_args():
                    help="N>1: pairs of the single-GPU figures = 2^this (default 28, the N = 1 workload; pairs per GPU + 1 in a rehearsal)")
     p.add_argument("--force-dist", action="store_true",
                    help="run the multi-GPU code path (partition + all-to-all + local sort) even with one rank")
+    p.add_argument("--as-rank-of", type=int, default=1,
+                   help="with --force-dist: the keys are drawn from the key range ONE rank of an R-GPU sort owns (its 256 / R "
+                        "buckets), so that this GPU's local sort has the runs it would have there (2^27 pairs at R = 8: 16384 per "
+                        "(bucket, next byte)); a rehearsal of a rank's compute, not a line for the scaling curve")
     p.add_argument("--rehearse-one-gpu", action="store_true",
                    help="NOT a measurement: run the N>1 code path with all ranks on GPU 0 (gloo process group, glu_dist over "
                         "the file transport named by GLU_HIP_RCCL_LIB, tests/cpp/mock_rccl.cpp) to check that the launch, the "
@@ -78,13 +82,17 @@ def parse_args():
     return p.parse_args()
 
 
-def make_input(torch, n, kind, seed, device, index_base=0):
+def make_input(torch, n, kind, seed, device, index_base=0, as_rank_of=1):
     """keys: uniform over the full [0, 2^32) (bit 31 set half of the time), vals: global index mod 2^32;
-    both held as int32 bit patterns."""
+    both held as int32 bit patterns.  as_rank_of = R > 1: uniform over the first 1 / R of the key space (the buckets the first
+    rank of R owns)."""
     g = torch.Generator(device=device)
     g.manual_seed(0x5EED + seed)
     if kind == "zero":
         keys = torch.zeros(n, dtype=torch.int32, device=device)
+    elif as_rank_of > 1:
+        keys = torch.randint(0, 2**32 // as_rank_of, (n,), dtype=torch.int64, device=device, generator=g)
+        keys = torch.where(keys >= 2**31, keys - 2**32, keys).to(torch.int32)
     else:
         keys = torch.randint(-2**31, 2**31, (n,), dtype=torch.int32, device=device, generator=g)
     vals = (torch.arange(n, dtype=torch.int64, device=device) + index_base).to(torch.int32)
@@ -102,6 +110,20 @@ def verify_sorted(torch, keys0, out_k, out_v, vals_are_local_iota):
         eq = out_k[1:] == out_k[:-1]
         ok = ok and bool((idx[1:][eq] > idx[:-1][eq]).all())
     return ok
+
+
+def pair_fingerprint(torch, keys, vals):
+    """Two order-independent 64-bit sums over hashes of the (key, value) pairs (int64 arithmetic that wraps): equal for two
+    arrays of pairs exactly when -- up to a 2^-64-ish chance -- they hold the same multiset of pairs.  Sums, not xor: every
+    torch.distributed backend all-reduces sums."""
+    def s64(x):  # a 64-bit constant as the int64 with the same bits
+        return x - (1 << 64) if x >= 1 << 63 else x
+    k = keys.to(torch.int64) & 0xFFFFFFFF
+    v = vals.to(torch.int64) & 0xFFFFFFFF
+    h = k * s64(0x9E3779B97F4A7C15) + v * s64(0xC2B2AE3D27D4EB4F) + s64(0x165667B19E3779F9)
+    h = (h ^ ((h >> 29) & 0x7FFFFFFFF)) * s64(0xBF58476D1CE4E5B9)
+    g = (h ^ ((h >> 32) & 0xFFFFFFFF)) * s64(0x94D049BB133111EB)
+    return torch.stack([h.sum(), g.sum()])
 
 
 def cpu_baseline(sample_log2, keys_host=None, vals_host=None):
@@ -368,7 +390,10 @@ def main():
         for i in range(W):
             step(i)
         barrier()
-        sorter.set_profiling(not args.no_kernel_events)
+        # LIGHT per-kernel events in the timed region: only around the kernels that move the data (the scatter of every pass
+        # that is expected to run, the in-LDS pass) -- an event between two kernels costs the queue microseconds, and all 28 of
+        # a sort that ends in LDS were 4 % of its time; count / scan kernel times come from three more sorts after the region
+        sorter.set_profiling("light" if not args.no_kernel_events else False)
         step_events = []
         t0 = time.perf_counter()
         for i in range(W, W + K):
@@ -385,6 +410,17 @@ def main():
         step_ms = sorted(a.elapsed_time(b) for a, b in step_events)
         prof = sorter.read_profile()
         sorter.set_profiling(False)
+        detail = {"count_ms": 0.0, "scan_ms": 0.0, "passes": 0}
+        if not args.no_kernel_events:  # (outside the timed region: every kernel boundary of three more sorts)
+            sorter.set_profiling(True)
+            for i in range(W + K, W + K + 3):
+                k, v = sets[i % copies]
+                k.copy_(keys0)
+                v.copy_(vals0)
+                sorter.run_ptr(k.data_ptr(), v.data_ptr(), n, 0, stream)
+            torch.cuda.synchronize()
+            detail = sorter.read_profile()
+            sorter.set_profiling(False)
         bits = sorter.digit_bits
         units = n * K
         verified = None
@@ -434,8 +470,10 @@ def main():
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_launch_ms": round(scatter_ms, 4),
                 "launches_timed": passes,
-                "count_kernel_avg_ms": round(prof["count_ms"] / passes, 4),
-                "scan_kernel_avg_ms": round(prof["scan_ms"] / passes, 4),
+                "count_kernel_avg_ms": round(detail["count_ms"] / max(int(detail["passes"]), 1), 4),
+                "scan_kernel_avg_ms": round(detail["scan_ms"] / max(int(detail["passes"]), 1), 4),
+                "timing": "HIP events around every scatter launch and every in-LDS pass of the timed steps (on the sort's stream); "
+                          "count / scan kernels: three more sorts after the timed region with events at every kernel boundary",
             },
             "whole_sort": {
                 "passes": passes_per_sort, "digit_bits": bits,
@@ -561,7 +599,7 @@ def main():
     else:
         from glu_hip import dist as D
 
-        keys0, vals0 = make_input(torch, n, args.keys, rank, device, index_base=rank * n)
+        keys0, vals0 = make_input(torch, n, args.keys, rank, device, index_base=rank * n, as_rank_of=args.as_rank_of if args.force_dist else 1)
 
         def sharded(native):
             """The whole N > 1 measurement over one transport (native = glu_dist_* inside libglu_hip.so with its own RCCL
@@ -589,7 +627,7 @@ def main():
                 dsort.phase_times()  # drop the warm-up stamps
                 sorters = dsort.local_sorters()
                 for srt in sorters:
-                    srt.set_profiling(not args.no_kernel_events)
+                    srt.set_profiling("light" if not args.no_kernel_events else False)  # (events around the scatter / in-LDS kernels only)
                 t0 = time.perf_counter()
                 handle = None
                 for i in range(K):
@@ -640,6 +678,8 @@ def main():
             dsort, handle, profs, sorters = r1["dsort"], r1["handle"], r1["profs"], r1["sorters"]
             res["native_c_abi"] = bool(dsort.native)
             res["local_sort"] = (dsort._slots[0]["native"].last_local_sort() if dsort.native else dsort.last_local_sort)
+            # did rank 0's segmented local sort end in LDS (one counting pass + one in-LDS pass instead of three passes)?
+            res["local_sort_in_lds_rank0"] = sorters[0].read_seg_finish()
             if args.rehearse_one_gpu:
                 res["rehearsal"] = "NOT A MEASUREMENT: %d ranks share one GPU and exchange through files (tests/cpp/mock_rccl.cpp)" % world
             rk, rv, cnt = handle.synchronize()
@@ -683,10 +723,37 @@ def main():
                             ok = False
                         prev_last = l
                 ok = ok and int(total.item()) == n * world
+                # the VALUES: (1) the output pairs of all ranks are the input pairs of all ranks (two all-reduced sums over pair
+                # hashes: every value is still with its key, nothing lost, nothing doubled); (2) equal keys keep ascending
+                # values -- the values are global input indices, so that IS the stable order -- inside a rank and across the
+                # boundaries between ranks
+                fp = pair_fingerprint(torch, rk[:cnt], rv[:cnt]) - pair_fingerprint(torch, keys0, vals0)
+                dist.all_reduce(fp)
+                ok = ok and bool((fp == 0).all())
+                uv = rv[:cnt].to(torch.int64) & 0xFFFFFFFF
+                eq = rk[1:cnt] == rk[:cnt - 1]
+                ok = ok and bool((uv[1:][eq] > uv[:-1][eq]).all())
+                ends = torch.zeros(1, 4, dtype=torch.int64, device=device)  # first key, first value, last key, last value
+                if cnt > 0:
+                    ends[0, 0], ends[0, 1], ends[0, 2], ends[0, 3] = flipped[0], uv[0], flipped[cnt - 1], uv[cnt - 1]
+                ends_all = [torch.zeros_like(ends) for _ in range(world)]
+                dist.all_gather(ends_all, ends)
+                counts_all = [torch.zeros_like(total) for _ in range(world)]
+                dist.all_gather(counts_all, torch.tensor([cnt], dtype=torch.int64, device=device))
+                prev = None
+                for e, c in zip(ends_all, counts_all):
+                    if int(c.item()) == 0:
+                        continue
+                    if prev is not None and int(e[0, 0]) == int(prev[0, 2]) and not int(e[0, 1]) > int(prev[0, 3]):
+                        ok = False  # the same key on both sides of a rank boundary, values not ascending
+                    prev = e
                 flag = torch.tensor([1 if ok else 0], device=device)
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
                 verified = bool(flag.item())
             res["verified"] = verified
+            res["verified_what"] = ("keys ascending inside and across ranks; counts add up; the output pairs of all ranks are the input "
+                                    "pairs of all ranks (all-reduced sums of pair hashes); equal keys keep ascending values (= input "
+                                    "order) inside a rank and across rank boundaries")
             res["shard_pairs_rank0"] = int(cnt)
             workload = ("2^%d uint32 key+val pairs per GPU (%d GPUs, 2^%.2f total), uniform-random keys; top-8-bit bucket "
                         "partition + one RCCL all-to-all over xGMI + local sort") % (log2n, world, log2n + __import__("math").log2(world))

@@ -219,7 +219,9 @@ struct glu_dist_s
     // the exchange in ROUNDS (world > 1, large shards): round j carries the j-th group of every rank's buckets on the side
     // stream while the local sort of group j - 1 runs on the sort's stream (dist_sort_finish)
     static constexpr int kMaxRounds = 8;
-    int rounds = 3;                     // glu_dist_set_rounds / GLU_HIP_DIST_ROUNDS (1 .. kMaxRounds)
+    int rounds = 1;                     // glu_dist_set_rounds / GLU_HIP_DIST_ROUNDS (1 .. kMaxRounds); glu_dist_create: 3 from four
+                                        // ranks up (at two, half of the data stays on the rank and the one link to the peer
+                                        // bounds the exchange far above the local sort: rounds only cost compute there)
     size_t rounds_min = (size_t) 1 << 24; // GLU_HIP_DIST_ROUNDS_MIN: pairs per rank (global count / world) from which rounds are used
     hipEvent_t ev_part = nullptr, ev_round[kMaxRounds] = {};
     uint32_t last_rounds = 1;           // rounds of the last sort's exchange (glu_dist_last_rounds)
@@ -234,6 +236,8 @@ struct glu_dist_s
     size_t marks_used = 0;
     Scratch part_k, part_v;             // the local slice grouped by bucket (send side)
     Scratch recv_k, recv_v;             // receive side of glu_dist_sort_ptr (glu_dist_sort_finish takes the caller's)
+    Scratch land_k, land_v;             // where the exchange lands when the local sort is segmented (round 5: the sorter's scratch
+                                        // arrays are the third pair that a segmented sort that ends in LDS passes through)
     Scratch hist;                       // [kDistRow] local row, [world * kDistRow] gathered rows, [4 + world] status words
     uint32_t* all_hist_host = nullptr;  // pinned: the gathered rows; behind them 8 words of trailer staging, 4 + world of status
     std::vector<uint32_t> hist_dense;   // [world][256] the bucket counts of the gathered rows
@@ -315,6 +319,7 @@ glu_status glu_dist_create(const void* unique_id, size_t id_bytes, int world_siz
         if (atoll(e) > 0) d->shard_limit = (uint64_t) atoll(e);
     if (const char* e = getenv("GLU_HIP_DIST_SEG_MIN")) d->seg_min = (size_t) atoll(e);
     if (const char* e = getenv("GLU_HIP_DIST_SEG")) d->seg_enabled = atoi(e) != 0, d->seg_forced = atoi(e) == 2;
+    d->rounds = world_size >= 4 ? 3 : 1;
     if (const char* e = getenv("GLU_HIP_DIST_ROUNDS"))
         if (atoi(e) >= 1 && atoi(e) <= glu_dist_s::kMaxRounds) d->rounds = atoi(e);
     if (const char* e = getenv("GLU_HIP_DIST_ROUNDS_MIN")) d->rounds_min = (size_t) atoll(e);
@@ -373,6 +378,8 @@ glu_status glu_dist_destroy(glu_dist d)
     d->part_v.release();
     d->recv_k.release();
     d->recv_v.release();
+    d->land_k.release();
+    d->land_v.release();
     d->hist.release();
     delete d;
     return GLU_OK;
@@ -412,6 +419,7 @@ glu_status glu_dist_prepare(glu_dist d, size_t local_count, size_t recv_capacity
     // of arrays that were chosen, not drawn (place_pair_by_measurement; plain allocations for small arrays)
     GLU_TRY(place_pair_by_measurement(d->sorter, std::max<size_t>(local_count, 1), d->part_k, d->part_v));
     if (recv_capacity) GLU_TRY(place_pair_by_measurement(d->sorter, recv_capacity, d->recv_k, d->recv_v));
+    if (recv_capacity) GLU_TRY(place_pair_by_measurement(d->sorter, recv_capacity, d->land_k, d->land_v));
     // segmented local sort: one table row per sub-block (at most pieces + workgroups: world x buckets owned + CUs) and the
     // descriptor image of its two pass shapes
     const size_t rows = (size_t) kDistBuckets * (size_t) std::min(d->world, 16) + (size_t) g_dev.num_cus;
@@ -690,6 +698,13 @@ glu_status dist_sort_finish(glu_dist_s* d, uint32_t* recv_keys, uint32_t* recv_v
         const uint64_t tiles_per_wg = n_recv / LinesGeometry<uint32_t, 8, true>::TILE / usable_cus(d->sorter);
         segmented = !plan.by_copies && (d->seg_forced || plan.max_subs_per_wg() <= 2 + tiles_per_wg / 6);
     }
+    if (segmented)
+    {
+        // the landing arrays (grown here when glu_dist_prepare did not size them: an allocation, agreed on like every other)
+        note(d->land_k.reserve(n_recv * sizeof(uint32_t)));
+        note(d->land_v.reserve(n_recv * sizeof(uint32_t)));
+        if (local != GLU_OK) segmented = false;
+    }
     d->last_local_sort = segmented ? 1u : 0u;
 
     if (d->world > 1)
@@ -716,10 +731,11 @@ glu_status dist_sort_finish(glu_dist_s* d, uint32_t* recv_keys, uint32_t* recv_v
 
     const uint32_t* part_k = (const uint32_t*) d->part_k.ptr;
     const uint32_t* part_v = (const uint32_t*) d->part_v.ptr;
-    // where the exchange delivers: the segmented sort reads the shard from the sorter's scratch arrays and leaves its
-    // result (after an odd number of passes) in the caller's; the ordinary sort works in place in the caller's
-    uint32_t* land_k = segmented ? (uint32_t*) d->sorter->keys.ptr : recv_keys;
-    uint32_t* land_v = segmented ? (uint32_t*) d->sorter->vals.ptr : recv_vals;
+    // where the exchange delivers: the segmented sort reads the shard from the object's landing arrays and leaves its
+    // result in the caller's (through the sorter's scratch arrays when it ends in LDS); the ordinary sort works in place in the
+    // caller's
+    uint32_t* land_k = segmented ? (uint32_t*) d->land_k.ptr : recv_keys;
+    uint32_t* land_v = segmented ? (uint32_t*) d->land_v.ptr : recv_vals;
 
     // 4. the exchange.  One grouped exchange (ncclSend / ncclRecv to and from every peer between ncclGroupStart / End) per
     // ROUND.  With one round a rank's message to a peer is all of the peer's buckets and everything runs on `st`: partition

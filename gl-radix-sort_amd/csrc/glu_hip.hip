@@ -458,10 +458,22 @@ struct glu_radix_sort_s
     SegStage seg_stage[16]; // (a sharded sort in rounds makes one segmented sort per round, up to 8: the host never waits for its own sort)
     uint32_t seg_stage_next = 0;
     // a segmented sort that ends in LDS (seg_run_plan): the longest run its first pass found (device word), and what the host knows
+    Scratch long_image, long_hdr; // the long runs of a whole-key sort that ends in LDS: their segment descriptors, built on the device
     Scratch seg_gate;
     bool seg_finish = true;             // GLU_HIP_SEG_LDS_FINISH=0: always the ordinary segmented passes (tests / tuning)
     bool last_seg_finish_attempted = false;
-    uint32_t last_seg_finish_capacity = 0, last_seg_finish_runs = 0;
+    uint32_t last_seg_finish_capacity = 0, last_seg_finish_runs = 0, last_seg_finish_tile = 0, last_seg_finish_split = 0;
+    // Runs that do not fit the largest tile that still shares a CU (512 x 18 = 9216 pairs) could be taken whole by one workgroup
+    // per CU (1024 x 17) or split over 2^k workgroups by key ranges; measured on the runs of the sharded sort at eight ranks
+    // (16384 pairs, 2^27 per rank: profiles/r05/force_dist_as_rank_of_8.txt) neither beats the three ordinary passes (1.72 /
+    // 1.78 / 2.03 against 1.67 ms), so both are OFF by default and such sorts make no attempt.
+    uint32_t seg_split_max = 0;         // GLU_HIP_SEG_SPLIT_MAX: a run is split over at most 2^this workgroups (tests / tuning; up to 3)
+    uint32_t seg_split_min = 0;         // GLU_HIP_SEG_SPLIT_MIN: ... and over at least 2^this (tests)
+    // the rounds of an in-LDS pass with more than this many bits left to order rank the top 16 .. 23 of them and repair ties
+    // (radix_lds_finish.hpp: 64-bit keys, a segmented sort by 32 bits).  GLU_HIP_FINISH_RANK_BITS=N (tuning; 48: all rounds)
+    uint32_t finish_rank_bits = 16;
+    uint32_t seg_split_geo = 3;         // GLU_HIP_SEG_SPLIT_GEO: the largest tile geometry split runs take (tuning)
+    uint32_t seg_max_geo = 4;           // GLU_HIP_SEG_MAX_GEO: the largest tile geometry whole runs take (tests / tuning; up to 5)
     uint32_t digit_bits = 8;
     uint32_t max_blocks = 0;   // GLU_HIP_SORT_BLOCKS: cap on the number of workgroups (tuning)
     uint32_t reserved_cus = 0; // CUs the pass kernels leave free (glu_dist: RCCL kernels run beside them); the grid of a pass
@@ -488,6 +500,7 @@ struct glu_radix_sort_s
     Scratch finish_lengths;       // [65536] run lengths,
     Scratch finish_starts;        // [65537] run starts
     bool lds_finish = true;       // GLU_HIP_SORT_LDS_FINISH=0: always the four passes of the ordinary sort (tests / tuning)
+    bool long_runs = true;        // GLU_HIP_SORT_LONG_RUNS=0: a run longer than the in-LDS pass's tile refuses the whole sort, as in round 4 (tests / tuning)
     size_t finish_min = 0;        // GLU_HIP_SORT_FINISH_MIN=N: element count from which the attempt is made (tests / tuning)
     // A refused attempt costs one read of the keys.  The plan kernel notes each attempt's outcome in a pinned host word
     // (attempt number << 1 | accepted); a later sort call that finds its LAST attempt refused skips the next
@@ -503,12 +516,18 @@ struct glu_radix_sort_s
     uint32_t last_finish_top = 0; // what the last sort assumed (glu_radix_sort_read_finish)
     uint32_t finish_backoff = 8;  // GLU_HIP_SORT_FINISH_BACKOFF=N (0: every sort attempts: tests)
     bool last_finish_attempted = false; // the last sort enqueued both sequences (glu_radix_sort_read_finish)
+    bool last_finish_long_ok = false;   // ... and the segmented passes for runs longer than the tile (glu_radix_sort_read_long_runs)
     uint32_t last_finish_capacity = 0;  // and the longest run its last pass would take
     size_t large_min = 0;         // GLU_HIP_SORT_LARGE_MIN=N: element count from which the large geometry is used (tuning)
-    // optional per-kernel timing: 4 events per pass (before count, after count, after scan, after scatter)
-    bool profiling = false;
-    std::vector<hipEvent_t> events;
+    // optional per-kernel timing: 4 marks per pass (before count, after count, after scan, after scatter).  profiling = 1: every
+    // mark records an event.  profiling = 2 (LIGHT): only the two marks around the kernel that moves the data of a pass that is
+    // expected to run -- the scatter of a pass, the in-LDS pass -- record one; the others are placeholders.  An event between two
+    // kernels costs the queue a few microseconds: 28 of them per sort that ends in LDS were 4 % of its time (bench.py's timed
+    // region runs light).
+    int profiling = 0;
+    std::vector<hipEvent_t> events;  // the pool
     size_t events_used = 0;
+    std::vector<hipEvent_t> slots;   // one per mark: the event recorded there, or nullptr
     hipEvent_t next_event()
     {
         if (events_used == events.size())
@@ -520,14 +539,20 @@ struct glu_radix_sort_s
         return events[events_used++];
     }
     // what the four events of a pass belong to: 0 = a pass of the ordinary sort, 1 = a top-bit pass of a sort that tries to
-    // end in LDS, 2 = its in-LDS pass (glu_radix_sort_read_profile books them by which of the two sequences ran)
+    // end in LDS, 2 = its in-LDS pass (glu_radix_sort_read_profile books them by which of the two sequences ran); 3 = the
+    // counting pass of a SEGMENTED sort that tries to end in LDS, 4 = an ordinary segmented pass enqueued behind such an attempt
     std::vector<uint8_t> pass_kinds;
     uint8_t cur_kind = 0;
-    void mark(hipStream_t stream)
+    bool cur_behind = false; // the pass being enqueued belongs to the sequence that is expected NOT to run
+    // around_data_kernel: this mark is one of the two around the scatter kernel / the in-LDS pass
+    void mark(hipStream_t stream, bool around_data_kernel = false)
     {
         if (!profiling) return;
-        if (events_used % 4 == 0) pass_kinds.push_back(cur_kind);
-        if (hipEvent_t e = next_event()) (void) hipEventRecord(e, stream);
+        if (slots.size() % 4 == 0) pass_kinds.push_back(cur_kind);
+        hipEvent_t e = nullptr;
+        if (profiling == 1 || (around_data_kernel && !cur_behind))
+            if ((e = next_event()) != nullptr) (void) hipEventRecord(e, stream);
+        slots.push_back(e);
     }
 };
 
@@ -589,6 +614,13 @@ glu_status sort_prepare(glu_radix_sort_s* s, size_t count, size_t key_size, bool
         {
             GLU_TRY(s->finish_lengths.reserve((size_t) kFinishRuns * sizeof(uint32_t)));
             GLU_TRY(s->finish_starts.reserve(((size_t) kFinishRuns + 1) * sizeof(uint32_t)));
+            if (key_size == 4 && with_vals)
+            {
+                // runs longer than the in-LDS pass's tile are sorted by two segmented passes (radix_finish_long_runs_kernel)
+                GLU_TRY(s->long_image.reserve((size_t) LongRunsLayout((uint32_t) g_dev.num_cus).words * sizeof(uint32_t)));
+                GLU_TRY(s->long_hdr.reserve(64));
+                GLU_TRY(s->table.reserve(((size_t) kLongRunsMax + g_dev.num_cus) * 256 * sizeof(uint32_t)));
+            }
             if (!s->finish_hint)
             {
                 HIP_TRY(hipHostMalloc((void**) &s->finish_hint, 64));
@@ -618,6 +650,7 @@ struct PlanArgs
     uint32_t finish_geo_first = 0, finish_geo_last = 0; // tile geometries of the in-LDS pass that are enqueued (0: not such a pass)
     uint32_t finish_first_ordinary = 0, finish_num_ordinary = 0;
     uint32_t finish_seq = 0, finish_top_bit = 0, finish_key_bits = 0;
+    bool finish_long_ok = false; // runs longer than the tile go to segmented passes (sort_bits enqueues them behind the in-LDS pass)
 };
 
 // XF: this pass encodes keys on load and / or decodes them on store (first / last pass of a typed sort); every other
@@ -674,7 +707,7 @@ glu_status launch_pass(glu_radix_sort_s* s, const KeyT* src_k, const uint32_t* s
                            pa.may_skip ? pa.plan : (PassPlan*) nullptr, pa.pass);
         HIP_TRY(hipGetLastError());
     }
-    s->mark(stream);
+    s->mark(stream, true);
     if (histogram_out)
     {
         HIP_TRY(hipMemcpyAsync(histogram_out, totals, ((size_t) 1 << bits) * sizeof(uint32_t), hipMemcpyDeviceToDevice,
@@ -684,7 +717,7 @@ glu_status launch_pass(glu_radix_sort_s* s, const KeyT* src_k, const uint32_t* s
     hipLaunchKernelGGL(fused ? scatter_fused : scatter, dim3(nb), dim3(G::THREADS), sizeof(Smem), stream, src_k, src_v, dst_k,
                        dst_v, (const uint32_t*) table, (const uint32_t*) totals, (uint32_t) count, shift, mask, tiles,
                        (unsigned long long*) nullptr, xform, pa.plan, pa.pass, (uint32_t*) nullptr);
-    s->mark(stream);
+    s->mark(stream, true);
     HIP_TRY(hipGetLastError());
     return GLU_OK;
 }
@@ -832,10 +865,16 @@ glu_status launch_pass_lines(glu_radix_sort_s* s, const KeyT* src_k, const uint3
         hipLaunchKernelGGL(radix_finish_plan_kernel, dim3(kFinishPlanBlocks), dim3(1024), 0, stream, (const uint32_t*) s->finish_lengths.ptr,
                            (uint32_t*) s->finish_starts.ptr, (uint32_t) count, pa.finish_geo_first, pa.finish_geo_last, pa.plan, pa.pass,
                            pa.finish_first_ordinary, pa.finish_num_ordinary, s->finish_hint, pa.finish_seq, pa.finish_top_bit,
-                           pa.finish_key_bits);
+                           pa.finish_key_bits, pa.finish_long_ok ? 1u : 0u);
         HIP_TRY(hipGetLastError());
+        if (pa.finish_long_ok)
+        {
+            hipLaunchKernelGGL(radix_finish_long_runs_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t*) s->finish_starts.ptr,
+                               (const PassPlan*) pa.plan, usable_cus(s), (uint32_t*) s->long_image.ptr, (uint32_t*) s->long_hdr.ptr);
+            HIP_TRY(hipGetLastError());
+        }
     }
-    s->mark(stream);
+    s->mark(stream, true);
     if (histogram_out)
     {
         HIP_TRY(hipMemcpyAsync(histogram_out, totals, ((size_t) 1 << bits) * sizeof(uint32_t), hipMemcpyDeviceToDevice,
@@ -845,7 +884,7 @@ glu_status launch_pass_lines(glu_radix_sort_s* s, const KeyT* src_k, const uint3
     hipLaunchKernelGGL(scatter, dim3(nb), dim3(G::THREADS), sizeof(Smem), stream, src_k, src_v, dst_k, dst_v,
                        (const uint32_t*) table, (const uint32_t*) totals, (uint32_t) count, shift, mask, tiles,
                        (unsigned long long*) nullptr, xform, pa.plan, pa.pass, ranges, share, (const uint32_t*) nullptr, (const uint32_t*) nullptr, 0u, 0u);
-    s->mark(stream);
+    s->mark(stream, true);
     HIP_TRY(hipGetLastError());
     return GLU_OK;
 }
@@ -959,27 +998,85 @@ glu_status sort_single_block(KeyT* keys, uint32_t* vals, size_t count, uint32_t 
 // A sort that ends in LDS (radix_lds_finish.hpp): the tile geometry of its last pass that suits uniformly drawn keys -- the
 // longest of 65536 runs stays below mean + 6 sigma.  The launches of that geometry and of the next larger ones are enqueued
 // and the device picks by the longest run it counted.  0: no geometry holds such runs (more than about 2^29 pairs).
-inline uint32_t finish_geometry_for(size_t count, size_t runs = kFinishRuns)
+inline uint32_t finish_geometry_for(size_t count, size_t runs = kFinishRuns, uint32_t geometries = kFinishGeometries)
 {
     const double mean = (double) count / (double) runs;
     const double need = mean + 6.0 * std::sqrt(mean) + 8.0;
-    for (uint32_t g = 1; g <= kFinishGeometries; g++)
+    for (uint32_t g = 1; g <= geometries; g++)
         if (need <= (double) finish_geometry_capacity(g)) return g;
     return 0;
+}
+
+// More than 16 bits left to order (64-bit keys; a segmented sort by 32 bits): the rounds of the in-LDS pass rank the top 16 .. 23
+// of them and ties are repaired exactly (radix_lds_finish.hpp).  glu_radix_sort_s::finish_rank_bits.
+inline uint32_t finish_rank_from(uint32_t low_bits, uint32_t rank_bits)
+{
+    return low_bits > rank_bits ? ((low_bits - rank_bits) / 8u) * 8u : 0u;
+}
+
+// The in-LDS pass of a segmented sort, src -> dst over `nruns` runs (seg_run_plan): tile geometry `geo` (1 .. 4); split_log2 = 0: a
+// workgroup per run for the runs that fit the tile and radix_finish_ranges_kernel behind it for the longer ones; split_log2 > 0:
+// every run is split over 2^split_log2 workgroups of the ranges kernel.  Both return at once if the longest run (*gate) is
+// beyond gate_cap.
+template<int THREADS, int KPT>
+glu_status launch_seg_finish_geo(const uint32_t* src_k, const uint32_t* src_v, uint32_t* dst_k, uint32_t* dst_v, const uint32_t* starts,
+                                 uint32_t nruns, uint32_t geo, uint32_t split_log2, uint32_t low_bits, const uint32_t* gate, uint32_t gate_cap,
+                                 uint32_t rank_bits, hipStream_t stream)
+{
+    using Smem = FinishSmem<uint32_t, THREADS, KPT, true>;
+    auto sort_kernel = radix_finish_sort_kernel<uint32_t, THREADS, KPT, true, false, false>;
+    auto ranges_kernel = radix_finish_ranges_kernel<uint32_t, THREADS, KPT, true, false>;
+    static std::once_flag lds_opt_in;
+    static hipError_t lds_opt_in_result = hipSuccess;
+    std::call_once(lds_opt_in, [&] {
+        lds_opt_in_result = hipFuncSetAttribute((const void*) sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sizeof(Smem));
+        if (lds_opt_in_result == hipSuccess)
+            lds_opt_in_result = hipFuncSetAttribute((const void*) ranges_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sizeof(Smem));
+    });
+    HIP_TRY(lds_opt_in_result);
+    const uint32_t rank_from = finish_rank_from(low_bits, rank_bits);
+    if (split_log2 == 0)
+    {
+        hipLaunchKernelGGL(sort_kernel, dim3(nruns), dim3(THREADS), sizeof(Smem), stream, const_cast<uint32_t*>(src_k), const_cast<uint32_t*>(src_v),
+                           dst_k, dst_v, starts, low_bits, (const PassPlan*) nullptr, 0u, geo, 0u, nruns, gate, gate_cap, rank_from,
+                           (unsigned long long*) nullptr);
+        HIP_TRY(hipGetLastError());
+    }
+    const uint64_t items = (((uint64_t) nruns + 7u) & ~7ull) << split_log2;
+    // (the long runs alone: workgroups that loop over the runs and skip the short ones)
+    const uint32_t grid = (uint32_t) (split_log2 == 0 ? std::min<uint64_t>(items, 2048u) : items);
+    hipLaunchKernelGGL(ranges_kernel, dim3(grid), dim3(THREADS), sizeof(Smem), stream, src_k, src_v, dst_k, dst_v, starts, nruns, low_bits,
+                       rank_from, split_log2, split_log2 == 0 ? (uint32_t) (THREADS * KPT) : 0u, gate, gate_cap, 0u);
+    HIP_TRY(hipGetLastError());
+    return GLU_OK;
+}
+
+inline glu_status launch_seg_finish(const uint32_t* src_k, const uint32_t* src_v, uint32_t* dst_k, uint32_t* dst_v, const uint32_t* starts,
+                                    uint32_t nruns, uint32_t geo, uint32_t split_log2, uint32_t low_bits, const uint32_t* gate, uint32_t gate_cap,
+                                    uint32_t rank_bits, hipStream_t stream)
+{
+#define GLU_SEG_FINISH(GEO_, THREADS_, KPT_)                                                                                                 \
+    if (geo == GEO_)                                                                                                                         \
+    {                                                                                                                                        \
+        static_assert(finish_geometry_capacity(GEO_) == THREADS_ * KPT_, "geometry table");                                                  \
+        return launch_seg_finish_geo<THREADS_, KPT_>(src_k, src_v, dst_k, dst_v, starts, nruns, geo, split_log2, low_bits, gate, gate_cap, rank_bits, stream); \
+    }
+    GLU_SEG_FINISH(1, 256, 6)
+    GLU_SEG_FINISH(2, 256, 10)
+    GLU_SEG_FINISH(3, 256, 18)
+    GLU_SEG_FINISH(4, 512, 18)
+    GLU_SEG_FINISH(5, 1024, 17)
+#undef GLU_SEG_FINISH
+    return fail(GLU_ERROR_INVALID_STATE, "no such tile geometry: %u", geo);
 }
 
 template<typename KeyT, bool VALS, bool XF>
 glu_status launch_finish(KeyT* keys_a, uint32_t* vals_a, KeyT* keys_b, uint32_t* vals_b, const uint32_t* starts,
                          uint32_t geo_first, uint32_t geo_last, uint32_t geo_expected, uint32_t low_bits, const PassPlan* plan,
-                         uint32_t pass, uint32_t key_xf, hipStream_t stream, uint32_t nruns = kFinishRuns, const uint32_t* gate = nullptr)
+                         uint32_t pass, uint32_t key_xf, hipStream_t stream, uint32_t rank_bits, uint32_t nruns = kFinishRuns,
+                         const uint32_t* gate = nullptr, uint32_t gate_cap = 0)
 {
-    // More than 16 bits left to order (64-bit keys; a segmented sort by 32 bits): the rounds rank the top 16 .. 23 of them and
-    // ties are repaired exactly (radix_lds_finish.hpp).  GLU_HIP_FINISH_RANK_BITS=N (tuning): rank at least N bits (48: all).
-    static const uint32_t rank_bits = [] {
-        const char* e = getenv("GLU_HIP_FINISH_RANK_BITS");
-        return e && atoi(e) >= 8 ? (uint32_t) atoi(e) : 16u;
-    }();
-    const uint32_t rank_from = low_bits > rank_bits ? ((low_bits - rank_bits) / 8u) * 8u : 0u;
+    const uint32_t rank_from = finish_rank_from(low_bits, rank_bits);
     // the geometry the sort is expected to take gets a workgroup per run, the others 8192 workgroups that loop
 #define GLU_FINISH(GEO_, THREADS_, KPT_)                                                                                          \
     if (geo_first <= GEO_ && GEO_ <= geo_last)                                                                                    \
@@ -1000,7 +1097,7 @@ glu_status launch_finish(KeyT* keys_a, uint32_t* vals_a, KeyT* keys_b, uint32_t*
         hipLaunchKernelGGL(kern, dim3(GEO_ == geo_expected ? nruns : std::min(nruns, 8192u)), dim3(THREADS_),                     \
                            sizeof(FinishSmem<KeyT, THREADS_, KPT_, VALS>), stream,                                                \
                            keys_a, vals_a, keys_b, vals_b, starts, low_bits, plan, pass, (uint32_t) GEO_, key_xf, nruns, gate,     \
-                           geo_first, geo_last, rank_from);                                                                       \
+                           gate_cap, rank_from, (unsigned long long*) nullptr);                                                   \
         HIP_TRY(hipGetLastError());                                                                                               \
     }
     GLU_FINISH(1, 256, 6)
@@ -1021,6 +1118,44 @@ glu_status launch_finish(KeyT* keys_a, uint32_t* vals_a, KeyT* keys_b, uint32_t*
     return GLU_OK;
 }
 
+// The two segmented passes over the LONG runs of a whole-key sort that ends in LDS (radix_finish_long_runs_kernel built their
+// descriptors; hdr[0] = 0: there are none, or the sort was refused -- every kernel returns at once): key bits [0, 8) from the
+// arrays that hold the data (PassPlan::flip[2], known on the device) into the other pair, bits [8, 16) back.
+glu_status launch_long_run_passes(glu_radix_sort_s* s, uint32_t* a_k, uint32_t* a_v, uint32_t* b_k, uint32_t* b_v, size_t count, hipStream_t stream)
+{
+    using G = LinesGeometry<uint32_t, 8, true>;
+    constexpr int RADIX = 256;
+    constexpr int RS = (G::KPT + 2) / 3;
+    using Smem = LineSmem<uint32_t, 8, G::THREADS, G::KPT, true>;
+    auto scatter = radix_scatter_lines_kernel<uint32_t, 8, G::THREADS, G::KPT, false, true, 0, false, RS, true, true, 0, true>;
+    static std::once_flag lds_opt_in;
+    static hipError_t lds_opt_in_result = hipSuccess;
+    std::call_once(lds_opt_in, [&] {
+        lds_opt_in_result = hipFuncSetAttribute((const void*) scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sizeof(Smem));
+    });
+    HIP_TRY(lds_opt_in_result);
+    const uint32_t nwg = usable_cus(s);
+    const LongRunsLayout lay(nwg);
+    const uint32_t* image = (const uint32_t*) s->long_image.ptr;
+    const uint32_t* hdr = (const uint32_t*) s->long_hdr.ptr;
+    uint32_t* table = (uint32_t*) s->table.ptr;
+    const PassPlan* plan = (const PassPlan*) s->plan.ptr;
+    for (uint32_t p = 0; p < 2; p++)
+    {
+        hipLaunchKernelGGL((radix_seg_count_kernel<8, 1024>), dim3(nwg), dim3(1024), 0, stream, (const uint32_t*) a_k, (const uint2*) image,
+                           image + lay.off_first, table, p * 8u, 255u, hdr, 0u, kSegGateIfNot, (const uint32_t*) b_k, plan, 2u, p);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL((radix_seg_scan_kernel<RADIX>), dim3(kLongRunsMax), dim3(RADIX), 0, stream, table, image + lay.off_list,
+                           image + lay.off_start, hdr, 0u, kSegGateIfNot, hdr);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(scatter, dim3(nwg), dim3(G::THREADS), sizeof(Smem), stream, (const uint32_t*) a_k, (const uint32_t*) a_v, b_k, b_v,
+                           (const uint32_t*) table, (const uint32_t*) nullptr, (uint32_t) count, p * 8u, 255u, 0u, (unsigned long long*) nullptr, 0u,
+                           const_cast<PassPlan*>(plan), 2u, (const uint2*) image, p, image + lay.off_first, hdr, 0u, kSegGateIfNot);
+        HIP_TRY(hipGetLastError());
+    }
+    return GLU_OK;
+}
+
 // vals == nullptr: keys-only sort (no value traffic, no value scratch)
 template<typename KeyT>
 glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t count, uint32_t first_bit, uint32_t end_bit,
@@ -1033,14 +1168,15 @@ glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t cou
     GLU_TRY(sort_prepare(s, count, sizeof(KeyT), vals != nullptr)); // RadixSort.hpp:281 (no-op when prepared)
     s->last_planned = false; // (what glu_radix_sort_read_plan / read_finish report is about THIS sort)
     s->last_finish_attempted = false;
+    s->last_finish_long_ok = false;
 
     if (count <= single_block_limit<KeyT>() && !s->no_single_block)
     {
         s->mark(stream); // profiling: booked as one "scatter" launch (count / scan intervals are empty)
         s->mark(stream);
-        s->mark(stream);
+        s->mark(stream, true);
         GLU_TRY(sort_single_block<KeyT>(keys, vals, count, first_bit, end_bit, stream, key_xf | (key_xf << 2)));
-        s->mark(stream);
+        s->mark(stream, true);
         return GLU_OK;
     }
 
@@ -1123,6 +1259,10 @@ glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t cou
         passes[1] = PassDesc{finish_top_bit - 8u, 8u, 0u, 0};
         num_passes += 2;
     }
+    // runs longer than the tile: segmented passes over just them (4-byte untyped keys with values, all 16 low bits inside two digits)
+    const bool finish_long_ok = finish_kpt && sizeof(KeyT) == 4 && vals && key_xf == KEY_XF_NONE && s->long_runs && s->long_image.ptr &&
+                                finish_top_bit >= 16 && finish_top_bit - 16u <= 16u;
+    s->last_finish_long_ok = finish_long_ok;
     s->last_finish_top = finish_kpt ? finish_top_bit : 0u;
     s->last_finish_attempted = finish_kpt != 0;
     const uint32_t finish_last = std::min<uint32_t>(finish_kpt + 2, kFinishGeometries); // the larger tiles enqueued behind it
@@ -1180,6 +1320,7 @@ glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t cou
             }
             s->cur_kind = finish_kpt && pass < 2 ? 1 : 0;
             pa.behind_attempt = finish_kpt && pass >= 2;
+            s->cur_behind = pa.behind_attempt; // (light profiling: no events around the sequence that is expected to return at once)
             if (finish_kpt && pass == 0)
             {
                 pa.finish_geo_first = finish_kpt;
@@ -1189,6 +1330,7 @@ glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t cou
                 pa.finish_seq = s->finish_seq;
                 pa.finish_top_bit = finish_top_bit;
                 pa.finish_key_bits = end_bit;
+                pa.finish_long_ok = finish_long_ok;
             }
             GLU_TRY(dispatch_pass<KeyT>(s, kbuf[0], vbuf[0], kbuf[1], vbuf[1], count, shift, bits, nullptr, stream, xform, pa));
             {
@@ -1197,13 +1339,14 @@ glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t cou
                     // the in-LDS pass, in place on whichever pair of arrays holds the data now (returns at once if the
                     // device chose the ordinary passes, which follow)
                     s->cur_kind = 2;
+                    s->cur_behind = false;
                     s->mark(stream);
                     s->mark(stream);
-                    s->mark(stream);
+                    s->mark(stream, true);
 #define GLU_LAUNCH_FINISH(VALS_, XF_)                                                                                             \
     GLU_TRY((launch_finish<KeyT, VALS_, XF_>(kbuf[0], VALS_ ? vbuf[0] : nullptr, kbuf[1], VALS_ ? vbuf[1] : nullptr,              \
                                              (const uint32_t*) s->finish_starts.ptr, finish_kpt, finish_last, finish_expected,    \
-                                             finish_top_bit - 16u, pa.plan, 2u, key_xf, stream)))
+                                             finish_top_bit - 16u, pa.plan, 2u, key_xf, stream, s->finish_rank_bits)))
                     if (vals)
                     {
                         if (key_xf != KEY_XF_NONE) GLU_LAUNCH_FINISH(true, true);
@@ -1215,7 +1358,10 @@ glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t cou
                         else GLU_LAUNCH_FINISH(false, false);
                     }
 #undef GLU_LAUNCH_FINISH
-                    s->mark(stream);
+                    s->mark(stream, true);
+                    if constexpr (sizeof(KeyT) == 4)
+                        if (finish_long_ok)
+                            GLU_TRY(launch_long_run_passes(s, (uint32_t*) kbuf[0], vbuf[0], (uint32_t*) kbuf[1], vbuf[1], count, stream));
                 }
             }
         }
@@ -1226,6 +1372,7 @@ glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t cou
             cur ^= 1;
         }
     }
+    s->cur_behind = false;
     if (planned)
     {
         // the data is home unless an odd number of passes ran: decided and, if need be, copied on the device
@@ -1318,8 +1465,8 @@ glu_status tune_scratch_placement(glu_radix_sort_s* s, size_t count, size_t key_
     double worst = 0;
     uint32_t tried = 0;
     s->tuning = true;
-    const bool was_profiling = s->profiling;
-    s->profiling = false; // the calibration sorts are not the caller's
+    const int was_profiling = s->profiling;
+    s->profiling = 0; // the calibration sorts are not the caller's
     s->keys.release();
     s->vals.release();
     auto cleanup = [&](glu_status status) {
@@ -1461,8 +1608,8 @@ glu_status place_pair_by_measurement(glu_radix_sort_s* s, size_t count, Scratch&
     double worst = 0;
     uint32_t tried = 0;
     const auto t_begin = std::chrono::steady_clock::now();
-    const bool was_profiling = s->profiling;
-    s->profiling = false;
+    const int was_profiling = s->profiling;
+    s->profiling = 0;
     s->tuning = true; // (the sorts below must not start a search of their own)
     glu_status status = GLU_OK;
     for (size_t i = 0; i < candidates && status == GLU_OK; i++)
@@ -1636,11 +1783,11 @@ glu_status launch_seg_pass(glu_radix_sort_s* s, const uint32_t* src_k, const uin
     const uint2* subs = (const uint2*) image;
     s->mark(stream);
     hipLaunchKernelGGL((radix_seg_count_kernel<8, 1024>), dim3(img.nwg), dim3(1024), 0, stream, src_k, subs, image + img.off_first, table,
-                       shift, 255u, gate, gate_cap, gm_count);
+                       shift, 255u, gate, gate_cap, gm_count, (const uint32_t*) nullptr, (const PassPlan*) nullptr, 0u, 0u);
     HIP_TRY(hipGetLastError());
     s->mark(stream);
     hipLaunchKernelGGL((radix_seg_scan_kernel<RADIX>), dim3(img.nseg), dim3(RADIX), 0, stream, table, image + img.off_list,
-                       image + img.off_start, gate, gate_cap, gm_count);
+                       image + img.off_start, gate, gate_cap, gm_count, (const uint32_t*) nullptr);
     HIP_TRY(hipGetLastError());
     if (attempt)
     {
@@ -1648,12 +1795,12 @@ glu_status launch_seg_pass(glu_radix_sort_s* s, const uint32_t* src_k, const uin
                            image + img.off_start, img.nseg, runs_end, (uint32_t*) s->finish_starts.ptr, (uint32_t*) s->seg_gate.ptr);
         HIP_TRY(hipGetLastError());
     }
-    s->mark(stream);
+    s->mark(stream, true);
     hipLaunchKernelGGL(s->nt_stores ? scatter_nt : scatter_plain, dim3(img.nwg), dim3(G::THREADS), sizeof(Smem), stream, src_k, src_v,
                        dst_k, dst_v, (const uint32_t*) table, (const uint32_t*) nullptr, (uint32_t) count, shift, 255u, 0u,
                        (unsigned long long*) nullptr, 0u, (PassPlan*) nullptr, 0u, subs, 0u, image + img.off_first, gate, gate_cap, gate_mode);
     HIP_TRY(hipGetLastError());
-    s->mark(stream);
+    s->mark(stream, true);
     return GLU_OK;
 }
 
@@ -1707,7 +1854,8 @@ glu_status seg_run_plan(glu_radix_sort_s* s, const SegPlan& plan, uint32_t* in_k
 {
     const size_t count = plan.count;
     const uint32_t passes = plan.passes, nseg = plan.nseg;
-    GLU_TRY(sort_prepare(s, count, sizeof(uint32_t), true));
+    // (the scratch arrays are indexed like `out`: a plan with an origin -- a group of a sharded sort's rounds -- reaches further)
+    GLU_TRY(sort_prepare(s, (plan.seg_start.empty() ? 0 : (size_t) plan.seg_start[0]) + count, sizeof(uint32_t), true));
     if (plan.by_copies)
     {
         // small (or unaligned, or nothing to sort by): lay the segments out with copies, then one sort per segment
@@ -1755,38 +1903,51 @@ glu_status seg_run_plan(glu_radix_sort_s* s, const SegPlan& plan, uint32_t* in_k
     const uint32_t* image_later = image_first + first.words.size();
 
     // A segmented sort that ENDS IN LDS (radix_seg_passes.hpp, radix_lds_finish.hpp): ONE counting pass, on the top digit of the
-    // bits to sort by, straight from the caller's pieces into `out` -- after it the array is nseg x 256 runs (segment, top digit)
-    // whose starts are in the pass's scanned table -- and one pass that orders every run by the remaining low bits inside LDS, in
-    // place: 20 + 16 B per pair instead of passes x 20.  The device decides by the longest run (the gate) before the pass's
-    // scatter moves anything; the ordinary passes are enqueued behind and return at once when the attempt was accepted.  The
-    // tile geometries that are enqueued: the one that suits uniformly drawn keys (mean run + 6 sigma) and the next two larger.
+    // bits to sort by, straight from the caller's pieces into the sort's own scratch arrays -- after it the array is nseg x 256
+    // runs (segment, top digit) whose starts are in the pass's scanned table -- and one pass that orders every run by the
+    // remaining low bits inside LDS on its way into `out`: 20 + 16 B per pair instead of passes x 20.  The tile and, for long
+    // runs, the number of workgroups a run is split over follow from the run length uniformly drawn keys would give (mean + 6
+    // sigma); runs that come out longer are walked in pieces by radix_finish_ranges_kernel.  The device decides by the longest
+    // run (the gate) before the pass's scatter moves anything: beyond 32 tiles per workgroup the ordinary passes, enqueued
+    // behind, run instead (they return at once otherwise).  Needs the scratch arrays to be a third pair (in != scratch != out).
     uint32_t gate_mode = kSegGateNone, gate_cap = 0;
     const uint64_t nruns = (uint64_t) nseg * 256u;
     s->last_seg_finish_attempted = false;
-    if (s->seg_finish && s->lds_finish && passes >= 2 && plan.bits == passes * 8 && nruns <= kSegFinishMaxRuns)
+    const bool third_pair = tmp_k != in_k && tmp_k != out_k && tmp_v != in_v && tmp_v != out_v;
+    if (s->seg_finish && s->lds_finish && passes >= 2 && plan.bits == passes * 8 && nruns <= kSegFinishMaxRuns && third_pair)
     {
-        const uint32_t geo = finish_geometry_for(count, (size_t) nruns);
+        // (the runs of the LARGEST segment: segments may be of any sizes, empty ones included, and the host knows them)
+        uint64_t largest = 0;
+        for (uint32_t g = 0; g < nseg; g++) largest = std::max<uint64_t>(largest, plan.seg_start[g + 1] - plan.seg_start[g]);
+        uint32_t geo = 0, split_log2 = std::min(s->seg_split_min, s->seg_split_max);
+        for (; split_log2 <= s->seg_split_max && !geo; split_log2++)
+        {
+            geo = finish_geometry_for((size_t) (largest >> split_log2), 256u, std::min(s->seg_max_geo, kSegFinishGeometries));
+            if (split_log2 > 0 && geo > s->seg_split_geo) geo = 0; // (split runs take the tiles that share a CU four at a time)
+        }
         if (geo)
         {
-            const uint32_t geo_last = std::min<uint32_t>(geo + 2, kFinishGeometries);
+            split_log2--;
             GLU_TRY(s->finish_starts.reserve(((size_t) std::max<uint64_t>(nruns, kFinishRuns) + 1) * sizeof(uint32_t)));
             GLU_TRY(s->seg_gate.reserve(64));
-            gate_cap = finish_geometry_capacity(geo_last);
+            gate_cap = (uint32_t) std::min<uint64_t>(0xFFFFFFFFull, (uint64_t) finish_geometry_capacity(geo) * 32u << split_log2);
             const uint32_t end = (uint32_t) (plan.seg_start[0] + count);
-            GLU_TRY(launch_seg_pass(s, in_k, in_v, out_k, out_v, count, plan.bits - 8, image_first, first, stream, kSegGateIfFits, gate_cap, end));
+            s->cur_kind = 3;
+            GLU_TRY(launch_seg_pass(s, in_k, in_v, tmp_k, tmp_v, count, plan.bits - 8, image_first, first, stream, kSegGateIfFits, gate_cap, end));
             s->cur_kind = 2;
             s->mark(stream);
             s->mark(stream);
-            s->mark(stream);
-            // (the expected geometry gets a workgroup per run, the others loop: launch_finish)
-            GLU_TRY((launch_finish<uint32_t, true, false>(out_k, out_v, out_k, out_v, (const uint32_t*) s->finish_starts.ptr, geo, geo_last, geo,
-                                                          plan.bits - 8, nullptr, 0u, 0u, stream, (uint32_t) nruns, (const uint32_t*) s->seg_gate.ptr)));
-            s->mark(stream);
+            s->mark(stream, true);
+            GLU_TRY(launch_seg_finish(tmp_k, tmp_v, out_k, out_v, (const uint32_t*) s->finish_starts.ptr, (uint32_t) nruns, geo, split_log2,
+                                      plan.bits - 8, (const uint32_t*) s->seg_gate.ptr, gate_cap, s->finish_rank_bits, stream));
+            s->mark(stream, true);
             s->cur_kind = 0;
             gate_mode = kSegGateIfNot;
             s->last_seg_finish_attempted = true;
             s->last_seg_finish_capacity = gate_cap;
             s->last_seg_finish_runs = (uint32_t) nruns;
+            s->last_seg_finish_tile = finish_geometry_capacity(geo);
+            s->last_seg_finish_split = 1u << split_log2;
         }
     }
 
@@ -1799,11 +1960,15 @@ glu_status seg_run_plan(glu_radix_sort_s* s, const SegPlan& plan, uint32_t* in_k
         const bool last = p + 1 == passes;
         uint32_t* dst_k = last ? out_k : (src_k == in_k ? ((passes & 1u) ? out_k : tmp_k) : in_k);
         uint32_t* dst_v = last ? out_v : (src_v == in_v ? ((passes & 1u) ? out_v : tmp_v) : in_v);
+        s->cur_kind = gate_mode == kSegGateIfNot ? 4 : 0;
+        s->cur_behind = gate_mode == kSegGateIfNot;
         GLU_TRY(launch_seg_pass(s, src_k, src_v, dst_k, dst_v, count, p * 8, p == 0 ? image_first : image_later,
                                 p == 0 ? first : later, stream, gate_mode, gate_cap));
         src_k = dst_k;
         src_v = dst_v;
     }
+    s->cur_kind = 0;
+    s->cur_behind = false;
     return GLU_OK;
 }
 } // namespace
@@ -1837,6 +2002,13 @@ glu_status glu_radix_sort_create(glu_radix_sort* out)
     if (const char* e = getenv("GLU_HIP_SORT_PAIR_MIN")) s->pair_min = (size_t) atoll(e);
     if (const char* e = getenv("GLU_HIP_SORT_LDS_FINISH")) s->lds_finish = atoi(e) != 0;
     if (const char* e = getenv("GLU_HIP_SEG_LDS_FINISH")) s->seg_finish = atoi(e) != 0;
+    if (const char* e = getenv("GLU_HIP_SORT_LONG_RUNS")) s->long_runs = atoi(e) != 0;
+    if (const char* e = getenv("GLU_HIP_SEG_SPLIT_MAX")) s->seg_split_max = (uint32_t) std::min(std::max(atoi(e), 0), 3);
+    if (const char* e = getenv("GLU_HIP_FINISH_RANK_BITS"))
+        if (atoi(e) >= 8) s->finish_rank_bits = (uint32_t) atoi(e);
+    if (const char* e = getenv("GLU_HIP_SEG_SPLIT_MIN")) s->seg_split_min = (uint32_t) std::min(std::max(atoi(e), 0), 3);
+    if (const char* e = getenv("GLU_HIP_SEG_MAX_GEO")) s->seg_max_geo = (uint32_t) std::min(std::max(atoi(e), 1), 5);
+    if (const char* e = getenv("GLU_HIP_SEG_SPLIT_GEO")) s->seg_split_geo = (uint32_t) std::min(std::max(atoi(e), 1), 4);
     if (const char* e = getenv("GLU_HIP_SORT_FINISH_MIN")) s->finish_min = (size_t) atoll(e);
     if (const char* e = getenv("GLU_HIP_SORT_FINISH_BACKOFF")) s->finish_backoff = (uint32_t) std::max(0, atoi(e));
     if (const char* e = getenv("GLU_HIP_SORT_PAIR_UNIT_DIV"))
@@ -1858,7 +2030,7 @@ glu_status glu_radix_sort_destroy(glu_radix_sort sort)
     // library queue, before its scratch goes away (RAII of the reference: RadixSort.hpp:194-200, gl_utils.hpp:184-188)
     (void) hipDeviceSynchronize();
     for (Scratch* sc : {&sort->keys, &sort->vals, &sort->table, &sort->plan, &sort->pair_t2, &sort->pair_table, &sort->pair_ranges,
-                        &sort->pair_sub, &sort->seg_desc, &sort->seg_zero, &sort->finish_lengths, &sort->finish_starts, &sort->seg_gate})
+                        &sort->pair_sub, &sort->seg_desc, &sort->seg_zero, &sort->finish_lengths, &sort->finish_starts, &sort->seg_gate, &sort->long_image, &sort->long_hdr})
         sc->release();
     if (sort->finish_hint) (void) hipHostFree(sort->finish_hint);
     for (hipEvent_t e : sort->events) (void) hipEventDestroy(e);
@@ -2144,8 +2316,8 @@ glu_status glu_radix_sort_set_profiling(glu_radix_sort sort, int enable)
 {
     GLU_TRY(enter());
     if (!sort) return fail(GLU_ERROR_INVALID_ARGUMENT, "sort is NULL");
-    sort->profiling = enable != 0;
-    if (!enable) sort->events_used = 0;
+    sort->profiling = enable == 2 ? 2 : (enable != 0 ? 1 : 0);
+    if (!enable) sort->events_used = 0, sort->slots.clear(), sort->pass_kinds.clear();
     return GLU_OK;
 }
 
@@ -2188,7 +2360,7 @@ glu_status glu_radix_sort_plan_finish(size_t count, uint32_t key_bytes, uint32_t
 }
 
 glu_status glu_radix_sort_read_seg_finish(glu_radix_sort sort, uint32_t* attempted, uint32_t* accepted, uint32_t* longest_run,
-                                          uint32_t* capacity, uint32_t* runs)
+                                          uint32_t* capacity, uint32_t* runs, uint32_t* tile, uint32_t* split)
 {
     GLU_TRY(enter());
     if (!sort) return fail(GLU_ERROR_INVALID_ARGUMENT, "sort is NULL");
@@ -2200,6 +2372,21 @@ glu_status glu_radix_sort_read_seg_finish(glu_radix_sort sort, uint32_t* attempt
     if (longest_run) *longest_run = longest;
     if (capacity) *capacity = tried ? sort->last_seg_finish_capacity : 0u;
     if (runs) *runs = tried ? sort->last_seg_finish_runs : 0u;
+    if (tile) *tile = tried ? sort->last_seg_finish_tile : 0u;
+    if (split) *split = tried ? sort->last_seg_finish_split : 0u;
+    return GLU_OK;
+}
+
+glu_status glu_radix_sort_read_long_runs(glu_radix_sort sort, uint32_t* runs, uint32_t* sub_blocks, uint32_t* pairs)
+{
+    GLU_TRY(enter());
+    if (!sort) return fail(GLU_ERROR_INVALID_ARGUMENT, "sort is NULL");
+    uint32_t hdr[3] = {0, 0, 0};
+    const bool tried = sort->plan.ptr && sort->last_planned && sort->last_finish_attempted && sort->last_finish_long_ok && sort->long_hdr.ptr;
+    if (tried) HIP_TRY(hipMemcpy(hdr, sort->long_hdr.ptr, sizeof(hdr), hipMemcpyDeviceToHost));
+    if (runs) *runs = hdr[0];
+    if (sub_blocks) *sub_blocks = hdr[1];
+    if (pairs) *pairs = hdr[2];
     return GLU_OK;
 }
 
@@ -2234,8 +2421,8 @@ glu_status read_profile_impl(glu_radix_sort sort, double* count_ms, double* scan
     if (!sort) return fail(GLU_ERROR_INVALID_ARGUMENT, "sort is NULL");
     double acc[3] = {0, 0, 0}, fin = 0;
     uint64_t live = 0, fin_n = 0;
-    const size_t n = sort->events_used / 4;
-    if (n > 0) HIP_TRY(hipEventSynchronize(sort->events[n * 4 - 1]));
+    const size_t n = sort->slots.size() / 4;
+    if (sort->events_used > 0) HIP_TRY(hipEventSynchronize(sort->events[sort->events_used - 1]));
     bool accepted = false;
     if (sort->last_planned && sort->last_finish_attempted && sort->plan.ptr)
     {
@@ -2243,16 +2430,31 @@ glu_status read_profile_impl(glu_radix_sort sort, double* count_ms, double* scan
         HIP_TRY(hipMemcpy(&host, sort->plan.ptr, sizeof(host), hipMemcpyDeviceToHost));
         accepted = host.finish != 0;
     }
+    bool seg_accepted = false;
+    if (sort->last_seg_finish_attempted && sort->seg_gate.ptr)
+    {
+        uint32_t longest = 0;
+        HIP_TRY(hipMemcpy(&longest, sort->seg_gate.ptr, sizeof(longest), hipMemcpyDeviceToHost));
+        seg_accepted = longest <= sort->last_seg_finish_capacity;
+    }
     for (size_t p = 0; p < n; p++)
     {
         float ms[3] = {0.f, 0.f, 0.f};
-        for (int k = 0; k < 3; k++) HIP_TRY(hipEventElapsedTime(&ms[k], sort->events[p * 4 + k], sort->events[p * 4 + k + 1]));
+        for (int k = 0; k < 3; k++) // (light profiling: an interval without both of its events reads as zero)
+            if (sort->slots[p * 4 + k] && sort->slots[p * 4 + k + 1])
+                HIP_TRY(hipEventElapsedTime(&ms[k], sort->slots[p * 4 + k], sort->slots[p * 4 + k + 1]));
         const uint8_t kind = p < sort->pass_kinds.size() ? sort->pass_kinds[p] : 0;
         if (kind == 2)
         {
-            if (accepted) fin += ms[2], fin_n++;
+            if (accepted || seg_accepted) fin += ms[2], fin_n++;
             continue;
         }
+        if (kind == 3 && !seg_accepted)
+        {
+            acc[0] += ms[0], acc[1] += ms[1]; // its count and scan ran before the device said no
+            continue;
+        }
+        if (kind == 4 && seg_accepted) continue; // the sequence not taken
         if (kind == 1 && !accepted)
         {
             acc[0] += ms[0]; // the leader's count kernel ran before the device said no
@@ -2263,6 +2465,7 @@ glu_status read_profile_impl(glu_radix_sort sort, double* count_ms, double* scan
         live++;
     }
     sort->events_used = 0;
+    sort->slots.clear();
     sort->pass_kinds.clear();
     if (count_ms) *count_ms = acc[0];
     if (scan_ms) *scan_ms = acc[1];
@@ -2301,7 +2504,7 @@ glu_status glu_radix_sort_scratch_size(glu_radix_sort sort, size_t* bytes)
     if (!sort || !bytes) return fail(GLU_ERROR_INVALID_ARGUMENT, "NULL argument");
     *bytes = sort->keys.size + sort->vals.size + sort->table.size + sort->plan.size + sort->pair_t2.size + sort->pair_table.size +
              sort->pair_ranges.size + sort->pair_sub.size + sort->seg_desc.size + sort->seg_zero.size + sort->finish_lengths.size +
-             sort->finish_starts.size + sort->seg_gate.size;
+             sort->finish_starts.size + sort->seg_gate.size + sort->long_image.size + sort->long_hdr.size;
     return GLU_OK;
 }
 

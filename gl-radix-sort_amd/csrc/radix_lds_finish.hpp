@@ -80,9 +80,12 @@ constexpr uint32_t kFinishPlanBlocks = kFinishRuns / 1024;
 // tile geometries of the in-LDS pass: 1 = 256 threads x 6 pairs, 2 = 256 x 10, 3 = 256 x 18 (39 KiB of LDS: four workgroups per
 // CU), 4 = 512 x 18 (78 KiB: two per CU, the largest that still overlaps one run's memory time with another's ranking)
 constexpr uint32_t kFinishGeometries = 4;
+// (segmented sorts only, round 5) 5 = 1024 x 17: 147 KiB, ONE workgroup per CU -- nothing overlaps one run's memory time there, but
+// the runs of the sharded sort at eight ranks (16384 pairs) fit it whole
+constexpr uint32_t kSegFinishGeometries = 5;
 __host__ __device__ constexpr uint32_t finish_geometry_capacity(uint32_t g)
 {
-    return g == 1 ? 256u * 6u : g == 2 ? 256u * 10u : g == 3 ? 256u * 18u : g == 4 ? 512u * 18u : 0u;
+    return g == 1 ? 256u * 6u : g == 2 ? 256u * 10u : g == 3 ? 256u * 18u : g == 4 ? 512u * 18u : g == 5 ? 1024u * 17u : 0u;
 }
 // the smallest of the enqueued tile geometries [geo_first, geo_last] that holds the longest run (0: none does)
 __host__ __device__ inline uint32_t finish_geometry_choice(uint32_t longest, uint32_t geo_first, uint32_t geo_last)
@@ -92,17 +95,26 @@ __host__ __device__ inline uint32_t finish_geometry_choice(uint32_t longest, uin
         if (longest <= finish_geometry_capacity(g)) geo = g;
     return geo;
 }
+// long_ok (round 5: 4-byte untyped keys with values): runs LONGER than the chosen tile do not refuse the sort any more -- they
+// are segments for two segmented counting passes over just their elements (radix_finish_long_runs_kernel builds the
+// descriptors on the device, radix_seg_passes.hpp the passes), the in-LDS pass leaves them alone.  The tile is then the smallest
+// enqueued one that leaves at most kLongRunsMax runs and an eighth of the pairs to those passes; failing that the largest one,
+// if it leaves at most half of the pairs; failing that the sort is refused as before (keys crowded into few runs are better off
+// with the ordinary passes and their skipping of constant digits).
+constexpr uint32_t kLongRunsMax = 8192;
 __global__ __launch_bounds__(1024) void radix_finish_plan_kernel(const uint32_t* __restrict__ lengths, uint32_t* __restrict__ starts,
                                                                  uint32_t n, uint32_t geo_first, uint32_t geo_last, PassPlan* plan,
                                                                  uint32_t pass,
                                                                  uint32_t first_ordinary, uint32_t num_ordinary,
                                                                  uint32_t* hint, uint32_t attempt, uint32_t top_bit,
-                                                                 uint32_t key_bits)
+                                                                 uint32_t key_bits, uint32_t long_ok)
 {
     __shared__ uint32_t tmp[3][16];
+    __shared__ uint32_t over_tmp[2][kFinishGeometries][16];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
     const bool tables = !(plan->off[pass] || plan->skip[pass] == kSkipWithoutCounting); // (kernel-uniform)
     uint32_t before = 0, all = 0, longest = 0, mine = 0;
+    uint32_t over_len[kFinishGeometries] = {}, over_cnt[kFinishGeometries] = {}; // per tile geometry: pairs in / number of longer runs
     if (tables)
     {
 #pragma unroll 8
@@ -113,6 +125,16 @@ __global__ __launch_bounds__(1024) void radix_finish_plan_kernel(const uint32_t*
             before += j < b ? v : 0u;
             longest = max(longest, v);
             mine = j == b ? v : mine;
+            if (long_ok)
+            {
+#pragma unroll
+                for (uint32_t g = 0; g < kFinishGeometries; g++)
+                {
+                    const bool over = v > finish_geometry_capacity(g + 1);
+                    over_len[g] += over ? v : 0u;
+                    over_cnt[g] += over ? 1u : 0u;
+                }
+            }
         }
     }
     uint32_t wtotal;
@@ -123,6 +145,20 @@ __global__ __launch_bounds__(1024) void radix_finish_plan_kernel(const uint32_t*
         before += __shfl_xor(before, o);
         all += __shfl_xor(all, o);
         longest = max(longest, (uint32_t) __shfl_xor(longest, o));
+    }
+    if (long_ok)
+    {
+#pragma unroll
+        for (uint32_t g = 0; g < kFinishGeometries; g++)
+        {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1)
+            {
+                over_len[g] += __shfl_xor(over_len[g], o);
+                over_cnt[g] += __shfl_xor(over_cnt[g], o);
+            }
+            if (lane == 0) over_tmp[0][g][wave] = over_len[g], over_tmp[1][g][wave] = over_cnt[g];
+        }
     }
     if (lane == 0) tmp[0][wave] = before, tmp[1][wave] = all, tmp[2][wave] = longest;
     __shared__ uint32_t wsum[16];
@@ -137,7 +173,21 @@ __global__ __launch_bounds__(1024) void radix_finish_plan_kernel(const uint32_t*
         longest = max(longest, tmp[2][w]);
         if ((uint32_t) w < wave) excl += wsum[w];
     }
-    const uint32_t geo = finish_geometry_choice(longest, geo_first, geo_last);
+    uint32_t geo = finish_geometry_choice(longest, geo_first, geo_last);
+    if (long_ok && geo != geo_first && geo_first >= 1)
+    {
+        // (some run outgrows the tile that suits uniform keys: may it, and a few others, go to the segmented passes instead?)
+        uint32_t pick = 0;
+        for (uint32_t g = geo_last; g >= geo_first; g--)
+        {
+            uint32_t ol = 0, oc = 0;
+            for (int w = 0; w < 16; w++) ol += over_tmp[0][g - 1][w], oc += over_tmp[1][g - 1][w];
+            const bool few = oc <= kLongRunsMax && ol <= n / 8u;
+            const bool tolerable = g == geo_last && oc <= kLongRunsMax && ol <= n / 2u;
+            if (few || (tolerable && pick == 0)) pick = g;
+        }
+        if (pick) geo = geo == 0 ? pick : min(geo, pick);
+    }
     // The runs are the values of key bits [top_bit - 16, top_bit): that orders the keys only if no key bit from top_bit up
     // varies -- the host assumed so from what this object's last sort saw, the count kernel of this one has looked
     // (PassPlan::bits_or / bits_nor).  Typed keys and sorts that do not collect the bits are launched with top_bit = key_bits.
@@ -178,6 +228,131 @@ __global__ __launch_bounds__(1024) void radix_finish_plan_kernel(const uint32_t*
         }
     }
     if (b == 0 && accept && tid < num_ordinary) plan->off[first_ordinary + tid] = 1;
+}
+
+// The runs longer than the tile the plan chose, as SEGMENTS of segmented passes (radix_seg_passes.hpp): the descriptor image
+// the host builds for the sharded sort's local sort (seg_build_image in glu_hip.hip), built on the device from the run starts.
+// The long runs laid end to end are cut into nwg equal shares, a sub-block is the part of one run inside one share:
+//   image + 0:          subs[kLongRunsMax + nwg] (begin, end) element ranges, in the order of the runs
+//   image + off_first:  seg_first[nwg + 1]       first sub-block of every workgroup's share
+//   image + off_list:   seg_list[kLongRunsMax + 1]  first sub-block of every long run
+//   image + off_start:  seg_start[kLongRunsMax]     where the run starts (it stays where it is)
+//   hdr[0] = number of long runs (0: none, or the sort does not end in LDS: the segmented kernels return at once), hdr[1] = sub-blocks,
+//   hdr[2] = pairs in long runs
+// One workgroup; thread t owns the runs [64 t, 64 t + 64).
+struct LongRunsLayout
+{
+    uint32_t nwg, off_first, off_list, off_start, words;
+    __host__ __device__ explicit LongRunsLayout(uint32_t nwg_) : nwg(nwg_)
+    {
+        off_first = 2u * (kLongRunsMax + nwg);
+        off_list = off_first + nwg + 1u;
+        off_start = off_list + kLongRunsMax + 1u;
+        words = off_start + kLongRunsMax;
+    }
+};
+__global__ __launch_bounds__(1024) void radix_finish_long_runs_kernel(const uint32_t* __restrict__ starts, const PassPlan* plan,
+                                                                      uint32_t nwg, uint32_t* __restrict__ image, uint32_t* __restrict__ hdr)
+{
+    const LongRunsLayout lay(nwg);
+    __shared__ uint32_t wsum[2][16];
+    __shared__ uint32_t totals[2];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t geo = plan->finish;
+    const uint32_t cap = finish_geometry_capacity(geo);
+    constexpr uint32_t PER = kFinishRuns / 1024;
+    // (every workgroup's share starts empty; the sub-block that begins at a share's first position fills it in)
+    for (uint32_t w = tid; w <= nwg; w += 1024) image[lay.off_first + w] = 0xFFFFFFFFu;
+    uint32_t cnt = 0, len = 0;
+    if (geo != 0)
+    {
+        uint32_t a = starts[tid * PER];
+        for (uint32_t j = 0; j < PER; j++)
+        {
+            const uint32_t e = starts[tid * PER + j + 1];
+            if (e - a > cap) cnt++, len += e - a;
+            a = e;
+        }
+    }
+    auto block_exclusive = [&](uint32_t v, int slot, uint32_t& total) -> uint32_t {
+        uint32_t wtotal;
+        uint32_t excl = wave_exclusive_sum(v, lane, wtotal);
+        if (lane == 0) wsum[slot][wave] = wtotal;
+        __syncthreads();
+        total = 0;
+        for (uint32_t w = 0; w < 16; w++)
+        {
+            excl += w < wave ? wsum[slot][w] : 0u;
+            total += wsum[slot][w];
+        }
+        return excl;
+    };
+    uint32_t nseg, total;
+    uint32_t seg = block_exclusive(cnt, 0, nseg);
+    uint32_t pos = block_exclusive(len, 1, total);
+    // (the plan kernel allowed at most kLongRunsMax long runs; a sort that did not ask for this has none that are not refused)
+    const bool active = geo != 0 && nseg != 0 && nseg <= kLongRunsMax;
+    if (tid == 0)
+    {
+        hdr[0] = active ? nseg : 0u;
+        hdr[2] = active ? total : 0u;
+    }
+    __syncthreads();
+    if (!active) // (workgroup-uniform)
+    {
+        if (tid == 0) hdr[1] = 0u;
+        return;
+    }
+    const uint32_t share = (total + nwg - 1) / nwg; // >= cap / nwg > 0
+    // sub-blocks of this thread's long runs, then their numbers
+    uint32_t subs = 0;
+    {
+        uint32_t a = starts[tid * PER], p = pos;
+        for (uint32_t j = 0; j < PER; j++)
+        {
+            const uint32_t e = starts[tid * PER + j + 1], l = e - a;
+            if (l > cap)
+            {
+                subs += (p + l - 1) / share - p / share + 1;
+                p += l;
+            }
+            a = e;
+        }
+    }
+    uint32_t nsb;
+    uint32_t sb = block_exclusive(subs, 0, nsb);
+    {
+        uint32_t a = starts[tid * PER], p = pos, g = seg;
+        for (uint32_t j = 0; j < PER; j++)
+        {
+            const uint32_t e = starts[tid * PER + j + 1], l = e - a;
+            if (l > cap)
+            {
+                image[lay.off_list + g] = sb;
+                image[lay.off_start + g] = a;
+                for (uint32_t w = p / share; w <= (p + l - 1) / share; w++)
+                {
+                    const uint32_t b0 = max(p, w * share), b1 = min(p + l, (w + 1) * share);
+                    image[2 * sb] = a + (b0 - p);
+                    image[2 * sb + 1] = a + (b1 - p);
+                    if (b0 == w * share) image[lay.off_first + w] = sb; // (this sub-block begins workgroup w's share)
+                    sb++;
+                }
+                p += l;
+                g++;
+            }
+            a = e;
+        }
+    }
+    __syncthreads();
+    if (tid == 0)
+    {
+        hdr[1] = nsb;
+        image[lay.off_list + nseg] = nsb;
+    }
+    // shares behind the last pair (total < nwg * share) are empty: they begin and end at nsb
+    for (uint32_t w = tid; w <= nwg; w += 1024)
+        if (image[lay.off_first + w] == 0xFFFFFFFFu) image[lay.off_first + w] = nsb;
 }
 
 // The stage of 64-bit keys: only the low 48 key bits differ inside a run (the bits above are the run's, or constant over the
@@ -237,25 +412,18 @@ struct FinishSmem
 };
 static_assert(sizeof(FinishSmem<uint32_t, 256, 18, true>) <= 40 * 1024, "four workgroups per CU");
 static_assert(sizeof(FinishSmem<uint32_t, 512, 18, true>) <= 80 * 1024, "two workgroups per CU");
+static_assert(sizeof(FinishSmem<uint32_t, 1024, 17, true>) <= 160 * 1024 - 256, "one workgroup per CU");
 static_assert(sizeof(FinishSmem<uint64_t, 512, 9, true>) <= 53 * 1024, "64-bit keys: three workgroups per CU");
 
 // the longest run a workgroup of this geometry takes
 template<int THREADS, int KPT>
 constexpr uint32_t finish_capacity() { return (uint32_t) (THREADS * KPT); }
 
-// A workgroup per run r: pairs [starts[r], starts[r + 1]) of the arrays that hold the data after pass `pass`
-// - 1 (PassPlan::flip[pass]) are ordered by key bits [0, low_bits), stably, in place.  Wave-striped items, wave-private
-// running digit counters, one scan over (digit, wave), staging in ranked order: the body of radix_sort_single_block_kernel.
-// Every wave takes an equal share of the run (a multiple of 64 slots) and ranks only the items its share has -- a run of
-// 4096 pairs costs 16 items per lane, not the 18 the longest run needs.  Slots past the run's end hold the key ~0 (largest
-// digit in every round, behind every real pair in input order); their loads read the run's last element instead of being
-// predicated, so that all loads of a lane are in flight at once.
-// 64-bit keys: the same with 8-byte keys in registers and LDS and six rounds for the low 48 bits (low_bits = 48).
-// LOOP = false: launched with a workgroup per run (the hardware's dispatcher is the loop over the runs, and the next workgroup
-// starts while this one drains its stores: 0.96-0.99 ms for 2^28 pairs where a loop inside the kernel takes 1.05-1.16).  LOOP =
-// true: fewer workgroups, each takes every gridDim.x-th run -- for the geometries that are enqueued besides the expected one:
-// 65536 workgroups that return at once cost 15-29 us, 8192 cost 5.
-// XF: typed keys (signed integers, floats): the first top-bit pass encoded them on load, this pass decodes them on store.
+// The rounds of the in-LDS pass on what a workgroup holds in registers: `items` wave-striped items per lane (key[i], val[i] =
+// slot wave_off + i * 64 of the tile; slots from `len` on are pads: key ~0, behind every real pair), ordered stably by the key
+// bits [0, low_bits) -- on return key[i], val[i] are slot wave_off + i * 64 of the ORDERED tile.  Rounds of 8 bits of rank /
+// scan / re-stage as in radix_sort_single_block_kernel: ballot ranking against wave-private digit counters, one scan over
+// (digit, wave), staging in ranked order.
 //
 // rank_from > 0 (keys with more than 16 bits left to order: 64-bit keys, a segmented sort by 32 bits): the rounds rank only the
 // key bits [rank_from, low_bits) -- the TOP of what is left, two rounds instead of six for 64-bit keys -- which orders the run
@@ -266,61 +434,58 @@ constexpr uint32_t finish_capacity() { return (uint32_t) (THREADS * KPT); }
 // longer than kTieMaxGroup, a walk of more than kTieMaxBack steps or more groups than the list holds mark the run as one that
 // does not suit this (keys that crowd on the ranked bits): the workgroup then runs ALL rounds, [0, low_bits), on what is staged --
 // a stable permutation of the run, so the result is the same.  Groups of EQUAL keys of any length need no repair and cost nothing.
-//
-// Two callers.  The whole-key sort (plan != nullptr): 65536 runs, the geometry and the arrays come from the PassPlan.  The
-// segmented sort (plan == nullptr, radix_seg_passes.hpp: the local sort of the sharded sort): `nruns` runs of (segment, top
-// digit of the low bits) in keys_a / vals_a, and the geometry follows from the longest run the runs kernel found (*gate):
-// the smallest of [geo_first, geo_last] that holds it; none does: the kernel returns, the ordinary segmented passes run.
-template<typename KeyT, int THREADS, int KPT, bool VALS, bool LOOP, bool XF = false>
-__global__ __launch_bounds__(THREADS) void radix_finish_sort_kernel(KeyT* keys_a, uint32_t* vals_a, KeyT* keys_b,
-                                                                    uint32_t* vals_b, const uint32_t* __restrict__ starts,
-                                                                    uint32_t low_bits, const PassPlan* plan, uint32_t pass,
-                                                                    uint32_t geometry, uint32_t key_xf = 0,
-                                                                    uint32_t nruns = kFinishRuns, const uint32_t* gate = nullptr,
-                                                                    uint32_t geo_first = 0, uint32_t geo_last = 0,
-                                                                    uint32_t rank_from = 0)
+// Phase clock of the in-LDS pass (tools/finish_stamps_bench.hip builds the STAMPS = true instantiation; the library does not):
+// s_memtime at phase boundaries, summed per phase by the first and the last wave of every workgroup into the workgroup's own 16
+// words of `out` (plain stores: atomics on shared words slow the very loads that are being timed).
+//   0 load issue -> keys and values in registers (first barrier)   1 ranking (ballots)   2 offsets scan
+//   3 staging (put, barrier, get)   4 tie detection + repair   5 store issue   6 (spare)   7 whole workgroup
+template<bool STAMPS>
+struct FinishClock
 {
-    const KeyCodec<KeyT, XF> codec_out(key_xf);
-    // (kernel-uniform: the device chose another geometry, or the ordinary passes)
-    if (plan ? plan->finish != geometry : finish_geometry_choice(*gate, geo_first, geo_last) != geometry) return;
+    unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = 0, t0 = 0;
+    __device__ __forceinline__ void start()
+    {
+        if (STAMPS) tprev = t0 = __builtin_amdgcn_s_memtime();
+    }
+    __device__ __forceinline__ void stamp(int slot)
+    {
+        if (STAMPS)
+        {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            acc[slot] += t - tprev;
+            tprev = t;
+        }
+    }
+    __device__ __forceinline__ void flush(unsigned long long* out, uint32_t lane, uint32_t wave, uint32_t waves)
+    {
+        if (STAMPS && out && lane == 0 && (wave == 0 || wave == waves - 1))
+        {
+            acc[7] = __builtin_amdgcn_s_memtime() - t0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) out[(size_t) blockIdx.x * 16 + (wave == 0 ? 0 : 8) + i] = acc[i];
+        }
+    }
+};
+
+// TIES = false (4-byte keys: at most 24 bits are ever left, and the repair's registers would cost the 256 x 18 tile its fourth
+// workgroup per CU): every round runs, rank_from is not looked at.
+template<typename KeyT, int THREADS, int KPT, bool VALS, bool TIES = (sizeof(KeyT) == 8), bool STAMPS = false>
+__device__ __forceinline__ void finish_rank_rounds(FinishSmem<KeyT, THREADS, KPT, VALS>& s, KeyT (&key)[KPT], uint32_t (&val)[KPT],
+                                                   uint32_t items, uint32_t len, uint32_t wave_off, uint32_t low_bits,
+                                                   uint32_t rank_from_arg, KeyT run_top, uint32_t tid, uint32_t lane, uint32_t wave,
+                                                   FinishClock<STAMPS>& clock)
+{
+    const uint32_t rank_from = TIES ? rank_from_arg : 0u;
     using Smem = FinishSmem<KeyT, THREADS, KPT, VALS>;
     constexpr int RADIX = Smem::RADIX;
     constexpr int WAVES = Smem::WAVES;
-    constexpr int WQ = WAVES / 4;
+    // the offsets scan: a thread per (digit, group of GW waves' counters); GW = 4 where the waves come in fours, else all
+    constexpr int GW = WAVES % 4 == 0 ? 4 : WAVES;
+    constexpr int WQ = WAVES / GW;
     constexpr int SCAN_THREADS = RADIX * WQ;
     constexpr int SCAN_WAVES = (SCAN_THREADS + kWave - 1) / kWave;
-    static_assert(WAVES % 4 == 0 && SCAN_THREADS <= THREADS, "offset scan geometry");
-
-    KeyT* keys = plan && plan->flip[pass] ? keys_b : keys_a;
-    uint32_t* vals = plan && plan->flip[pass] ? vals_b : vals_a;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    Smem& s = *reinterpret_cast<Smem*>(smem_raw);
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (uint32_t run = blockIdx.x; run < nruns; run += LOOP ? gridDim.x : nruns)
-    {
-    const uint32_t begin = starts[run], end = starts[run + 1];
-    const uint32_t len = end - begin;
-    if (len == 0 || (!XF && len == 1)) continue; // (workgroup-uniform; a single typed key still has to be decoded)
-    // (64-bit keys: the key bits from 48 up, the same for every pair of the run -- and of a pad that comes back from the stage)
-    const KeyT run_top = sizeof(KeyT) == 8 ? (KeyT) (keys[begin] & (KeyT) 0xFFFF000000000000ull) : (KeyT) 0;
-    const uint32_t share = ((len + WAVES * kWave - 1) / (WAVES * kWave)) * kWave; // slots per wave: <= kWave * KPT
-    const uint32_t items = share / kWave;
-    const uint32_t wave_off = wave * share + lane;
-
-    KeyT key[KPT];
-    uint32_t val[KPT];
-#pragma unroll
-    for (int i = 0; i < KPT; i++)
-    {
-        const uint32_t p = wave_off + i * kWave;
-        const bool ok = p < len;
-        const uint32_t pc = ok ? p : len - 1;
-        const KeyT k = keys[begin + pc];
-        const uint32_t v = VALS ? vals[begin + pc] : 0u;
-        key[i] = ok ? k : (KeyT) ~(KeyT) 0;
-        val[i] = ok ? v : 0u;
-    }
-
+    static_assert(SCAN_THREADS <= THREADS, "offset scan geometry");
     uint16_t* my_cnt = s.wcnt[wave];
     // (workgroup-uniform) the first attempt ranks [rank_from, low_bits) and repairs ties; if the run does not suit that, the
     // second ranks everything
@@ -332,6 +497,7 @@ __global__ __launch_bounds__(THREADS) void radix_finish_sort_kernel(KeyT* keys_a
         constexpr uint32_t MASK = 255u;
         for (int i = tid; i < WAVES * RADIX / 2; i += THREADS) reinterpret_cast<uint32_t*>(&s.wcnt[0][0])[i] = 0;
         __syncthreads();
+        clock.stamp(shift == shift_begin && shift_begin == rank_from ? 0 : 3);
 
         uint32_t rank[KPT];
 #pragma unroll
@@ -358,22 +524,23 @@ __global__ __launch_bounds__(THREADS) void radix_finish_sort_kernel(KeyT* keys_a
             *cnt = (uint16_t) (prev + total);
         }
         __syncthreads();
+        clock.stamp(1);
 
         {
-            const uint32_t sd = tid / WQ, sw = (tid % WQ) * 4;
-            uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-            if (tid < SCAN_THREADS)
+            const uint32_t sd = tid / WQ, sw = (tid % WQ) * GW;
+            uint32_t c[GW];
+            uint32_t csum = 0;
+#pragma unroll
+            for (int g = 0; g < GW; g++)
             {
-                c0 = s.wcnt[sw + 0][sd];
-                c1 = s.wcnt[sw + 1][sd];
-                c2 = s.wcnt[sw + 2][sd];
-                c3 = s.wcnt[sw + 3][sd];
+                c[g] = tid < SCAN_THREADS ? (uint32_t) s.wcnt[sw + g][sd] : 0u;
+                csum += c[g];
             }
             uint32_t excl = 0;
             if (wave < SCAN_WAVES)
             {
                 uint32_t wtotal;
-                excl = wave_exclusive_sum(c0 + c1 + c2 + c3, lane, wtotal);
+                excl = wave_exclusive_sum(csum, lane, wtotal);
                 if (SCAN_WAVES > 1 && lane == 0) s.scan_tmp[wave] = wtotal;
             }
             if (SCAN_WAVES > 1)
@@ -383,13 +550,16 @@ __global__ __launch_bounds__(THREADS) void radix_finish_sort_kernel(KeyT* keys_a
             }
             if (tid < SCAN_THREADS)
             {
-                s.wcnt[sw + 0][sd] = (uint16_t) excl;
-                s.wcnt[sw + 1][sd] = (uint16_t) (excl + c0);
-                s.wcnt[sw + 2][sd] = (uint16_t) (excl + c0 + c1);
-                s.wcnt[sw + 3][sd] = (uint16_t) (excl + c0 + c1 + c2);
+#pragma unroll
+                for (int g = 0; g < GW; g++)
+                {
+                    s.wcnt[sw + g][sd] = (uint16_t) excl;
+                    excl += c[g];
+                }
             }
         }
         __syncthreads();
+        clock.stamp(2);
 
 #pragma unroll
         for (int i = 0; i < KPT; i++)
@@ -406,8 +576,10 @@ __global__ __launch_bounds__(THREADS) void radix_finish_sort_kernel(KeyT* keys_a
         }
         if (shift + 8 < low_bits) __syncthreads();
     }
-    if (shift_begin == 0) break;
+    clock.stamp(3);
+    if (!TIES || shift_begin == 0) break;
     // ---- tie repair on the stage (the registers hold a copy of it)
+    if constexpr (TIES)
     {
         constexpr uint32_t kTieMaxBack = 16, kTieMaxGroup = 32;
         uint16_t* const list = &s.wcnt[0][0];
@@ -415,14 +587,26 @@ __global__ __launch_bounds__(THREADS) void radix_finish_sort_kernel(KeyT* keys_a
         const KeyT low_mask = low_bits >= 8u * sizeof(KeyT) ? (KeyT) ~(KeyT) 0 : (KeyT) ((((KeyT) 1) << low_bits) - 1);
         auto tied = [&](KeyT a, KeyT b) { return (((a ^ b) & low_mask) >> shift_begin) == 0; };
         auto above = [&](KeyT a, KeyT b) { return (a & low_mask) > (b & low_mask); };
+        // Every position against its successor, from REGISTERS: position p = wave_off + i * 64 is item i of this lane, its
+        // successor is item i of the next lane -- for lane 63 item i + 1 of lane 0, and behind the wave's last item the first slot
+        // of the next wave's share, the one key that comes from the stage.  (Reading both keys of every position from the stage
+        // made this phase a third of the pass: profiles/r05/finish_stamps_u64_rank16_before.txt.)
+        const KeyT next_wave_first = s.stage.key_at(min(wave_off - lane + items * kWave, (uint32_t) Smem::TILE - 1u));
 #pragma unroll
         for (int i = 0; i < KPT; i++)
         {
             if ((uint32_t) i >= items) continue;
             const uint32_t p = wave_off + i * kWave;
-            // (positions from len on are the pads; the key of position p is in key[i], up to the bits above low_bits)
+            // (positions from len on are the pads)
             const bool in = p + 1 < len;
-            const KeyT kp = s.stage.key_at(in ? p : 0u), kn = s.stage.key_at(in ? p + 1 : 0u);
+            const KeyT kp = key[i];
+            KeyT kn = (KeyT) __shfl_down((unsigned long long) key[i], 1);
+            {
+                KeyT first_of_next = next_wave_first;
+                if (i + 1 < KPT)
+                    if ((uint32_t) (i + 1) < items) first_of_next = (KeyT) __shfl((unsigned long long) key[i + 1 < KPT ? i + 1 : i], 0);
+                if (lane == 63) kn = first_of_next;
+            }
             if (in && tied(kp, kn) && above(kp, kn))
             {
                 // the first out-of-order neighbours of a tie group list the group's first position
@@ -502,10 +686,90 @@ __global__ __launch_bounds__(THREADS) void radix_finish_sort_kernel(KeyT* keys_a
                 s.stage.get(wave_off + i * kWave, key[i], val[i], run_top);
             }
         }
+        clock.stamp(4);
         if (!bad) break;
         __syncthreads(); // (the counters -- the list -- are zeroed by the next round)
     }
     }
+}
+
+// A workgroup per run r: the pairs [starts[r], starts[r + 1]) are ordered by key bits [0, low_bits), stably.  Every wave takes
+// an equal share of the run (a multiple of 64 slots) and ranks only the items its share has -- a run of 4096 pairs costs 16
+// items per lane, not the 18 the longest run needs.  Slots past the run's end hold the key ~0 (largest digit in every round,
+// behind every real pair in input order); their loads read the run's last element instead of being predicated, so that all
+// loads of a lane are in flight at once.  64-bit keys: 8-byte keys in registers, 6 + 4 bytes per slot in LDS.
+// LOOP = false: launched with a workgroup per run (the hardware's dispatcher is the loop over the runs, and the next workgroup
+// starts while this one drains its stores: 0.96-0.99 ms for 2^28 pairs where a loop inside the kernel takes 1.05-1.16).  LOOP =
+// true: fewer workgroups, each takes every gridDim.x-th run -- for the geometries that are enqueued besides the expected one:
+// 65536 workgroups that return at once cost 15-29 us, 8192 cost 5.
+// XF: typed keys (signed integers, floats): the first top-bit pass encoded them on load, this pass decodes them on store.
+//
+// Two callers.  The whole-key sort (plan != nullptr): 65536 runs IN PLACE in the arrays that hold the data after pass `pass` - 1
+// (PassPlan::flip[pass]); the geometry comes from the PassPlan.  The segmented sort (plan == nullptr, radix_seg_passes.hpp: the
+// local sort of the sharded sort): `nruns` runs of (segment, top digit of the low bits) FROM keys_a / vals_a TO keys_b / vals_b,
+// if the longest run the runs kernel found (*gate) is at most gate_cap (otherwise the ordinary segmented passes run); runs
+// longer than this geometry's tile are left to radix_finish_ranges_kernel.
+#ifndef GLU_FINISH_U64_WAVES
+#define GLU_FINISH_U64_WAVES 6 // (tuning builds: 1 = no such request)
+#endif
+#ifndef GLU_FINISH_KERNEL_ATTR
+#define GLU_FINISH_KERNEL_ATTR // (tuning builds of tools/finish_stamps_bench.hip: e.g. __attribute__((amdgpu_waves_per_eu(6))))
+#endif
+// (8-byte keys, 512 x 9: the 53 KiB stage lets three workgroups share a CU, which takes at most 80 VGPRs: the second launch bound
+// asks the compiler for six waves per SIMD -- it needs 81 without it)
+template<typename KeyT, int THREADS, int KPT, bool VALS, bool LOOP, bool XF = false, bool STAMPS = false>
+__global__ __launch_bounds__(THREADS, (sizeof(KeyT) == 8 && THREADS == 512 ? GLU_FINISH_U64_WAVES : 1)) GLU_FINISH_KERNEL_ATTR void radix_finish_sort_kernel(KeyT* keys_a, uint32_t* vals_a, KeyT* keys_b,
+                                                                    uint32_t* vals_b, const uint32_t* __restrict__ starts,
+                                                                    uint32_t low_bits, const PassPlan* plan, uint32_t pass,
+                                                                    uint32_t geometry, uint32_t key_xf = 0,
+                                                                    uint32_t nruns = kFinishRuns, const uint32_t* gate = nullptr,
+                                                                    uint32_t gate_cap = 0, uint32_t rank_from = 0,
+                                                                    unsigned long long* stamps = nullptr)
+{
+    FinishClock<STAMPS> clock;
+    const KeyCodec<KeyT, XF> codec_out(key_xf);
+    // (kernel-uniform: the device chose another geometry, or the ordinary passes)
+    if (plan ? plan->finish != geometry : *gate > gate_cap) return;
+    using Smem = FinishSmem<KeyT, THREADS, KPT, VALS>;
+    constexpr int WAVES = Smem::WAVES;
+
+    const KeyT* keys = plan && plan->flip[pass] ? keys_b : keys_a;
+    const uint32_t* vals = plan && plan->flip[pass] ? vals_b : vals_a;
+    KeyT* out_keys = plan ? const_cast<KeyT*>(keys) : keys_b;
+    uint32_t* out_vals = plan ? const_cast<uint32_t*>(vals) : vals_b;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    Smem& s = *reinterpret_cast<Smem*>(smem_raw);
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (uint32_t run = blockIdx.x; run < nruns; run += LOOP ? gridDim.x : nruns)
+    {
+    const uint32_t begin = starts[run], end = starts[run + 1];
+    const uint32_t len = end - begin;
+    if (len == 0 || (plan && !XF && len == 1)) continue; // (workgroup-uniform; a single typed key still has to be decoded)
+    // (a run longer than the tile: radix_finish_ranges_kernel's in a segmented sort, the segmented passes' in a whole-key sort)
+    if (len > (uint32_t) Smem::TILE) continue;
+    // (64-bit keys: the key bits from 48 up, the same for every pair of the run -- and of a pad that comes back from the stage)
+    const KeyT run_top = sizeof(KeyT) == 8 ? (KeyT) (keys[begin] & (KeyT) 0xFFFF000000000000ull) : (KeyT) 0;
+    const uint32_t share = ((len + WAVES * kWave - 1) / (WAVES * kWave)) * kWave; // slots per wave: <= kWave * KPT
+    const uint32_t items = share / kWave;
+    const uint32_t wave_off = wave * share + lane;
+
+    clock.start();
+    KeyT key[KPT];
+    uint32_t val[KPT];
+#pragma unroll
+    for (int i = 0; i < KPT; i++)
+    {
+        const uint32_t p = wave_off + i * kWave;
+        const bool ok = p < len;
+        const uint32_t pc = ok ? p : len - 1;
+        const KeyT k = keys[begin + pc];
+        const uint32_t v = VALS ? vals[begin + pc] : 0u;
+        key[i] = ok ? k : (KeyT) ~(KeyT) 0;
+        val[i] = ok ? v : 0u;
+    }
+
+    finish_rank_rounds<KeyT, THREADS, KPT, VALS, (sizeof(KeyT) == 8), STAMPS>(s, key, val, items, len, wave_off, low_bits, rank_from, run_top,
+                                                                             tid, lane, wave, clock);
 
 #pragma unroll
     for (int i = 0; i < KPT; i++)
@@ -513,11 +777,228 @@ __global__ __launch_bounds__(THREADS) void radix_finish_sort_kernel(KeyT* keys_a
         const uint32_t p = wave_off + i * kWave;
         if ((uint32_t) i < items && p < len)
         {
-            __builtin_nontemporal_store(codec_out.decode(key[i]), &keys[begin + p]);
-            if (VALS) __builtin_nontemporal_store(val[i], &vals[begin + p]);
+            __builtin_nontemporal_store(codec_out.decode(key[i]), &out_keys[begin + p]);
+            if (VALS) __builtin_nontemporal_store(val[i], &out_vals[begin + p]);
         }
     }
+    clock.stamp(5);
     if (LOOP) __syncthreads(); // (the stage and the counters are reused)
+    }
+    clock.flush(stamps, lane, wave, WAVES);
+}
+
+// The general form of the in-LDS pass, OUT OF PLACE (src -> dst), for what the kernel above does not take: runs longer than a
+// tile, and runs that are SPLIT over several workgroups.
+//
+// An item of work is (run r, part j of 2^split_log2): the pairs of run r whose key bits [0, low_bits) lie in the j-th of
+// 2^split_log2 equal ranges of that key space, [klo, khi) -- the sharded sort at eight ranks has runs of 16384 pairs, four
+// workgroups take a quarter of the key range each.  The workgroup walks its range in pieces [lo, hi) that fit its tile:
+//   * COUNT: every wave streams over its contiguous share of the run (from L2: the workgroups of a run are neighbours in launch
+//     order on one XCD) and counts the pairs whose key lies in [lo, hi) -- ballot, popcount, no barrier inside the stream; one
+//     barrier for the waves' counts;
+//   * more than TILE: hi moves down (in proportion, at least halving towards lo + 1) and the count is repeated.  A single key value
+//     that alone outgrows the tile is copied through in input order (equal keys are in order already);
+//   * at most TILE: PLACE -- a second stream appends those pairs to the stage in input order (every wave from its own first
+//     position) --, the staged pairs are ordered by finish_rank_rounds and stored at the cursor: the run's start + the number
+//     of the run's pairs below klo (counted by the first stream) + what the workgroup has stored so far.
+// So any run of any key distribution comes out right; what it costs is reads of the run from L2, once per piece.
+// min_len: runs of at most this many pairs are the kernel above's (0: every run is this kernel's).
+// done (whole-key sort, in place otherwise): done[r] = 1 tells the copy-back kernel that run r's result is in dst.
+template<typename KeyT, int THREADS, int KPT, bool VALS, bool XF = false>
+__global__ __launch_bounds__(THREADS) void radix_finish_ranges_kernel(const KeyT* __restrict__ src_keys, const uint32_t* __restrict__ src_vals,
+                                                                      KeyT* __restrict__ dst_keys, uint32_t* __restrict__ dst_vals,
+                                                                      const uint32_t* __restrict__ starts, uint32_t nruns,
+                                                                      uint32_t low_bits, uint32_t rank_from, uint32_t split_log2,
+                                                                      uint32_t min_len, const uint32_t* gate, uint32_t gate_cap,
+                                                                      uint32_t key_xf = 0)
+{
+    const KeyCodec<KeyT, XF> codec_out(key_xf);
+    if (gate && *gate > gate_cap) return; // (kernel-uniform: the ordinary passes run)
+    using Smem = FinishSmem<KeyT, THREADS, KPT, VALS>;
+    constexpr int WAVES = Smem::WAVES;
+    constexpr uint32_t TILE = (uint32_t) Smem::TILE;
+    constexpr int CK = 8;                  // keys per lane and chunk of the gather
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    Smem& s = *reinterpret_cast<Smem*>(smem_raw);
+    __shared__ uint32_t gcnt[2][WAVES]; // the waves' counts of a stream: pairs in the range, pairs below the workgroup's range
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint64_t key_space = low_bits >= 64u ? ~0ull : (1ull << low_bits); // (low_bits <= 48 for 64-bit keys)
+    const uint64_t low_mask = key_space - 1ull;
+    const uint32_t parts = 1u << split_log2;
+    // items in launch order: the parts of one run are 8 workgroups apart, i.e. neighbours on one XCD (workgroups are dealt to
+    // the eight XCDs round-robin), so that one of them brings the run into that XCD's L2 and the others find it there
+    const uint32_t runs8 = (nruns + 7u) & ~7u;
+    const uint64_t nitems = (uint64_t) runs8 * parts;
+    for (uint64_t item = blockIdx.x; item < nitems; item += gridDim.x)
+    {
+    const uint32_t xcd = (uint32_t) (item & 7u);
+    const uint64_t in_xcd = item >> 3;
+    const uint32_t part = (uint32_t) (in_xcd & (parts - 1u));
+    const uint32_t run = (uint32_t) (in_xcd >> split_log2) * 8u + xcd;
+    if (run >= nruns) continue;
+    const uint32_t begin = starts[run], end = starts[run + 1];
+    const uint32_t len = end - begin;
+    if (len == 0 || len <= min_len) continue; // (workgroup-uniform)
+    const KeyT run_top = sizeof(KeyT) == 8 ? (KeyT) (src_keys[begin] & (KeyT) 0xFFFF000000000000ull) : (KeyT) 0;
+    const uint64_t klo = split_log2 ? (uint64_t) part << (low_bits - split_log2) : 0ull;
+    const uint64_t khi = split_log2 ? (uint64_t) (part + 1u) << (low_bits - split_log2) : key_space;
+    uint32_t below_klo = 0; // pairs of the run below the workgroup's key range (known after the first count)
+
+    // Every wave streams over ITS contiguous share of the run (a multiple of 64 slots), batches of CK keys per lane in flight at
+    // once; no barrier inside the streams, so the waves of the CU hide each other's load latency.
+    const uint32_t wshare = ((len + WAVES * kWave - 1) / (WAVES * kWave)) * kWave;
+    const uint32_t wbegin = wave * wshare;
+    const uint32_t batches = (wshare + kWave * CK - 1) / (kWave * CK);
+    auto load_keys = [&](uint32_t b, KeyT (&k)[CK]) {
+#pragma unroll
+        for (int i = 0; i < CK; i++)
+        {
+            const uint32_t p = wbegin + b * (kWave * CK) + i * kWave + lane;
+            k[i] = src_keys[begin + (p < len ? p : len - 1u)];
+        }
+    };
+    auto load_vals = [&](uint32_t b, uint32_t (&v)[CK]) {
+#pragma unroll
+        for (int i = 0; i < CK; i++)
+        {
+            const uint32_t p = wbegin + b * (kWave * CK) + i * kWave + lane;
+            v[i] = VALS ? src_vals[begin + (p < len ? p : len - 1u)] : 0u;
+        }
+    };
+    auto in_share = [&](uint32_t b, int i) { // (is slot i of batch b of this lane a pair of the run and of this wave's share?)
+        const uint32_t off = b * (kWave * CK) + i * kWave + lane;
+        return off < wshare && wbegin + off < len;
+    };
+    // COUNT: how many pairs of the run have lo <= key bits < hi (returned: all waves'; wbase: those of the waves before this
+    // one); count_below: also how many lie below klo (into below_klo).  One barrier.
+    uint32_t wbase = 0;
+    // (a key lies in [lo, hi) iff (key bits - lo) <= hi - lo - 1 in the key's own unsigned arithmetic: one compare, no 64-bit
+    // arithmetic for 4-byte keys)
+    const KeyT kmask = (KeyT) low_mask, klo_k = (KeyT) klo;
+    auto count_range = [&](uint64_t lo, uint64_t hi, bool count_below) -> uint32_t {
+        const KeyT lo_k = (KeyT) lo, span_k = (KeyT) (hi - lo - 1ull);
+        uint32_t wcount = 0, below = 0;
+        for (uint32_t b = 0; b < batches; b++)
+        {
+            KeyT cur[CK];
+            load_keys(b, cur);
+#pragma unroll
+            for (int i = 0; i < CK; i++)
+            {
+                const KeyT kl = cur[i] & kmask;
+                const bool ok = in_share(b, i);
+                wcount += (uint32_t) __popcll(__ballot(ok && (KeyT) (kl - lo_k) <= span_k));
+                if (count_below) below += (uint32_t) __popcll(__ballot(ok && kl < klo_k));
+            }
+        }
+        if (lane == 0) gcnt[0][wave] = wcount, gcnt[1][wave] = below;
+        __syncthreads();
+        uint32_t total = 0;
+        wbase = 0;
+#pragma unroll
+        for (int w = 0; w < WAVES; w++)
+        {
+            const uint32_t c = gcnt[0][w];
+            wbase += (uint32_t) w < wave ? c : 0u;
+            total += c;
+            if (count_below) below_klo += gcnt[1][w];
+        }
+        __syncthreads(); // (gcnt is rewritten by the next count)
+        // (workgroup-uniform values that come out of LDS or of vector arithmetic: told to the compiler, so that the loops around
+        // this stay scalar control flow)
+        if (count_below) below_klo = (uint32_t) __builtin_amdgcn_readfirstlane((int) below_klo);
+        return (uint32_t) __builtin_amdgcn_readfirstlane((int) total);
+    };
+    // PLACE: the pairs counted by the last count_range go to the stage in input order (positions wbase .. of this wave), or
+    // -- through -- straight to dst at `out` (a single key value: they are in order).  One barrier at the end.
+    auto place_range = [&](uint64_t lo, uint64_t hi, bool through, uint32_t out) {
+        const KeyT lo_k = (KeyT) lo, span_k = (KeyT) (hi - lo - 1ull);
+        uint32_t pos0 = wbase;
+        for (uint32_t b = 0; b < batches; b++)
+        {
+            KeyT cur[CK];
+            uint32_t vcur[CK];
+            load_keys(b, cur);
+            load_vals(b, vcur);
+#pragma unroll
+            for (int i = 0; i < CK; i++)
+            {
+                const bool in = in_share(b, i) && (KeyT) ((cur[i] & kmask) - lo_k) <= span_k;
+                const uint64_t bal = __ballot(in);
+                const uint32_t pos = pos0 + __builtin_amdgcn_mbcnt_hi((uint32_t) (bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) bal, 0u));
+                if (in)
+                {
+                    if (through)
+                    {
+                        dst_keys[out + pos] = codec_out.decode(cur[i]);
+                        if (VALS) dst_vals[out + pos] = vcur[i];
+                    }
+                    else
+                        s.stage.put(pos, cur[i], vcur[i]);
+                }
+                pos0 += (uint32_t) __popcll(bal);
+            }
+        }
+        __syncthreads(); // the stage is complete
+    };
+
+    uint32_t cursor = begin;
+    bool first = true;
+    for (uint64_t lo = klo; lo < khi;)
+    {
+        uint64_t hi = khi;
+        uint32_t c;
+        for (;;)
+        {
+            c = count_range(lo, hi, first && split_log2 != 0);
+            if (first) cursor = begin + below_klo;
+            first = false;
+            if (c <= TILE || hi - lo == 1ull) break;
+            // too many for the tile: a smaller piece (in proportion to what was found, with a margin; at least one key value)
+            const uint64_t span = hi - lo;
+            uint64_t next = (uint64_t) ((double) span * (0.85 * (double) TILE / (double) c));
+            next = next < 1ull ? 1ull : next;
+            next = next > span / 2ull + (span & 1ull) ? span / 2ull + (span & 1ull) : next;
+            next = (uint64_t) (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) next) |
+                   ((uint64_t) (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) (next >> 32)) << 32); // (uniform)
+            hi = lo + next;
+        }
+        if (c > TILE)
+            place_range(lo, hi, true, cursor); // one key value, more pairs than a tile: they are in order -- copied through
+        else if (c > 0)
+        {
+            place_range(lo, hi, false, 0u);
+            const uint32_t share = ((c + WAVES * kWave - 1) / (WAVES * kWave)) * kWave;
+            const uint32_t items = share / kWave;
+            const uint32_t wave_off = wave * share + lane;
+            KeyT key[KPT];
+            uint32_t val[KPT];
+#pragma unroll
+            for (int i = 0; i < KPT; i++)
+            {
+                const uint32_t p = wave_off + i * kWave;
+                key[i] = (KeyT) ~(KeyT) 0;
+                val[i] = 0u;
+                if ((uint32_t) i < items && p < c) s.stage.get(p, key[i], val[i], run_top);
+            }
+            __syncthreads(); // (the stage is rewritten by the rounds)
+            FinishClock<false> clock;
+            finish_rank_rounds<KeyT, THREADS, KPT, VALS>(s, key, val, items, c, wave_off, low_bits, rank_from, run_top, tid, lane, wave, clock);
+#pragma unroll
+            for (int i = 0; i < KPT; i++)
+            {
+                const uint32_t p = wave_off + i * kWave;
+                if ((uint32_t) i < items && p < c)
+                {
+                    __builtin_nontemporal_store(codec_out.decode(key[i]), &dst_keys[cursor + p]);
+                    if (VALS) __builtin_nontemporal_store(val[i], &dst_vals[cursor + p]);
+                }
+            }
+        }
+        cursor += c;
+        lo = hi;
+        __syncthreads(); // (the stage, the counters and the chunk counts are reused)
+    }
     }
 }
 

@@ -106,6 +106,15 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
     const uint32_t* __restrict__ src_vals = vals_a;
     KeyT* __restrict__ dst_keys = keys_b;
     uint32_t* __restrict__ dst_vals = vals_b;
+    if (SEG && plan && ((plan->flip[pass] ^ share) & 1u))
+    {
+        // (the long runs of a whole-key sort that ends in LDS: which pair of arrays holds the data is known on the device only;
+        // `share`, otherwise unused by segmented passes, is 1 for the pass that goes back)
+        src_keys = keys_b;
+        src_vals = vals_b;
+        dst_keys = const_cast<KeyT*>(keys_a);
+        dst_vals = const_cast<uint32_t*>(vals_a);
+    }
     if (!SEG && plan)
     {
         const uint32_t flip = pass > 0 ? plan->flip[pass] : 0u;

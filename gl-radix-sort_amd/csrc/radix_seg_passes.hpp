@@ -78,9 +78,13 @@ __global__ __launch_bounds__(THREADS) void radix_seg_count_kernel(const uint32_t
                                                                   const uint32_t* __restrict__ seg_first,
                                                                   uint32_t* __restrict__ table, uint32_t shift, uint32_t mask,
                                                                   const uint32_t* gate = nullptr, uint32_t gate_cap = 0,
-                                                                  uint32_t gate_mode = kSegGateNone)
+                                                                  uint32_t gate_mode = kSegGateNone,
+                                                                  const uint32_t* __restrict__ keys_alt = nullptr,
+                                                                  const PassPlan* plan = nullptr, uint32_t flip_pass = 0, uint32_t swap = 0)
 {
     if (seg_gate_closed(gate, gate_cap, gate_mode)) return; // (kernel-uniform)
+    // (the long runs of a whole-key sort that ends in LDS: which pair of arrays holds the data is known on the device only)
+    if (plan && ((plan->flip[flip_pass] ^ swap) & 1u)) keys = keys_alt;
     constexpr int RADIX = 1 << BITS;
     constexpr int WAVES = THREADS / kWave;
     __shared__ uint32_t hist[WAVES][RADIX];
@@ -156,9 +160,10 @@ __global__ __launch_bounds__(RADIX) void radix_seg_scan_kernel(uint32_t* __restr
                                                                const uint32_t* __restrict__ seg_list,
                                                                const uint32_t* __restrict__ seg_start,
                                                                const uint32_t* gate = nullptr, uint32_t gate_cap = 0,
-                                                               uint32_t gate_mode = kSegGateNone)
+                                                               uint32_t gate_mode = kSegGateNone, const uint32_t* nseg_dev = nullptr)
 {
     if (seg_gate_closed(gate, gate_cap, gate_mode)) return; // (kernel-uniform)
+    if (nseg_dev && blockIdx.x >= *nseg_dev) return;        // (segments counted on the device: the grid is their upper bound)
     constexpr int WAVES = (RADIX + kWave - 1) / kWave;
     __shared__ uint32_t wave_sums[WAVES];
     const uint32_t d = threadIdx.x, lane = d & 63, wave = d >> 6;

@@ -74,7 +74,8 @@ SYMBOLS = [
                                                   _P(ctypes.c_double), _P(_u64)]),
     ("glu_radix_sort_plan_finish", _int, [_sz, _u32, _P(_u32), _P(_u32)]),
     ("glu_radix_sort_read_finish", _int, [_vp, _P(_u32), _P(_u32), _P(_u32), _P(_u32), _P(_u32)]),
-    ("glu_radix_sort_read_seg_finish", _int, [_vp, _P(_u32), _P(_u32), _P(_u32), _P(_u32), _P(_u32)]),
+    ("glu_radix_sort_read_long_runs", _int, [_vp, _P(_u32), _P(_u32), _P(_u32)]),
+    ("glu_radix_sort_read_seg_finish", _int, [_vp, _P(_u32), _P(_u32), _P(_u32), _P(_u32), _P(_u32), _P(_u32), _P(_u32)]),
     ("glu_scan_create", _int, [_int, _P(_vp)]),
     ("glu_scan_destroy", _int, [_vp]),
     ("glu_scan_prepare", _int, [_vp, _sz, _sz]),
@@ -282,7 +283,9 @@ class RadixSort:
         return {"candidates": int(n.value), "chosen_ms": float(a.value), "slowest_ms": float(b.value)}
 
     def set_profiling(self, enable):
-        check(lib().glu_radix_sort_set_profiling(self._h, 1 if enable else 0))
+        """True: events at every kernel boundary of a pass; "light": only around the kernel that moves a pass's data (the scatter,
+        the in-LDS pass) -- a few microseconds of queue time per event saved; False: off."""
+        check(lib().glu_radix_sort_set_profiling(self._h, 2 if enable == "light" else (1 if enable else 0)))
 
     def read_profile(self):
         """{count_ms, scan_ms, scatter_ms, passes}: summed device time per kernel class since the last read."""
@@ -309,13 +312,20 @@ class RadixSort:
                                                ctypes.byref(e)))
         return {"attempted": a.value, "accepted": b.value, "longest_run": c.value, "capacity": d.value, "top_bit": e.value}
 
+    def read_long_runs(self):
+        """{runs, sub_blocks, pairs}: what the last sort that ended in LDS gave to the segmented passes for runs longer than the tile
+        (glu_radix_sort_read_long_runs); waits for the device."""
+        a, b, c = _u32(0), _u32(0), _u32(0)
+        check(lib().glu_radix_sort_read_long_runs(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        return {"runs": a.value, "sub_blocks": b.value, "pairs": c.value}
+
     def read_seg_finish(self):
-        """{attempted, accepted, longest_run, capacity, runs} of the last SEGMENTED sort: did it try to / did it end in LDS
-        (glu_radix_sort_read_seg_finish); waits for the device."""
-        a, b, c, d, e = _u32(0), _u32(0), _u32(0), _u32(0), _u32(0)
-        check(lib().glu_radix_sort_read_seg_finish(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c), ctypes.byref(d),
-                                                   ctypes.byref(e)))
-        return {"attempted": a.value, "accepted": b.value, "longest_run": c.value, "capacity": d.value, "runs": e.value}
+        """{attempted, accepted, longest_run, capacity, runs, tile, split} of the last SEGMENTED sort: did it try to / did it end
+        in LDS (glu_radix_sort_read_seg_finish); waits for the device."""
+        a, b, c, d, e, f, g = (_u32(0) for _ in range(7))
+        check(lib().glu_radix_sort_read_seg_finish(self._h, *(ctypes.byref(x) for x in (a, b, c, d, e, f, g))))
+        return {"attempted": a.value, "accepted": b.value, "longest_run": c.value, "capacity": d.value, "runs": e.value,
+                "tile": f.value, "split": g.value}
 
     def __call__(self, key_buffer, val_buffer, count, num_steps=0, key_bytes=4):
         kb = key_buffer.handle() if isinstance(key_buffer, ShaderStorageBuffer) else key_buffer

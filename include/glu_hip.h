@@ -252,6 +252,9 @@ GLU_API glu_status glu_radix_sort_scratch_size(glu_radix_sort sort, size_t* byte
  * while enabled, every counting pass records HIP events on its stream around the count, scan and scatter
  * kernels.  glu_radix_sort_read_profile waits for the recorded work, returns the summed device milliseconds
  * per kernel class and the number of passes since the previous read, and resets the accumulation. */
+/* enable = 2 ("light"): only the two events around the kernel that moves the data of a pass that is expected to run are
+ * recorded (the scatter kernel of a counting pass, the in-LDS pass); count_ms / scan_ms then read 0.  An event between two
+ * kernels costs the queue a few microseconds: the 28 of a large sort that ends in LDS were 4 % of its time. */
 GLU_API glu_status glu_radix_sort_set_profiling(glu_radix_sort sort, int enable);
 GLU_API glu_status glu_radix_sort_read_profile(glu_radix_sort sort, double* count_ms, double* scan_ms,
                                                double* scatter_ms, uint64_t* passes);
@@ -302,14 +305,26 @@ GLU_API glu_status glu_radix_sort_plan_finish(size_t count, uint32_t key_bytes, 
                                               uint32_t* last_capacity);
 GLU_API glu_status glu_radix_sort_read_finish(glu_radix_sort sort, uint32_t* attempted, uint32_t* accepted,
                                               uint32_t* longest_run, uint32_t* capacity, uint32_t* top_bit);
+/* Runs LONGER than the tile of the in-LDS pass (round 5; 4-byte untyped keys with values): they no longer send the whole sort back
+ * to the ordinary passes -- the device lists them as segments, two segmented counting passes (the reference's pass per segment,
+ * glu/RadixSort.hpp:142-182) order just their elements by the low 16 key bits, and the in-LDS pass takes every other run.  The
+ * tile is the smallest enqueued one that leaves at most 8192 runs and an eighth of the pairs to those passes (failing that the
+ * largest, if it leaves at most half); keys crowded into few runs are still refused.  runs / sub_blocks / pairs: what the last
+ * sort gave to the segmented passes (all 0: nothing, or the sort did not end in LDS).  GLU_HIP_SORT_LONG_RUNS=0 in the environment
+ * of glu_radix_sort_create restores the round-4 rule (one run longer than the largest enqueued tile refuses the sort). */
+GLU_API glu_status glu_radix_sort_read_long_runs(glu_radix_sort sort, uint32_t* runs, uint32_t* sub_blocks, uint32_t* pairs);
 /* The same question for the last SEGMENTED sort of the object (glu_radix_sort_run_segments_ptr; the local sort of glu_dist_*):
- * a segmented sort by 16 key bits or more first tries ONE counting pass on the top digit of those bits and one pass that orders
- * every run (segment, top digit) by the remaining bits inside LDS (the reference's pass, glu/RadixSort.hpp:289-333, once instead
- * of three times for 24 bits).  attempted: both sequences were enqueued; accepted: the device found no run longer than
- * `capacity` pairs and ended the sort in LDS (otherwise the ordinary segmented passes ran); runs = segments x 256.
+ * a segmented sort by 16 key bits or more first tries ONE counting pass on the top digit of those bits (into the object's scratch
+ * arrays) and one pass that orders every run (segment, top digit) by the remaining bits inside LDS on its way into the output --
+ * the reference's pass, glu/RadixSort.hpp:289-333, once instead of three times for 24 bits.  `tile`: pairs a workgroup orders at
+ * a time; `split`: workgroups a run is split over (by ranges of the remaining key bits: runs of the sharded sort at eight ranks are
+ * four tiles long); runs that come out longer than tile x split are walked in pieces.  attempted: both sequences were enqueued;
+ * accepted: the device found no run longer than `capacity` (32 tiles per workgroup) and ended the sort in LDS -- otherwise the
+ * ordinary segmented passes ran; runs = segments x 256.
  * GLU_HIP_SEG_LDS_FINISH=0 in the environment of glu_radix_sort_create switches the attempt off.  Waits for the device. */
 GLU_API glu_status glu_radix_sort_read_seg_finish(glu_radix_sort sort, uint32_t* attempted, uint32_t* accepted,
-                                                  uint32_t* longest_run, uint32_t* capacity, uint32_t* runs);
+                                                  uint32_t* longest_run, uint32_t* capacity, uint32_t* runs, uint32_t* tile,
+                                                  uint32_t* split);
 
 /* ---- exclusive scan: replaces glu::BlellochScan (glu/BlellochScan.hpp:80-191) ---------------------- */
 
@@ -398,7 +413,8 @@ GLU_API glu_status glu_dist_sort_ptr(glu_dist dist, const uint32_t* keys, const 
  * all 32 bits (small shards, shards made of very many tiny pieces, a partition on a lower byte). */
 GLU_API glu_status glu_dist_last_local_sort(glu_dist dist, uint32_t* segmented);
 /* The exchange in ROUNDS.  With more than one rank and large shards (2^24 pairs per rank and more; GLU_HIP_DIST_ROUNDS_MIN)
- * every rank's buckets are cut into `rounds` groups of about equal size (1 .. 8, default 3, GLU_HIP_DIST_ROUNDS), round j
+ * every rank's buckets are cut into `rounds` groups of about equal size (1 .. 8; default 3 from four ranks up, 1 below: at two
+ * ranks half of the data never leaves and the one link to the peer bounds the exchange far above the sort; GLU_HIP_DIST_ROUNDS), round j
  * carries group j of every rank on a side stream, and the local sort of group j runs on the sort's stream behind round j
  * only: the later groups travel while the earlier ones are sorted, so ONE sort takes about partition + one round +
  * max(the other rounds, the sorts) instead of partition + exchange + sort.  The price is compute: a group is sorted by its

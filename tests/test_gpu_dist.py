@@ -122,11 +122,12 @@ def test_prepare_places_every_array_of_the_sharded_sort(built):
     ok, held, scratch_searches, pair_searches, candidates = q.get(timeout=600)
     p.join(timeout=60)
     assert ok
-    assert scratch_searches == 1 and pair_searches == 2 and candidates >= 3 * 8  # three searches, at least eight candidates each
-    # what prepare holds afterwards: 3 pairs of 2^27 (+ 4096) 4-byte words, tables, the communicator's buffers (0.7 GiB) and what
+    # four searches (the sorter's scratch, the send pair, the receive pair, the landing pair), at least eight candidates each
+    assert scratch_searches == 1 and pair_searches == 3 and candidates >= 4 * 8
+    # what prepare holds afterwards: 4 pairs of 2^27 (+ 4096) 4-byte words, tables, the communicator's buffers (0.7 GiB) and what
     # the HIP allocator keeps of freed blocks (about 1 GiB, reused by later allocations: tools/place_probe_dist.py) -- not the
-    # 24+ candidates, their spacers or the calibration arrays
-    assert held < 6 * ((1 << 27) + 4096) * 4 + (3 << 30), held
+    # 32+ candidates, their spacers or the calibration arrays
+    assert held < 8 * ((1 << 27) + 4096) * 4 + (3 << 30), held
 
 
 def _repartition_worker(q):
@@ -614,13 +615,15 @@ def _default_settings_worker(rank, world, unique_id, mock_lib, mock_dir, q, n):
     d.destroy()
 
 
-def test_native_two_ranks_with_the_library_defaults_at_production_size(built, tmp_path):
-    """Two ranks of 2^24 pairs each with NOTHING overridden: the sizes from which the library by itself posts the exchange in
-    rounds (three) and sorts the shard group by group with segmented passes, after a prepare that placed every array by
-    measurement -- over the asynchronous test double, against the oracle."""
+@pytest.mark.parametrize("world", [2, 8])
+def test_native_ranks_with_the_library_defaults_at_production_size(built, tmp_path, world):
+    """Two and EIGHT ranks of 2^24 pairs each with NOTHING overridden: the sizes from which the library by itself sorts the shard
+    with the segmented sort that ends in LDS and -- from four ranks up -- posts the exchange in rounds (three) and sorts group by
+    group, after a prepare that placed every array by measurement -- over the asynchronous test double, against the oracle.
+    (World 8 is the shape of BASELINE.json configs[3] at an eighth of its size: eight processes share the one GPU.)"""
     import torch.multiprocessing as mp
 
-    world, n = 2, 1 << 24
+    n = 1 << 24
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     mock_lib = os.path.join(root, "tests", "cpp", "bin", "libmock_rccl.so")
     unique_id = os.urandom(128)
@@ -629,7 +632,7 @@ def test_native_two_ranks_with_the_library_defaults_at_production_size(built, tm
     procs = [ctx.Process(target=_default_settings_worker, args=(r, world, unique_id, mock_lib, str(tmp_path), q, n)) for r in range(world)]
     for p in procs:
         p.start()
-    results = _collect(q, procs, world, 600)
+    results = _collect(q, procs, world, 900)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -640,10 +643,10 @@ def test_native_two_ranks_with_the_library_defaults_at_production_size(built, tm
     gk = np.concatenate([results[r][0] for r in range(world)])
     gv = np.concatenate([results[r][1] for r in range(world)])
     assert gk.size == ek.size and (gk == ek).all() and (gv == ev).all()
-    # three rounds everywhere; a rank's local sort is the segmented one from 2^24 pairs up (the split is not exactly even, so the
-    # two ranks may well differ: one posts its rounds into the group-major layout, the other into the source-major one)
+    # three rounds from four ranks up, one below; a rank's local sort is the segmented one from 2^24 pairs up (the split is not
+    # exactly even, so the ranks may well differ: one lands its rounds in the group-major layout, another in the source-major one)
     for r in range(world):
-        assert results[r][3] == 3, results[r][2:]
+        assert results[r][3] == (3 if world >= 4 else 1), results[r][2:]
         assert results[r][2] == ("segmented" if results[r][0].size >= (1 << 24) else "ordinary"), (results[r][0].size, results[r][2])
 
 
@@ -863,6 +866,7 @@ def test_bench_multi_gpu_command_line_rehearsal(built, mock_async):
     #                                                                                  really has two exchanges in flight)
     if mock_async == "1":
         env["GLU_HIP_DIST_ROUNDS_MIN"] = "1"  # ... and the one-at-a-time sorts post their exchange in rounds, as large shards do
+        env["GLU_HIP_DIST_ROUNDS"] = "3"      # from four ranks up by default: asked for here
     p = subprocess.run(["bash", os.path.join(root, "tools", "rehearse_multi_gpu.sh"), "2", "20"], capture_output=True, text=True,
                        env=env, timeout=900)
     assert p.returncode == 0, p.stderr[-2000:]

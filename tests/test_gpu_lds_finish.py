@@ -141,15 +141,101 @@ def _with_one_run_of(n, length, seed, run=0x1234):
                                                       (2560, 1, 2560), (2561, 1, 4608), (4608, 1, 4608), (4609, 0, 4608),
                                                       (4608 + 5000, 0, 4608)])
 def test_the_longest_run_decides(G, length, accepted, capacity):
-    """The in-LDS pass is enqueued in the tile geometry that suits uniform keys of this count (here 256 x 6 = 1536 pairs) and in
-    the next two larger ones; the device runs the smallest whose tile holds the longest run.  A run of exactly a tile's
-    capacity is sorted in that tile, one pair more takes the next, and one pair more than the largest enqueued tile sends
-    the sort to the ordinary passes."""
+    """Round-4 rule (GLU_HIP_SORT_LONG_RUNS=0; still the rule for 64-bit, typed and keys-only sorts): the in-LDS pass is enqueued
+    in the tile geometry that suits uniform keys of this count (here 256 x 6 = 1536 pairs) and in the next two larger ones; the
+    device runs the smallest whose tile holds the longest run.  A run of exactly a tile's capacity is sorted in that tile, one
+    pair more takes the next, and one pair more than the largest enqueued tile sends the sort to the ordinary passes."""
     keys = _with_one_run_of(N_SMALL, length, 5)
     vals = np.arange(N_SMALL, dtype=np.uint32)
-    gk, gv, fin = _run(G, _sorter(G, **SMALL), keys, vals)
+    gk, gv, fin = _run(G, _sorter(G, GLU_HIP_SORT_LONG_RUNS=0, **SMALL), keys, vals)
     _check(keys, vals, gk, gv)
     assert fin["attempted"] == 1 and fin["accepted"] == accepted and fin["longest_run"] == length and fin["capacity"] == capacity
+
+
+# ---- round 5: runs longer than the tile go to two segmented passes over just their elements; the rest of the sort ends in LDS
+
+@pytest.mark.parametrize("length", [CAP_SMALL, CAP_SMALL + 1, 4609, 4608 + 5000, 200_000])
+def test_one_long_run_no_longer_refuses_the_sort(G, length):
+    keys = _with_one_run_of(N_SMALL, length, 5)
+    vals = np.arange(N_SMALL, dtype=np.uint32)
+    s = _sorter(G, **SMALL)
+    gk, gv, fin = _run(G, s, keys, vals)
+    _check(keys, vals, gk, gv)
+    assert fin["attempted"] == 1 and fin["accepted"] == 1 and fin["longest_run"] == length and fin["capacity"] == CAP_SMALL, fin
+    lr = s.read_long_runs()
+    assert lr["runs"] == (1 if length > CAP_SMALL else 0) and lr["pairs"] == (length if length > CAP_SMALL else 0), lr
+
+
+@pytest.mark.parametrize("shape", ["long_run_first", "long_run_last", "many_long_runs", "long_runs_of_equal_keys", "zeros_1_percent",
+                                   "an_eighth_in_long_runs", "more_than_half_in_long_runs", "too_many_long_runs"])
+def test_mixed_long_and_short_runs(G, shape):
+    """Long runs at index 0 and 65535, hundreds of them, long runs of one key value, and the two ways out: more than half of the
+    pairs in long runs, or more than 8192 long runs, still send the sort to the ordinary passes."""
+    rng = np.random.default_rng(77)
+    n = N_SMALL  # mean run 64; the tile for uniform keys holds 1536, the largest enqueued 4608
+    keys = rng.integers(0, 2**32, n, dtype=np.uint32)
+    want = {"accepted": 1}
+    if shape == "long_run_first":
+        keys[rng.choice(n, 7000, replace=False)] &= np.uint32(0x0000FFFF)
+    elif shape == "long_run_last":
+        keys[rng.choice(n, 9001, replace=False)] |= np.uint32(0xFFFF0000)
+    elif shape == "many_long_runs":
+        pos = rng.choice(n, 200 * 2000, replace=False)  # (a tenth of the pairs: below the eighth that would move the sort to a larger tile)
+        keys[pos] = (rng.integers(0, 200, pos.size, dtype=np.uint32) * np.uint32(97) << np.uint32(16)) | (keys[pos] & np.uint32(0xFFFF))
+    elif shape == "long_runs_of_equal_keys":
+        pos = rng.choice(n, 40 * 5000, replace=False)
+        keys[pos] = (rng.integers(0, 40, pos.size, dtype=np.uint32) * np.uint32(0x01010101)) | np.uint32(0x00100000)
+    elif shape == "zeros_1_percent":
+        keys[rng.random(n) < 0.01] = 0
+    elif shape == "an_eighth_in_long_runs":
+        pos = rng.choice(n, n // 9, replace=False)
+        keys[pos] = (rng.integers(0, 30, pos.size, dtype=np.uint32) << np.uint32(16)) | (keys[pos] & np.uint32(0xFFFF))
+    elif shape == "more_than_half_in_long_runs":
+        pos = rng.choice(n, n * 6 // 10, replace=False)
+        keys[pos] = (rng.integers(0, 30, pos.size, dtype=np.uint32) << np.uint32(16)) | (keys[pos] & np.uint32(0xFFFF))
+        want = {"accepted": 0}
+    else:  # too_many_long_runs: 9000 runs of 1600 pairs need more than three segments' worth of ... 14.4 M pairs: a larger input
+        n = 9000 * 1600 + (1 << 22)
+        keys = rng.integers(0, 2**32, n, dtype=np.uint32)
+        keys[: 9000 * 1600] = (np.repeat(np.arange(9000, dtype=np.uint32), 1600) * np.uint32(7) << np.uint32(16)) | (keys[: 9000 * 1600] & np.uint32(0xFFFF))
+        keys = keys[rng.permutation(n)]
+    vals = np.arange(keys.size, dtype=np.uint32)
+    s = _sorter(G, **SMALL)
+    gk, gv, fin = _run(G, s, keys, vals)
+    _check(keys, vals, gk, gv)
+    lengths = np.bincount((keys >> 16).astype(np.int64), minlength=65536)
+    lr = s.read_long_runs()
+    if shape == "too_many_long_runs":
+        # (the uniform-keys tile of this count is 1536 too: 9000 runs outgrow it, and the next tile takes them whole)
+        assert fin["accepted"] == 1 and fin["capacity"] == 2560 and lr["runs"] == int((lengths > 2560).sum()), (fin, lr)
+        return
+    assert fin["attempted"] == 1 and fin["accepted"] == want["accepted"], fin
+    if want["accepted"]:
+        cap = fin["capacity"]
+        assert lr["runs"] == int((lengths > cap).sum()) and lr["pairs"] == int(lengths[lengths > cap].sum()), (fin, lr)
+        assert lr["runs"] > 0
+    else:
+        assert lr["runs"] == 0
+
+
+def test_long_runs_on_one_object_back_to_back(G):
+    """accepted with long runs, accepted without, refused, with long runs again: the descriptors of one sort are rewritten by the
+    next in stream order, nothing of a sort survives into the next"""
+    rng = np.random.default_rng(78)
+    s = _sorter(G, GLU_HIP_SORT_FINISH_BACKOFF=0, **SMALL)
+    n = N_SMALL
+    for it, kind in enumerate(["long", "plain", "refused", "long", "long"]):
+        keys = rng.integers(0, 2**32, n, dtype=np.uint32)
+        if kind == "long":
+            keys[rng.choice(n, 3000 + 4000 * it, replace=False)] &= np.uint32(0x0007FFFF)  # 8 runs share them
+        elif kind == "refused":
+            keys &= np.uint32(0x000FFFFF)
+        vals = np.arange(n, dtype=np.uint32)
+        gk, gv, fin = _run(G, s, keys, vals)
+        _check(keys, vals, gk, gv)
+        lr = s.read_long_runs()
+        assert fin["accepted"] == (0 if kind == "refused" else 1), (kind, fin)
+        assert (lr["runs"] > 0) == (kind == "long"), (kind, lr)
 
 
 def test_empty_runs_and_runs_of_one(G):
@@ -237,7 +323,9 @@ def test_after_a_refusal_the_next_sorts_do_not_ask_again(G):
     asks again (inputs that fit are taken up again, inputs that never fit pay once in nine sorts)."""
     s = _sorter(G, **SMALL)
     vals = np.arange(N_SMALL, dtype=np.uint32)
-    narrow = _with_one_run_of(N_SMALL, 6000, 13)  # (full-range keys, one run too long for the largest enqueued tile)
+    narrow = _uniform(N_SMALL, 13)  # (full-range keys, but six in ten crowd into thirty runs: beyond what the long-run passes take)
+    crowd = np.random.default_rng(13).choice(N_SMALL, N_SMALL * 6 // 10, replace=False)
+    narrow[crowd] = (np.random.default_rng(14).integers(0, 30, crowd.size, dtype=np.uint32) * np.uint32(2001) << np.uint32(16)) | (narrow[crowd] & np.uint32(0xFFFF))
     wide = _uniform(N_SMALL, 14)
     seen = []
     for i in range(11):
@@ -577,3 +665,79 @@ def test_typed_keys_in_runs_of_one_are_decoded(G, name):
     code = (u ^ top) if dt.kind == "i" else np.where(u & top, ~u, u ^ top)
     order = np.argsort(code, kind="stable")
     assert (kb.get_data(dt).view(u.dtype) == u[order]).all() and (vb.get_data(np.uint32) == vals[order]).all()
+
+
+# ---- 64-bit keys, round 5: the in-LDS pass ranks key bits [32, 48) only (two rounds) and repairs ties on them exactly; runs
+# whose keys crowd on those bits fall back to all six rounds inside the same workgroup
+
+def _u64_with_low48(n, seed, low48):
+    """uniform top 16 bits (the runs), the low 48 bits from low48(rng, n)"""
+    rng = np.random.default_rng(seed)
+    return (rng.integers(0, 65536, n, dtype=np.uint64) << np.uint64(48)) | (low48(rng, n).astype(np.uint64) & np.uint64((1 << 48) - 1))
+
+
+@pytest.mark.parametrize("shape", ["ties_on_ranked_bits_reversed_below", "equal_on_16_64_reversed_on_0_16", "all_low_bits_equal",
+                                   "pairs_of_ties", "one_tie_group_longer_than_the_repair_bound", "tie_groups_of_equal_keys",
+                                   "only_bits_0_32_vary", "walk_back_limit"])
+@pytest.mark.parametrize("with_vals", [True, False])
+def test_u64_tie_repair_adversarial_shapes(G, shape, with_vals):
+    n = N_SMALL
+    if shape == "ties_on_ranked_bits_reversed_below":
+        # every run: the ranked bits take 8 values, the bits below count down in input order -- every tie group is out of order
+        low = lambda rng, n: (rng.integers(0, 8, n).astype(np.uint64) << np.uint64(32)) | (np.uint64(n) - np.arange(n, dtype=np.uint64))
+    elif shape == "equal_on_16_64_reversed_on_0_16":
+        low = lambda rng, n: np.uint64(0xABCD12340000) | ((np.uint64(n) - np.arange(n, dtype=np.uint64)) & np.uint64(0xFFFF))
+    elif shape == "all_low_bits_equal":
+        low = lambda rng, n: np.full(n, 0x123456789ABC, dtype=np.uint64)
+    elif shape == "pairs_of_ties":
+        # neighbours in the input share the ranked bits and come in descending order below them
+        def low(rng, n):
+            hi = np.repeat(rng.integers(0, 65536, (n + 1) // 2).astype(np.uint64), 2)[:n]
+            return (hi << np.uint64(32)) | np.where(np.arange(n) % 2 == 0, np.uint64(7), np.uint64(3))
+    elif shape == "one_tie_group_longer_than_the_repair_bound":
+        def low(rng, n):
+            k = rng.integers(0, 2**48, n, dtype=np.uint64)
+            k[: n // 300] = (np.uint64(0x5A5A) << np.uint64(32)) | rng.integers(0, 2**32, n // 300, dtype=np.uint64)  # ~ 14 000 ties, 0.2 per run .. no: spread over all runs
+            return k
+    elif shape == "tie_groups_of_equal_keys":
+        low = lambda rng, n: rng.integers(0, 5, n).astype(np.uint64) * np.uint64(0x111100000001)
+    elif shape == "only_bits_0_32_vary":
+        low = lambda rng, n: rng.integers(0, 2**32, n, dtype=np.uint64)
+    else:  # walk_back_limit: tie groups of 20 in ascending order whose last two are swapped
+        def low(rng, n):
+            g = np.arange(n, dtype=np.uint64) // np.uint64(20)
+            w = np.arange(n, dtype=np.uint64) % np.uint64(20)
+            w = np.where(w == 18, np.uint64(19), np.where(w == 19, np.uint64(18), w))
+            return ((g % np.uint64(65536)) << np.uint64(32)) | w
+    keys = _u64_with_low48(n, 41, low)
+    if shape == "one_tie_group_longer_than_the_repair_bound":
+        keys[:100] = (np.uint64(0x0042) << np.uint64(48)) | (np.uint64(0x5A5A) << np.uint64(32)) | (np.uint64(1000) - np.arange(100, dtype=np.uint64))
+    if shape == "walk_back_limit":
+        # groups of 20 must be neighbours inside their run: one run for all
+        keys = (keys & np.uint64((1 << 48) - 1)) | (np.repeat(np.arange((n + 1199) // 1200, dtype=np.uint64), 1200)[:n] << np.uint64(48))
+    vals = np.arange(n, dtype=np.uint32) if with_vals else None
+    gk, gv, fin = _run64(G, _sorter(G, **SMALL), keys, vals)
+    assert fin["attempted"] == 1 and fin["accepted"] == 1, fin
+    if with_vals:
+        ek, ev = O.stable_sort_pairs(keys, vals)
+        assert (gk == ek).all() and (gv == ev).all()
+    else:
+        assert (gk == np.sort(keys, kind="stable")).all()
+
+
+@pytest.mark.parametrize("rank_bits", [16, 24, 48])
+def test_u64_rank_bits_switch(G, rank_bits):
+    """GLU_HIP_FINISH_RANK_BITS (tuning): 16 (default) = two rounds + tie repair, 24 = three, 48 = all six rounds as in round 4."""
+    keys, vals = _uniform64(N_SMALL, 43), np.arange(N_SMALL, dtype=np.uint32)
+    keys[::3] &= np.uint64(0xFFFFFFFF0000FFFF)  # a third of the keys tie on bits [16, 32)
+    old = os.environ.get("GLU_HIP_FINISH_RANK_BITS")
+    os.environ["GLU_HIP_FINISH_RANK_BITS"] = str(rank_bits)
+    try:
+        gk, gv, fin = _run64(G, _sorter(G, **SMALL), keys, vals)
+    finally:
+        if old is None:
+            del os.environ["GLU_HIP_FINISH_RANK_BITS"]
+        else:
+            os.environ["GLU_HIP_FINISH_RANK_BITS"] = old
+    ek, ev = O.stable_sort_pairs(keys, vals)
+    assert (gk == ek).all() and (gv == ev).all() and fin["accepted"] == 1

@@ -188,8 +188,9 @@ def test_segmented_sort_argument_checks(G):
     torch.cuda.synchronize()
 
 
-# ---- a segmented sort that ends in LDS (round 5): one counting pass on the top digit of the bits + one in-LDS pass over the
-# runs (segment, top digit), decided on the device by the longest run; the ordinary passes behind it otherwise
+# ---- a segmented sort that ends in LDS (round 5): one counting pass on the top digit of the bits (into the sorter's scratch) +
+# one in-LDS pass over the runs (segment, top digit) into the output; runs longer than a tile are walked in pieces or split over
+# several workgroups; the device decides by the longest run, the ordinary passes run behind it otherwise
 
 def _run_with_report(G, keys, vals, begin, length, seg, nseg, key_bits, env=None):
     import os
@@ -211,7 +212,7 @@ def _run_with_report(G, keys, vals, begin, length, seg, nseg, key_bits, env=None
 @pytest.mark.parametrize("key_bits", [16, 24, 32])
 @pytest.mark.parametrize("n,sources,nseg", [(700_001, 8, 32), (3_000_000, 2, 128), (2_500_000, 3, 1)])
 def test_segmented_sort_ends_in_lds(G, n, sources, nseg, key_bits):
-    """Uniform keys: the runs (segment, top digit) are short, the device accepts, and the result is the oracle's."""
+    """Uniform keys: the device accepts, and the result is the oracle's.  One segment of 2.5 M pairs has runs of 9800."""
     rng = np.random.default_rng(n * 3 + key_bits)
     keys = rng.integers(0, 2**32, n, dtype=np.uint32)
     vals = np.arange(n, dtype=np.uint32)
@@ -219,56 +220,98 @@ def test_segmented_sort_ends_in_lds(G, n, sources, nseg, key_bits):
     gk, gv, rep = _run_with_report(G, keys, vals, begin, length, seg, nseg, key_bits)
     ek, ev = expected(keys, vals, begin, length, seg, nseg, key_bits)
     assert (gk == ek).all() and (gv == ev).all()
-    if n / (nseg * 256) + 6 * (n / (nseg * 256)) ** 0.5 + 8 <= 512 * 18:
-        assert rep["attempted"] == 1 and rep["accepted"] == 1 and rep["runs"] == nseg * 256, rep
-        assert 0 < rep["longest_run"] <= rep["capacity"]
+    if nseg == 1:
+        # runs of 9800 pairs outgrow the largest tile that shares a CU: by default no attempt (the ordinary passes); the two ways
+        # to take such runs are switches -- one workgroup per CU with a tile of 17408, or every run split over four workgroups
+        assert rep["attempted"] == 0, rep
+        for env, tile, split in (({"GLU_HIP_SEG_MAX_GEO": "5"}, 17408, 1), ({"GLU_HIP_SEG_SPLIT_MAX": "3"}, 4608, 4)):
+            gk, gv, rep = _run_with_report(G, keys, vals, begin, length, seg, nseg, key_bits, env=env)
+            assert (gk == ek).all() and (gv == ev).all()
+            assert rep["accepted"] == 1 and rep["tile"] == tile and rep["split"] == split, rep
+        return
+    assert rep["attempted"] == 1 and rep["accepted"] == 1 and rep["runs"] == nseg * 256, rep
+    assert 0 < rep["longest_run"] <= rep["tile"] and rep["split"] == 1, rep
     # and the same input by the ordinary passes (the attempt switched off) gives the same arrays
     pk, pv, rep0 = _run_with_report(G, keys, vals, begin, length, seg, nseg, key_bits, env={"GLU_HIP_SEG_LDS_FINISH": "0"})
     assert rep0["attempted"] == 0
     assert (pk == ek).all() and (pv == ev).all()
 
 
-@pytest.mark.parametrize("shape", ["one_long_run", "run_of_exactly_the_capacity", "one_pair_more", "all_keys_equal", "empty_segments",
-                                   "long_run_in_last_segment"])
-def test_segmented_sort_lds_ending_decides_by_the_longest_run(G, shape):
-    """Runs longer than the largest enqueued tile send the whole segmented sort to the ordinary passes; a run of exactly the
-    capacity is still taken.  With 1 M pairs in 16 segments the uniform-keys tile holds 1536 pairs and the largest enqueued 4608."""
+@pytest.mark.parametrize("split", [1, 2, 3])
+@pytest.mark.parametrize("shape", ["uniform", "skewed_parts", "few_values"])
+def test_segmented_sort_runs_split_over_workgroups(G, split, shape):
+    """Every run split over 2, 4, 8 workgroups by ranges of the low bits (what the sharded sort does at eight ranks), forced on
+    runs that would fit one tile; parts that outgrow their tile (skew) are walked in pieces."""
+    rng = np.random.default_rng(split * 7 + len(shape))
+    n, nseg, sources = 1_200_000, 4, 5
+    keys = rng.integers(0, 2**32, n, dtype=np.uint32)
+    if shape == "skewed_parts":
+        keys[rng.random(n) < 0.8] &= np.uint32(0xFFFF07FF)  # 80 % of every run in the lowest of 32 ranges of the low 16 bits
+    elif shape == "few_values":
+        keys = (keys & np.uint32(0xFFFF0000)) | (rng.integers(0, 3, n, dtype=np.uint32) * np.uint32(0x5555))
+    vals = np.arange(n, dtype=np.uint32)
+    begin, length, seg = source_major_pieces(rng, n, sources, nseg)
+    gk, gv, rep = _run_with_report(G, keys, vals, begin, length, seg, nseg, 24, env={"GLU_HIP_SEG_SPLIT_MIN": str(split), "GLU_HIP_SEG_SPLIT_MAX": "3"})
+    ek, ev = expected(keys, vals, begin, length, seg, nseg, 24)
+    assert (gk == ek).all() and (gv == ev).all()
+    assert rep["accepted"] == 1 and rep["split"] == 1 << split, rep
+
+
+@pytest.mark.parametrize("shape", ["one_long_run", "run_of_exactly_a_tile", "one_pair_more_than_a_tile", "one_key_value_longer_than_a_tile",
+                                   "long_run_crowded_low_bits", "run_at_the_gate", "run_beyond_the_gate", "all_keys_equal",
+                                   "empty_segments", "long_run_in_last_segment"])
+def test_segmented_sort_lds_ending_long_runs(G, shape):
+    """1 M pairs in 16 segments: the uniform-keys tile holds 1536 pairs.  Runs longer than that are walked in pieces that fit
+    (radix_finish_ranges_kernel), whatever their keys; a run beyond 32 tiles sends the sort to the ordinary passes."""
     rng = np.random.default_rng(11)
     n, nseg, sources = 1_048_576, 16, 4
     keys = rng.integers(0, 2**32, n, dtype=np.uint32)
     vals = np.arange(n, dtype=np.uint32)
-    skew = None
-    if shape == "empty_segments":
-        skew = [1, 0, 0, 2, 0, 1, 1, 0, 1, 1, 0, 0, 0, 1, 0, 0]
+    skew = [1, 0, 0, 2, 0, 1, 1, 0, 1, 1, 0, 0, 0, 1, 0, 0] if shape == "empty_segments" else None
     begin, length, seg = source_major_pieces(rng, n, sources, nseg, skew=skew)
-    # the elements of segment 5, in the segment's own order, through their indices in the input
-    def seg_indices(g):
+
+    def seg_indices(g):  # the elements of segment g, through their indices in the input
         return np.concatenate([np.arange(begin[i], begin[i] + length[i]) for i in range(len(seg)) if seg[i] == g]).astype(np.int64)
-    want_accept = True
-    if shape in ("one_long_run", "long_run_in_last_segment"):
-        idx = seg_indices(5 if shape == "one_long_run" else nseg - 1)
-        keys[idx[:6000]] = (keys[idx[:6000]] & np.uint32(0xFF00FFFF)) | np.uint32(0x00A50000)  # 6000 + chance pairs in run (g, 0xA5)
-        want_accept = False
-    elif shape in ("run_of_exactly_the_capacity", "one_pair_more"):
-        idx = seg_indices(5)
+
+    def fill_run(g, m, low=None):
+        """exactly m pairs of segment g get the top digit 0xA5 (low: their low 16 bits)"""
+        idx = seg_indices(g)
         in_run = ((keys[idx] >> 16) & 0xFF) == 0xA5
-        keys[idx[in_run]] ^= np.uint32(0x00010000)  # nobody is in run (5, 0xA5) ...
-        m = 4608 + (1 if shape == "one_pair_more" else 0)
+        keys[idx[in_run]] ^= np.uint32(0x00010000)
         pick = idx[rng.choice(idx.size, m, replace=False)]
-        keys[pick] = (keys[pick] & np.uint32(0xFF00FFFF)) | np.uint32(0x00A50000)  # ... but exactly m pairs
-        want_accept = shape == "run_of_exactly_the_capacity"
+        keys[pick] = (keys[pick] & np.uint32(0xFF00FFFF)) | np.uint32(0x00A50000)
+        if low is not None:
+            keys[pick] = (keys[pick] & np.uint32(0xFFFF0000)) | low(m).astype(np.uint32)
+        return m
+
+    want_accept, longest = True, None
+    if shape == "one_long_run":
+        longest = fill_run(5, 6000)
+    elif shape == "long_run_in_last_segment":
+        longest = fill_run(nseg - 1, 7001)
+    elif shape == "run_of_exactly_a_tile":
+        longest = fill_run(5, 1536)
+    elif shape == "one_pair_more_than_a_tile":
+        longest = fill_run(5, 1537)
+    elif shape == "one_key_value_longer_than_a_tile":
+        longest = fill_run(5, 5000, low=lambda m: np.where(np.arange(m) % 10 == 0, rng.integers(0, 65536, m), 0x1234))
+    elif shape == "long_run_crowded_low_bits":
+        longest = fill_run(5, 9000, low=lambda m: np.where(rng.random(m) < 0.9, rng.integers(0, 40, m), rng.integers(0, 65536, m)))
+    elif shape == "run_at_the_gate":
+        longest = fill_run(5, 1536 * 32)
+    elif shape == "run_beyond_the_gate":
+        longest = fill_run(5, 1536 * 32 + 1)
+        want_accept = False
     elif shape == "all_keys_equal":
         keys[:] = 0x12345678
         want_accept = False
     gk, gv, rep = _run_with_report(G, keys, vals, begin, length, seg, nseg, 24)
     ek, ev = expected(keys, vals, begin, length, seg, nseg, 24)
     assert (gk == ek).all() and (gv == ev).all()
-    assert rep["attempted"] == 1 and rep["capacity"] == 4608, rep
+    assert rep["attempted"] == 1 and rep["tile"] == 1536 and rep["split"] == 1 and rep["capacity"] == 1536 * 32, rep
     assert rep["accepted"] == (1 if want_accept else 0), rep
-    if shape == "run_of_exactly_the_capacity":
-        assert rep["longest_run"] == 4608
-    if shape == "one_pair_more":
-        assert rep["longest_run"] == 4609
+    if longest is not None:
+        assert rep["longest_run"] == longest, rep
 
 
 def test_segmented_sort_lds_ending_back_to_back_with_changing_outcomes(G):
@@ -278,7 +321,7 @@ def test_segmented_sort_lds_ending_back_to_back_with_changing_outcomes(G):
 
     sorter = G.RadixSort()
     rng = np.random.default_rng(5)
-    n, nseg = 600_000, 8
+    n, nseg = 600_000, 2
     sorter.prepare_internal_buffers(n)
     st = torch.cuda.Stream()
     outs, exps = [], []
@@ -286,7 +329,7 @@ def test_segmented_sort_lds_ending_back_to_back_with_changing_outcomes(G):
         for it in range(6):
             keys = rng.integers(0, 2**32, n, dtype=np.uint32)
             if it % 2:
-                keys[: n // 3] &= np.uint32(0xFF00FFFF)  # a third of the pairs in the runs (g, 0): far beyond any tile
+                keys[: n // 2] &= np.uint32(0xFF00FFFF)  # half of the pairs in the two runs (g, 0): 150 000 each, beyond 32 tiles of 1536
             vals = np.arange(n, dtype=np.uint32)
             begin, length, seg = source_major_pieces(rng, n, 2 + it, nseg)
             kin = torch.from_numpy(keys.view(np.int32)).cuda()
@@ -299,4 +342,5 @@ def test_segmented_sort_lds_ending_back_to_back_with_changing_outcomes(G):
         st.synchronize()
     for (_, _, kout, vout), (ek, ev) in zip(outs, exps):
         assert (kout.cpu().numpy().view(np.uint32) == ek).all() and (vout.cpu().numpy().view(np.uint32) == ev).all()
-    assert sorter.read_seg_finish()["accepted"] == 0  # (the last one was a refused one)
+    rep = sorter.read_seg_finish()
+    assert rep["attempted"] == 1 and rep["accepted"] == 0, rep  # (the last one was a refused one)
