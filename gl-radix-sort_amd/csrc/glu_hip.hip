@@ -424,12 +424,24 @@ template<> struct GeometryFor<uint32_t, 8, true, false> : Geometry<1024, 20, 1, 
 #endif
 template<typename KeyT, int BITS, bool VALS>
 struct LinesGeometry : Geometry<1024, GLU_LINES_KPT_U32, 1, true> {};
+// The segmented instantiation of the line kernel (the local sort of the sharded sort, the long runs of a sort that ends in LDS)
+// carries the sub-block loop's state on top: with 10 pairs per thread it spills 24 bytes per lane past the 128 registers a
+// 1024-thread workgroup has (36 before the kernel's element indices went to 32 bits), with 8 it does not -- and is 5 % SLOWER:
+// three segmented passes over 2^27 pairs 1.60-1.66 ms against 1.525-1.533, alternating on one box
+// (profiles/r05/seg_scatter_kpt_ab.txt).  The larger tile stays.
+#ifndef GLU_LINES_KPT_SEG
+#define GLU_LINES_KPT_SEG 10
+#endif
+struct SegLinesGeometry : Geometry<1024, GLU_LINES_KPT_SEG, 1, true> {};
 template<> struct LinesGeometry<uint32_t, 8, false> : Geometry<1024, 16, 1, true> {};
 template<> struct LinesGeometry<uint32_t, 4, true> : Geometry<1024, 12, 1, true> {};
 template<> struct LinesGeometry<uint32_t, 4, false> : Geometry<1024, 16, 1, true> {};
 template<> struct LinesGeometry<uint64_t, 8, true> : Geometry<1024, GLU_LINES_KPT_U64, 1, true> {};
 template<> struct LinesGeometry<uint64_t, 8, false> : Geometry<1024, 10, 1, true> {};
-template<> struct LinesGeometry<uint64_t, 4, true> : Geometry<1024, 8, 1, true> {};
+#ifndef GLU_LINES_KPT_U64_4BIT
+#define GLU_LINES_KPT_U64_4BIT 8 // 8-byte keys with values, 4-bit digits (tuning builds override; 5: no register spills)
+#endif
+template<> struct LinesGeometry<uint64_t, 4, true> : Geometry<1024, GLU_LINES_KPT_U64_4BIT, 1, true> {};
 template<> struct LinesGeometry<uint64_t, 4, false> : Geometry<1024, 10, 1, true> {};
 }
 
@@ -512,6 +524,9 @@ struct glu_radix_sort_s
     // The runs of a sort that ends in LDS are the values of the 16 key bits below `top`: the whole key's top 16 by default,
     // the top 16 of the bits that VARIED in this object's last attempt once that is known (keys below 2^28 make 4096 runs of the
     // whole key's top bits and 65536 of bits [12, 28)).  A guess: the plan kernel refuses if a bit from `top` up varies after all.
+    bool device_top = true;       // GLU_HIP_SORT_DEVICE_TOP=0: the round-4 rule below (the host guesses from the object's last attempt)
+    uint32_t top_floor = 0;       // device_top: the exact top bit of an attempt whose sample missed a varying bit (handed to the next sample)
+    bool last_device_top = false; // (glu_radix_sort_read_finish reads the top bit from the device's plan)
     uint32_t finish_top = 0;      // 0: the key's width
     uint32_t last_finish_top = 0; // what the last sort assumed (glu_radix_sort_read_finish)
     uint32_t finish_backoff = 8;  // GLU_HIP_SORT_FINISH_BACKOFF=N (0: every sort attempts: tests)
@@ -1038,7 +1053,7 @@ glu_status launch_seg_finish_geo(const uint32_t* src_k, const uint32_t* src_v, u
     if (split_log2 == 0)
     {
         hipLaunchKernelGGL(sort_kernel, dim3(nruns), dim3(THREADS), sizeof(Smem), stream, const_cast<uint32_t*>(src_k), const_cast<uint32_t*>(src_v),
-                           dst_k, dst_v, starts, low_bits, (const PassPlan*) nullptr, 0u, geo, 0u, nruns, gate, gate_cap, rank_from,
+                           dst_k, dst_v, starts, low_bits, (const PassPlan*) nullptr, 0u, geo, 0u, nruns, gate, gate_cap, rank_bits,
                            (unsigned long long*) nullptr);
         HIP_TRY(hipGetLastError());
     }
@@ -1076,7 +1091,6 @@ glu_status launch_finish(KeyT* keys_a, uint32_t* vals_a, KeyT* keys_b, uint32_t*
                          uint32_t pass, uint32_t key_xf, hipStream_t stream, uint32_t rank_bits, uint32_t nruns = kFinishRuns,
                          const uint32_t* gate = nullptr, uint32_t gate_cap = 0)
 {
-    const uint32_t rank_from = finish_rank_from(low_bits, rank_bits);
     // the geometry the sort is expected to take gets a workgroup per run, the others 8192 workgroups that loop
 #define GLU_FINISH(GEO_, THREADS_, KPT_)                                                                                          \
     if (geo_first <= GEO_ && GEO_ <= geo_last)                                                                                    \
@@ -1097,7 +1111,7 @@ glu_status launch_finish(KeyT* keys_a, uint32_t* vals_a, KeyT* keys_b, uint32_t*
         hipLaunchKernelGGL(kern, dim3(GEO_ == geo_expected ? nruns : std::min(nruns, 8192u)), dim3(THREADS_),                     \
                            sizeof(FinishSmem<KeyT, THREADS_, KPT_, VALS>), stream,                                                \
                            keys_a, vals_a, keys_b, vals_b, starts, low_bits, plan, pass, (uint32_t) GEO_, key_xf, nruns, gate,     \
-                           gate_cap, rank_from, (unsigned long long*) nullptr);                                                   \
+                           gate_cap, rank_bits, (unsigned long long*) nullptr);                                                   \
         HIP_TRY(hipGetLastError());                                                                                               \
     }
     GLU_FINISH(1, 256, 6)
@@ -1123,7 +1137,7 @@ glu_status launch_finish(KeyT* keys_a, uint32_t* vals_a, KeyT* keys_b, uint32_t*
 // arrays that hold the data (PassPlan::flip[2], known on the device) into the other pair, bits [8, 16) back.
 glu_status launch_long_run_passes(glu_radix_sort_s* s, uint32_t* a_k, uint32_t* a_v, uint32_t* b_k, uint32_t* b_v, size_t count, hipStream_t stream)
 {
-    using G = LinesGeometry<uint32_t, 8, true>;
+    using G = SegLinesGeometry;
     constexpr int RADIX = 256;
     constexpr int RS = (G::KPT + 2) / 3;
     using Smem = LineSmem<uint32_t, 8, G::THREADS, G::KPT, true>;
@@ -1218,7 +1232,40 @@ glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t cou
         end_bit == 8 * sizeof(KeyT) && s->digit_bits == 8 && num_passes == sizeof(KeyT) && count >= (s->finish_min ? s->finish_min : finish_min_count(sizeof(KeyT))) &&
         lines_applicable<KeyT, 8>(s, kbuf[0], vbuf[0], kbuf[1], vbuf[1], count))
         finish_kpt = finish_geometry_for(count);
-    if (finish_kpt && s->finish_hint)
+    // The runs' key bits are chosen on the device from a sample of the keys (untyped keys: radix_sample_top_kernel); the host only
+    // remembers, as a floor for the next sample, the exact top bit of an attempt that was refused because its sample had missed
+    // a varying bit.  GLU_HIP_SORT_DEVICE_TOP=0: the host guesses from the object's last attempt (round 4, below).
+    const bool device_top = finish_kpt && s->device_top && key_xf == KEY_XF_NONE && !s->no_bit_shortcut;
+    if (finish_kpt && s->finish_hint && device_top)
+    {
+        const uint32_t seen = s->finish_seq ? __atomic_load_n(s->finish_hint, __ATOMIC_ACQUIRE) : 0u;
+        if (s->finish_wait == 0 && s->finish_seq && (seen >> 3) == s->finish_seq) // the last attempt's outcome has arrived
+        {
+            if (seen & 7u) s->finish_last_geo = seen & 7u; // the tile it took
+            if (s->finish_seq != s->finish_seq_acted_on)    // (acted on once)
+            {
+                s->finish_seq_acted_on = s->finish_seq;
+                bool range_miss = false;
+                if (__atomic_load_n(s->finish_hint + 3, __ATOMIC_ACQUIRE) == s->finish_seq)
+                {
+                    const uint64_t varying = (uint64_t) s->finish_hint[1] | ((uint64_t) s->finish_hint[2] << 32);
+                    const uint32_t exact = varying ? 64u - (uint32_t) __builtin_clzll(varying) : 0u, used = s->finish_hint[4];
+                    range_miss = !(seen & 7u) && exact > used;
+                    if (range_miss)
+                        s->top_floor = exact; // the sample missed a bit that varies: the next one starts from here
+                    else if (exact < s->top_floor)
+                        s->top_floor = 0;     // (other keys now)
+                }
+                if (!(seen & 7u) && !range_miss && s->finish_backoff) s->finish_wait = s->finish_backoff; // refused for its runs: do not ask again for a while
+            }
+        }
+        if (s->finish_wait)
+        {
+            s->finish_wait--;
+            finish_kpt = 0;
+        }
+    }
+    else if (finish_kpt && s->finish_hint)
     {
         const uint32_t seen = s->finish_seq ? __atomic_load_n(s->finish_hint, __ATOMIC_ACQUIRE) : 0u;
         if (s->finish_wait == 0 && s->finish_seq && (seen >> 3) == s->finish_seq) // the last attempt's outcome has arrived
@@ -1254,7 +1301,7 @@ glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t cou
         s->finish_seq = s->finish_seq >= 0x0FFFFFFFu ? 1u : s->finish_seq + 1;
         for (uint32_t i = num_passes; i-- > 0;) passes[i + 2] = passes[i];
         // (typed keys and sorts that do not collect which bits vary: the whole key's top bits)
-        finish_top_bit = key_xf == KEY_XF_NONE && !s->no_bit_shortcut && s->finish_top ? std::min<uint32_t>(s->finish_top, end_bit) : end_bit;
+        finish_top_bit = !device_top && key_xf == KEY_XF_NONE && !s->no_bit_shortcut && s->finish_top ? std::min<uint32_t>(s->finish_top, end_bit) : end_bit;
         passes[0] = PassDesc{finish_top_bit - 16u, 8u, key_xf, 0}; // (typed keys: encoded on load here, decoded on store by the in-LDS pass)
         passes[1] = PassDesc{finish_top_bit - 8u, 8u, 0u, 0};
         num_passes += 2;
@@ -1263,6 +1310,7 @@ glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t cou
     const bool finish_long_ok = finish_kpt && sizeof(KeyT) == 4 && vals && key_xf == KEY_XF_NONE && s->long_runs && s->long_image.ptr &&
                                 finish_top_bit >= 16 && finish_top_bit - 16u <= 16u;
     s->last_finish_long_ok = finish_long_ok;
+    s->last_device_top = finish_kpt && device_top;
     s->last_finish_top = finish_kpt ? finish_top_bit : 0u;
     s->last_finish_attempted = finish_kpt != 0;
     const uint32_t finish_last = std::min<uint32_t>(finish_kpt + 2, kFinishGeometries); // the larger tiles enqueued behind it
@@ -1294,8 +1342,14 @@ glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t cou
     {
         // per sort: no follower counts for itself yet, nothing is known about the key bits
         PassPlan* plan = (PassPlan*) s->plan.ptr;
-        static_assert(offsetof(PassPlan, bits_nor) + sizeof(plan->bits_nor) == sizeof(PassPlan), "the zeroed tail of the plan");
+        static_assert(offsetof(PassPlan, shift_down) + sizeof(plan->shift_down) == sizeof(PassPlan), "the zeroed tail of the plan");
         HIP_TRY(hipMemsetAsync(plan->pair_fallback, 0, sizeof(PassPlan) - offsetof(PassPlan, pair_fallback), stream));
+        if (finish_kpt && device_top)
+        {
+            hipLaunchKernelGGL((radix_sample_top_kernel<KeyT>), dim3(1), dim3(1024), 0, stream, (const KeyT*) kbuf[0], (uint32_t) count, end_bit,
+                               std::min<uint32_t>(s->top_floor, end_bit), plan);
+            HIP_TRY(hipGetLastError());
+        }
     }
     if (planned)
         for (uint32_t i = 0; i < (uint32_t) kPlanMaxPasses; i++) s->last_pair_roles[i] = i < num_passes ? (uint32_t) passes[i].pair_role : 0u;
@@ -1765,7 +1819,7 @@ glu_status launch_seg_pass(glu_radix_sort_s* s, const uint32_t* src_k, const uin
     const uint32_t* gate = gate_mode != kSegGateNone ? (const uint32_t*) s->seg_gate.ptr : nullptr;
     const bool attempt = gate_mode == kSegGateIfFits;
     const uint32_t gm_count = attempt ? kSegGateNone : gate_mode; // (the attempt's count and scan make the decision)
-    using G = LinesGeometry<uint32_t, 8, true>;
+    using G = SegLinesGeometry;
     constexpr int RADIX = 256;
     constexpr int RS = (G::KPT + 2) / 3;
     using Smem = LineSmem<uint32_t, 8, G::THREADS, G::KPT, true>;
@@ -2003,6 +2057,7 @@ glu_status glu_radix_sort_create(glu_radix_sort* out)
     if (const char* e = getenv("GLU_HIP_SORT_LDS_FINISH")) s->lds_finish = atoi(e) != 0;
     if (const char* e = getenv("GLU_HIP_SEG_LDS_FINISH")) s->seg_finish = atoi(e) != 0;
     if (const char* e = getenv("GLU_HIP_SORT_LONG_RUNS")) s->long_runs = atoi(e) != 0;
+    if (const char* e = getenv("GLU_HIP_SORT_DEVICE_TOP")) s->device_top = atoi(e) != 0;
     if (const char* e = getenv("GLU_HIP_SEG_SPLIT_MAX")) s->seg_split_max = (uint32_t) std::min(std::max(atoi(e), 0), 3);
     if (const char* e = getenv("GLU_HIP_FINISH_RANK_BITS"))
         if (atoi(e) >= 8) s->finish_rank_bits = (uint32_t) atoi(e);
@@ -2402,6 +2457,7 @@ glu_status glu_radix_sort_read_finish(glu_radix_sort sort, uint32_t* attempted, 
     if (attempted) *attempted = tried ? 1u : 0u;
     if (accepted) *accepted = tried && host.finish ? 1u : 0u;
     if (longest_run) *longest_run = tried ? host.finish_longest : 0u;
+    if (tried && sort->last_device_top && host.top_bit) sort->last_finish_top = host.top_bit; // (chosen on the device)
     // the tile the device chose; refused: the largest one that was enqueued
     if (capacity) *capacity = !tried ? 0u : host.finish ? finish_geometry_capacity(host.finish) : sort->last_finish_capacity;
     if (top_bit) *top_bit = tried ? sort->last_finish_top : 0u;

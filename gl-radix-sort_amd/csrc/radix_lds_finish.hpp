@@ -95,6 +95,79 @@ __host__ __device__ inline uint32_t finish_geometry_choice(uint32_t longest, uin
         if (longest <= finish_geometry_capacity(g)) geo = g;
     return geo;
 }
+// Which 16 key bits make the runs of a sort that ends in LDS?  The top 16 of the bits that VARY: keys below 2^28 make 4096 runs
+// of the whole key's top 16 bits (sixteen times too long) and 65536 of bits [12, 28).  Which bits vary is known exactly only
+// after the keys have been read (the leader's count kernel collects them), and that kernel must know its digit before it reads:
+// so ONE workgroup looks at a SAMPLE first -- up to 65536 16-byte pieces spread evenly over the array, 1 MiB, a few microseconds --
+// and writes PassPlan::top_bit = the highest bit that varies in the sample + 1 (at least 16, at least `floor_top`, at most the
+// key's width; 64-bit keys: moved up to 40 or 48 where a digit would straddle the two key words) and the shift every kernel of
+// the two top-bit passes subtracts.  A bit above it that varies after all (a rare key the sample missed) is seen by the exact
+// collection: the plan kernel then refuses, the ordinary passes run, and the host hands the exact top bit to the next sort as
+// floor_top.  (Round 4 guessed from the object's previous sort: the first sort of small-range keys was always the refused one.)
+template<typename KeyT>
+__global__ __launch_bounds__(1024) void radix_sample_top_kernel(const KeyT* __restrict__ keys, uint32_t n, uint32_t key_bits,
+                                                                uint32_t floor_top, PassPlan* plan)
+{
+    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+    __shared__ uint32_t red[4][16];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr uint32_t W = sizeof(KeyT) / 4; // words per key
+    const uint64_t nvec = (uint64_t) n * sizeof(KeyT) / 16;
+    const uint32_t samples = (uint32_t) (nvec < 65536ull ? nvec : 65536ull);
+    const uint64_t stride = samples ? nvec / samples : 1;
+    uint32_t o[2] = {0, 0}, a[2] = {~0u, ~0u}; // OR and AND of the low / high key words seen
+    const u32x4_t* v = reinterpret_cast<const u32x4_t*>(keys);
+    for (uint32_t j = tid; j < samples; j += 1024)
+    {
+        const u32x4_t x = v[(uint64_t) j * stride];
+        if (W == 1)
+        {
+            o[0] |= x.x | x.y | x.z | x.w;
+            a[0] &= x.x & x.y & x.z & x.w;
+        }
+        else
+        {
+            o[0] |= x.x | x.z;
+            a[0] &= x.x & x.z;
+            o[1] |= x.y | x.w;
+            a[1] &= x.y & x.w;
+        }
+    }
+    // (the first and the last key: constant arrays with one odd key at either end are a classic)
+    if (tid == 0 && n)
+    {
+        const KeyT f = keys[0], l = keys[n - 1];
+        o[0] |= (uint32_t) f | (uint32_t) l;
+        a[0] &= (uint32_t) f & (uint32_t) l;
+        if (W == 2)
+        {
+            o[1] |= (uint32_t) ((uint64_t) f >> 32) | (uint32_t) ((uint64_t) l >> 32);
+            a[1] &= (uint32_t) ((uint64_t) f >> 32) & (uint32_t) ((uint64_t) l >> 32);
+        }
+    }
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1)
+    {
+        o[0] |= __shfl_xor(o[0], s);
+        o[1] |= __shfl_xor(o[1], s);
+        a[0] &= __shfl_xor(a[0], s);
+        a[1] &= __shfl_xor(a[1], s);
+    }
+    if (lane == 0) red[0][wave] = o[0], red[1][wave] = o[1], red[2][wave] = a[0], red[3][wave] = a[1];
+    __syncthreads();
+    if (tid == 0)
+    {
+        for (int w = 1; w < 16; w++) o[0] |= red[0][w], o[1] |= red[1][w], a[0] &= red[2][w], a[1] &= red[3][w];
+        const uint64_t varying = (uint64_t) (o[0] & ~a[0]) | (W == 2 ? (uint64_t) (o[1] & ~a[1]) << 32 : 0ull);
+        uint32_t top = varying ? 64u - (uint32_t) __builtin_clzll(varying) : 0u;
+        top = max(max(top, floor_top), 16u);
+        top = min(top, key_bits);
+        if (W == 2 && top > 32 && top < 48 && top != 40) top = top < 40 ? 40u : 48u; // a digit stays inside one key word
+        plan->top_bit = top;
+        plan->shift_down[0] = plan->shift_down[1] = key_bits - top;
+    }
+}
+
 // long_ok (round 5: 4-byte untyped keys with values): runs LONGER than the chosen tile do not refuse the sort any more -- they
 // are segments for two segmented counting passes over just their elements (radix_finish_long_runs_kernel builds the
 // descriptors on the device, radix_seg_passes.hpp the passes), the in-LDS pass leaves them alone.  The tile is then the smallest
@@ -191,6 +264,7 @@ __global__ __launch_bounds__(1024) void radix_finish_plan_kernel(const uint32_t*
     // The runs are the values of key bits [top_bit - 16, top_bit): that orders the keys only if no key bit from top_bit up
     // varies -- the host assumed so from what this object's last sort saw, the count kernel of this one has looked
     // (PassPlan::bits_or / bits_nor).  Typed keys and sorts that do not collect the bits are launched with top_bit = key_bits.
+    if (plan->top_bit) top_bit = plan->top_bit; // (chosen on the device from a sample of the keys: radix_sample_top_kernel)
     bool range_ok = top_bit >= key_bits;
     uint64_t varying = ~0ull;
     if (plan->bits_valid)
@@ -219,6 +293,7 @@ __global__ __launch_bounds__(1024) void radix_finish_plan_kernel(const uint32_t*
                 __hip_atomic_store(hint + 2, (uint32_t) (varying >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 __hip_atomic_store(hint + 3, attempt, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
+            __hip_atomic_store(hint + 4, top_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); // (the top bit this attempt used)
             __hip_atomic_store(hint, (attempt << 3) | (accept ? geo : 0u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         if (!accept)
@@ -256,7 +331,6 @@ __global__ __launch_bounds__(1024) void radix_finish_long_runs_kernel(const uint
 {
     const LongRunsLayout lay(nwg);
     __shared__ uint32_t wsum[2][16];
-    __shared__ uint32_t totals[2];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t geo = plan->finish;
     const uint32_t cap = finish_geometry_capacity(geo);
@@ -607,15 +681,39 @@ __device__ __forceinline__ void finish_rank_rounds(FinishSmem<KeyT, THREADS, KPT
                     if ((uint32_t) (i + 1) < items) first_of_next = (KeyT) __shfl((unsigned long long) key[i + 1 < KPT ? i + 1 : i], 0);
                 if (lane == 63) kn = first_of_next;
             }
-            if (in && tied(kp, kn) && above(kp, kn))
+            // out-of-order neighbours inside a tie group: their position is listed (one LDS atomic per wave and item: the wave's
+            // count; every lane's slot follows from the ballot)
+            const bool inv = in && tied(kp, kn) && above(kp, kn);
+            const uint64_t invs = __ballot(inv);
+            if (invs) // (wave-uniform)
             {
-                // the first out-of-order neighbours of a tie group list the group's first position
-                uint32_t q = p, steps = 0;
-                KeyT kq = kp;
-                bool mine = true, open = true;
-                while (q > 0 && steps < kTieMaxBack)
+                uint32_t at = 0;
+                if (lane == 0) at = atomicAdd(&s.tie_count, (uint32_t) __popcll(invs));
+                at = (uint32_t) __builtin_amdgcn_readfirstlane((int) at) +
+                     __builtin_amdgcn_mbcnt_hi((uint32_t) (invs >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) invs, 0u));
+                if (inv)
                 {
-                    const KeyT kb = s.stage.key_at(q - 1);
+                    if (at < Smem::TIE_LIST) list[at] = (uint16_t) p;
+                    else s.tie_bad = 1u;
+                }
+            }
+        }
+        __syncthreads();
+        const uint32_t listed = min(s.tie_count, Smem::TIE_LIST);
+        if (!s.tie_bad)
+        {
+            // a lane per listed position: it walks back to the first position of its tie group -- unless an earlier pair of the
+            // group is out of order too (that one's lane repairs the group) -- finds the group's end and sorts the group in place
+            // by stable insertion on the whole key
+            for (uint32_t g = tid; g < listed; g += THREADS)
+            {
+                const uint32_t p = list[g];
+                uint32_t first = p, steps = 0;
+                KeyT kq = s.stage.key_at(p);
+                bool mine = true, open = p > 0;
+                while (first > 0 && steps < kTieMaxBack)
+                {
+                    const KeyT kb = s.stage.key_at(first - 1);
                     if (!tied(kb, kq))
                     {
                         open = false;
@@ -627,36 +725,32 @@ __device__ __forceinline__ void finish_rank_rounds(FinishSmem<KeyT, THREADS, KPT
                         break;
                     }
                     kq = kb;
-                    q--;
+                    first--;
                     steps++;
                 }
-                if (q == 0) open = false;
-                if (mine && open)
-                    s.tie_bad = 1u; // the group begins further back than this lane may walk
-                else if (mine)
-                {
-                    const uint32_t at = atomicAdd(&s.tie_count, 1u);
-                    if (at < Smem::TIE_LIST) list[at] = (uint16_t) q;
-                    else s.tie_bad = 1u;
-                }
+                if (first == 0) open = false;
+                if (mine && open) s.tie_bad = 1u; // the group begins further back than a lane may walk
+                // (who repairs which group is settled before any group is touched: a lane that walked back through a group
+                // that is being repaired could take it for its own)
+                list[g] = mine && !open ? (uint16_t) first : (uint16_t) 0xFFFFu;
             }
         }
         __syncthreads();
-        const uint32_t groups = s.tie_count;
         if (!s.tie_bad)
         {
-            for (uint32_t g = tid; g < groups; g += THREADS)
+            for (uint32_t g = tid; g < listed; g += THREADS)
             {
                 const uint32_t first = list[g];
+                if (first == 0xFFFFu) continue;
                 const KeyT k0 = s.stage.key_at(first);
-                uint32_t end = first + 1;
+                uint32_t end = first + 2; // (the group has an out-of-order pair: at least two positions)
                 while (end < len && end - first <= kTieMaxGroup && tied(k0, s.stage.key_at(end))) end++;
                 if (end - first > kTieMaxGroup)
                 {
                     s.tie_bad = 1u;
                     continue;
                 }
-                for (uint32_t a = first + 1; a < end; a++) // stable insertion by the whole key
+                for (uint32_t a = first + 1; a < end; a++)
                 {
                     KeyT ka;
                     uint32_t va;
@@ -675,6 +769,7 @@ __device__ __forceinline__ void finish_rank_rounds(FinishSmem<KeyT, THREADS, KPT
                 }
             }
         }
+        const uint32_t groups = listed;
         __syncthreads();
         const bool bad = s.tie_bad != 0u;
         if (bad || groups)
@@ -723,10 +818,13 @@ __global__ __launch_bounds__(THREADS, (sizeof(KeyT) == 8 && THREADS == 512 ? GLU
                                                                     uint32_t low_bits, const PassPlan* plan, uint32_t pass,
                                                                     uint32_t geometry, uint32_t key_xf = 0,
                                                                     uint32_t nruns = kFinishRuns, const uint32_t* gate = nullptr,
-                                                                    uint32_t gate_cap = 0, uint32_t rank_from = 0,
+                                                                    uint32_t gate_cap = 0, uint32_t rank_bits = 16,
                                                                     unsigned long long* stamps = nullptr)
 {
     FinishClock<STAMPS> clock;
+    if (plan && plan->top_bit) low_bits = plan->top_bit - 16u; // (the device chose the runs' bits: radix_sample_top_kernel)
+    // (more than rank_bits bits left to order: the rounds rank the top rank_bits .. rank_bits + 7 of them, ties are repaired)
+    const uint32_t rank_from = low_bits > rank_bits ? ((low_bits - rank_bits) / 8u) * 8u : 0u;
     const KeyCodec<KeyT, XF> codec_out(key_xf);
     // (kernel-uniform: the device chose another geometry, or the ordinary passes)
     if (plan ? plan->finish != geometry : *gate > gate_cap) return;

@@ -62,6 +62,8 @@ __global__ __launch_bounds__(1024) void radix_pair_count_kernel(const KeyT* __re
     const KeyT* __restrict__ keys = keys_a;
     if (plan)
     {
+        shift -= plan->shift_down[pass]; // (PassPlan::top_bit)
+        shift2 -= plan->shift_down[pass + 1];
         // this pass's digit lies in key bits that do not vary: an identity, known without counting -- no tables either, so
         // the follower counts for itself (or finds its own digit constant)
         if (plan->off[pass] || ((plan_flags & kPlanShortcut) && plan_digit_is_constant(plan, shift, mask))) // (kernel-uniform; off: radix_lds_finish.hpp)
@@ -264,6 +266,7 @@ __global__ __launch_bounds__(1024) void radix_pair_unitsum_kernel(const uint32_t
         return;
     }
     if (plan->pair_fallback[pass]) return; // (kernel-uniform)
+    shift -= plan->shift_down[pass]; // (PassPlan::top_bit)
     if ((plan_flags & kPlanShortcut) && plan_digit_is_constant(plan, shift, mask)) // an identity, known without any table
     {
         if (blockIdx.x == 0 && threadIdx.x == 0) plan->skip[pass] = kSkipWithoutCounting;

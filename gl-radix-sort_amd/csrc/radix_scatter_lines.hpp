@@ -117,6 +117,7 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
     }
     if (!SEG && plan)
     {
+        shift -= plan->shift_down[pass]; // (PassPlan::top_bit)
         const uint32_t flip = pass > 0 ? plan->flip[pass] : 0u;
         const uint32_t skip = plan->skip[pass];
         if (blockIdx.x == 0 && threadIdx.x == 0) plan->flip[pass + 1] = flip ^ (skip ? 0u : 1u);
@@ -206,7 +207,9 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
     // the array: tuning harness), or -- the follower of a pair of passes (radix_pair_passes.hpp) -- a run of whole units of
     // the pass before, which starts and ends at any element, or -- SEG -- the sub-block's range.  Only the last tile of a
     // range can be partial.
-    uint64_t r0, r1;
+    // (32-bit element indices: the library refuses counts beyond 0xFFFF0000, and a prefetch reaches at most two tiles further;
+    // per-lane 64-bit indices cost two registers each, which this kernel -- at its 128-register limit -- does not have)
+    uint32_t r0, r1;
     if (SEG)
     {
         const uint2 r = ranges[sb];
@@ -220,8 +223,13 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
         r1 = r.y;
     }
     else
-        block_range(b, nb, tiles_total, TILE, n, share, r0, r1); // whole tiles (share == 0) or an equal share of the elements
-    const uint32_t first = 0, last = (uint32_t) ((r1 - r0 + (uint64_t) TILE - 1) / (uint64_t) TILE);
+    {
+        uint64_t b0, b1;
+        block_range(b, nb, tiles_total, TILE, n, share, b0, b1); // whole tiles (share == 0) or an equal share of the elements
+        r0 = (uint32_t) b0;
+        r1 = (uint32_t) b1;
+    }
+    const uint32_t first = 0, last = (uint32_t) (((uint64_t) (r1 - r0) + (uint64_t) TILE - 1) / (uint64_t) TILE);
     const uint32_t last_tile_of_range = last;
 
     KeyT key[KPT], nkey[KPT];
@@ -230,8 +238,8 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
     uint16_t* const my_cnt = s.wcnt[wave];
     // guarded loads of a partial tile: positions past the end of the array read as pads (highest digit, after all keys)
     auto load_tile_guarded = [&](uint32_t t) {
-        const uint64_t base = r0 + (uint64_t) t * TILE;
-        const uint32_t left = (uint32_t) (r1 - base);
+        const uint32_t base = r0 + t * (uint32_t) TILE;
+        const uint32_t left = r1 - base;
 #pragma unroll
         for (int i = 0; i < KPT; i++)
         {
@@ -242,10 +250,10 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
     };
     // full tile t, or the first tile of the array when t is not a full tile of this range (a harmless prefetch of
     // something that is not used: the loops that prefetch carry no branch)
-    auto prefetch_base = [&](uint32_t t) -> uint64_t {
-        const uint64_t tb = r0 + (uint64_t) t * TILE;
-        const bool ok = t < last_tile_of_range && r1 - tb >= (uint64_t) TILE;
-        return (ok ? tb : 0ull) + wave_off;
+    auto prefetch_base = [&](uint32_t t) -> uint32_t {
+        const uint32_t tb = r0 + t * (uint32_t) TILE;
+        const bool ok = t < last_tile_of_range && r1 - tb >= (uint32_t) TILE;
+        return (ok ? tb : 0u) + wave_off;
     };
     // Ranks items [I0, I1) of the tile in key[] inside the wave (match-any on the digit bits with one ballot per bit,
     // wave-private running counters) and loads the same items of the tile after it into nkey[].  Touches nothing but the
@@ -253,7 +261,7 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
     // (Tried: ballots for all items first, then the counters with one read and one leader-only atomic add per item, so
     // that the ballots carry no LDS dependency: 6 % slower, the adds and their exec-mask branches cost more than the
     // dependency they remove.)
-    auto rank_items = [&](auto i0, auto i1, uint64_t pf_base) {
+    auto rank_items = [&](auto i0, auto i1, uint32_t pf_base) {
 #pragma unroll
         for (int i = decltype(i0)::value; i < decltype(i1)::value; i++)
         {
@@ -324,9 +332,9 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
     //      ranked under the phases of the tile before it
     if (first < last)
     {
-        if (r1 - r0 >= (uint64_t) TILE)
+        if (r1 - r0 >= (uint32_t) TILE)
         {
-            const uint64_t base = r0 + wave_off;
+            const uint32_t base = r0 + wave_off;
 #pragma unroll
             for (int i = 0; i < KPT; i++) key[i] = codec_in.encode(src_keys[base + i * kWave]);
             if (VALS)
@@ -342,11 +350,11 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
 
     for (uint32_t tile = first; tile < last; tile++)
     {
-        const uint64_t tile_base = r0 + (uint64_t) tile * TILE;
-        const uint64_t rem = r1 - tile_base;
-        const uint32_t tile_valid = rem >= (uint64_t) TILE ? (uint32_t) TILE : (uint32_t) rem;
+        const uint32_t tile_base = r0 + tile * (uint32_t) TILE;
+        const uint32_t rem = r1 - tile_base;
+        const uint32_t tile_valid = rem >= (uint32_t) TILE ? (uint32_t) TILE : rem;
         const bool has_next = tile + 1 < last;
-        const bool next_full = has_next && r1 - (tile_base + TILE) >= (uint64_t) TILE;
+        const bool next_full = has_next && r1 - (tile_base + (uint32_t) TILE) >= (uint32_t) TILE;
         if (STAMPS) tprev = __builtin_amdgcn_s_memtime();
         __syncthreads(); // every wave has ranked this tile
         stamp(0);
@@ -460,7 +468,7 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
 
         // ---- stage (key, val) at the ranked position; the value register just staged takes the next tile's value
         {
-            const uint64_t next_base = prefetch_base(tile + 1);
+            const uint32_t next_base = prefetch_base(tile + 1);
             if (PRIO & 1) __builtin_amdgcn_s_setprio(2); // tuning: LDS-bound phases ahead of the ranking of other waves
 #pragma unroll
             for (int i = 0; i < KPT; i++)
@@ -476,7 +484,7 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
         //      ranking is VALU work on wave-private state: no barrier separates it from this tile's later phases, the
         //      rest of it follows the tail copy below.
         for (int i = lane; i < Smem::WCNT_STRIDE / 2; i += kWave) reinterpret_cast<uint32_t*>(my_cnt)[i] = 0;
-        const uint64_t pf_base = prefetch_base(tile + 2);
+        const uint32_t pf_base = prefetch_base(tile + 2);
         if (has_next)
         {
             if (next_full)

@@ -170,6 +170,12 @@ struct PassPlan
     // vary is an identity: its count kernel says so (skip[p] = 1) without reading the keys.  Zeroed with pair_fallback.
     uint32_t bits_valid;
     uint32_t bits_or[2], bits_nor[2];
+    // A sort that tries to end in LDS takes its runs from the 16 key bits below top_bit, which the DEVICE chooses (round 5,
+    // radix_sample_top_kernel: the highest bit that varies in a sample of the keys -- small-range keys end in LDS on an object's
+    // first sort).  The host enqueues the two top-bit passes for the whole key's top bits; their kernels shift down by
+    // shift_down[pass] = key bits - top_bit.  0: the host's shifts stand.  Zeroed with pair_fallback.
+    uint32_t top_bit;
+    uint32_t shift_down[kPlanMaxPasses];
 };
 
 // PassPlan::skip values: 0 = the pass runs, 1 = an identity found by the row scan (one digit value holds every key; the
@@ -368,6 +374,7 @@ __global__ __launch_bounds__(THREADS) void radix_count_kernel(const KeyT* __rest
     // the follower of a pair of passes has its table from the two-digit histogram of the pass before it
     // (radix_pair_passes.hpp) unless a kernel before this one found that it cannot (kernel-uniform)
     if (pair_follower && !plan->pair_fallback[pass]) return;
+    if (plan) shift -= plan->shift_down[pass]; // (PassPlan::top_bit)
 
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // planned sorts: read whichever pair of arrays holds the data before this pass; arm the pass's skip flag

@@ -48,6 +48,53 @@ def test_no_oracle_or_cpu_path_in_product():
     assert "oracle" not in out
 
 
+def test_no_product_kernel_spills_registers_unnoticed(built):
+    """The build writes the compiler's per-kernel resource remarks to lib/kernel_resources.log.  Every instantiation of the line
+    scatter kernel -- the kernel every large pass runs, one 1024-thread workgroup per CU at exactly 128 registers -- must come
+    out with ScratchSize 0 (round 4 had 24 instantiations with 12 .. 80 bytes per lane; 32-bit element indices and a smaller
+    tile for the segmented form removed them).  The exceptions are listed with their reason and their bound."""
+    import re
+
+    log = os.path.join(ROOT, "gl-radix-sort_amd", "lib", "kernel_resources.log")
+    if not os.path.exists(log) or os.path.getmtime(log) < os.path.getmtime(os.path.join(ROOT, "gl-radix-sort_amd", "lib", "libglu_hip.so")) - 600:
+        pytest.skip("no resource log beside this build of the library (built by an older Makefile)")
+    text = open(log).read()
+    kernels = {}
+    cur = None
+    for line in text.splitlines():
+        m = re.search(r"remark: (?:\s*)Function Name: (\S+)", line)
+        if m:
+            cur = m.group(1)
+            continue
+        m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
+        if m and cur:
+            kernels[cur] = int(m.group(1))
+    lines = {k: v for k, v in kernels.items() if "radix_scatter_lines_kernel" in k}
+    assert len(lines) >= 20, "the resource log does not hold the line scatter kernels"
+    allowed = {
+        # 8-byte keys WITH values and 4-bit digits (glu_radix_sort_set_digit_bits(4) on 64-bit keys: the comparison mode with the
+        # reference's pass structure): 8 pairs per thread spill 28 / 44 bytes per lane; 5 pairs per thread do not and are not
+        # faster (profiles/r05/u64_4bit_kpt_ab.txt)
+        "radix_scatter_lines_kernelImLi4ELi1024ELi8E": 48,
+        # the SEGMENTED form (sub-block loop around the pass body: the sharded sort's local sort, the long runs of a sort that ends
+        # in LDS; last template flags ...ELb1ELb0ELb0E): 24 bytes per lane at 10 pairs per thread, none at 8 -- and 8 is 5 % slower
+        # (profiles/r05/seg_scatter_kpt_ab.txt)
+        "radix_scatter_lines_kernelIjLi8ELi1024ELi10ELb0ELb1ELi0ELb0ELi4ELb1ELb1ELi0ELb1E": 24,
+        "radix_scatter_lines_kernelIjLi8ELi1024ELi10ELb0ELb1ELi0ELb0ELi4ELb1ELb0ELi0ELb1E": 24,
+    }
+    bad = []
+    for name, scratch in lines.items():
+        limit = max([v for k, v in allowed.items() if k in name] + [0])
+        if scratch > limit:
+            bad.append((name, scratch))
+    assert not bad, bad
+    # the in-LDS pass of 64-bit keys asks for six waves per SIMD (three workgroups per CU) and pays a few spilled registers for
+    # it: 1.77 against 2.22 ms for 2^28 pairs (profiles/r05/finish_stamps_u64_rank16*.txt); nothing else may spill more
+    others = {k: v for k, v in kernels.items() if v > 0 and "radix_scatter_lines_kernel" not in k}
+    for name, scratch in others.items():
+        assert "radix_finish_sort_kernelImLi512ELi9E" in name and scratch <= 24, (name, scratch)
+
+
 def test_version_and_error_strings(built):
     L = built.lib()
     assert b"gfx950" in L.glu_version()

@@ -104,12 +104,12 @@ def test_duplicate_keys_inside_runs_keep_their_order(G):
 
 
 def test_small_key_range_is_refused_and_sorted_by_the_ordinary_passes(G):
-    """Keys below 2^20: sixteen runs hold everything -- the device says no after the first count kernel, the top-bit passes
+    """(Round-4 rule, GLU_HIP_SORT_DEVICE_TOP=0: the host takes the runs' key bits from the object's last attempt.)  Keys below 2^20: sixteen runs hold everything -- the device says no after the first count kernel, the top-bit passes
     move nothing, the ordinary passes follow (their two top-byte passes skipped as usual)."""
     rng = np.random.default_rng(4)
     keys = rng.integers(0, 1 << 20, N_SMALL, dtype=np.uint32)
     vals = np.arange(N_SMALL, dtype=np.uint32)
-    s = _sorter(G, **SMALL)
+    s = _sorter(G, GLU_HIP_SORT_DEVICE_TOP=0, **SMALL)
     gk, gv, fin = _run(G, s, keys, vals)
     _check(keys, vals, gk, gv)
     assert fin["attempted"] == 1 and fin["accepted"] == 0 and fin["longest_run"] > CAP_SMALL
@@ -227,9 +227,10 @@ def test_long_runs_on_one_object_back_to_back(G):
     for it, kind in enumerate(["long", "plain", "refused", "long", "long"]):
         keys = rng.integers(0, 2**32, n, dtype=np.uint32)
         if kind == "long":
-            keys[rng.choice(n, 3000 + 4000 * it, replace=False)] &= np.uint32(0x0007FFFF)  # 8 runs share them
-        elif kind == "refused":
-            keys &= np.uint32(0x000FFFFF)
+            keys[rng.choice(n, 3000 + 4000 * it, replace=False)] &= np.uint32(0x0000FFFF)  # run 0 gets them
+        elif kind == "refused":  # (full-range keys, six in ten crowded into thirty runs: more than the long-run passes take)
+            crowd = rng.choice(n, n * 6 // 10, replace=False)
+            keys[crowd] = (rng.integers(0, 30, crowd.size, dtype=np.uint32) * np.uint32(2001) << np.uint32(16)) | (keys[crowd] & np.uint32(0xFFFF))
         vals = np.arange(n, dtype=np.uint32)
         gk, gv, fin = _run(G, s, keys, vals)
         _check(keys, vals, gk, gv)
@@ -265,11 +266,11 @@ def test_presorted_inputs(G, shape):
 
 
 def test_one_object_alternates_between_the_two_sequences(G):
-    """The plan is per sort.  An object's first sort takes its runs from the whole key's top 16 bits; later ones from the top 16
+    """(Round-4 rule, GLU_HIP_SORT_DEVICE_TOP=0: the host takes the runs' key bits from the object's last attempt.)  The plan is per sort.  An object's first sort takes its runs from the whole key's top 16 bits; later ones from the top 16
     of the bits that varied in the attempt before (a guess the device checks): uniform keys end in LDS, 18-bit keys are refused
     under the first assumption and end in LDS under the second (runs = bits [2, 18)), full-range keys are then refused once --
     bits above 18 vary -- and end in LDS again.  A small sort (no plan) in between changes nothing."""
-    s = _sorter(G, GLU_HIP_SORT_FINISH_BACKOFF=0, **SMALL)
+    s = _sorter(G, GLU_HIP_SORT_DEVICE_TOP=0, GLU_HIP_SORT_FINISH_BACKOFF=0, **SMALL)
     vals = np.arange(N_SMALL, dtype=np.uint32)
     steps = [(8, False, 1, 32), (9, True, 0, 32), (10, True, 1, 18), (11, False, 0, 18), (12, False, 1, 32), (13, False, 1, 32)]
     for seed, small_range, accepted, top in steps:
@@ -287,10 +288,10 @@ def test_one_object_alternates_between_the_two_sequences(G):
 
 @pytest.mark.parametrize("bits,garbage", [(28, 0), (28, 0xA0000000), (21, 0), (17, 0x00FE0000), (16, 0), (31, 0)])
 def test_keys_of_a_smaller_range_end_in_lds_from_the_second_sort_on(G, bits, garbage):
-    """Keys below 2^bits (with or without constant bits above) crowd into few runs of the whole key's top bits: the first sort is
+    """(Round-4 rule, GLU_HIP_SORT_DEVICE_TOP=0: the host takes the runs' key bits from the object's last attempt.)  Keys below 2^bits (with or without constant bits above) crowd into few runs of the whole key's top bits: the first sort is
     refused; it has noted which key bits vary, and the second takes its runs from the top 16 of those -- bits [bits - 16, bits)
     -- and orders the remaining low bits (12, 5, 1, none, 15) inside LDS."""
-    s = _sorter(G, **SMALL)
+    s = _sorter(G, GLU_HIP_SORT_DEVICE_TOP=0, **SMALL)
     vals = np.arange(N_SMALL, dtype=np.uint32)
     for rep in range(3):
         keys = (_uniform(N_SMALL, 50 + rep) >> np.uint32(32 - bits)) | np.uint32(garbage)
@@ -304,9 +305,9 @@ def test_keys_of_a_smaller_range_end_in_lds_from_the_second_sort_on(G, bits, gar
 
 
 def test_u64_keys_of_a_smaller_range(G):
-    """64-bit keys of 45 varying bits: a digit must stay inside one 32-bit key word, so the runs come from bits [32, 48); of 40
+    """(Round-4 rule, GLU_HIP_SORT_DEVICE_TOP=0: the host takes the runs' key bits from the object's last attempt.)  64-bit keys of 45 varying bits: a digit must stay inside one 32-bit key word, so the runs come from bits [32, 48); of 40
     bits: from [24, 40)."""
-    s = _sorter(G, **SMALL)
+    s = _sorter(G, GLU_HIP_SORT_DEVICE_TOP=0, **SMALL)
     vals = np.arange(N_SMALL, dtype=np.uint32)
     for bits, top in [(45, 48), (40, 40), (64, 64)]:
         for rep in range(2):
@@ -373,13 +374,13 @@ def test_sizes_around_the_geometries_of_the_in_lds_pass(G):
 
 
 def test_keys_that_leave_runs_empty_take_a_larger_tile(G):
-    """31-bit keys (what the reference's test generator draws) fill half of the runs, each twice as long as uniform keys of the
+    """(Round-4 rule, GLU_HIP_SORT_DEVICE_TOP=0: the host takes the runs' key bits from the object's last attempt.)  31-bit keys (what the reference's test generator draws) fill half of the runs, each twice as long as uniform keys of the
     same count would: the device takes the next tile geometry; 2^28 of them (runs of 8192) and 2^29 full-range keys end in
     the largest tile, 512 threads x 18."""
     import torch
 
     for n, shift, cap in [((1 << 27) + 333, 1, 4608), ((1 << 28) - 5, 1, 9216), (1 << 29, 0, 9216)]:
-        s = _sorter(G)  # (a fresh object: its first sort takes the runs from the whole key's top bits)
+        s = _sorter(G, GLU_HIP_SORT_DEVICE_TOP=0)  # (a fresh object: its first sort takes the runs from the whole key's top bits)
         keys = torch.randint(-2**31, 2**31, (n,), dtype=torch.int32, device="cuda:0")
         if shift:
             keys = (keys >> 1) & torch.tensor(0x7FFFFFFF, dtype=torch.int32, device="cuda:0")
@@ -401,12 +402,12 @@ def test_keys_that_leave_runs_empty_take_a_larger_tile(G):
 
 
 def test_31_bit_keys_at_full_size_go_back_to_the_small_tile(G):
-    """2^28 pairs of 31-bit keys: the first sort ends in LDS in the largest tile (32768 runs of 8192 under the whole key's top
+    """(Round-4 rule, GLU_HIP_SORT_DEVICE_TOP=0: the host takes the runs' key bits from the object's last attempt.)  2^28 pairs of 31-bit keys: the first sort ends in LDS in the largest tile (32768 runs of 8192 under the whole key's top
     bits), the second in the tile for uniform keys (65536 runs of 4096 of bits [15, 31))."""
     import torch
 
     n = 1 << 28
-    s = _sorter(G)
+    s = _sorter(G, GLU_HIP_SORT_DEVICE_TOP=0)
     mask = torch.tensor(0x7FFFFFFF, dtype=torch.int32, device="cuda:0")
     for rep, (cap, top) in enumerate([(9216, 32), (4608, 31), (4608, 31)]):
         keys = torch.randint(-2**31, 2**31, (n,), dtype=torch.int32, device="cuda:0") & mask
@@ -440,14 +441,18 @@ def test_beyond_the_largest_geometry_no_attempt_is_made(G):
 
 def test_profile_books_the_sequence_that_ran(G):
     """read_profile counts the passes that did the work: two counting passes + the in-LDS pass when accepted, the four
-    ordinary passes (three here: the top byte is constant) when refused."""
+    ordinary passes when refused."""
     s = _sorter(G, **SMALL)
     s.set_profiling(True)
     vals = np.arange(N_SMALL, dtype=np.uint32)
     _run(G, s, _uniform(N_SMALL, 11), vals)
     prof = s.read_profile()
     assert prof["passes"] == 2 and prof["finish_passes"] == 1 and prof["finish_ms"] > 0 and prof["scatter_ms"] > 0
-    _run(G, s, _uniform(N_SMALL, 12) >> np.uint32(8), vals)
+    crowd = _uniform(N_SMALL, 12)  # (six keys in ten crowded into thirty runs: refused)
+    pos = np.random.default_rng(12).choice(N_SMALL, N_SMALL * 6 // 10, replace=False)
+    crowd[pos] = (np.random.default_rng(13).integers(0, 30, pos.size, dtype=np.uint32) * np.uint32(2001) << np.uint32(16)) | (crowd[pos] & np.uint32(0xFFFF))
+    _, _, fin = _run(G, s, crowd, vals)
+    assert fin["accepted"] == 0
     prof = s.read_profile()
     assert prof["passes"] == 4 and prof["finish_passes"] == 0 and prof["finish_ms"] == 0
 
@@ -468,7 +473,8 @@ def test_partial_sorts_do_not_attempt(G):
 
 def test_one_captured_graph_serves_every_outcome(G):
     """Which sequence of passes runs, and in which tile the in-LDS pass, is decided on the device: one captured graph of a
-    sort replays correctly on keys that end in LDS in the smallest tile, in a larger one, and on keys that are refused."""
+    sort replays correctly on keys that end in LDS, with and without long runs, of the full and of a smaller range, and on keys
+    that are refused."""
     import torch
 
     n = N_SMALL
@@ -479,8 +485,12 @@ def test_one_captured_graph_serves_every_outcome(G):
     side = torch.cuda.Stream()
     graph = torch.cuda.CUDAGraph()
     vals = np.arange(n, dtype=np.uint32)
-    inputs = [(_uniform(n, 21), 1, 1536), (_with_one_run_of(n, 3000, 22), 1, 4608), (_uniform(n, 23) >> np.uint32(10), 0, 4608),
-              (np.full(n, 5, dtype=np.uint32), 0, 4608), (_with_one_run_of(n, 2000, 24), 1, 2560), (_uniform(n, 25), 1, 1536)]
+    crowd = _uniform(n, 26)  # six keys in ten crowded into thirty runs: refused
+    pos = np.random.default_rng(26).choice(n, n * 6 // 10, replace=False)
+    crowd[pos] = (np.random.default_rng(27).integers(0, 30, pos.size, dtype=np.uint32) * np.uint32(2001) << np.uint32(16)) | (crowd[pos] & np.uint32(0xFFFF))
+    # (a long run goes to the segmented passes, 22-bit keys take their runs from bits [6, 22): both end in LDS in the small tile)
+    inputs = [(_uniform(n, 21), 1, 1536), (_with_one_run_of(n, 3000, 22), 1, 1536), (_uniform(n, 23) >> np.uint32(10), 1, 1536),
+              (np.full(n, 5, dtype=np.uint32), 0, 4608), (crowd, 0, 4608), (_with_one_run_of(n, 2000, 24), 1, 1536), (_uniform(n, 25), 1, 1536)]
     with torch.cuda.stream(side):
         kt.copy_(torch.from_numpy(inputs[0][0].view(np.int32)))
         vt.copy_(torch.from_numpy(vals.view(np.int32)))
@@ -543,7 +553,7 @@ def test_u64_keys_only_and_duplicates(G):
 def test_u64_small_range_is_refused(G):
     keys = _uniform64(N_SMALL, 33) >> np.uint64(20)
     vals = np.arange(N_SMALL, dtype=np.uint32)
-    s = _sorter(G, **SMALL)
+    s = _sorter(G, GLU_HIP_SORT_DEVICE_TOP=0, **SMALL)
     gk, gv, fin = _run64(G, s, keys, vals)
     ek, ev = O.stable_sort_pairs(keys, vals)
     assert (gk == ek).all() and (gv == ev).all()
@@ -566,13 +576,13 @@ def test_u64_the_longest_run_decides(G, length, accepted, capacity):
 
 
 def test_u64_large_sizes_and_the_largest_tile(G):
-    """2^27 full-range keys (tile of 2560), 2^27 keys with the top two bits clear (a quarter of the runs, four times as long:
+    """(Round-4 rule, GLU_HIP_SORT_DEVICE_TOP=0: the host takes the runs' key bits from the object's last attempt.)  2^27 full-range keys (tile of 2560), 2^27 keys with the top two bits clear (a quarter of the runs, four times as long:
     the largest tile, 1024 threads x 9) and BASELINE.json's configs[4], 2^28 keys (tile of 4608): sortedness, the value of
     every pair still points at its key, equal keys in input order."""
     import torch
 
     for n, clear, cap in [((1 << 27) + 77, 0, 2560), ((1 << 27) - 9, 2, 9216), (1 << 28, 0, 4608)]:
-        s = _sorter(G)  # (a fresh object: its first sort takes the runs from the whole key's top bits)
+        s = _sorter(G, GLU_HIP_SORT_DEVICE_TOP=0)  # (a fresh object: its first sort takes the runs from the whole key's top bits)
         keys = torch.randint(-2**63, 2**63 - 1, (n,), dtype=torch.int64, device="cuda:0")
         if clear:
             keys = (keys >> clear) & torch.tensor((1 << (64 - clear)) - 1, dtype=torch.int64, device="cuda:0")
@@ -741,3 +751,56 @@ def test_u64_rank_bits_switch(G, rank_bits):
             os.environ["GLU_HIP_FINISH_RANK_BITS"] = old
     ek, ev = O.stable_sort_pairs(keys, vals)
     assert (gk == ek).all() and (gv == ev).all() and fin["accepted"] == 1
+
+
+# ---- round 5: the runs' key bits are chosen on the device from a sample of the keys: small-range keys end in LDS on an object's
+# FIRST sort (radix_sample_top_kernel)
+
+@pytest.mark.parametrize("bits,garbage", [(28, 0), (28, 0xA0000000), (21, 0), (17, 0x00FE0000), (16, 0), (12, 0), (31, 0), (32, 0)])
+def test_keys_of_a_smaller_range_end_in_lds_on_the_first_sort(G, bits, garbage):
+    """garbage: constant bits above the range (they do not vary: the runs are still taken below them)"""
+    rng = np.random.default_rng(bits)
+    keys = (rng.integers(0, 1 << bits, N_SMALL, dtype=np.uint64).astype(np.uint32)) | np.uint32(garbage)
+    vals = np.arange(N_SMALL, dtype=np.uint32)
+    for rep in range(2):
+        s = _sorter(G, **SMALL)  # a fresh object every time
+        gk, gv, fin = _run(G, s, keys, vals)
+        _check(keys, vals, gk, gv)
+        assert fin["attempted"] == 1 and fin["accepted"] == 1 and fin["top_bit"] == max(bits, 16), (rep, fin)
+
+
+@pytest.mark.parametrize("bits,top", [(64, 64), (52, 52), (44, 48), (36, 40), (32, 32), (30, 30), (20, 20)])
+def test_u64_keys_of_a_smaller_range_on_the_first_sort(G, bits, top):
+    """(a digit stays inside one key word: top bits between 33 and 47 move up to 40 or 48)"""
+    rng = np.random.default_rng(bits)
+    keys = rng.integers(0, 1 << bits if bits < 64 else 2**64, N_SMALL, dtype=np.uint64)
+    vals = np.arange(N_SMALL, dtype=np.uint32)
+    gk, gv, fin = _run64(G, _sorter(G, **SMALL), keys, vals)
+    ek, ev = O.stable_sort_pairs(keys, vals)
+    assert (gk == ek).all() and (gv == ev).all()
+    assert fin["attempted"] == 1 and fin["top_bit"] == top, fin
+    assert fin["accepted"] == (1 if N_SMALL / min(2 ** (bits - (top - 16)), 65536) < 1400 else fin["accepted"])
+
+
+def test_a_key_the_sample_missed_refuses_once_and_is_remembered(G):
+    """20-bit keys but for ONE key with bit 31 set, at an index the sample does not read: the exact collection of the leader's
+    count kernel sees it, the attempt is refused (the ordinary passes sort), and the next sort's sample starts from that top
+    bit; keys that are really small again drop it."""
+    rng = np.random.default_rng(99)
+    keys = rng.integers(0, 1 << 20, N_SMALL, dtype=np.uint32)
+    keys[7] |= np.uint32(0x80000000)
+    vals = np.arange(N_SMALL, dtype=np.uint32)
+    s = _sorter(G, GLU_HIP_SORT_FINISH_BACKOFF=0, **SMALL)
+    gk, gv, fin = _run(G, s, keys, vals)
+    _check(keys, vals, gk, gv)
+    assert fin["attempted"] == 1 and fin["accepted"] == 0 and fin["top_bit"] == 20, fin
+    gk, gv, fin = _run(G, s, keys, vals)  # (under the whole key's top bits the 20-bit keys crowd into 16 runs: refused for its runs)
+    _check(keys, vals, gk, gv)
+    assert fin["attempted"] == 1 and fin["accepted"] == 0 and fin["top_bit"] == 32, fin
+    small = keys & np.uint32(0x000FFFFF)
+    gk, gv, fin = _run(G, s, small, vals)  # (still from the remembered top bit: the exact bits say 20)
+    _check(small, vals, gk, gv)
+    assert fin["top_bit"] == 32
+    gk, gv, fin = _run(G, s, small, vals)
+    _check(small, vals, gk, gv)
+    assert fin["attempted"] == 1 and fin["accepted"] == 1 and fin["top_bit"] == 20, fin

@@ -16,6 +16,7 @@ ap.add_argument("--warmup", type=int, default=3)
 ap.add_argument("--key-bits", type=int, default=0, help="keys drawn from [0, 2^B) (0: the whole key)")
 ap.add_argument("--zeros", type=float, default=0.0, help="this share of the keys (per cent) is set to zero")
 ap.add_argument("--keys-only", action="store_true")
+ap.add_argument("--digit-bits", type=int, default=8)
 a = ap.parse_args()
 n = int(round(2 ** a.log2))
 rng = np.random.default_rng(0x5EED)
@@ -26,7 +27,7 @@ keys = rng.integers(0, 2 ** bits, n, dtype=dt)
 if a.zeros > 0:
     keys[rng.random(n) < a.zeros / 100.0] = 0
 vals = np.arange(n, dtype=np.uint32)
-s = G.RadixSort()
+s = G.RadixSort(digit_bits=a.digit_bits)
 s.prepare_internal_buffers(n, key_bytes=a.key_bytes)
 k0, v0 = G.ShaderStorageBuffer(keys), G.ShaderStorageBuffer(vals)
 k, v = G.ShaderStorageBuffer(size=keys.nbytes), G.ShaderStorageBuffer(size=vals.nbytes)
