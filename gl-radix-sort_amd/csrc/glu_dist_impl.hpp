@@ -236,6 +236,7 @@ struct glu_dist_s
     size_t marks_used = 0;
     Scratch part_k, part_v;             // the local slice grouped by bucket (send side)
     Scratch recv_k, recv_v;             // receive side of glu_dist_sort_ptr (glu_dist_sort_finish takes the caller's)
+    Scratch retired_k, retired_v;       // receive arrays that glu_dist_sort_ptr outgrew: alive until the call after (its results alias them)
     Scratch land_k, land_v;             // where the exchange lands when the local sort is segmented (round 5: the sorter's scratch
                                         // arrays are the third pair that a segmented sort that ends in LDS passes through)
     Scratch hist;                       // [kDistRow] local row, [world * kDistRow] gathered rows, [4 + world] status words
@@ -380,6 +381,8 @@ glu_status glu_dist_destroy(glu_dist d)
     d->recv_v.release();
     d->land_k.release();
     d->land_v.release();
+    d->retired_k.release();
+    d->retired_v.release();
     d->hist.release();
     delete d;
     return GLU_OK;
@@ -915,9 +918,18 @@ glu_status glu_dist_sort_ptr(glu_dist d, const uint32_t* keys, const uint32_t* v
     // from here to the exchange a failure of this rank alone must not return: the ranks agree on it in dist_sort_finish
     glu_status grown = GLU_OK;
     const size_t have = d->recv_k.size / sizeof(uint32_t);
+    // (the arrays a sort before the last one returned are released now: nobody may still hold them)
+    d->retired_k.release();
+    d->retired_v.release();
     if (have < std::max<size_t>(n_recv, 1))
     {
-        // the exchange has not been posted yet: the partition may still be running on `stream`, the old arrays are idle
+        // the exchange has not been posted yet: the partition may still be running on `stream`, the old arrays are idle.  They
+        // are what the LAST sort returned (*out_keys / *out_vals, tensors of glu_hip.dist alias them): kept until the next call
+        // instead of being freed under the caller's feet
+        d->retired_k = d->recv_k;
+        d->retired_v = d->recv_v;
+        d->recv_k = Scratch();
+        d->recv_v = Scratch();
         const size_t want = n_recv + n_recv / 8 + 4096;
         grown = d->recv_k.reserve(want * sizeof(uint32_t));
         if (grown == GLU_OK) grown = d->recv_v.reserve(want * sizeof(uint32_t));

@@ -277,32 +277,34 @@ GLU_API glu_status glu_radix_sort_read_profile_finish(glu_radix_sort sort, doubl
  * passes <= 32. */
 GLU_API glu_status glu_radix_sort_read_plan(glu_radix_sort sort, uint32_t* skipped, uint32_t* counted_alone,
                                             uint32_t* pair_role, size_t passes);
-/* A sort that ends in LDS.  A sort of whole 32-bit or 64-bit keys (any key type) of 2^25 (64-bit keys: 1.26e7) .. about 2^29 elements with 8-bit
- * digits first tries a shorter way to the same result: the two counting passes on the TOP 16 key bits, after which the array
- * is 65536 runs of keys that share those bits, and one pass in which a workgroup per run orders the run by the remaining low
- * bits inside LDS (two rounds of 8 bits for 32-bit keys, six for 64-bit keys), in place -- 52.25 instead of 72.5 bytes of
- * memory traffic per pair with 32-bit keys, 80.5 instead of 225 with 64-bit keys.  That works if no run is longer than a
- * workgroup's LDS tile, which the device checks from exact run lengths before anything is moved: the in-LDS pass is enqueued
- * in the tile geometry that suits uniformly drawn keys of this count (1536 / 2560 / 4608 / 9216 pairs) and in the next
- * larger ones, and the device runs the smallest that holds the longest run (`capacity`) -- so keys that leave some runs empty
- * and make the others longer (31-bit keys, mild skew) still end in LDS.  Otherwise (keys crowded into few runs: small value
- * ranges, heavy duplicates) the four ordinary passes run, at the cost of one extra read of the keys; an object whose last
- * attempt was refused skips the next eight attempts.  The launch sequence is the same either way (the kernels of the sequence not taken return at once), so
- * the sort stays asynchronous and capturable.  This reports, for the last sort on the object (the caller has synchronised
- * its stream): attempted = 1 if both sequences were enqueued, accepted = 1 if the sort ended in LDS, longest_run = the
- * longest run counted (0xFFFFFFFF: not counted), capacity = the tile the device chose (refused: the largest one enqueued).
- * glu_radix_sort_read_plan describes the ordinary passes (all "skipped without counting" when accepted = 1).
- * top_bit: the runs were the values of key bits [top_bit - 16, top_bit).  That is the whole key's top 16 bits for an object's
- * first sort; afterwards it is the top 16 of the bits that VARIED in the object's last attempt (unsigned keys; the count kernel
- * notes them): keys below 2^28 make 4096 long runs of the whole key's top bits and are refused, and 65536 short ones of bits
- * [12, 28) from the second sort on.  It is a guess that the device checks: if a bit from top_bit up varies after all, the
- * ordinary passes run (and the next sort guesses better).
- * GLU_HIP_SORT_LDS_FINISH=0 in the environment of glu_radix_sort_create switches the attempt off.  Any pointer may be NULL. */
 /* Host only (no device needed): the tiles of the in-LDS pass a whole-key sort of `count` elements of 4- or 8-byte keys
  * enqueues by default -- first_capacity: the tile that suits uniformly drawn keys, last_capacity: the largest one enqueued
  * behind it; both 0: such a sort makes no attempt (too small, or its runs would outgrow the largest tile). */
 GLU_API glu_status glu_radix_sort_plan_finish(size_t count, uint32_t key_bytes, uint32_t* first_capacity,
                                               uint32_t* last_capacity);
+/* A sort that ends in LDS (replaces six of the reference's eight 4-bit steps, glu/RadixSort.hpp:289-333, by one pass).  A sort of
+ * whole 32-bit or 64-bit keys (any key type) of 2^25 (64-bit keys: 1.26e7) .. about 2^29 elements with 8-bit digits first tries a
+ * shorter way to the same result: two counting passes on 16 TOP key bits, after which the array is 65536 runs of keys that share
+ * those bits, and one pass in which a workgroup per run orders the run by the remaining low bits inside LDS, in place -- 52.25
+ * instead of 72.5 bytes of memory traffic per pair with 32-bit keys, 80.25 instead of 225 with 64-bit keys (which rank key bits
+ * [32, 48) and repair ties exactly).  The device decides from exact run lengths before anything is moved: the in-LDS pass is
+ * enqueued in the tile geometry that suits uniformly drawn keys of this count (1536 / 2560 / 4608 / 9216 pairs) and in the next
+ * larger ones, and the device runs the smallest that holds the runs (`capacity`); runs longer than the tile go to segmented
+ * passes (glu_radix_sort_read_long_runs below) or -- 64-bit, typed and keys-only sorts; keys crowded into few runs -- send the sort
+ * to the ordinary passes, at the cost of one extra read of the keys; an object whose last attempt was refused skips the next
+ * eight attempts.  The launch sequence is the same either way (the kernels of the sequence not taken return at once), so the
+ * sort stays asynchronous and capturable.
+ * This reports, for the last sort on the object (the caller has synchronised its stream): attempted = 1 if both sequences were
+ * enqueued, accepted = 1 if the sort ended in LDS, longest_run = the longest run counted (0xFFFFFFFF: not counted), capacity =
+ * the tile the device chose (refused: the largest one enqueued).  glu_radix_sort_read_plan describes the ordinary passes (all
+ * "skipped without counting" when accepted = 1).
+ * top_bit: the runs were the values of key bits [top_bit - 16, top_bit).  Untyped keys: the device chooses it from a sample of
+ * the keys -- the highest bit that varies in the sample + 1, at least 16 (64-bit keys: moved up to 40 or 48 where a digit would
+ * straddle the key words) -- so keys below 2^28 make 65536 runs of bits [12, 28) on an object's FIRST sort; the exact bits
+ * collected by the first count kernel check the sample: a missed bit refuses the attempt and becomes the floor of the next
+ * sort's sample.  Typed keys (and GLU_HIP_SORT_DEVICE_TOP=0): the whole key's top 16 bits / the round-4 guess from the object's
+ * previous attempt.
+ * GLU_HIP_SORT_LDS_FINISH=0 in the environment of glu_radix_sort_create switches the attempt off.  Any pointer may be NULL. */
 GLU_API glu_status glu_radix_sort_read_finish(glu_radix_sort sort, uint32_t* attempted, uint32_t* accepted,
                                               uint32_t* longest_run, uint32_t* capacity, uint32_t* top_bit);
 /* Runs LONGER than the tile of the in-LDS pass (round 5; 4-byte untyped keys with values): they no longer send the whole sort back
@@ -405,7 +407,7 @@ GLU_API glu_status glu_dist_sort_begin(glu_dist dist, const uint32_t* keys, cons
  * local sort, enqueued on `stream` (no host synchronisation). */
 GLU_API glu_status glu_dist_sort_finish(glu_dist dist, uint32_t* recv_keys, uint32_t* recv_vals, size_t capacity, void* stream);
 /* Both halves with receive arrays owned by `dist` (grown if the shard does not fit); *out_keys / *out_vals are device
- * pointers valid until the next sort on `dist`. */
+ * pointers valid until the next sort on `dist` returns (arrays the next sort outgrows are freed by the sort after it). */
 GLU_API glu_status glu_dist_sort_ptr(glu_dist dist, const uint32_t* keys, const uint32_t* vals, size_t local_count,
                                      void* stream, uint32_t** out_keys, uint32_t** out_vals, size_t* out_count);
 /* 1 if the local sort of the last sort on `dist` ran as three segmented passes over the low 24 bits (the shard arrives as

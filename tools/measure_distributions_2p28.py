@@ -1,0 +1,88 @@
+"""Sort time by key distribution at 2^28 pairs (uint32 key + uint32 value), at HEAD: does the sort end in LDS, with which run bits, how
+many runs go to the segmented passes, how many bytes per pair move.  Every distribution is sorted on a FRESH object first (the first
+sort of such keys) and then four more times on the same object (restored input); the line holds the first sort's time and the median
+of the later ones.  The result of the first sort is checked for ascending keys on the host.
+   python tools/measure_distributions_2p28.py [log2 pairs = 28]
+Record: profiles/r05/distributions_2p28.txt"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "gl-radix-sort_amd"))
+import numpy as np
+import glu_hip as G
+
+log2n = int(sys.argv[1]) if len(sys.argv) > 1 else 28
+n = 1 << log2n
+rng = np.random.default_rng(2028)
+print(G.device_info())
+print("2^%d pairs; columns: first sort on a fresh object (ms) | median of 4 later sorts (ms) | ended in LDS | run bits below | tile | runs (pairs) "
+      "given to the segmented passes | bytes per pair moved | Gkeys/s (later sorts)" % log2n)
+
+
+def uniform(bits=32):
+    return rng.integers(0, 2 ** bits, n, dtype=np.uint64).astype(np.uint32)
+
+
+def with_zeros(percent):
+    k = uniform()
+    k[rng.random(n) < percent / 100.0] = 0
+    return k
+
+
+def zipf_scattered():
+    # P(rank k) ~ 1 / k over 2^20 ranks (log-uniform ranks), every rank a pseudo-random 32-bit value: heavy hitters anywhere in the key space
+    ranks = np.floor(np.exp(rng.random(n) * np.log(float(1 << 20)))).astype(np.uint64)
+    x = ranks * np.uint64(0x9E3779B97F4A7C15)
+    x ^= x >> np.uint64(29)
+    x *= np.uint64(0xBF58476D1CE4E5B9)
+    return (x >> np.uint64(32)).astype(np.uint32)
+
+
+def zipf_small_integers():
+    return np.floor(np.exp(rng.random(n) * np.log(float(1 << 20)))).astype(np.uint32)  # the ranks themselves: 20-bit keys, rank 1 the most frequent
+
+
+dists = [
+    ("uniform, full range", lambda: uniform()),
+    ("uniform, 31-bit keys", lambda: uniform(31)),
+    ("uniform, 30-bit keys", lambda: uniform(30)),
+    ("uniform, 28-bit keys", lambda: uniform(28)),
+    ("uniform, 24-bit keys", lambda: uniform(24)),
+    ("uniform + 0.01 % zeros", lambda: with_zeros(0.01)),
+    ("uniform + 1 % zeros", lambda: with_zeros(1.0)),
+    ("Zipf(1.0) over 2^20 values, values scattered", zipf_scattered),
+    ("Zipf(1.0) over 2^20 values, values = ranks", zipf_small_integers),
+    ("sorted (uniform, ascending)", lambda: np.sort(uniform())),
+    ("reversed (uniform, descending)", lambda: np.sort(uniform())[::-1].copy()),
+    ("three values", lambda: rng.integers(0, 3, n, dtype=np.uint32) * np.uint32(0x55555555)),
+    ("all zero (the reference README's benchmark input)", lambda: np.zeros(n, dtype=np.uint32)),
+]
+vals = np.arange(n, dtype=np.uint32)
+v0 = G.ShaderStorageBuffer(vals)
+k = G.ShaderStorageBuffer(size=4 * n)
+v = G.ShaderStorageBuffer(size=4 * n)
+for name, make in dists:
+    keys = make()
+    k0 = G.ShaderStorageBuffer(keys)
+    s = G.RadixSort()
+    s.prepare_internal_buffers(n)
+    times = []
+    for rep in range(5):
+        G.check(G.lib().glu_buffer_copy(k0.handle(), k.handle(), 4 * n, 0, 0))
+        G.check(G.lib().glu_buffer_copy(v0.handle(), v.handle(), 4 * n, 0, 0))
+        times.append(G.measure_elapsed_time(lambda: s(k, v, n)) * 1e-6)
+        if rep == 0:
+            out = k.get_data(np.uint32)
+            assert bool((out[1:] >= out[:-1]).all()), name
+            del out
+    fin, lr = s.read_finish(), s.read_long_runs()
+    later = sorted(times[1:])[len(times[1:]) // 2]
+    if fin["accepted"]:
+        moved = 2 * 16 + 4 + (2 * 256 * 256 * 512 + 2 * 65536 * 4) / n + 16 * (1 - lr["pairs"] / n) + 2 * 20 * lr["pairs"] / n
+        what = "yes  bits [%2d,%2d)  tile %4d  long runs %5d (%9d pairs)" % (fin["top_bit"] - 16, fin["top_bit"], fin["capacity"], lr["runs"], lr["pairs"])
+    else:
+        skipped, alone, roles = s.read_plan(4, roles=True)
+        reads = sum(1 for p in range(4) if skipped[p] != 2 and not (roles[p] == 2 and not alone[p])) + (1 if fin["attempted"] else 0)
+        moved = 16 * sum(1 for p in range(4) if not skipped[p]) + 4 * reads
+        what = "no   (%s; %d of 4 ordinary passes ran)" % ("refused" if fin["attempted"] else "not attempted", sum(1 for p in range(4) if not skipped[p]))
+    print("%-52s %7.3f | %7.3f | %-72s | %5.1f B | %6.1f" % (name, times[0], later, what, moved, n / later / 1e6), flush=True)
+    del k0, keys, s
