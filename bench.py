@@ -53,6 +53,9 @@ def parse_args():
     p.add_argument("--no-verify", action="store_true")
     p.add_argument("--no-kernel-events", action="store_true",
                    help="do not record per-kernel HIP events in the timed region (roofline fields become null)")
+    p.add_argument("--full-kernel-events", action="store_true",
+                   help="record events at EVERY kernel boundary inside the timed region (the round-4 behaviour; for the A/B in "
+                        "profiles/r05/bench_events_ab.txt) instead of only around the kernels that move data")
     p.add_argument("--no-alt", action="store_true", help="skip the extra 4-bit-digit (reference pass structure) measurement")
     p.add_argument("--pipeline-depth", type=int, default=2,
                    help="N>1: consecutive independent sorts in flight in the line's timed region (own stream, buffers and "
@@ -393,7 +396,7 @@ def main():
         # LIGHT per-kernel events in the timed region: only around the kernels that move the data (the scatter of every pass
         # that is expected to run, the in-LDS pass) -- an event between two kernels costs the queue microseconds, and all 28 of
         # a sort that ends in LDS were 4 % of its time; count / scan kernel times come from three more sorts after the region
-        sorter.set_profiling("light" if not args.no_kernel_events else False)
+        sorter.set_profiling(False if args.no_kernel_events else (True if args.full_kernel_events else "light"))
         step_events = []
         t0 = time.perf_counter()
         for i in range(W, W + K):

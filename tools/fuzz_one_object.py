@@ -20,9 +20,23 @@ print("seed", seed, flush=True)
 def draw(n, bits):
     dt = np.uint32 if bits == 32 else np.uint64
     full = rng.integers(0, 2 ** bits, n, dtype=dt)
-    kind = int(rng.integers(0, 7))
+    kind = int(rng.integers(0, 10))
     if kind == 0:
         return full
+    if kind == 7:  # (round 5) several long runs of different lengths among uniform keys: the segmented passes of a sort that ends in LDS
+        out = full.copy()
+        for r in range(int(rng.integers(2, 40))):
+            m = int(rng.integers(1600, 60000))
+            pos = rng.choice(n, size=min(m, n), replace=False)
+            out[pos] = (out[pos] & dt((1 << (bits - 16)) - 1)) | (dt(int(rng.integers(0, 65536))) << dt(bits - 16))
+        return out
+    if kind == 8:  # (round 5) a share of one key value among uniform keys
+        out = full.copy()
+        out[rng.random(n) < float(rng.choice([0.0001, 0.01, 0.2]))] = dt(int(rng.integers(0, 2 ** 31)))
+        return out
+    if kind == 9:  # (round 5) keys that tie on the bits the in-LDS pass of 64-bit keys ranks: few values in bits [bits - 32, bits - 16)
+        few = rng.integers(0, int(rng.integers(1, 300)), n).astype(dt) << dt(bits - 32)
+        return (full & ~(dt(0xFFFF) << dt(bits - 32))) | few
     if kind == 1:  # a smaller range, with or without constant bits above it
         k = int(rng.integers(8, bits))
         out = full >> dt(bits - k)

@@ -70,7 +70,7 @@ all_k = {
         entry(cfg_f, cfg_w, ("radix_scatter_lines_kernel<unsigned long, 4",), N * 24, "same, 4-bit digits"),
         entry(cfg_f, cfg_w, ("radix_pair_count_kernel<unsigned long",), N * 8 + T2, "count kernel of a pair of passes, 64-bit keys"),
         entry(cfg_f, cfg_w, ("radix_pair4_count_kernel<unsigned long",), N * 8 + T2_4, "count kernel of a pair of passes, 64-bit keys, 4-bit digits"),
-        entry(cfg_f, cfg_w, ("radix_finish_sort_kernel<unsigned long, 512, 9, true, false",), N * 24, "in-LDS pass of BASELINE.json configs[4] (2^28 u64 keys + u32 vals: six rounds on the low 48 bits)"),
+        entry(cfg_f, cfg_w, ("radix_finish_sort_kernel<unsigned long, 512, 9, true, false",), N * 24, "in-LDS pass of BASELINE.json configs[4] (2^28 u64 keys + u32 vals: two rounds on key bits [32, 48) + exact tie repair)"),
         entry(cfg_f, cfg_w, ("scan_chunks_kernel",), N * 8, "glu::BlellochScan 2^28 u32 (chained single pass)"),
     ],
 }
