@@ -1159,8 +1159,8 @@ glu_status launch_long_run_passes(glu_radix_sort_s* s, uint32_t* a_k, uint32_t* 
         hipLaunchKernelGGL((radix_seg_count_kernel<8, 1024>), dim3(nwg), dim3(1024), 0, stream, (const uint32_t*) a_k, (const uint2*) image,
                            image + lay.off_first, table, p * 8u, 255u, hdr, 0u, kSegGateIfNot, (const uint32_t*) b_k, plan, 2u, p);
         HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL((radix_seg_scan_kernel<RADIX>), dim3(kLongRunsMax), dim3(RADIX), 0, stream, table, image + lay.off_list,
-                           image + lay.off_start, hdr, 0u, kSegGateIfNot, hdr);
+        hipLaunchKernelGGL((radix_seg_scan_kernel<RADIX>), dim3(512), dim3(RADIX), 0, stream, table, image + lay.off_list,
+                           image + lay.off_start, hdr, 0u, kSegGateIfNot, hdr); // (workgroups loop over the device-counted segments)
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(scatter, dim3(nwg), dim3(G::THREADS), sizeof(Smem), stream, (const uint32_t*) a_k, (const uint32_t*) a_v, b_k, b_v,
                            (const uint32_t*) table, (const uint32_t*) nullptr, (uint32_t) count, p * 8u, 255u, 0u, (unsigned long long*) nullptr, 0u,
@@ -1342,11 +1342,11 @@ glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t cou
     {
         // per sort: no follower counts for itself yet, nothing is known about the key bits
         PassPlan* plan = (PassPlan*) s->plan.ptr;
-        static_assert(offsetof(PassPlan, shift_down) + sizeof(plan->shift_down) == sizeof(PassPlan), "the zeroed tail of the plan");
+        static_assert(offsetof(PassPlan, sample_done) + sizeof(plan->sample_done) == sizeof(PassPlan), "the zeroed tail of the plan");
         HIP_TRY(hipMemsetAsync(plan->pair_fallback, 0, sizeof(PassPlan) - offsetof(PassPlan, pair_fallback), stream));
         if (finish_kpt && device_top)
         {
-            hipLaunchKernelGGL((radix_sample_top_kernel<KeyT>), dim3(1), dim3(1024), 0, stream, (const KeyT*) kbuf[0], (uint32_t) count, end_bit,
+            hipLaunchKernelGGL((radix_sample_top_kernel<KeyT>), dim3(kSampleTopBlocks), dim3(256), 0, stream, (const KeyT*) kbuf[0], (uint32_t) count, end_bit,
                                std::min<uint32_t>(s->top_floor, end_bit), plan);
             HIP_TRY(hipGetLastError());
         }

@@ -98,51 +98,54 @@ __host__ __device__ inline uint32_t finish_geometry_choice(uint32_t longest, uin
 // Which 16 key bits make the runs of a sort that ends in LDS?  The top 16 of the bits that VARY: keys below 2^28 make 4096 runs
 // of the whole key's top 16 bits (sixteen times too long) and 65536 of bits [12, 28).  Which bits vary is known exactly only
 // after the keys have been read (the leader's count kernel collects them), and that kernel must know its digit before it reads:
-// so ONE workgroup looks at a SAMPLE first -- up to 65536 16-byte pieces spread evenly over the array, 1 MiB, a few microseconds --
+// so a few workgroups look at a SAMPLE first -- 16384 16-byte pieces spread evenly over the array, every thread one load, all in flight
+// at once (one workgroup walking 65536 pieces took 122 us: a TLB miss per load, in series) --
 // and writes PassPlan::top_bit = the highest bit that varies in the sample + 1 (at least 16, at least `floor_top`, at most the
 // key's width; 64-bit keys: moved up to 40 or 48 where a digit would straddle the two key words) and the shift every kernel of
 // the two top-bit passes subtracts.  A bit above it that varies after all (a rare key the sample missed) is seen by the exact
 // collection: the plan kernel then refuses, the ordinary passes run, and the host hands the exact top bit to the next sort as
 // floor_top.  (Round 4 guessed from the object's previous sort: the first sort of small-range keys was always the refused one.)
+constexpr uint32_t kSampleTopBlocks = 64; // x 256 threads x one 16-byte piece: 256 KiB of keys, all loads in flight at once
 template<typename KeyT>
-__global__ __launch_bounds__(1024) void radix_sample_top_kernel(const KeyT* __restrict__ keys, uint32_t n, uint32_t key_bits,
-                                                                uint32_t floor_top, PassPlan* plan)
+__global__ __launch_bounds__(256) void radix_sample_top_kernel(const KeyT* __restrict__ keys, uint32_t n, uint32_t key_bits,
+                                                               uint32_t floor_top, PassPlan* plan)
 {
     typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-    __shared__ uint32_t red[4][16];
+    __shared__ uint32_t red[4][4];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr uint32_t W = sizeof(KeyT) / 4; // words per key
     const uint64_t nvec = (uint64_t) n * sizeof(KeyT) / 16;
-    const uint32_t samples = (uint32_t) (nvec < 65536ull ? nvec : 65536ull);
+    const uint32_t total = gridDim.x * 256u;
+    const uint32_t samples = (uint32_t) (nvec < total ? nvec : total);
     const uint64_t stride = samples ? nvec / samples : 1;
-    uint32_t o[2] = {0, 0}, a[2] = {~0u, ~0u}; // OR and AND of the low / high key words seen
-    const u32x4_t* v = reinterpret_cast<const u32x4_t*>(keys);
-    for (uint32_t j = tid; j < samples; j += 1024)
+    uint32_t o[2] = {0, 0}, no[2] = {0, 0}; // OR of the low / high key words seen, OR of their complements
+    const uint32_t j = blockIdx.x * 256u + tid;
+    if (j < samples)
     {
-        const u32x4_t x = v[(uint64_t) j * stride];
+        const u32x4_t x = reinterpret_cast<const u32x4_t*>(keys)[(uint64_t) j * stride];
         if (W == 1)
         {
-            o[0] |= x.x | x.y | x.z | x.w;
-            a[0] &= x.x & x.y & x.z & x.w;
+            o[0] = x.x | x.y | x.z | x.w;
+            no[0] = ~x.x | ~x.y | ~x.z | ~x.w;
         }
         else
         {
-            o[0] |= x.x | x.z;
-            a[0] &= x.x & x.z;
-            o[1] |= x.y | x.w;
-            a[1] &= x.y & x.w;
+            o[0] = x.x | x.z;
+            no[0] = ~x.x | ~x.z;
+            o[1] = x.y | x.w;
+            no[1] = ~x.y | ~x.w;
         }
     }
     // (the first and the last key: constant arrays with one odd key at either end are a classic)
-    if (tid == 0 && n)
+    if (blockIdx.x == 0 && tid == 0 && n)
     {
         const KeyT f = keys[0], l = keys[n - 1];
         o[0] |= (uint32_t) f | (uint32_t) l;
-        a[0] &= (uint32_t) f & (uint32_t) l;
+        no[0] |= ~(uint32_t) f | ~(uint32_t) l;
         if (W == 2)
         {
             o[1] |= (uint32_t) ((uint64_t) f >> 32) | (uint32_t) ((uint64_t) l >> 32);
-            a[1] &= (uint32_t) ((uint64_t) f >> 32) & (uint32_t) ((uint64_t) l >> 32);
+            no[1] |= ~(uint32_t) ((uint64_t) f >> 32) | ~(uint32_t) ((uint64_t) l >> 32);
         }
     }
 #pragma unroll
@@ -150,21 +153,37 @@ __global__ __launch_bounds__(1024) void radix_sample_top_kernel(const KeyT* __re
     {
         o[0] |= __shfl_xor(o[0], s);
         o[1] |= __shfl_xor(o[1], s);
-        a[0] &= __shfl_xor(a[0], s);
-        a[1] &= __shfl_xor(a[1], s);
+        no[0] |= __shfl_xor(no[0], s);
+        no[1] |= __shfl_xor(no[1], s);
     }
-    if (lane == 0) red[0][wave] = o[0], red[1][wave] = o[1], red[2][wave] = a[0], red[3][wave] = a[1];
+    if (lane == 0) red[0][wave] = o[0], red[1][wave] = o[1], red[2][wave] = no[0], red[3][wave] = no[1];
     __syncthreads();
     if (tid == 0)
     {
-        for (int w = 1; w < 16; w++) o[0] |= red[0][w], o[1] |= red[1][w], a[0] &= red[2][w], a[1] &= red[3][w];
-        const uint64_t varying = (uint64_t) (o[0] & ~a[0]) | (W == 2 ? (uint64_t) (o[1] & ~a[1]) << 32 : 0ull);
-        uint32_t top = varying ? 64u - (uint32_t) __builtin_clzll(varying) : 0u;
-        top = max(max(top, floor_top), 16u);
-        top = min(top, key_bits);
-        if (W == 2 && top > 32 && top < 48 && top != 40) top = top < 40 ? 40u : 48u; // a digit stays inside one key word
-        plan->top_bit = top;
-        plan->shift_down[0] = plan->shift_down[1] = key_bits - top;
+        for (int w = 1; w < 4; w++) o[0] |= red[0][w], o[1] |= red[1][w], no[0] |= red[2][w], no[1] |= red[3][w];
+        // the workgroups' words meet in the plan (agent-scope atomics); the last one to arrive draws the conclusion
+        __hip_atomic_fetch_or(&plan->sample_or[0], o[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_or(&plan->sample_nor[0], no[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (W == 2)
+        {
+            __hip_atomic_fetch_or(&plan->sample_or[1], o[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_or(&plan->sample_nor[1], no[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const uint32_t done = __hip_atomic_fetch_add(&plan->sample_done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (done + 1 == gridDim.x)
+        {
+            const uint32_t vo0 = __hip_atomic_load(&plan->sample_or[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t vn0 = __hip_atomic_load(&plan->sample_nor[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t vo1 = W == 2 ? __hip_atomic_load(&plan->sample_or[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            const uint32_t vn1 = W == 2 ? __hip_atomic_load(&plan->sample_nor[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            const uint64_t varying = (uint64_t) (vo0 & vn0) | ((uint64_t) (vo1 & vn1) << 32);
+            uint32_t top = varying ? 64u - (uint32_t) __builtin_clzll(varying) : 0u;
+            top = max(max(top, floor_top), 16u);
+            top = min(top, key_bits);
+            if (W == 2 && top > 32 && top < 48 && top != 40) top = top < 40 ? 40u : 48u; // a digit stays inside one key word
+            plan->top_bit = top;
+            plan->shift_down[0] = plan->shift_down[1] = key_bits - top;
+        }
     }
 }
 
@@ -198,7 +217,7 @@ __global__ __launch_bounds__(1024) void radix_finish_plan_kernel(const uint32_t*
             before += j < b ? v : 0u;
             longest = max(longest, v);
             mine = j == b ? v : mine;
-            if (long_ok)
+            if (long_ok && b == 0) // (workgroup 0 makes the decision for all: plan->finish)
             {
 #pragma unroll
                 for (uint32_t g = 0; g < kFinishGeometries; g++)
@@ -219,7 +238,7 @@ __global__ __launch_bounds__(1024) void radix_finish_plan_kernel(const uint32_t*
         all += __shfl_xor(all, o);
         longest = max(longest, (uint32_t) __shfl_xor(longest, o));
     }
-    if (long_ok)
+    if (long_ok && b == 0)
     {
 #pragma unroll
         for (uint32_t g = 0; g < kFinishGeometries; g++)
@@ -247,7 +266,7 @@ __global__ __launch_bounds__(1024) void radix_finish_plan_kernel(const uint32_t*
         if ((uint32_t) w < wave) excl += wsum[w];
     }
     uint32_t geo = finish_geometry_choice(longest, geo_first, geo_last);
-    if (long_ok && geo != geo_first && geo_first >= 1)
+    if (long_ok && b == 0 && geo != geo_first && geo_first >= 1)
     {
         // (some run outgrows the tile that suits uniform keys: may it, and a few others, go to the segmented passes instead?)
         uint32_t pick = 0;
@@ -272,12 +291,10 @@ __global__ __launch_bounds__(1024) void radix_finish_plan_kernel(const uint32_t*
         varying = (uint64_t) (plan->bits_or[0] & plan->bits_nor[0]) | ((uint64_t) (plan->bits_or[1] & plan->bits_nor[1]) << 32);
         if (top_bit < key_bits) range_ok = (varying >> top_bit) == 0;
     }
-    const bool accept = tables && all == n && geo != 0 && range_ok;
-    if (accept)
-    {
-        starts[b * 1024u + tid] = before + excl;
-        if (b == 0 && tid == 0) starts[kFinishRuns] = n;
-    }
+    const bool accept = tables && all == n && geo != 0 && range_ok; // (workgroup 0's is the decision: only it knows of long runs)
+    // (the run starts are written whatever the decision: nobody reads them unless plan->finish says so)
+    starts[b * 1024u + tid] = before + excl;
+    if (b == 0 && tid == 0) starts[kFinishRuns] = n;
     if (b == 0 && tid == 0)
     {
         plan->finish = accept ? geo : 0u;
@@ -335,6 +352,11 @@ __global__ __launch_bounds__(1024) void radix_finish_long_runs_kernel(const uint
     const uint32_t geo = plan->finish;
     const uint32_t cap = finish_geometry_capacity(geo);
     constexpr uint32_t PER = kFinishRuns / 1024;
+    if (geo == 0 || plan->finish_longest <= cap) // (kernel-uniform) refused, or no run outgrows the tile: nothing to list
+    {
+        if (tid < 3) hdr[tid] = 0u;
+        return;
+    }
     // (every workgroup's share starts empty; the sub-block that begins at a share's first position fills it in)
     for (uint32_t w = tid; w <= nwg; w += 1024) image[lay.off_first + w] = 0xFFFFFFFFu;
     uint32_t cnt = 0, len = 0;

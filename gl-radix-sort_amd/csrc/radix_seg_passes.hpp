@@ -163,11 +163,13 @@ __global__ __launch_bounds__(RADIX) void radix_seg_scan_kernel(uint32_t* __restr
                                                                uint32_t gate_mode = kSegGateNone, const uint32_t* nseg_dev = nullptr)
 {
     if (seg_gate_closed(gate, gate_cap, gate_mode)) return; // (kernel-uniform)
-    if (nseg_dev && blockIdx.x >= *nseg_dev) return;        // (segments counted on the device: the grid is their upper bound)
     constexpr int WAVES = (RADIX + kWave - 1) / kWave;
     __shared__ uint32_t wave_sums[WAVES];
     const uint32_t d = threadIdx.x, lane = d & 63, wave = d >> 6;
-    const uint32_t g = blockIdx.x;
+    // (segments counted on the device -- nseg_dev: the workgroups loop over them; else a workgroup per segment)
+    const uint32_t nseg = nseg_dev ? *nseg_dev : gridDim.x;
+    for (uint32_t g = blockIdx.x; g < nseg; g += gridDim.x)
+    {
     const uint32_t i0 = seg_list[g], i1 = seg_list[g + 1];
     uint32_t run = 0;
     uint32_t i = i0;
@@ -195,6 +197,8 @@ __global__ __launch_bounds__(RADIX) void radix_seg_scan_kernel(uint32_t* __restr
     for (uint32_t w = 0; w < wave; w++) excl += wave_sums[w];
     const uint32_t add = seg_start[g] + excl;
     for (i = i0; i < i1; i++) table[(size_t) i * RADIX + d] += add;
+    __syncthreads(); // (wave_sums is rewritten for the next segment)
+    }
 }
 
 } // namespace glu_hip

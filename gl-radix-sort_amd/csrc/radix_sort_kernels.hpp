@@ -176,6 +176,8 @@ struct PassPlan
     // shift_down[pass] = key bits - top_bit.  0: the host's shifts stand.  Zeroed with pair_fallback.
     uint32_t top_bit;
     uint32_t shift_down[kPlanMaxPasses];
+    // (radix_sample_top_kernel's workgroups: OR of the sampled keys, OR of their complements, low / high word; workgroups done)
+    uint32_t sample_or[2], sample_nor[2], sample_done;
 };
 
 // PassPlan::skip values: 0 = the pass runs, 1 = an identity found by the row scan (one digit value holds every key; the

@@ -73,7 +73,8 @@ namespace glu
             return (*this)(static_cast<const uint32_t*>(k), static_cast<const uint32_t*>(v), local_count, nullptr);
         }
 
-        /// true if the local sort of the last sort ran as three segmented passes over the low 24 bits (the shard arrives as one
+        /// true if the local sort of the last sort was the segmented sort of the low 24 bits per bucket -- one segmented pass + an
+        /// in-LDS pass where the runs fit an LDS tile, else three segmented passes -- (the shard arrives as one
         /// message per source rank, each grouped by bucket: RadixSort::sort_segments), false for the ordinary sort of all 32
         /// bits (small or very fragmented shards, a partition on a lower key byte).
         [[nodiscard]] bool last_local_sort_was_segmented() const

@@ -8,7 +8,8 @@ for.  Rank r holds slice r of the global array.  Steps:
   2. all-gather of the R x 256 histogram -> every rank derives the same contiguous bucket -> rank assignment;
   3. ONE grouped exchange of keys and values (RCCL: ncclSend / ncclRecv to and from every peer inside one
      ncclGroupStart / ncclGroupEnd), receive segments ordered by source rank;
-  4. each rank: local stable sort of what it received -- three segmented passes over the low 24 bits per bucket
+  4. each rank: local stable sort of what it received -- the segmented sort of the low 24 bits per bucket (one segmented
+     pass + an in-LDS pass where the runs fit, else three segmented passes)
      (glu_radix_sort_run_segments_ptr: the shard arrives as one message per source rank, each grouped by bucket, and the
      first pass regroups it), or the ordinary sort of all 32 bits for small / fragmented shards.
 

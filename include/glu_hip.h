@@ -410,9 +410,11 @@ GLU_API glu_status glu_dist_sort_finish(glu_dist dist, uint32_t* recv_keys, uint
  * pointers valid until the next sort on `dist` returns (arrays the next sort outgrows are freed by the sort after it). */
 GLU_API glu_status glu_dist_sort_ptr(glu_dist dist, const uint32_t* keys, const uint32_t* vals, size_t local_count,
                                      void* stream, uint32_t** out_keys, uint32_t** out_vals, size_t* out_count);
-/* 1 if the local sort of the last sort on `dist` ran as three segmented passes over the low 24 bits (the shard arrives as
- * one message per source rank, each grouped by bucket; glu_radix_sort_run_segments_ptr), 0 if it was the ordinary sort of
- * all 32 bits (small shards, shards made of very many tiny pieces, a partition on a lower byte). */
+/* 1 if the local sort of the last sort on `dist` was the SEGMENTED sort of the low 24 bits per bucket (the shard arrives as one
+ * message per source rank, each grouped by bucket; glu_radix_sort_run_segments_ptr: one segmented counting pass + an in-LDS pass
+ * when the runs (bucket, next byte) fit an LDS tile -- up to four ranks x 2^27 pairs --, else three segmented passes;
+ * glu_radix_sort_read_seg_finish on glu_dist_local_sorter tells which), 0 if it was the ordinary sort of all 32 bits (small
+ * shards, shards made of very many tiny pieces, a partition on a lower byte). */
 GLU_API glu_status glu_dist_last_local_sort(glu_dist dist, uint32_t* segmented);
 /* The exchange in ROUNDS.  With more than one rank and large shards (2^24 pairs per rank and more; GLU_HIP_DIST_ROUNDS_MIN)
  * every rank's buckets are cut into `rounds` groups of about equal size (1 .. 8; default 3 from four ranks up, 1 below: at two
