@@ -719,7 +719,7 @@ glu_status launch_pass(glu_radix_sort_s* s, const KeyT* src_k, const uint32_t* s
     if (!fused)
     {
         hipLaunchKernelGGL((radix_row_scan_kernel<256>), dim3(RADIX), dim3(256), 0, stream, table, totals, nb, (uint32_t) count,
-                           pa.may_skip ? pa.plan : (PassPlan*) nullptr, pa.pass);
+                           pa.may_skip ? pa.plan : (PassPlan*) nullptr, pa.pass, 0u, pa.plan, (uint32_t*) nullptr, 1u);
         HIP_TRY(hipGetLastError());
     }
     s->mark(stream, true);
@@ -857,7 +857,7 @@ glu_status launch_pass_lines(glu_radix_sort_s* s, const KeyT* src_k, const uint3
         // 4-bit leader: its count kernel wrote the table per sub-block; one scan gives where every (digit value, sub-block)
         // unit starts, the digit totals, and -- every kPairSub-th entry -- the usual per-block table of the scatter
         hipLaunchKernelGGL((radix_row_scan_kernel<256>), dim3(RADIX), dim3(256), 0, stream, sub_table, totals, nb * kPairSub,
-                           (uint32_t) count, pa.may_skip ? pa.plan : (PassPlan*) nullptr, pa.pass, 0u, (PassPlan*) nullptr, table,
+                           (uint32_t) count, pa.may_skip ? pa.plan : (PassPlan*) nullptr, pa.pass, 0u, pa.plan, table,
                            kPairSub);
     }
     else

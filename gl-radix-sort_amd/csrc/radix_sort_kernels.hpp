@@ -501,8 +501,11 @@ __global__ __launch_bounds__(THREADS) void radix_row_scan_kernel(uint32_t* __res
     constexpr int WAVES = THREADS / kWave;
     __shared__ uint32_t wave_sums[WAVES];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // the count kernel before this one found the pass an identity without counting (plan_digit_is_constant): no table
-    if (plan && plan->skip[pass] == kSkipWithoutCounting) return;
+    // the count kernel before this one found the pass an identity without counting (plan_digit_is_constant), or the pass belongs
+    // to the sequence not taken: no table.  (`plan` is only given when the scan may MARK the pass an identity -- not for the encode /
+    // decode passes of typed keys --; pair_plan is the plan whenever there is one: ADVICE r4)
+    const PassPlan* any_plan = plan ? plan : pair_plan;
+    if (any_plan && any_plan->skip[pass] == kSkipWithoutCounting) return;
     uint32_t* row = table + (size_t) blockIdx.x * num_blocks;
     uint32_t carry = 0;
     for (uint32_t base = 0; base < num_blocks; base += THREADS)
