@@ -580,7 +580,9 @@ constexpr size_t kPairMinKeyBytes = (size_t) 1 << 28;
 // a sort that tries to end in LDS (radix_lds_finish.hpp) pairs its two top-bit passes and pays the same tables, but replaces
 // more: it is faster from about 2^24.5 pairs up (tools/finish_midsize_probe.py: 2^25 0.637 -> 0.586 ms, 2^25.5 0.907 -> 0.736)
 // (64-bit keys, where it replaces six passes, not two: from about 2^23: 2^24 1.01 -> 0.74 ms, 2^25 1.81 -> 1.07)
-constexpr size_t finish_min_count(size_t key_size) { return key_size == 8 ? (size_t) 3 << 22 : (size_t) 1 << 25; }
+// (round 5, with the launches that the long-run passes and the sample added: 32-bit keys still from 2^24.8, 2^25: 0.638 -> 0.578 ms;
+// 64-bit keys from 2^23: 0.615 -> 0.474 ms; profiles/r05/finish_midsize_any*.txt, host time from the call to the end of the sort)
+constexpr size_t finish_min_count(size_t key_size) { return key_size == 8 ? (size_t) 1 << 23 : (size_t) 1 << 25; }
 constexpr size_t kPlanMinCount = (size_t) 1 << 22; // planned sorts: see PlanArgs below
 
 // CUs the pass kernels of `s` may fill (glu_dist reserves some for RCCL kernels that run beside them)
