@@ -499,6 +499,7 @@ struct glu_radix_sort_s
     uint32_t tuned_spacer_mib = 0, tuned_candidates = 0; double tuned_ms = 0, tuned_worst_ms = 0; // what the last tuning saw and chose
     bool no_lines = false;        // GLU_HIP_SORT_NO_LINES=1: never use the 128-byte-line scatter kernel (tests / tuning)
     bool nt_stores = true;        // GLU_HIP_SORT_NT_STORES=0: plain instead of non-temporal line stores in the line scatter (tuning)
+    size_t nt_min_bytes = (size_t) 320 << 20; // GLU_HIP_SORT_NT_MIN_BYTES: arrays (keys + values) from this size get the non-temporal stores
     bool no_bit_shortcut = false; // GLU_HIP_SORT_NO_BIT_SHORTCUT=1: passes on key bits that do not vary still count (tests / tuning)
     bool equal_shares = false;    // GLU_HIP_SORT_EQUAL_SHARES=1: line path: equal element shares per workgroup instead of whole tiles (tuning)
     bool pairs = true;            // GLU_HIP_SORT_PAIRS=0: every pass of a large sort counts for itself (tests / tuning)
@@ -786,8 +787,12 @@ glu_status launch_pass_lines(glu_radix_sort_s* s, const KeyT* src_k, const uint3
             lds_opt_in_result = hipFuncSetAttribute((const void*) scatter_behind, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sizeof(Smem));
     });
     HIP_TRY(lds_opt_in_result);
-    auto scatter = s->nt_stores ? scatter_nt : scatter_plain;
-    if (pa.behind_attempt && kHasBehind && s->nt_stores) scatter = scatter_behind;
+    // ... when the arrays are far larger than the 256 MiB Infinity Cache.  Below about 320 MiB of keys + values plain stores
+    // win: part of what a pass wrote is still cached when the next pass reads it (4-byte keys with values, 4.3 M .. 36 M pairs:
+    // 3-7 % of the sort; 44 M and up: non-temporal ahead; profiles/r05/nt_stores_by_size.txt)
+    const bool nt = s->nt_stores && (uint64_t) count * (sizeof(KeyT) + (VALS ? sizeof(uint32_t) : 0)) >= s->nt_min_bytes;
+    auto scatter = nt ? scatter_nt : scatter_plain;
+    if (pa.behind_attempt && kHasBehind && nt) scatter = scatter_behind;
 
     const uint2* ranges = nullptr;
     s->mark(stream);
@@ -906,6 +911,7 @@ glu_status launch_pass_lines(glu_radix_sort_s* s, const KeyT* src_k, const uint3
     return GLU_OK;
 }
 
+constexpr size_t kSmallResidentPerCU = 4; // workgroups of the small pair geometry (512 x 8) that share a CU (measured: the step in sort time sits at 256 x 4 x 4096 pairs)
 // does a pass over these arrays run the line kernel?  (launch_pass_sized and the pairing of passes in sort_bits)
 template<typename KeyT, int BITS>
 bool lines_applicable(const glu_radix_sort_s* s, const void* src_k, const void* src_v, const void* dst_k, const void* dst_v, size_t count)
@@ -915,9 +921,15 @@ bool lines_applicable(const glu_radix_sort_s* s, const void* src_k, const void* 
     // because a planned sort swaps their roles on the device.  Same size rule as the large geometry, with its tile.
     const size_t lines_tile = vals ? LinesGeometry<KeyT, BITS, true>::TILE : LinesGeometry<KeyT, BITS, false>::TILE;
     const bool aligned = (((uintptr_t) src_k | (uintptr_t) src_v | (uintptr_t) dst_k | (uintptr_t) dst_v) & 15u) == 0;
+    // ... and not before the small geometry needs a second round of workgroups: its 4096-element tiles sit four to a CU, and up
+    // to that many the whole sort is one tile's latency chain per pass (4-byte keys with values, 256 CUs: 4.01 M pairs 122 us
+    // small against 146 us by lines, 4.26 M 158 against 154: profiles/r05/geometry_switch_pairs.txt).  Only that family has
+    // its 3/2 large tiles per CU below the small geometry's capacity.
+    const size_t small_tile = vals ? GeometryFor<KeyT, BITS, false, true>::TILE : GeometryFor<KeyT, BITS, false, false>::TILE;
+    const size_t small_capacity = (size_t) g_dev.num_cus * kSmallResidentPerCU * small_tile;
+    const size_t from = s->large_min ? s->large_min : std::max<size_t>((size_t) g_dev.num_cus * lines_tile * 3 / 2, sizeof(KeyT) == 4 && vals ? small_capacity + 1 : 0);
     // (at least one whole tile: the kernel's branch-free prefetch reads tile 0 when it has nothing better to read)
-    return aligned && !s->no_lines && !s->force_small && count >= lines_tile &&
-           count >= (s->large_min ? s->large_min : (size_t) g_dev.num_cus * lines_tile * 3 / 2);
+    return aligned && !s->no_lines && !s->force_small && count >= lines_tile && count >= from;
 }
 
 template<typename KeyT, int BITS>
@@ -2074,6 +2086,7 @@ glu_status glu_radix_sort_create(glu_radix_sort* out)
         if (v >= 0) s->pair_unit_div = (uint32_t) v;
     }
     if (const char* e = getenv("GLU_HIP_SORT_NT_STORES")) s->nt_stores = atoi(e) != 0;
+    if (const char* e = getenv("GLU_HIP_SORT_NT_MIN_BYTES")) s->nt_min_bytes = (size_t) atoll(e);
     if (const char* e = getenv("GLU_HIP_SORT_LARGE_MIN")) s->large_min = (size_t) atoll(e);
     *out = s;
     return GLU_OK;

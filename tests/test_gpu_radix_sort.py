@@ -195,7 +195,7 @@ def test_line_kernel_with_fewer_workgroups(G, blocks, monkeypatch):
     """GLU_HIP_SORT_BLOCKS caps the grid: other range boundaries (first / last partial lines of a range), many tiles per
     workgroup, a single workgroup that owns everything."""
     monkeypatch.setenv("GLU_HIP_SORT_BLOCKS", str(blocks))
-    n = 256 * 10240 * 3 // 2 + 777
+    n = 256 * 4 * 4096 + 777  # (just past what the small geometry takes in one round of workgroups: the line kernel's first size)
     rng = np.random.default_rng(blocks)
     keys = rng.integers(0, 2**32, n, dtype=np.uint32)
     keys[::5] &= np.uint32(0xFF00FFFF)
@@ -909,13 +909,41 @@ def test_bit_range_argument_checks(G):
             sorter.sort_bit_range_ptr(kb.device_ptr(), None, 64, begin, end, None, kbytes)
 
 
+@pytest.mark.parametrize("kind", ["constant_byte_1", "constant_bytes_0_and_2", "16_bit_keys", "all_equal"])
+def test_pass_plan_on_the_small_geometry(G, kind):
+    """2^22 pairs: the one size that is sorted with a device-side pass plan (passes on constant digits are skipped, the arrays'
+    roles follow on the device, an odd number of executed passes is brought home) by the small geometry's kernels."""
+    n = 1 << 22
+    rng = np.random.default_rng(len(kind))
+    keys = rng.integers(0, 2**32, n, dtype=np.uint32)
+    if kind == "constant_byte_1":
+        keys = (keys & np.uint32(0xFFFF00FF)) | np.uint32(0x00005A00)  # three passes run: the result comes home from the scratch
+    elif kind == "constant_bytes_0_and_2":
+        keys = (keys & np.uint32(0xFF00FF00)) | np.uint32(0x00C30011)
+    elif kind == "16_bit_keys":
+        keys &= np.uint32(0xFFFF)
+    else:
+        keys[:] = 0xDEADBEEF
+    vals = np.arange(n, dtype=np.uint32)
+    s = G.RadixSort()
+    kb, vb = G.ShaderStorageBuffer(keys), G.ShaderStorageBuffer(vals)
+    s(kb, vb, n)
+    ek, ev = O.stable_sort_pairs(keys, vals)
+    assert (kb.get_data(np.uint32) == ek).all() and (vb.get_data(np.uint32) == ev).all()
+    skipped = s.read_plan(4)[0]
+    expected = {"constant_byte_1": [0, 1, 0, 0], "constant_bytes_0_and_2": [1, 0, 1, 0], "16_bit_keys": [0, 0, 1, 1], "all_equal": [1, 1, 1, 1]}[kind]
+    assert [1 if x else 0 for x in skipped] == expected
+
+
 @pytest.mark.parametrize("mode,threshold", [("pairs", 256 * 10240 * 3 // 2), ("keys", 256 * 16384 * 3 // 2), ("u64", 256 * 8192 * 3 // 2),
-                                            ("pairs", 256 * 12288 * 3 // 2), ("pairs", 256 * 9216 * 3 // 2)])
+                                            ("pairs", 256 * 12288 * 3 // 2), ("pairs", 256 * 9216 * 3 // 2), ("pairs", 256 * 4 * 4096 + 1)])
 @pytest.mark.parametrize("delta", [-1, 0, 1, 12287])
 def test_geometry_switch_points(G, mode, threshold, delta):
     """Sizes right at the small -> large geometry switch of each kernel family (3/2 large tiles per CU on 256 CUs; the
     large tile is 10240 pairs / 16384 keys for the 128-byte-line kernel of 32-bit keys, 8192 pairs for 64-bit keys;
-    12288 pairs / 8192 pairs are the switches of the kernel that unaligned arrays fall back to)."""
+    12288 pairs / 8192 pairs are the switches of the kernel that unaligned arrays fall back to; 32-bit keys with values
+    stay on the small geometry while one round of its workgroups takes the input: 256 CUs x 4 x 4096 pairs -- the last of
+    those sizes, 2^22, is also the first one sorted with a device-side pass plan)."""
     n = threshold + delta
     rng = np.random.default_rng(n)
     if mode == "u64":
