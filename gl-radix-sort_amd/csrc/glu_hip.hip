@@ -912,24 +912,40 @@ glu_status launch_pass_lines(glu_radix_sort_s* s, const KeyT* src_k, const uint3
 }
 
 constexpr size_t kSmallResidentPerCU = 4; // workgroups of the small pair geometry (512 x 8) that share a CU (measured: the step in sort time sits at 256 x 4 x 4096 pairs)
+
+// The element count from which a pass runs a large-tile kernel (the 128-byte-line scatter, or the large geometry that arrays
+// it cannot take fall back to) instead of the small geometry.  Three rules, all measured on 256 CUs:
+//   * 3/2 large tiles per CU: with one to one-and-a-half tiles per workgroup a few workgroups get two tiles and set the kernel
+//     time (3.2 M pairs: 145 us large vs 117 us small, 4.2 M: 149 vs 132, 6 M: 162 vs 188);
+//   * 4-byte keys with values: not before the small geometry needs a second round of workgroups -- its 4096-element tiles sit
+//     four to a CU, and up to that many the whole sort is one tile's latency chain per pass (4.01 M pairs 122 us small against
+//     146 us by lines, 4.26 M 158 against 154: profiles/r05/geometry_switch_pairs.txt);
+//   * keys-only sorts of 4-byte keys, 8-bit digits: the line kernel's 16 384-key tiles, one workgroup per CU, make sort time a
+//     staircase with steps of 4.2 M keys, and the small geometry stays ahead of or level with it up to 2^25 keys (6 .. 30 M
+//     keys: 0-15 % by where on a step the size falls; from 37 M the line kernel wins by 7 % and more:
+//     profiles/r05/geometry_switch_keys_only.txt).
+template<typename KeyT, int BITS>
+size_t large_tiles_from(const glu_radix_sort_s* s, bool vals, size_t large_tile)
+{
+    if (s->large_min) return s->large_min; // GLU_HIP_SORT_LARGE_MIN (tests / tuning)
+    size_t from = (size_t) g_dev.num_cus * large_tile * 3 / 2;
+    const size_t small_tile = vals ? GeometryFor<KeyT, BITS, false, true>::TILE : GeometryFor<KeyT, BITS, false, false>::TILE;
+    if (sizeof(KeyT) == 4 && vals) from = std::max<size_t>(from, (size_t) g_dev.num_cus * kSmallResidentPerCU * small_tile + 1);
+    if (sizeof(KeyT) == 4 && !vals && BITS == 8) from = std::max<size_t>(from, (size_t) 1 << 25);
+    return from;
+}
+
 // does a pass over these arrays run the line kernel?  (launch_pass_sized and the pairing of passes in sort_bits)
 template<typename KeyT, int BITS>
 bool lines_applicable(const glu_radix_sort_s* s, const void* src_k, const void* src_v, const void* dst_k, const void* dst_v, size_t count)
 {
     const bool vals = src_v != nullptr;
     // whole-line stores need 16-byte aligned destinations (hipMalloc gives 256); both pairs of arrays are checked
-    // because a planned sort swaps their roles on the device.  Same size rule as the large geometry, with its tile.
+    // because a planned sort swaps their roles on the device.
     const size_t lines_tile = vals ? LinesGeometry<KeyT, BITS, true>::TILE : LinesGeometry<KeyT, BITS, false>::TILE;
     const bool aligned = (((uintptr_t) src_k | (uintptr_t) src_v | (uintptr_t) dst_k | (uintptr_t) dst_v) & 15u) == 0;
-    // ... and not before the small geometry needs a second round of workgroups: its 4096-element tiles sit four to a CU, and up
-    // to that many the whole sort is one tile's latency chain per pass (4-byte keys with values, 256 CUs: 4.01 M pairs 122 us
-    // small against 146 us by lines, 4.26 M 158 against 154: profiles/r05/geometry_switch_pairs.txt).  Only that family has
-    // its 3/2 large tiles per CU below the small geometry's capacity.
-    const size_t small_tile = vals ? GeometryFor<KeyT, BITS, false, true>::TILE : GeometryFor<KeyT, BITS, false, false>::TILE;
-    const size_t small_capacity = (size_t) g_dev.num_cus * kSmallResidentPerCU * small_tile;
-    const size_t from = s->large_min ? s->large_min : std::max<size_t>((size_t) g_dev.num_cus * lines_tile * 3 / 2, sizeof(KeyT) == 4 && vals ? small_capacity + 1 : 0);
     // (at least one whole tile: the kernel's branch-free prefetch reads tile 0 when it has nothing better to read)
-    return aligned && !s->no_lines && !s->force_small && count >= lines_tile && count >= from;
+    return aligned && !s->no_lines && !s->force_small && count >= lines_tile && count >= large_tiles_from<KeyT, BITS>(s, vals, lines_tile);
 }
 
 template<typename KeyT, int BITS>
@@ -937,12 +953,10 @@ glu_status launch_pass_sized(glu_radix_sort_s* s, const KeyT* src_k, const uint3
                              size_t count, uint32_t shift, uint32_t bits, uint32_t* histogram_out, hipStream_t stream,
                              uint32_t xform = 0, PlanArgs pa = PlanArgs())
 {
-    // Large geometry from 3/2 large tiles per CU up: with one to one-and-a-half tiles per workgroup a few workgroups get
-    // two tiles and set the kernel time (3.2 M pairs: 145 us large vs 117 us small, 4.2 M: 149 vs 132, 6 M: 162 vs 188).
     // Keys-only sorts (no value arrays) run the VALS = false instantiations.
     const bool vals = src_v != nullptr;
     const size_t large_tile = vals ? GeometryFor<KeyT, BITS, true, true>::TILE : GeometryFor<KeyT, BITS, true, false>::TILE;
-    const bool large = count >= (s->large_min ? s->large_min : (size_t) g_dev.num_cus * large_tile * 3 / 2) && !s->force_small;
+    const bool large = count >= large_tiles_from<KeyT, BITS>(s, vals, large_tile) && !s->force_small;
     {
         if (lines_applicable<KeyT, BITS>(s, src_k, src_v, dst_k, dst_v, count))
         {

@@ -86,8 +86,8 @@ def test_uniform_keys_end_in_lds(G):
 
 
 def test_keys_only_end_in_lds(G):
-    keys = _uniform((1 << 23) + 4321, 2)  # (the keys-only line kernel starts at 6.3 M keys)
-    s = _sorter(G, **SMALL)
+    keys = _uniform((1 << 23) + 4321, 2)
+    s = _sorter(G, GLU_HIP_SORT_LARGE_MIN=1, **SMALL)  # (the keys-only line kernel -- and with it the attempt -- starts at 2^25 keys)
     gk, _, fin = _run(G, s, keys, None)
     _check(keys, None, gk, None)
     assert fin["attempted"] == 1 and fin["accepted"] == 1
@@ -623,7 +623,8 @@ def test_typed_keys_end_in_lds(G, name, with_vals):
         keys[::100000] = dt.type(-0.0)
         keys[1::100000] = dt.type(0.0)
     vals = np.arange(n, dtype=np.uint32)
-    s = _sorter(G, **SMALL)
+    # (keys-only sorts of 4-byte keys run the line kernel -- and make the attempt -- from 2^25 keys: forced here)
+    s = _sorter(G, **SMALL) if with_vals or dt.itemsize == 8 else _sorter(G, GLU_HIP_SORT_LARGE_MIN=1, **SMALL)
     kb = G.ShaderStorageBuffer(keys)
     vb = G.ShaderStorageBuffer(vals) if with_vals else None
     s.sort_typed_ptr(kb.device_ptr(), vb.device_ptr() if with_vals else None, n, name)

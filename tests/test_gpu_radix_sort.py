@@ -936,14 +936,15 @@ def test_pass_plan_on_the_small_geometry(G, kind):
 
 
 @pytest.mark.parametrize("mode,threshold", [("pairs", 256 * 10240 * 3 // 2), ("keys", 256 * 16384 * 3 // 2), ("u64", 256 * 8192 * 3 // 2),
-                                            ("pairs", 256 * 12288 * 3 // 2), ("pairs", 256 * 9216 * 3 // 2), ("pairs", 256 * 4 * 4096 + 1)])
+                                            ("pairs", 256 * 12288 * 3 // 2), ("pairs", 256 * 9216 * 3 // 2), ("pairs", 256 * 4 * 4096 + 1), ("keys", 1 << 25)])
 @pytest.mark.parametrize("delta", [-1, 0, 1, 12287])
 def test_geometry_switch_points(G, mode, threshold, delta):
     """Sizes right at the small -> large geometry switch of each kernel family (3/2 large tiles per CU on 256 CUs; the
     large tile is 10240 pairs / 16384 keys for the 128-byte-line kernel of 32-bit keys, 8192 pairs for 64-bit keys;
     12288 pairs / 8192 pairs are the switches of the kernel that unaligned arrays fall back to; 32-bit keys with values
     stay on the small geometry while one round of its workgroups takes the input: 256 CUs x 4 x 4096 pairs -- the last of
-    those sizes, 2^22, is also the first one sorted with a device-side pass plan)."""
+    those sizes, 2^22, is also the first one sorted with a device-side pass plan; keys-only sorts of 32-bit keys stay on it up to
+    2^25 keys, where the line kernel and the attempt to end in LDS begin)."""
     n = threshold + delta
     rng = np.random.default_rng(n)
     if mode == "u64":
