@@ -583,7 +583,11 @@ constexpr size_t kPairMinKeyBytes = (size_t) 1 << 28;
 // (64-bit keys, where it replaces six passes, not two: from about 2^23: 2^24 1.01 -> 0.74 ms, 2^25 1.81 -> 1.07)
 // (round 5, with the launches that the long-run passes and the sample added: 32-bit keys still from 2^24.8, 2^25: 0.638 -> 0.578 ms;
 // 64-bit keys from 2^23: 0.615 -> 0.474 ms; profiles/r05/finish_midsize_any*.txt, host time from the call to the end of the sort)
-constexpr size_t finish_min_count(size_t key_size) { return key_size == 8 ? (size_t) 1 << 23 : (size_t) 1 << 25; }
+// (later in round 5, on a finer ladder: 64-bit keys level at 6.3 M pairs or keys, 3-21 % ahead from 6.6 M .. 7.9 M: profiles/r05/finish_from_u64.txt)
+// (32-bit keys with values, once the line stores of sorts this size had become plain ones: level at 27.9 M pairs, 3.5 % ahead at 30.4 M,
+// 4.7 % at 33.1 M: profiles/r05/finish_from_u32_pairs.txt -- from 7 * 2^22; keys-only sorts of 32-bit keys reach the line kernel, and with it
+// the attempt, at 2^25 keys)
+constexpr size_t finish_min_count(size_t key_size) { return key_size == 8 ? (size_t) 3 << 21 : (size_t) 7 << 22; }
 constexpr size_t kPlanMinCount = (size_t) 1 << 22; // planned sorts: see PlanArgs below
 
 // CUs the pass kernels of `s` may fill (glu_dist reserves some for RCCL kernels that run beside them)

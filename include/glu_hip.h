@@ -283,7 +283,7 @@ GLU_API glu_status glu_radix_sort_read_plan(glu_radix_sort sort, uint32_t* skipp
 GLU_API glu_status glu_radix_sort_plan_finish(size_t count, uint32_t key_bytes, uint32_t* first_capacity,
                                               uint32_t* last_capacity);
 /* A sort that ends in LDS (replaces six of the reference's eight 4-bit steps, glu/RadixSort.hpp:289-333, by one pass).  A sort of
- * whole 32-bit or 64-bit keys (any key type) of 2^25 (64-bit keys: 2^23) .. about 2^29 elements with 8-bit digits first tries a
+ * whole 32-bit or 64-bit keys (any key type) of 7 * 2^22 (keys only: 2^25; 64-bit keys: 3 * 2^21) .. about 2^29 elements with 8-bit digits first tries a
  * shorter way to the same result: two counting passes on 16 TOP key bits, after which the array is 65536 runs of keys that share
  * those bits, and one pass in which a workgroup per run orders the run by the remaining low bits inside LDS, in place -- 52.25
  * instead of 72.5 bytes of memory traffic per pair with 32-bit keys, 80.25 instead of 225 with 64-bit keys (which rank key bits

@@ -1232,7 +1232,7 @@ def test_paired_passes_structured_inputs(G, case):
 
 
 def test_paired_passes_u64_keys_only_and_bit_ranges(G):
-    n = (1 << 23) - 4099  # (below 2^23: from there 64-bit keys first try to end in LDS, and these are the ordinary passes' tests)
+    n = (3 << 21) - 4099  # (below 3 * 2^21: from there 64-bit keys first try to end in LDS, and these are the ordinary passes' tests)
     rng = np.random.default_rng(36)
     k64 = rng.integers(0, 2**64, n, dtype=np.uint64)
     k64[::5] &= np.uint64(0x0000FFFFFFFFFFFF)
@@ -1426,9 +1426,9 @@ def test_passes_on_key_bits_that_do_not_vary_are_identities_without_counting(G, 
     gk, gv, skipped, alone = _sort_and_plan(G, same, vals, 4 * per, bits=bits)
     assert (gk == same).all() and (gv == vals).all()
     assert _sort_and_plan.last_skip_raw == [1] + [2] * (4 * per - 1)
-    # 64-bit keys holding 32-bit numbers, keys only (below 2^23 keys: from there such a sort ends in LDS, its runs taken from bits
+    # 64-bit keys holding 32-bit numbers, keys only (below 3 * 2^21 keys: from there such a sort ends in LDS, its runs taken from bits
     # [16, 32) -- tests/test_gpu_lds_finish.py::test_u64_keys_of_a_smaller_range_on_the_first_sort)
-    k64 = rng.integers(0, 2**32, (1 << 23) - 5000, dtype=np.uint64)
+    k64 = rng.integers(0, 2**32, (3 << 21) - 5000, dtype=np.uint64)
     gk, _, skipped, alone = _sort_and_plan(G, k64, None, 8 * per, key_bytes=8, bits=bits)
     assert (gk == np.sort(k64)).all()
     assert _sort_and_plan.last_skip_raw == [0] * (4 * per) + [2] * (4 * per)
