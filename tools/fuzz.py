@@ -16,7 +16,8 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time())
 rng = np.random.default_rng(seed)
 print("seed", seed, flush=True)
 SWITCH = [1024, 4096, 8192, 12288, 256 * 4096, 768 * 4096, 256 * 12288, 256 * 20480, 256 * 8192, 256 * 2048, 1 << 22,
-          256 * 10240 * 3 // 2, 256 * 16384 * 3 // 2, 256 * 8192 * 3 // 2, 256 * 6144 * 3 // 2, 256 * 6144 * 2 + 6144, 256 * 10240 * 2, 256 * 10240 * 2 + 10240]  # + line-kernel switch points
+          256 * 10240 * 3 // 2, 256 * 16384 * 3 // 2, 256 * 8192 * 3 // 2, 256 * 6144 * 3 // 2, 256 * 6144 * 2 + 6144, 256 * 10240 * 2, 256 * 10240 * 2 + 10240,  # + line-kernel switch points
+          256 * 4 * 4096 + 1, 3 << 21]  # (round 5) pairs: the line kernel's first size; 64-bit keys: the first size that tries to end in LDS
 
 
 LARGE = os.environ.get("FUZZ_LARGE") == "1"  # most sizes in [2^22, 2^23], passes paired from 2^22 elements up
