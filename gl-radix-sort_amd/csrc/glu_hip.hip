@@ -515,10 +515,12 @@ struct glu_radix_sort_s
     bool lds_finish = true;       // GLU_HIP_SORT_LDS_FINISH=0: always the four passes of the ordinary sort (tests / tuning)
     bool long_runs = true;        // GLU_HIP_SORT_LONG_RUNS=0: a run longer than the in-LDS pass's tile refuses the whole sort, as in round 4 (tests / tuning)
     size_t finish_min = 0;        // GLU_HIP_SORT_FINISH_MIN=N: element count from which the attempt is made (tests / tuning)
-    // A refused attempt costs one read of the keys.  The plan kernel notes each attempt's outcome in a pinned host word
-    // (attempt number << 1 | accepted); a later sort call that finds its LAST attempt refused skips the next
-    // `finish_backoff` attempts (no synchronisation: an outcome that is not there yet counts as unknown and the attempt is
-    // made).  Inputs that never fit thus pay for one count kernel in finish_backoff + 1 sorts.
+    // A refused attempt costs one read of the keys (4 % of a four-pass sort of 2^28 pairs; nothing when the keys are constant: the
+    // ordinary passes then skip on the bits that read collected).  The plan kernel notes each attempt's outcome in a pinned host
+    // word (attempt number << 3 | tile geometry, 0 = refused).  EVERY sort asks: what a sort costs does not depend on what the
+    // object sorted before (round 4 skipped the next eight attempts after a refusal, and uniform keys behind an all-zero input
+    // ran four passes: 4.5 instead of 3.0 ms).  GLU_HIP_SORT_FINISH_BACKOFF=N brings that back: a sort call that finds its LAST
+    // attempt refused skips the next N attempts (no synchronisation: an outcome that is not there yet counts as unknown).
     uint32_t* finish_hint = nullptr;
     uint32_t finish_seq = 0, finish_seq_acted_on = 0, finish_wait = 0;
     uint32_t finish_last_geo = 0; // the tile geometry the device chose for the last sort whose outcome is known (0: none yet)
@@ -530,7 +532,7 @@ struct glu_radix_sort_s
     bool last_device_top = false; // (glu_radix_sort_read_finish reads the top bit from the device's plan)
     uint32_t finish_top = 0;      // 0: the key's width
     uint32_t last_finish_top = 0; // what the last sort assumed (glu_radix_sort_read_finish)
-    uint32_t finish_backoff = 8;  // GLU_HIP_SORT_FINISH_BACKOFF=N (0: every sort attempts: tests)
+    uint32_t finish_backoff = 0;  // GLU_HIP_SORT_FINISH_BACKOFF=N (0, the default: every sort attempts)
     bool last_finish_attempted = false; // the last sort enqueued both sequences (glu_radix_sort_read_finish)
     bool last_finish_long_ok = false;   // ... and the segmented passes for runs longer than the tile (glu_radix_sort_read_long_runs)
     uint32_t last_finish_capacity = 0;  // and the longest run its last pass would take
@@ -1374,7 +1376,9 @@ glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t cou
     {
         // per sort: no follower counts for itself yet, nothing is known about the key bits
         PassPlan* plan = (PassPlan*) s->plan.ptr;
-        static_assert(offsetof(PassPlan, sample_done) + sizeof(plan->sample_done) == sizeof(PassPlan), "the zeroed tail of the plan");
+        static_assert(offsetof(PassPlan, sample_done) + sizeof(plan->sample_done) <= sizeof(PassPlan) && offsetof(PassPlan, sample_done) + 64 > sizeof(PassPlan),
+                      "sample_done is the last member of the zeroed tail of the plan");
+        static_assert(offsetof(PassPlan, pair_fallback) % 64 == 0 && sizeof(PassPlan) % 64 == 0, "one aligned fill");
         HIP_TRY(hipMemsetAsync(plan->pair_fallback, 0, sizeof(PassPlan) - offsetof(PassPlan, pair_fallback), stream));
         if (finish_kpt && device_top)
         {

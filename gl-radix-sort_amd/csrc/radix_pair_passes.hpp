@@ -133,6 +133,7 @@ __global__ __launch_bounds__(1024) void radix_pair_count_kernel(const KeyT* __re
     auto main_loop = [&](auto peel) {
         for (; vbase + 4 * THREADS <= nvec; vbase += 4 * THREADS) // block-uniform trip count, 4 x 16 B in flight per lane
         {
+            if (wave_tally_gives_up(peel, run)) break; // (peel mode only; the wave comes back in the stateless mode)
             VecT a = load_streaming(&vkeys[vbase + tid]);
             VecT b = load_streaming(&vkeys[vbase + tid + THREADS]);
             VecT c = load_streaming(&vkeys[vbase + tid + 2 * THREADS]);
@@ -417,6 +418,7 @@ __global__ __launch_bounds__(256) void radix_pair4_count_kernel(const KeyT* __re
         auto main_loop = [&](auto peel) { // (twice, chosen once per wave from its first keys: see wave_tally)
             for (; vbase + 4 * THREADS <= nvec; vbase += 4 * THREADS) // block-uniform trip count, 4 x 16 B in flight per lane
             {
+                if (wave_tally_gives_up(peel, run)) break; // (peel mode only; the wave comes back in the stateless mode)
                 VecT a = load_streaming(&vkeys[vbase + tid]);
                 VecT bq = load_streaming(&vkeys[vbase + tid + THREADS]);
                 VecT c = load_streaming(&vkeys[vbase + tid + 2 * THREADS]);

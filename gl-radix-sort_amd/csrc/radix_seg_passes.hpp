@@ -113,6 +113,7 @@ __global__ __launch_bounds__(THREADS) void radix_seg_count_kernel(const uint32_t
         auto main_loop = [&](auto peel) { // (twice, chosen once per wave and sub-block from its first keys: see wave_tally)
             for (; vbase + 4 * THREADS <= nvec; vbase += 4 * THREADS) // block-uniform trip count, 4 x 16 B in flight per lane
             {
+                if (wave_tally_gives_up(peel, run)) break; // (peel mode only; the wave comes back in the stateless mode)
                 const uint4 a = load_streaming(&vkeys[vbase + tid]);
                 const uint4 b = load_streaming(&vkeys[vbase + tid + THREADS]);
                 const uint4 c = load_streaming(&vkeys[vbase + tid + 2 * THREADS]);

@@ -152,13 +152,15 @@ __device__ __forceinline__ uint32_t sum_of_preceding_waves(const uint32_t* total
 // The scatter kernel of pass p publishes flip[p + 1] = flip[p] ^ !skip[p]; the count kernel of pass p + 1 runs after it.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kPlanMaxPasses = 32;
-struct PassPlan
+// (The part zeroed at the start of every sort begins and ends on a 64-byte boundary: hipMemsetAsync of a range that does not
+// becomes three fill kernels -- head, body, tail -- 14 us in front of every planned sort instead of 4.5.)
+struct alignas(64) PassPlan
 {
     uint32_t flip[kPlanMaxPasses + 1];
     uint32_t skip[kPlanMaxPasses];
     // paired passes (radix_pair_passes.hpp): 1 = pass p counts for itself although its table was to come from the
     // two-digit histogram of pass p - 1; zeroed at the start of every sort, set by kernels that run before pass p
-    uint32_t pair_fallback[kPlanMaxPasses + 1];
+    alignas(64) uint32_t pair_fallback[kPlanMaxPasses + 1];
     // A sort that tries to end in LDS (radix_lds_finish.hpp) enqueues two alternative sequences of passes; off[p] = 1: pass
     // p belongs to the sequence not taken -- its count kernels return at once and report it as skipped without counting.
     // finish = 1: the top-bit passes ran and the last pass orders every run in LDS; finish_longest: the longest run seen
@@ -260,6 +262,11 @@ __device__ __forceinline__ void wave_tally(uint32_t v, uint32_t lane, F&& add)
 struct TallyRun
 {
     uint32_t value = 0, count = 0; // wave-uniform
+    // (peel mode, wave_tally_cached) the values this wave keeps counting in registers, and how many of each it has seen since their
+    // last flush; ~0 is no digit value of any kernel
+    static constexpr int kCached = 8;
+    uint32_t hot_value[kCached] = {~0u, ~0u, ~0u, ~0u, ~0u, ~0u, ~0u, ~0u}, hot_count[kCached] = {0, 0, 0, 0, 0, 0, 0, 0}; // wave-uniform
+    uint32_t steps = 0, misses = 0, gave_up = 0; // (wave_tally_gives_up: more frequent values than registers, the stateless peel takes over)
 };
 template<typename F>
 __device__ __forceinline__ void wave_tally_flush(TallyRun& run, uint32_t lane, F&& add)
@@ -283,6 +290,80 @@ __device__ __forceinline__ void wave_tally_runs(uint32_t v, uint32_t lane, Tally
     else
         wave_tally<true>(v, lane, add);
 }
+// Peel mode with memory (round 5): a handful of key values in random order -- flags, categories, three values -- made the
+// stateless peel above the whole cost of a count kernel (three values, 2^28 pairs: the pair-count kernel 0.80 ms against 0.20 ms
+// on uniform keys: three ballots, three pairs of one-lane atomics and their bookkeeping per 64 keys; now 0.24 ms).  Here the wave
+// counts up to eight values in (wave-uniform) registers: a compare, a ballot and an add each per step, no counter is touched
+// while the step's values are all among them.  A step with other values gives the first of them the place of the entry seen
+// least since its flush (which is added to the counters then) and lets the lanes left over add one by one.
+// wave_tally_cached_flush adds what is still in the registers.  Inputs whose frequent values keep changing -- more than eight of
+// them, or short runs of equal keys one after the other (the later passes of a sort of Zipf-distributed keys) -- make every other
+// step such a step: a wave that sees that (wave_tally_gives_up) leaves its loop, flushes and goes on in the stateless peel mode,
+// which is what such inputs need.  Counts are not bounded: the pair kernels' 16-bit counters overflow for such inputs anyway, and an
+// overflow -- by many small adds or one large one -- breaks the row sums that radix_pair_count_kernel checks against the exact
+// 32-bit table; the 32-bit counters cannot overflow (a count is at most the input size).
+template<typename F>
+__device__ __forceinline__ void wave_tally_cached(uint32_t v, uint32_t lane, TallyRun& st, F&& add)
+{
+    uint64_t todo = ~0ull;
+#pragma unroll
+    for (int k = 0; k < TallyRun::kCached; k++)
+    {
+        const uint64_t m = __ballot(v == st.hot_value[k]);
+        st.hot_count[k] += (uint32_t) __popcll(m);
+        todo &= ~m;
+    }
+    if (todo != 0) // (wave-uniform)
+    {
+        st.misses++;
+        int victim = 0;
+        uint32_t fewest = st.hot_count[0]; // (no dynamic indexing of the register arrays: they would live in scratch memory)
+#pragma unroll
+        for (int k = 1; k < TallyRun::kCached; k++)
+            if (st.hot_count[k] < fewest) fewest = st.hot_count[k], victim = k;
+        const uint32_t first = (uint32_t) __ffsll((unsigned long long) todo) - 1u;
+        const uint32_t vg = (uint32_t) __builtin_amdgcn_readlane((int) v, (int) first);
+        const uint64_t grp = __ballot(v == vg);
+#pragma unroll
+        for (int k = 0; k < TallyRun::kCached; k++)
+            if (k == victim)
+            {
+                if (st.hot_count[k] != 0 && lane == 0) add(st.hot_value[k], st.hot_count[k]);
+                st.hot_value[k] = vg;
+                st.hot_count[k] = (uint32_t) __popcll(grp);
+            }
+        todo &= ~grp;
+        if ((todo >> lane) & 1ull) add(v, 1u);
+    }
+}
+// called once per iteration of a count loop (16 keys per lane): true = this wave's loop in peel mode should stop -- more than
+// half of the last 32 steps met values the registers did not hold (filling them takes eight such steps at most) -- and the wave
+// go on in the stateless mode (wave-uniform)
+template<typename Mode>
+__device__ __forceinline__ bool wave_tally_gives_up(Mode, TallyRun& st)
+{
+    if constexpr (Mode::value != 1)
+        return false;
+    else
+    {
+        if ((++st.steps & 1u) == 0)
+        {
+            if (st.misses > 16u) st.gave_up = 1;
+            st.misses = 0;
+        }
+        return st.gave_up != 0;
+    }
+}
+template<typename F>
+__device__ __forceinline__ void wave_tally_cached_flush(TallyRun& st, uint32_t lane, F&& add)
+{
+#pragma unroll
+    for (int k = 0; k < TallyRun::kCached; k++)
+    {
+        if (st.hot_count[k] != 0 && lane == 0) add(st.hot_value[k], st.hot_count[k]);
+        st.hot_count[k] = 0;
+    }
+}
 __device__ __forceinline__ bool wave_all_equal(uint32_t v) // wave-uniform
 {
     return __ballot(v != (uint32_t) __builtin_amdgcn_readfirstlane(v)) == 0;
@@ -291,13 +372,16 @@ __device__ __forceinline__ bool wave_all_equal(uint32_t v) // wave-uniform
 using TallyPlain = std::integral_constant<int, 0>;
 using TallyPeel = std::integral_constant<int, 1>;
 using TallyRuns = std::integral_constant<int, 2>;
+using TallyStateless = std::integral_constant<int, 3>; // the peel without memory: what a wave falls back to from mode 1
 template<typename Mode, typename F>
 __device__ __forceinline__ void wave_tally_mode(Mode, uint32_t v, uint32_t lane, TallyRun& run, F&& add)
 {
     if constexpr (Mode::value == 2)
         wave_tally_runs(v, lane, run, add);
+    else if constexpr (Mode::value == 1)
+        wave_tally_cached(v, lane, run, add);
     else
-        wave_tally<Mode::value == 1>(v, lane, add);
+        wave_tally<Mode::value == 3>(v, lane, add);
 }
 // runs `loop(mode)` in the mode the wave's first value suggests
 template<typename L, typename F>
@@ -309,7 +393,12 @@ __device__ __forceinline__ void wave_tally_dispatch(uint32_t first_value, uint32
         wave_tally_flush(run, lane, add);
     }
     else if (wave_many_equal(first_value))
+    {
+        run.steps = 0, run.misses = 0, run.gave_up = 0;
         loop(TallyPeel());
+        wave_tally_cached_flush(run, lane, add);
+        if (run.gave_up) loop(TallyStateless()); // (the rest of the wave's keys)
+    }
     else
         loop(TallyPlain());
 }
@@ -437,6 +526,7 @@ __global__ __launch_bounds__(THREADS) void radix_count_kernel(const KeyT* __rest
     auto main_loop = [&](auto peel) {
         for (; vbase + 4 * THREADS <= nvec; vbase += 4 * THREADS) // block-uniform trip count, 4 x 16 B in flight per lane
         {
+            if (wave_tally_gives_up(peel, run)) break; // (peel mode only; the wave comes back in the stateless mode)
             // non-temporal loads: the keys are read once; leaving them out of the Infinity Cache keeps the dirty lines of the
             // scatter that ran just before from being evicted under this kernel (0.255 -> 0.22 ms behind a scatter, 0.19 ->
             // 0.17 ms alone at 2^28 keys)

@@ -319,15 +319,34 @@ def test_u64_keys_of_a_smaller_range(G):
                 assert fin["attempted"] == 1 and fin["accepted"] == 1 and fin["top_bit"] == top, (bits, fin)
 
 
-def test_after_a_refusal_the_next_sorts_do_not_ask_again(G):
-    """A refused attempt costs a read of the keys; an object whose last attempt was refused skips the next eight attempts, then
-    asks again (inputs that fit are taken up again, inputs that never fit pay once in nine sorts)."""
-    s = _sorter(G, **SMALL)
-    vals = np.arange(N_SMALL, dtype=np.uint32)
+def _crowded_and_wide():
     narrow = _uniform(N_SMALL, 13)  # (full-range keys, but six in ten crowd into thirty runs: beyond what the long-run passes take)
     crowd = np.random.default_rng(13).choice(N_SMALL, N_SMALL * 6 // 10, replace=False)
     narrow[crowd] = (np.random.default_rng(14).integers(0, 30, crowd.size, dtype=np.uint32) * np.uint32(2001) << np.uint32(16)) | (narrow[crowd] & np.uint32(0xFFFF))
-    wide = _uniform(N_SMALL, 14)
+    return narrow, _uniform(N_SMALL, 14)
+
+
+def test_every_sort_asks_whatever_the_object_sorted_before(G):
+    """What a sort costs does not depend on the object's history: after refused attempts (crowded keys, all-zero keys) the next
+    sort of keys that fit ends in LDS at once."""
+    s = _sorter(G, **SMALL)
+    vals = np.arange(N_SMALL, dtype=np.uint32)
+    narrow, wide = _crowded_and_wide()
+    zeros = np.zeros(N_SMALL, dtype=np.uint32)
+    seen = []
+    for keys in (narrow, narrow, wide, zeros, zeros, wide, narrow, wide):
+        gk, gv, fin = _run(G, s, keys, vals)
+        _check(keys, vals, gk, gv)
+        seen.append((fin["attempted"], fin["accepted"]))
+    assert seen == [(1, 0), (1, 0), (1, 1), (1, 0), (1, 0), (1, 1), (1, 0), (1, 1)], seen
+
+
+def test_the_back_off_switch_skips_attempts_after_a_refusal(G):
+    """GLU_HIP_SORT_FINISH_BACKOFF=8 (round 4's default): an object whose last attempt was refused skips the next eight attempts,
+    then asks again (inputs that never fit pay for the refused attempt's read of the keys once in nine sorts)."""
+    s = _sorter(G, GLU_HIP_SORT_FINISH_BACKOFF=8, **SMALL)
+    vals = np.arange(N_SMALL, dtype=np.uint32)
+    narrow, wide = _crowded_and_wide()
     seen = []
     for i in range(11):
         keys = narrow if i < 10 else wide

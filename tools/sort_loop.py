@@ -15,6 +15,7 @@ ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--warmup", type=int, default=3)
 ap.add_argument("--key-bits", type=int, default=0, help="keys drawn from [0, 2^B) (0: the whole key)")
 ap.add_argument("--zeros", type=float, default=0.0, help="this share of the keys (per cent) is set to zero")
+ap.add_argument("--distinct", type=int, default=0, help="the keys are drawn from this many distinct values (0x55555555 * k)")
 ap.add_argument("--keys-only", action="store_true")
 ap.add_argument("--digit-bits", type=int, default=8)
 a = ap.parse_args()
@@ -24,6 +25,8 @@ kb = 8 * a.key_bytes
 bits = a.key_bits or kb
 dt = np.uint64 if a.key_bytes == 8 else np.uint32
 keys = rng.integers(0, 2 ** bits, n, dtype=dt)
+if a.distinct:
+    keys = (rng.integers(0, a.distinct, n, dtype=np.uint32) * np.uint32(0x55555555)).astype(dt)
 if a.zeros > 0:
     keys[rng.random(n) < a.zeros / 100.0] = 0
 vals = np.arange(n, dtype=np.uint32)

@@ -4,8 +4,9 @@ duration (us), name (a sort = everything after the last-but-one buffer-copy pair
 import csv, re, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-last_copy = max(i for i, r in enumerate(rows) if "copy" in r["Kernel_Name"].lower())
-seq = rows[last_copy + 1:]  # (kernels that are not the library's -- fills, copies -- are listed too)
+end = max(i for i, r in enumerate(rows) if "glu_hip::" in r["Kernel_Name"])          # the last kernel of the last sort
+begin = max([i for i in range(end) if "copy" in rows[i]["Kernel_Name"].lower()] + [-1]) + 1  # behind the copy that restored its input
+seq = rows[begin:end + 1]  # (kernels in between that are not the library's -- fills -- are listed too)
 t0 = int(seq[0]["Start_Timestamp"])
 prev_end = t0
 for r in seq:
