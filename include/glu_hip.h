@@ -291,8 +291,8 @@ GLU_API glu_status glu_radix_sort_plan_finish(size_t count, uint32_t key_bytes, 
  * enqueued in the tile geometry that suits uniformly drawn keys of this count (1536 / 2560 / 4608 / 9216 pairs) and in the next
  * larger ones, and the device runs the smallest that holds the runs (`capacity`); runs longer than the tile go to segmented
  * passes (glu_radix_sort_read_long_runs below) or -- 64-bit, typed and keys-only sorts; keys crowded into few runs -- send the sort
- * to the ordinary passes, at the cost of one extra read of the keys; an object whose last attempt was refused skips the next
- * eight attempts.  The launch sequence is the same either way (the kernels of the sequence not taken return at once), so the
+ * to the ordinary passes, at the cost of one extra read of the keys (every sort asks: its cost does not depend on what the
+ * object sorted before).  The launch sequence is the same either way (the kernels of the sequence not taken return at once), so the
  * sort stays asynchronous and capturable.
  * This reports, for the last sort on the object (the caller has synchronised its stream): attempted = 1 if both sequences were
  * enqueued, accepted = 1 if the sort ended in LDS, longest_run = the longest run counted (0xFFFFFFFF: not counted), capacity =
