@@ -483,7 +483,7 @@ def main():
                 "count_kernels_reading_keys": key_reads, "scatter_passes_run": scatters,
                 "ended_in_lds": ended_in_lds,
                 "in_lds_pass": ({
-                    "kernel": "radix_finish_sort_kernel", "avg_launch_ms": round(finish_ms, 4),
+                    "kernel": "radix_finish_bucket_kernel", "avg_launch_ms": round(finish_ms, 4),
                     "algorithmic_bytes_per_launch": alg_bytes,
                     "achieved_GBps": round(alg_bytes / (finish_ms * 1e-3) / 1e9, 1) if finish_ms > 0 else None,
                     "frac_of_peak": round(alg_bytes / (finish_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if finish_ms > 0 else None,

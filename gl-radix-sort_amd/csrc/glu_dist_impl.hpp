@@ -62,7 +62,7 @@ RcclApi& rccl()
     static RcclApi api;
     static std::once_flag once;
     std::call_once(once, [] {
-        const char* names[] = {getenv("GLU_HIP_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        const char* names[] = {glu_env("GLU_HIP_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
         for (const char* name : names)
         {
             if (!name || !*name) continue;
@@ -315,18 +315,18 @@ glu_status glu_dist_create(const void* unique_id, size_t id_bytes, int world_siz
     d->world = world_size;
     d->rank = rank;
     d->owner.assign(kDistBuckets, 0);
-    if (const char* e = getenv("GLU_HIP_DIST_TEST_REPARTITION")) d->repartition_at_world_1 = atoi(e) != 0;
-    if (const char* e = getenv("GLU_HIP_DIST_TEST_SHARD_LIMIT"))
+    if (const char* e = glu_env("GLU_HIP_DIST_TEST_REPARTITION")) d->repartition_at_world_1 = atoi(e) != 0;
+    if (const char* e = glu_env("GLU_HIP_DIST_TEST_SHARD_LIMIT"))
         if (atoll(e) > 0) d->shard_limit = (uint64_t) atoll(e);
-    if (const char* e = getenv("GLU_HIP_DIST_SEG_MIN")) d->seg_min = (size_t) atoll(e);
-    if (const char* e = getenv("GLU_HIP_DIST_SEG")) d->seg_enabled = atoi(e) != 0, d->seg_forced = atoi(e) == 2;
+    if (const char* e = glu_env("GLU_HIP_DIST_SEG_MIN")) d->seg_min = (size_t) atoll(e);
+    if (const char* e = glu_env("GLU_HIP_DIST_SEG")) d->seg_enabled = atoi(e) != 0, d->seg_forced = atoi(e) == 2;
     d->rounds = world_size >= 4 ? 3 : 1;
-    if (const char* e = getenv("GLU_HIP_DIST_ROUNDS"))
+    if (const char* e = glu_env("GLU_HIP_DIST_ROUNDS"))
         if (atoi(e) >= 1 && atoi(e) <= glu_dist_s::kMaxRounds) d->rounds = atoi(e);
-    if (const char* e = getenv("GLU_HIP_DIST_ROUNDS_MIN")) d->rounds_min = (size_t) atoll(e);
-    if (const char* e = getenv("GLU_HIP_DIST_TEST_FAULT"))
+    if (const char* e = glu_env("GLU_HIP_DIST_ROUNDS_MIN")) d->rounds_min = (size_t) atoll(e);
+    if (const char* e = glu_env("GLU_HIP_DIST_TEST_FAULT"))
         d->test_fault = strcmp(e, "no_hist_wait") == 0 ? 1 : (strcmp(e, "local_sort_unordered") == 0 ? 2 : 0);
-    if (const char* e = getenv("GLU_HIP_DIST_TEST_FAIL"))
+    if (const char* e = glu_env("GLU_HIP_DIST_TEST_FAIL"))
     {
         if (strncmp(e, "begin:", 6) == 0) d->test_fail_begin = atoi(e + 6);
         if (strncmp(e, "finish:", 7) == 0) d->test_fail_finish = atoi(e + 7);

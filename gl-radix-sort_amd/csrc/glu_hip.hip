@@ -10,6 +10,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <strings.h>
 #include <unordered_map>
 #include <vector>
 
@@ -19,7 +20,7 @@
 #include "radix_scatter_lines.hpp"
 #include "radix_pair_passes.hpp"
 #include "radix_seg_passes.hpp"
-#include "radix_lds_finish.hpp"
+#include "radix_lds_bucket.hpp"
 #include "scan_reduce_kernels.hpp"
 
 using namespace glu_hip;
@@ -30,6 +31,17 @@ using namespace glu_hip;
 namespace
 {
 thread_local std::string g_last_error;
+
+// GLU_VERBOSE=1: allocations and placement searches are narrated on stderr (read once per process)
+bool glu_verbose()
+{
+    static const bool on = getenv("GLU_VERBOSE") != nullptr;
+    return on;
+}
+
+// Every other environment variable the library reads goes through here: defaults of new sort objects (kSortOptions), the
+// tuning lists of the placement search / scan / reduce, and the test hooks of glu_dist (fault injection, the RCCL test double).
+const char* glu_env(const char* name) { return getenv(name); }
 
 glu_status fail(glu_status code, const char* fmt, ...)
 {
@@ -161,7 +173,7 @@ struct Scratch
         size = 0;
         HIP_TRY(hipMalloc(&ptr, bytes));
         size = bytes;
-        if (getenv("GLU_VERBOSE")) fprintf(stderr, "[glu_hip] scratch reallocated to: %zu\n", bytes);
+        if (glu_verbose()) fprintf(stderr, "[glu_hip] scratch reallocated to: %zu\n", bytes);
         return GLU_OK;
     }
     void release()
@@ -512,6 +524,24 @@ struct glu_radix_sort_s
     // a sort that ends in LDS (radix_lds_finish.hpp): large whole-key sorts try two top-bit passes + one in-LDS pass
     Scratch finish_lengths;       // [65536] run lengths,
     Scratch finish_starts;        // [65537] run starts
+    Scratch finish_crowded;       // the runs the bucket kernel of the in-LDS pass leaves to the ballot rounds (crowded_list_words)
+    // (round 6) A sort that tries to end in LDS enqueues two sequences of which the device runs one; the launches of the other
+    // return at once, 4.5-5.7 us each -- 22 of them were 105 us behind every accepted attempt (profiles/r05/last_sort_kernels_2p28.txt).
+    // They now go to a stream of the object's own that forks off the caller's queue behind the plan kernel and joins it in front
+    // of the last kernel: accepted, they return at once UNDER the first top-bit scatter; refused, the kernels left on the
+    // caller's queue do.  Forked too: the follower's unit sums (they need the leader's tables only, not its scatter) and the
+    // segmented passes over long runs (beside the in-LDS pass, which leaves those runs alone).  Event fork / join: capturable.
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_unit = nullptr, ev_fork2 = nullptr, ev_join = nullptr;
+    bool fork_behind = true;      // GLU_HIP_SORT_FORK=0: one queue, as in round 5 (tests / tuning)
+    bool ensure_side()
+    {
+        if (side) return true;
+        if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) return side = nullptr, false;
+        for (hipEvent_t* e : {&ev_fork, &ev_unit, &ev_fork2, &ev_join})
+            if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) return false;
+        return true;
+    }
     bool lds_finish = true;       // GLU_HIP_SORT_LDS_FINISH=0: always the four passes of the ordinary sort (tests / tuning)
     bool long_runs = true;        // GLU_HIP_SORT_LONG_RUNS=0: a run longer than the in-LDS pass's tile refuses the whole sort, as in round 4 (tests / tuning)
     size_t finish_min = 0;        // GLU_HIP_SORT_FINISH_MIN=N: element count from which the attempt is made (tests / tuning)
@@ -638,6 +668,7 @@ glu_status sort_prepare(glu_radix_sort_s* s, size_t count, size_t key_size, bool
         {
             GLU_TRY(s->finish_lengths.reserve((size_t) kFinishRuns * sizeof(uint32_t)));
             GLU_TRY(s->finish_starts.reserve(((size_t) kFinishRuns + 1) * sizeof(uint32_t)));
+            GLU_TRY(s->finish_crowded.reserve(crowded_list_words(kFinishRuns) * sizeof(uint32_t)));
             if (key_size == 4 && with_vals)
             {
                 // runs longer than the in-LDS pass's tile are sorted by two segmented passes (radix_finish_long_runs_kernel)
@@ -675,6 +706,8 @@ struct PlanArgs
     uint32_t finish_first_ordinary = 0, finish_num_ordinary = 0;
     uint32_t finish_seq = 0, finish_top_bit = 0, finish_key_bits = 0;
     bool finish_long_ok = false; // runs longer than the tile go to segmented passes (sort_bits enqueues them behind the in-LDS pass)
+    bool fork_side = false;      // behind the plan kernel of this pass the object's side stream forks off (glu_radix_sort_s::side)
+    bool unitsum_side = false;   // this follower's unit sums run on the side stream, under its leader's scatter
 };
 
 // XF: this pass encodes keys on load and / or decodes them on store (first / last pass of a typed sort); every other
@@ -846,9 +879,16 @@ glu_status launch_pass_lines(glu_radix_sort_s* s, const KeyT* src_k, const uint3
         totals = table + (size_t) RADIX * nb;
         ranges = (const uint2*) s->pair_ranges.ptr;
         if constexpr (BITS == 8)
-            hipLaunchKernelGGL(radix_pair_unitsum_kernel, dim3(nb), dim3(1024), 0, stream, (const uint32_t*) s->pair_t2.ptr,
+        {
+            hipLaunchKernelGGL(radix_pair_unitsum_kernel, dim3(nb), dim3(1024), 0, pa.unitsum_side ? s->side : stream, (const uint32_t*) s->pair_t2.ptr,
                                (const uint32_t*) leader_table, (const uint32_t*) (leader_table + (size_t) RADIX * nb), table,
                                (uint2*) s->pair_ranges.ptr, (uint32_t) count, pa.plan, pa.pass, shift, mask, pa.flags);
+            if (pa.unitsum_side)
+            {
+                HIP_TRY(hipEventRecord(s->ev_unit, s->side));
+                HIP_TRY(hipStreamWaitEvent(stream, s->ev_unit, 0));
+            }
+        }
         else
             hipLaunchKernelGGL(radix_pair4_unitsum_kernel, dim3(nb), dim3(1024), 0, stream, (const uint32_t*) s->pair_t2.ptr,
                                (const uint32_t*) sub_table, (const uint32_t*) (leader_table + (size_t) RADIX * nb), table,
@@ -893,13 +933,18 @@ glu_status launch_pass_lines(glu_radix_sort_s* s, const KeyT* src_k, const uint3
         hipLaunchKernelGGL(radix_finish_plan_kernel, dim3(kFinishPlanBlocks), dim3(1024), 0, stream, (const uint32_t*) s->finish_lengths.ptr,
                            (uint32_t*) s->finish_starts.ptr, (uint32_t) count, pa.finish_geo_first, pa.finish_geo_last, pa.plan, pa.pass,
                            pa.finish_first_ordinary, pa.finish_num_ordinary, s->finish_hint, pa.finish_seq, pa.finish_top_bit,
-                           pa.finish_key_bits, pa.finish_long_ok ? 1u : 0u);
+                           pa.finish_key_bits, pa.finish_long_ok ? 1u : 0u, (uint32_t*) s->finish_crowded.ptr);
         HIP_TRY(hipGetLastError());
         if (pa.finish_long_ok)
         {
             hipLaunchKernelGGL(radix_finish_long_runs_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t*) s->finish_starts.ptr,
                                (const PassPlan*) pa.plan, usable_cus(s), (uint32_t*) s->long_image.ptr, (uint32_t*) s->long_hdr.ptr);
             HIP_TRY(hipGetLastError());
+        }
+        if (pa.fork_side) // the decision is made: the sequence that is expected not to run leaves the caller's queue here
+        {
+            HIP_TRY(hipEventRecord(s->ev_fork, stream));
+            HIP_TRY(hipStreamWaitEvent(s->side, s->ev_fork, 0));
         }
     }
     s->mark(stream, true);
@@ -1088,7 +1133,7 @@ glu_status launch_seg_finish_geo(const uint32_t* src_k, const uint32_t* src_v, u
     {
         hipLaunchKernelGGL(sort_kernel, dim3(nruns), dim3(THREADS), sizeof(Smem), stream, const_cast<uint32_t*>(src_k), const_cast<uint32_t*>(src_v),
                            dst_k, dst_v, starts, low_bits, (const PassPlan*) nullptr, 0u, geo, 0u, nruns, gate, gate_cap, rank_bits,
-                           (unsigned long long*) nullptr);
+                           (unsigned long long*) nullptr, (const uint32_t*) nullptr);
         HIP_TRY(hipGetLastError());
     }
     const uint64_t items = (((uint64_t) nruns + 7u) & ~7ull) << split_log2;
@@ -1119,33 +1164,52 @@ inline glu_status launch_seg_finish(const uint32_t* src_k, const uint32_t* src_v
     return fail(GLU_ERROR_INVALID_STATE, "no such tile geometry: %u", geo);
 }
 
+// The in-LDS pass of a whole-key sort (round 6): radix_finish_bucket_kernel for every enqueued tile geometry -- the one the sort is
+// expected to take gets a workgroup per run, the others 8192 workgroups that loop --, and behind them ONE launch of round 5's
+// ballot-ranked kernel in the largest enqueued tile for the runs the bucket kernel listed as crowded (or for all of them:
+// PassPlan::finish_rounds); it returns at once when the lists are empty.
 template<typename KeyT, bool VALS, bool XF>
 glu_status launch_finish(KeyT* keys_a, uint32_t* vals_a, KeyT* keys_b, uint32_t* vals_b, const uint32_t* starts,
                          uint32_t geo_first, uint32_t geo_last, uint32_t geo_expected, uint32_t low_bits, const PassPlan* plan,
-                         uint32_t pass, uint32_t key_xf, hipStream_t stream, uint32_t rank_bits, uint32_t nruns = kFinishRuns,
-                         const uint32_t* gate = nullptr, uint32_t gate_cap = 0)
+                         uint32_t pass, uint32_t key_xf, hipStream_t stream, uint32_t rank_bits, uint32_t* crowded)
 {
-    // the geometry the sort is expected to take gets a workgroup per run, the others 8192 workgroups that loop
+    constexpr uint32_t nruns = kFinishRuns;
 #define GLU_FINISH(GEO_, THREADS_, KPT_)                                                                                          \
     if (geo_first <= GEO_ && GEO_ <= geo_last)                                                                                    \
     {                                                                                                                             \
         static_assert(finish_geometry_capacity(GEO_) == THREADS_ * KPT_, "geometry table");                                       \
-        auto kern = GEO_ == geo_expected ? radix_finish_sort_kernel<KeyT, THREADS_, KPT_, VALS, false, XF>                        \
-                                         : radix_finish_sort_kernel<KeyT, THREADS_, KPT_, VALS, true, XF>;                        \
+        using Smem = BucketSmem<KeyT, THREADS_, KPT_, VALS>;                                                                      \
+        auto kern = GEO_ == geo_expected ? radix_finish_bucket_kernel<KeyT, THREADS_, KPT_, VALS, false, XF>                      \
+                                         : radix_finish_bucket_kernel<KeyT, THREADS_, KPT_, VALS, true, XF>;                      \
         static std::once_flag lds_opt_in;                                                                                         \
         static hipError_t lds_opt_in_result = hipSuccess;                                                                         \
         std::call_once(lds_opt_in, [&] {                                                                                          \
-            for (const void* k : {(const void*) radix_finish_sort_kernel<KeyT, THREADS_, KPT_, VALS, false, XF>,                  \
-                                  (const void*) radix_finish_sort_kernel<KeyT, THREADS_, KPT_, VALS, true, XF>})                  \
+            for (const void* k : {(const void*) radix_finish_bucket_kernel<KeyT, THREADS_, KPT_, VALS, false, XF>,                \
+                                  (const void*) radix_finish_bucket_kernel<KeyT, THREADS_, KPT_, VALS, true, XF>})                \
                 if (lds_opt_in_result == hipSuccess)                                                                              \
-                    lds_opt_in_result = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize,                        \
-                                                            (int) sizeof(FinishSmem<KeyT, THREADS_, KPT_, VALS>));                \
+                    lds_opt_in_result = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sizeof(Smem));   \
         });                                                                                                                       \
         HIP_TRY(lds_opt_in_result);                                                                                               \
-        hipLaunchKernelGGL(kern, dim3(GEO_ == geo_expected ? nruns : std::min(nruns, 8192u)), dim3(THREADS_),                     \
-                           sizeof(FinishSmem<KeyT, THREADS_, KPT_, VALS>), stream,                                                \
-                           keys_a, vals_a, keys_b, vals_b, starts, low_bits, plan, pass, (uint32_t) GEO_, key_xf, nruns, gate,     \
-                           gate_cap, rank_bits, (unsigned long long*) nullptr);                                                   \
+        hipLaunchKernelGGL(kern, dim3(GEO_ == geo_expected ? nruns : std::min(nruns, 8192u)), dim3(THREADS_), sizeof(Smem),       \
+                           stream, keys_a, vals_a, keys_b, vals_b, starts, low_bits, plan, pass, (uint32_t) GEO_, key_xf, nruns,  \
+                           crowded);                                                                                              \
+        HIP_TRY(hipGetLastError());                                                                                               \
+    }
+    // (geometry 0 = whichever tile the device chose; the runs longer than THAT tile are the segmented passes')
+#define GLU_FINISH_ROUNDS(GEO_, THREADS_, KPT_)                                                                                   \
+    if (geo_last == GEO_)                                                                                                         \
+    {                                                                                                                             \
+        using Smem = FinishSmem<KeyT, THREADS_, KPT_, VALS>;                                                                      \
+        auto kern = radix_finish_sort_kernel<KeyT, THREADS_, KPT_, VALS, true, XF>;                                               \
+        static std::once_flag lds_opt_in;                                                                                         \
+        static hipError_t lds_opt_in_result = hipSuccess;                                                                         \
+        std::call_once(lds_opt_in, [&] {                                                                                          \
+            lds_opt_in_result = hipFuncSetAttribute((const void*) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sizeof(Smem)); \
+        });                                                                                                                       \
+        HIP_TRY(lds_opt_in_result);                                                                                               \
+        hipLaunchKernelGGL(kern, dim3(8192), dim3(THREADS_), sizeof(Smem), stream, keys_a, vals_a, keys_b, vals_b, starts,        \
+                           low_bits, plan, pass, 0u, key_xf, nruns, (const uint32_t*) nullptr, 0u, rank_bits,                     \
+                           (unsigned long long*) nullptr, (const uint32_t*) crowded);                                             \
         HIP_TRY(hipGetLastError());                                                                                               \
     }
     GLU_FINISH(1, 256, 6)
@@ -1154,15 +1218,19 @@ glu_status launch_finish(KeyT* keys_a, uint32_t* vals_a, KeyT* keys_b, uint32_t*
     {
         GLU_FINISH(3, 256, 18)
         GLU_FINISH(4, 512, 18)
+        GLU_FINISH_ROUNDS(3, 256, 18)
+        GLU_FINISH_ROUNDS(4, 512, 18)
     }
     else
     {
-        // 8-byte keys: 12 bytes per slot leave two workgroups per CU (one for the largest tile) whatever their shape, and six
-        // ranking rounds make the pass compute-bound: twice the waves per workgroup (256 x 18: 3.8 ms for 2^28 pairs)
+        // 8-byte keys: twice the waves per workgroup (the word stage is 8 bytes per slot: two workgroups per CU)
         GLU_FINISH(3, 512, 9)
         GLU_FINISH(4, 1024, 9)
+        GLU_FINISH_ROUNDS(3, 512, 9)
+        GLU_FINISH_ROUNDS(4, 1024, 9)
     }
 #undef GLU_FINISH
+#undef GLU_FINISH_ROUNDS
     return GLU_OK;
 }
 
@@ -1389,6 +1457,8 @@ glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t cou
     }
     if (planned)
         for (uint32_t i = 0; i < (uint32_t) kPlanMaxPasses; i++) s->last_pair_roles[i] = i < num_passes ? (uint32_t) passes[i].pair_role : 0u;
+    // (see glu_radix_sort_s::side)
+    const bool fork = planned && finish_kpt && s->fork_behind && s->ensure_side();
     uint32_t pass = 0;
     for (; pass < num_passes; pass++)
     {
@@ -1421,11 +1491,15 @@ glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t cou
                 pa.finish_top_bit = finish_top_bit;
                 pa.finish_key_bits = end_bit;
                 pa.finish_long_ok = finish_long_ok;
+                pa.fork_side = fork;
             }
-            GLU_TRY(dispatch_pass<KeyT>(s, kbuf[0], vbuf[0], kbuf[1], vbuf[1], count, shift, bits, nullptr, stream, xform, pa));
+            pa.unitsum_side = fork && pass == 1 && pa.pair_role == 2 && bits == 8;
+            GLU_TRY(dispatch_pass<KeyT>(s, kbuf[0], vbuf[0], kbuf[1], vbuf[1], count, shift, bits, nullptr,
+                                        fork && pa.behind_attempt ? s->side : stream, xform, pa));
             {
                 if (finish_kpt && pass == 1)
                 {
+                    if (fork) HIP_TRY(hipEventRecord(s->ev_fork2, stream)); // (the data is where the in-LDS pass and the long-run passes find it)
                     // the in-LDS pass, in place on whichever pair of arrays holds the data now (returns at once if the
                     // device chose the ordinary passes, which follow)
                     s->cur_kind = 2;
@@ -1436,7 +1510,8 @@ glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t cou
 #define GLU_LAUNCH_FINISH(VALS_, XF_)                                                                                             \
     GLU_TRY((launch_finish<KeyT, VALS_, XF_>(kbuf[0], VALS_ ? vbuf[0] : nullptr, kbuf[1], VALS_ ? vbuf[1] : nullptr,              \
                                              (const uint32_t*) s->finish_starts.ptr, finish_kpt, finish_last, finish_expected,    \
-                                             finish_top_bit - 16u, pa.plan, 2u, key_xf, stream, s->finish_rank_bits)))
+                                             finish_top_bit - 16u, pa.plan, 2u, key_xf, stream, s->finish_rank_bits,              \
+                                             (uint32_t*) s->finish_crowded.ptr)))
                     if (vals)
                     {
                         if (key_xf != KEY_XF_NONE) GLU_LAUNCH_FINISH(true, true);
@@ -1450,7 +1525,7 @@ glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t cou
 #undef GLU_LAUNCH_FINISH
                     s->mark(stream, true);
                     if constexpr (sizeof(KeyT) == 4)
-                        if (finish_long_ok)
+                        if (finish_long_ok && !fork)
                             GLU_TRY(launch_long_run_passes(s, (uint32_t*) kbuf[0], vbuf[0], (uint32_t*) kbuf[1], vbuf[1], count, stream));
                 }
             }
@@ -1463,16 +1538,27 @@ glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t cou
         }
     }
     s->cur_behind = false;
+    if (fork)
+    {
+        // the side stream: (behind the ordinary passes) the segmented passes over long runs, beside the in-LDS pass; then it joins
+        HIP_TRY(hipStreamWaitEvent(s->side, s->ev_fork2, 0));
+        if constexpr (sizeof(KeyT) == 4)
+            if (finish_long_ok)
+                GLU_TRY(launch_long_run_passes(s, (uint32_t*) kbuf[0], vbuf[0], (uint32_t*) kbuf[1], vbuf[1], count, s->side));
+        HIP_TRY(hipEventRecord(s->ev_join, s->side));
+        HIP_TRY(hipStreamWaitEvent(stream, s->ev_join, 0));
+    }
     if (planned)
     {
         // the data is home unless an odd number of passes ran: decided and, if need be, copied on the device
         const dim3 grid((uint32_t) std::min<size_t>((count + 255) / 256, (size_t) g_dev.num_cus * 16));
         if (vals)
             hipLaunchKernelGGL((radix_finalize_kernel<KeyT, true>), grid, dim3(256), 0, stream, kbuf[0], vbuf[0], (const KeyT*) kbuf[1],
-                               (const uint32_t*) vbuf[1], (uint32_t) count, (const PassPlan*) s->plan.ptr, pass);
+                               (const uint32_t*) vbuf[1], (uint32_t) count, (const PassPlan*) s->plan.ptr, pass, finish_kpt ? 2u : 0u);
         else
             hipLaunchKernelGGL((radix_finalize_kernel<KeyT, false>), grid, dim3(256), 0, stream, kbuf[0], (uint32_t*) nullptr,
-                               (const KeyT*) kbuf[1], (const uint32_t*) nullptr, (uint32_t) count, (const PassPlan*) s->plan.ptr, pass);
+                               (const KeyT*) kbuf[1], (const uint32_t*) nullptr, (uint32_t) count, (const PassPlan*) s->plan.ptr, pass,
+                               finish_kpt ? 2u : 0u);
         HIP_TRY(hipGetLastError());
         return GLU_OK;
     }
@@ -1531,8 +1617,9 @@ glu_status tune_scratch_placement(glu_radix_sort_s* s, size_t count, size_t key_
     // 15.5 GiB).  GLU_HIP_SCRATCH_TUNE_LIST=step_mib:count[:first_mib] fixes the list (no early end).
     size_t step_mib = 512, candidates = 16, first_mib = 0;
     const auto t_begin = std::chrono::steady_clock::now();
-    const bool fixed_list = getenv("GLU_HIP_SCRATCH_TUNE_LIST") != nullptr;
-    if (const char* e = getenv("GLU_HIP_SCRATCH_TUNE_LIST")) sscanf(e, "%zu:%zu:%zu", &step_mib, &candidates, &first_mib);
+    const char* const tune_list = glu_env("GLU_HIP_SCRATCH_TUNE_LIST");
+    const bool fixed_list = tune_list != nullptr;
+    if (const char* e = tune_list) sscanf(e, "%zu:%zu:%zu", &step_mib, &candidates, &first_mib);
     std::vector<size_t> spacers_mib;
     for (size_t i = 0; i < std::max<size_t>(candidates, 1); i++) spacers_mib.push_back(first_mib + i * step_mib);
     // room for the caller-side copies, one candidate with its spacer and the best so far (twice over, to be safe)
@@ -1540,7 +1627,7 @@ glu_status tune_scratch_placement(glu_radix_sort_s* s, size_t count, size_t key_
     s->tuned_candidates = 0, s->tuned_ms = s->tuned_worst_ms = 0.0, s->tuned_spacer_mib = 0;
     if (free_b < need_b)
     {
-        if (getenv("GLU_VERBOSE"))
+        if (glu_verbose())
             fprintf(stderr, "[glu_hip] scratch placement skipped: %zu MiB free, the search wants %zu MiB; plain allocation\n", free_b >> 20,
                     need_b >> 20);
         return GLU_OK;
@@ -1632,7 +1719,7 @@ glu_status tune_scratch_placement(glu_radix_sort_s* s, size_t count, size_t key_
             return cleanup(status);
         }
         if (ms < 1e29) worst = std::max(worst, ms);
-        if (getenv("GLU_VERBOSE")) fprintf(stderr, "[glu_hip]   candidate: keys %p values %p (spacer %zu MiB): %.3f ms\n", k, v, spacer_mib, ms);
+        if (glu_verbose()) fprintf(stderr, "[glu_hip]   candidate: keys %p values %p (spacer %zu MiB): %.3f ms\n", k, v, spacer_mib, ms);
         if (ms < best.ms)
         {
             if (best.k) (void) hipFree(best.k);
@@ -1653,7 +1740,7 @@ glu_status tune_scratch_placement(glu_radix_sort_s* s, size_t count, size_t key_
     s->tuned_ms = best.k ? best.ms : 0.0;
     s->tuned_worst_ms = best.k ? worst : 0.0;
     s->tuned_candidates = best.k ? tried : 0u;
-    if (getenv("GLU_VERBOSE"))
+    if (glu_verbose())
         fprintf(stderr, "[glu_hip] scratch placement: value array behind a %u MiB spacer, calibration sort %.3f ms (slowest candidate %.3f ms)\n",
                 best.spacer, best.ms, worst);
     return cleanup(GLU_OK);
@@ -1683,7 +1770,7 @@ glu_status place_pair_by_measurement(glu_radix_sort_s* s, size_t count, Scratch&
     const size_t step_mib = 512, candidates = 16;
     if (free_b < 2 * (2 * bytes + ((candidates - 1) * step_mib << 20)) + ((size_t) 1 << 30))
     {
-        if (getenv("GLU_VERBOSE")) fprintf(stderr, "[glu_hip] pair placement skipped: %zu MiB free; plain allocation\n", free_b >> 20);
+        if (glu_verbose()) fprintf(stderr, "[glu_hip] pair placement skipped: %zu MiB free; plain allocation\n", free_b >> 20);
         return plain();
     }
     if (hipDeviceSynchronize() != hipSuccess) return fail(GLU_ERROR_DEVICE, "hipDeviceSynchronize failed before the pair placement");
@@ -1739,7 +1826,7 @@ glu_status place_pair_by_measurement(glu_radix_sort_s* s, size_t count, Scratch&
             }
         }
         (void) hipStreamSynchronize(st);
-        if (getenv("GLU_VERBOSE")) fprintf(stderr, "[glu_hip]   pair candidate: keys %p values %p (spacer %zu MiB): %.3f ms\n", k, v, i * step_mib, ms);
+        if (glu_verbose()) fprintf(stderr, "[glu_hip]   pair candidate: keys %p values %p (spacer %zu MiB): %.3f ms\n", k, v, i * step_mib, ms);
         if (ms < 1e29) worst = std::max(worst, ms);
         if (status == GLU_OK && ms < best.ms)
         {
@@ -1765,7 +1852,7 @@ glu_status place_pair_by_measurement(glu_radix_sort_s* s, size_t count, Scratch&
     {
         keys.ptr = best.k, keys.size = bytes;
         vals.ptr = best.v, vals.size = bytes;
-        if (getenv("GLU_VERBOSE"))
+        if (glu_verbose())
             fprintf(stderr, "[glu_hip] pair placement: %u candidates, calibration sort %.3f ms (slowest %.3f ms)\n", tried, best.ms, worst);
     }
     if (status != GLU_OK) return status;
@@ -2063,6 +2150,49 @@ glu_status seg_run_plan(glu_radix_sort_s* s, const SegPlan& plan, uint32_t* in_k
 }
 } // namespace
 
+// The switches of a sort object (tests, tuning, A/B runs): one table for glu_radix_sort_set_option and for the environment
+// defaults glu_radix_sort_create reads (GLU_HIP_<NAME>).  Every field is documented where glu_radix_sort_s declares it.
+namespace
+{
+struct SortOption
+{
+    const char* name;
+    void (*set)(glu_radix_sort_s*, long long);
+};
+#define GLU_OPT(NAME, ...) {NAME, [](glu_radix_sort_s* s, long long v) { (void) v; __VA_ARGS__; }}
+const SortOption kSortOptions[] = {
+    GLU_OPT("DIGIT_BITS", if (v == 4 || v == 8) s->digit_bits = (uint32_t) v),
+    GLU_OPT("SORT_BLOCKS", if (v > 0) s->max_blocks = (uint32_t) v),
+    GLU_OPT("SORT_SMALL", s->force_small = v != 0),
+    GLU_OPT("SORT_NO_SINGLE_BLOCK", s->no_single_block = v != 0),
+    GLU_OPT("SORT_NO_FUSED_SCAN", s->no_fused_scan = v != 0),
+    GLU_OPT("SORT_NO_PLAN", s->no_plan = v != 0),
+    GLU_OPT("SORT_NO_LINES", s->no_lines = v != 0),
+    GLU_OPT("SCRATCH_TUNE", s->tune_scratch = v != 0),
+    GLU_OPT("SORT_PAIRS", s->pairs = v != 0),
+    GLU_OPT("SORT_EQUAL_SHARES", s->equal_shares = v != 0),
+    GLU_OPT("SORT_NO_BIT_SHORTCUT", s->no_bit_shortcut = v != 0),
+    GLU_OPT("SORT_PAIR_MIN", s->pair_min = (size_t) v),
+    GLU_OPT("SORT_LDS_FINISH", s->lds_finish = v != 0),
+    GLU_OPT("SEG_LDS_FINISH", s->seg_finish = v != 0),
+    GLU_OPT("SORT_LONG_RUNS", s->long_runs = v != 0),
+    GLU_OPT("SORT_DEVICE_TOP", s->device_top = v != 0),
+    GLU_OPT("SORT_FORK", s->fork_behind = v != 0),
+    GLU_OPT("SEG_SPLIT_MAX", s->seg_split_max = (uint32_t) std::min<long long>(std::max<long long>(v, 0), 3)),
+    GLU_OPT("FINISH_RANK_BITS", if (v >= 8) s->finish_rank_bits = (uint32_t) v),
+    GLU_OPT("SEG_SPLIT_MIN", s->seg_split_min = (uint32_t) std::min<long long>(std::max<long long>(v, 0), 3)),
+    GLU_OPT("SEG_MAX_GEO", s->seg_max_geo = (uint32_t) std::min<long long>(std::max<long long>(v, 1), 5)),
+    GLU_OPT("SEG_SPLIT_GEO", s->seg_split_geo = (uint32_t) std::min<long long>(std::max<long long>(v, 1), 4)),
+    GLU_OPT("SORT_FINISH_MIN", s->finish_min = (size_t) v),
+    GLU_OPT("SORT_FINISH_BACKOFF", s->finish_backoff = (uint32_t) std::max<long long>(0, v)),
+    GLU_OPT("SORT_PAIR_UNIT_DIV", if (v >= 0) s->pair_unit_div = (uint32_t) v), // 0: no limit
+    GLU_OPT("SORT_NT_STORES", s->nt_stores = v != 0),
+    GLU_OPT("SORT_NT_MIN_BYTES", s->nt_min_bytes = (size_t) v),
+    GLU_OPT("SORT_LARGE_MIN", s->large_min = (size_t) v),
+};
+#undef GLU_OPT
+}
+
 extern "C" {
 
 glu_status glu_radix_sort_create(glu_radix_sort* out)
@@ -2070,46 +2200,14 @@ glu_status glu_radix_sort_create(glu_radix_sort* out)
     GLU_TRY(enter());
     if (!out) return fail(GLU_ERROR_INVALID_ARGUMENT, "out is NULL");
     glu_radix_sort_s* s = new glu_radix_sort_s();
-    if (const char* e = getenv("GLU_HIP_DIGIT_BITS"))
+    // the process environment as DEFAULTS for new objects (GLU_HIP_<OPTION>=value, read here, when an object is created);
+    // programs and tests set options on the object: glu_radix_sort_set_option
+    for (const SortOption& o : kSortOptions)
     {
-        int b = atoi(e);
-        if (b == 4 || b == 8) s->digit_bits = (uint32_t) b;
+        char name[96];
+        snprintf(name, sizeof(name), "GLU_HIP_%s", o.name);
+        if (const char* e = glu_env(name)) o.set(s, atoll(e));
     }
-    if (const char* e = getenv("GLU_HIP_SORT_BLOCKS"))
-    {
-        int b = atoi(e);
-        if (b > 0) s->max_blocks = (uint32_t) b;
-    }
-    if (const char* e = getenv("GLU_HIP_SORT_SMALL")) s->force_small = atoi(e) != 0;
-    if (const char* e = getenv("GLU_HIP_SORT_NO_SINGLE_BLOCK")) s->no_single_block = atoi(e) != 0;
-    if (const char* e = getenv("GLU_HIP_SORT_NO_FUSED_SCAN")) s->no_fused_scan = atoi(e) != 0;
-    if (const char* e = getenv("GLU_HIP_SORT_NO_PLAN")) s->no_plan = atoi(e) != 0;
-    if (const char* e = getenv("GLU_HIP_SORT_NO_LINES")) s->no_lines = atoi(e) != 0;
-    if (const char* e = getenv("GLU_HIP_SCRATCH_TUNE")) s->tune_scratch = atoi(e) != 0;
-    if (const char* e = getenv("GLU_HIP_SORT_PAIRS")) s->pairs = atoi(e) != 0;
-    if (const char* e = getenv("GLU_HIP_SORT_EQUAL_SHARES")) s->equal_shares = atoi(e) != 0;
-    if (const char* e = getenv("GLU_HIP_SORT_NO_BIT_SHORTCUT")) s->no_bit_shortcut = atoi(e) != 0;
-    if (const char* e = getenv("GLU_HIP_SORT_PAIR_MIN")) s->pair_min = (size_t) atoll(e);
-    if (const char* e = getenv("GLU_HIP_SORT_LDS_FINISH")) s->lds_finish = atoi(e) != 0;
-    if (const char* e = getenv("GLU_HIP_SEG_LDS_FINISH")) s->seg_finish = atoi(e) != 0;
-    if (const char* e = getenv("GLU_HIP_SORT_LONG_RUNS")) s->long_runs = atoi(e) != 0;
-    if (const char* e = getenv("GLU_HIP_SORT_DEVICE_TOP")) s->device_top = atoi(e) != 0;
-    if (const char* e = getenv("GLU_HIP_SEG_SPLIT_MAX")) s->seg_split_max = (uint32_t) std::min(std::max(atoi(e), 0), 3);
-    if (const char* e = getenv("GLU_HIP_FINISH_RANK_BITS"))
-        if (atoi(e) >= 8) s->finish_rank_bits = (uint32_t) atoi(e);
-    if (const char* e = getenv("GLU_HIP_SEG_SPLIT_MIN")) s->seg_split_min = (uint32_t) std::min(std::max(atoi(e), 0), 3);
-    if (const char* e = getenv("GLU_HIP_SEG_MAX_GEO")) s->seg_max_geo = (uint32_t) std::min(std::max(atoi(e), 1), 5);
-    if (const char* e = getenv("GLU_HIP_SEG_SPLIT_GEO")) s->seg_split_geo = (uint32_t) std::min(std::max(atoi(e), 1), 4);
-    if (const char* e = getenv("GLU_HIP_SORT_FINISH_MIN")) s->finish_min = (size_t) atoll(e);
-    if (const char* e = getenv("GLU_HIP_SORT_FINISH_BACKOFF")) s->finish_backoff = (uint32_t) std::max(0, atoi(e));
-    if (const char* e = getenv("GLU_HIP_SORT_PAIR_UNIT_DIV"))
-    {
-        int v = atoi(e); // 0: no limit
-        if (v >= 0) s->pair_unit_div = (uint32_t) v;
-    }
-    if (const char* e = getenv("GLU_HIP_SORT_NT_STORES")) s->nt_stores = atoi(e) != 0;
-    if (const char* e = getenv("GLU_HIP_SORT_NT_MIN_BYTES")) s->nt_min_bytes = (size_t) atoll(e);
-    if (const char* e = getenv("GLU_HIP_SORT_LARGE_MIN")) s->large_min = (size_t) atoll(e);
     *out = s;
     return GLU_OK;
 }
@@ -2122,9 +2220,12 @@ glu_status glu_radix_sort_destroy(glu_radix_sort sort)
     // library queue, before its scratch goes away (RAII of the reference: RadixSort.hpp:194-200, gl_utils.hpp:184-188)
     (void) hipDeviceSynchronize();
     for (Scratch* sc : {&sort->keys, &sort->vals, &sort->table, &sort->plan, &sort->pair_t2, &sort->pair_table, &sort->pair_ranges,
-                        &sort->pair_sub, &sort->seg_desc, &sort->seg_zero, &sort->finish_lengths, &sort->finish_starts, &sort->seg_gate, &sort->long_image, &sort->long_hdr})
+                        &sort->pair_sub, &sort->seg_desc, &sort->seg_zero, &sort->finish_lengths, &sort->finish_starts, &sort->finish_crowded, &sort->seg_gate, &sort->long_image, &sort->long_hdr})
         sc->release();
     if (sort->finish_hint) (void) hipHostFree(sort->finish_hint);
+    for (hipEvent_t e : {sort->ev_fork, sort->ev_unit, sort->ev_fork2, sort->ev_join})
+        if (e) (void) hipEventDestroy(e);
+    if (sort->side) (void) hipStreamDestroy(sort->side);
     for (hipEvent_t e : sort->events) (void) hipEventDestroy(e);
     for (glu_radix_sort_s::SegStage& st : sort->seg_stage)
     {
@@ -2394,6 +2495,20 @@ glu_status glu_radix_sort_set_digit_bits(glu_radix_sort sort, uint32_t bits)
     if (bits != 4 && bits != 8) return fail(GLU_ERROR_INVALID_ARGUMENT, "digit bits must be 4 or 8 (got %u)", bits);
     sort->digit_bits = bits;
     return GLU_OK;
+}
+
+glu_status glu_radix_sort_set_option(glu_radix_sort sort, const char* name, long long value)
+{
+    GLU_TRY(enter());
+    if (!sort || !name) return fail(GLU_ERROR_INVALID_ARGUMENT, "sort / name is NULL");
+    if (strncasecmp(name, "GLU_HIP_", 8) == 0) name += 8; // (the environment's spelling is accepted)
+    for (const SortOption& o : kSortOptions)
+        if (strcasecmp(name, o.name) == 0)
+        {
+            o.set(sort, value);
+            return GLU_OK;
+        }
+    return fail(GLU_ERROR_INVALID_ARGUMENT, "no such option: %s", name);
 }
 
 glu_status glu_radix_sort_get_digit_bits(glu_radix_sort sort, uint32_t* bits)
@@ -2816,7 +2931,7 @@ glu_status reduce_launch(glu_reduce_s* r, Elem<S, N>* data, size_t count, hipStr
     const size_t vec = (aligned && sizeof(T) < 16) ? 16 / sizeof(T) : 1;
     const size_t packs = count / vec;
     static const size_t max_blocks = [] {
-        const char* e = getenv("GLU_HIP_REDUCE_BLOCKS"); // tuning override
+        const char* e = glu_env("GLU_HIP_REDUCE_BLOCKS"); // tuning override
         const long v = e ? atol(e) : 0;
         return (size_t) (v > 0 && v <= kReduceMaxBlocks ? v : kReduceDefaultBlocks);
     }();
@@ -2869,7 +2984,7 @@ glu_status glu_scan_create(glu_data_type data_type, glu_scan* out)
         return fail(GLU_ERROR_INVALID_ARGUMENT, "Invalid data type: %d", (int) data_type);
     glu_scan_s* s = new glu_scan_s();
     s->type = data_type;
-    if (const char* e = getenv("GLU_HIP_SCAN_CHAINED"))
+    if (const char* e = glu_env("GLU_HIP_SCAN_CHAINED"))
     {
         s->chained = atoi(e) != 0;
         if (atoi(e) == 2) s->chain_min_chunks = 2;

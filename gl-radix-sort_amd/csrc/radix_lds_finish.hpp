@@ -36,6 +36,25 @@ namespace glu_hip
 {
 constexpr uint32_t kFinishRuns = 65536; // runs = values of the 16 top-bit key bits
 
+// The runs that radix_finish_bucket_kernel (radix_lds_bucket.hpp, round 6) found crowded, for radix_finish_sort_kernel behind it:
+// kCrowdedLists lists by the run number's low bits -- 65536 workgroups appending to ONE list are 65536 atomics on one address,
+// 0.6 ms when every run is crowded -- each with its counter in a 128-byte line of its own:
+//   words [k * kCrowdedCountStride]                                            how many runs list k holds
+//   words [kCrowdedLists * kCrowdedCountStride + k * capacity + i]              the i-th of them
+// The counters are zeroed by radix_finish_plan_kernel.
+constexpr uint32_t kCrowdedLists = 256, kCrowdedCountStride = 32;
+__host__ __device__ constexpr uint32_t crowded_list_capacity(uint32_t nruns) { return (nruns + kCrowdedLists - 1u) / kCrowdedLists; }
+__host__ __device__ constexpr size_t crowded_list_words(uint32_t nruns)
+{
+    return (size_t) kCrowdedLists * kCrowdedCountStride + (size_t) kCrowdedLists * crowded_list_capacity(nruns);
+}
+__device__ __forceinline__ void crowded_list_append(uint32_t* lists, uint32_t nruns, uint32_t run)
+{
+    const uint32_t k = run & (kCrowdedLists - 1u);
+    const uint32_t i = atomicAdd(&lists[k * kCrowdedCountStride], 1u);
+    lists[kCrowdedLists * kCrowdedCountStride + k * crowded_list_capacity(nruns) + i] = run;
+}
+
 // lengths[e * 256 + d] = #keys with first top-bit digit d and second top-bit digit e: T2 rows (d, b) summed over the leader's nb
 // blocks.  One workgroup per d; thread (g, q) adds word q (counters e = 2q, 2q + 1) of the rows b = g, g + 8, ...
 __global__ __launch_bounds__(1024) void radix_finish_lengths_kernel(const uint32_t* __restrict__ t2, uint32_t nb,
@@ -199,7 +218,7 @@ __global__ __launch_bounds__(1024) void radix_finish_plan_kernel(const uint32_t*
                                                                  uint32_t pass,
                                                                  uint32_t first_ordinary, uint32_t num_ordinary,
                                                                  uint32_t* hint, uint32_t attempt, uint32_t top_bit,
-                                                                 uint32_t key_bits, uint32_t long_ok)
+                                                                 uint32_t key_bits, uint32_t long_ok, uint32_t* crowded_lists = nullptr)
 {
     __shared__ uint32_t tmp[3][16];
     __shared__ uint32_t over_tmp[2][kFinishGeometries][16];
@@ -295,10 +314,19 @@ __global__ __launch_bounds__(1024) void radix_finish_plan_kernel(const uint32_t*
     // (the run starts are written whatever the decision: nobody reads them unless plan->finish says so)
     starts[b * 1024u + tid] = before + excl;
     if (b == 0 && tid == 0) starts[kFinishRuns] = n;
+    if (b == 0 && crowded_lists && tid < kCrowdedLists) crowded_lists[tid * kCrowdedCountStride] = 0u;
     if (b == 0 && tid == 0)
     {
         plan->finish = accept ? geo : 0u;
         plan->finish_longest = tables ? longest : 0xFFFFFFFFu;
+        // which kernel orders the runs: with fewer than nine bits left to order -- or varying, where that is known -- one ballot
+        // round beats the bucket round (whose buckets such keys crowd)
+        {
+            const uint32_t low_bits = top_bit - 16u;
+            const uint64_t low_mask = low_bits >= 64u ? ~0ull : (1ull << low_bits) - 1ull;
+            const uint32_t to_order = plan->bits_valid ? (uint32_t) __popcll(varying & low_mask) : low_bits;
+            plan->finish_rounds = to_order < 9u ? 1u : 0u;
+        }
         // for the host, which reads it without synchronising: the outcome of attempt number `attempt` (pinned host memory)
         // (attempt << 3 | the geometry chosen, 0 = refused; and which key bits vary, for the next sort's choice of top_bit:
         // words 1, 2, valid for attempt number word 3)
@@ -317,6 +345,8 @@ __global__ __launch_bounds__(1024) void radix_finish_plan_kernel(const uint32_t*
         {
             plan->skip[pass] = kSkipWithoutCounting;
             plan->off[pass + 1] = 1;
+            // (the ordinary passes may start on a stream of their own before the two top-bit scatters have said so)
+            plan->flip[pass + 1] = plan->flip[pass + 2] = pass > 0 ? plan->flip[pass] : 0u;
         }
     }
     if (b == 0 && accept && tid < num_ordinary) plan->off[first_ordinary + tid] = 1;
@@ -841,7 +871,8 @@ __global__ __launch_bounds__(THREADS, (sizeof(KeyT) == 8 && THREADS == 512 ? GLU
                                                                     uint32_t geometry, uint32_t key_xf = 0,
                                                                     uint32_t nruns = kFinishRuns, const uint32_t* gate = nullptr,
                                                                     uint32_t gate_cap = 0, uint32_t rank_bits = 16,
-                                                                    unsigned long long* stamps = nullptr)
+                                                                    unsigned long long* stamps = nullptr,
+                                                                    const uint32_t* __restrict__ run_list = nullptr)
 {
     FinishClock<STAMPS> clock;
     if (plan && plan->top_bit) low_bits = plan->top_bit - 16u; // (the device chose the runs' bits: radix_sample_top_kernel)
@@ -849,7 +880,8 @@ __global__ __launch_bounds__(THREADS, (sizeof(KeyT) == 8 && THREADS == 512 ? GLU
     const uint32_t rank_from = low_bits > rank_bits ? ((low_bits - rank_bits) / 8u) * 8u : 0u;
     const KeyCodec<KeyT, XF> codec_out(key_xf);
     // (kernel-uniform: the device chose another geometry, or the ordinary passes)
-    if (plan ? plan->finish != geometry : *gate > gate_cap) return;
+    // (geometry 0: whichever tile the device chose -- the launch behind radix_finish_bucket_kernel that takes the runs it flagged)
+    if (plan ? (geometry ? plan->finish != geometry : plan->finish == 0u) : *gate > gate_cap) return;
     using Smem = FinishSmem<KeyT, THREADS, KPT, VALS>;
     constexpr int WAVES = Smem::WAVES;
 
@@ -860,13 +892,25 @@ __global__ __launch_bounds__(THREADS, (sizeof(KeyT) == 8 && THREADS == 512 ? GLU
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Smem& s = *reinterpret_cast<Smem*>(smem_raw);
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (uint32_t run = blockIdx.x; run < nruns; run += LOOP ? gridDim.x : nruns)
+    // (round 6: the whole-key sort's in-LDS pass is radix_finish_bucket_kernel, radix_lds_bucket.hpp; this kernel is launched
+    // behind it for the runs that one found crowded and listed: run_list = the crowded lists above)
+    // (or for every run, PassPlan::finish_rounds.  Workgroup i works off list i % kCrowdedLists: the grid is a multiple of that.)
+    const bool listed = run_list && !plan->finish_rounds;
+    if (run_list && !listed && !LOOP) return; // (the launch for all runs is the looping one)
+    const uint32_t list = blockIdx.x & (kCrowdedLists - 1u);
+    const uint32_t todo = listed ? run_list[list * kCrowdedCountStride] : nruns;
+    const uint32_t step = !LOOP ? todo : listed ? max(gridDim.x / kCrowdedLists, 1u) : gridDim.x;
+    const uint32_t* const my_list = run_list + kCrowdedLists * kCrowdedCountStride + list * crowded_list_capacity(nruns);
+    for (uint32_t it = listed ? blockIdx.x / kCrowdedLists : blockIdx.x; it < todo; it += step)
     {
+    const uint32_t run = listed ? my_list[it] : it;
     const uint32_t begin = starts[run], end = starts[run + 1];
     const uint32_t len = end - begin;
     if (len == 0 || (plan && !XF && len == 1)) continue; // (workgroup-uniform; a single typed key still has to be decoded)
     // (a run longer than the tile: radix_finish_ranges_kernel's in a segmented sort, the segmented passes' in a whole-key sort)
     if (len > (uint32_t) Smem::TILE) continue;
+    // (launched for whichever tile the device chose: the runs longer than THAT tile are the segmented passes' too)
+    if (plan && geometry == 0u && len > finish_geometry_capacity(plan->finish)) continue;
     // (64-bit keys: the key bits from 48 up, the same for every pair of the run -- and of a pad that comes back from the stage)
     const KeyT run_top = sizeof(KeyT) == 8 ? (KeyT) (keys[begin] & (KeyT) 0xFFFF000000000000ull) : (KeyT) 0;
     const uint32_t share = ((len + WAVES * kWave - 1) / (WAVES * kWave)) * kWave; // slots per wave: <= kWave * KPT

@@ -167,6 +167,9 @@ struct alignas(64) PassPlan
     // (~0: never counted).  Zeroed with pair_fallback, set by radix_finish_plan_kernel.
     uint32_t off[kPlanMaxPasses];
     uint32_t finish, finish_longest;
+    // (round 6) finish_rounds = 1: every run of the in-LDS pass is ordered by ballot rounds (radix_finish_sort_kernel) -- fewer than
+    // nine key bits are left to order or vary there, which one round does faster than radix_finish_bucket_kernel's buckets fill
+    uint32_t finish_rounds;
     // Which key bits vary over the input: collected by the count kernel of the first pass of an untyped sort (the OR of
     // all keys and the OR of all complemented keys, low / high word).  A later pass whose digit lies in bits that do not
     // vary is an identity: its count kernel says so (skip[p] = 1) without reading the keys.  Zeroed with pair_fallback.
@@ -1342,9 +1345,11 @@ template<typename KeyT, bool VALS>
 __global__ __launch_bounds__(256) void radix_finalize_kernel(KeyT* __restrict__ keys_a, uint32_t* __restrict__ vals_a,
                                                              const KeyT* __restrict__ keys_b,
                                                              const uint32_t* __restrict__ vals_b, uint32_t n,
-                                                             const PassPlan* plan, uint32_t passes)
+                                                             const PassPlan* plan, uint32_t passes, uint32_t attempt_passes = 0)
 {
-    if (!plan->flip[passes]) return;
+    // (a sort that ended in LDS: where its `attempt_passes` top-bit passes left the data -- the in-LDS pass works in place, and
+    // the ordinary passes behind them, which return at once on a stream of their own, have not kept flip[] in order)
+    if (!plan->flip[attempt_passes && plan->finish ? attempt_passes : passes]) return;
     const size_t stride = (size_t) gridDim.x * blockDim.x;
     for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
     {

@@ -64,6 +64,7 @@ SYMBOLS = [
     ("glu_radix_sort_run_segments_ptr", _int, [_vp, _vp, _vp, _vp, _vp, _sz, _P(_u64), _P(_u64), _P(_u32), _sz, _u32, _u32, _vp]),
     ("glu_radix_sort_plan_segments", _int, [_P(_u64), _P(_u64), _P(_u32), _sz, _u32, _u32, _P(_u32), _sz, _P(_u32), _P(_u32), _P(_u64), _P(_sz)]),
     ("glu_radix_sort_set_digit_bits", _int, [_vp, _u32]),
+    ("glu_radix_sort_set_option", _int, [_vp, ctypes.c_char_p, ctypes.c_longlong]),
     ("glu_radix_sort_get_digit_bits", _int, [_vp, _P(_u32)]),
     ("glu_radix_sort_scratch_size", _int, [_vp, _P(_sz)]),
     ("glu_radix_sort_scratch_placement", _int, [_vp, _P(_u32), _P(ctypes.c_double), _P(ctypes.c_double)]),
@@ -250,11 +251,18 @@ def plan_finish(count, key_bytes=4):
 class RadixSort:
     """glu::RadixSort (reference glu/RadixSort.hpp:186-354) over the C ABI."""
 
-    def __init__(self, digit_bits=None):
+    def __init__(self, digit_bits=None, options=None):
+        """options: {name: integer} switches for tests / tuning (glu_radix_sort_set_option; names as in the environment, with or
+        without the GLU_HIP_ prefix) -- set on THIS object, the process environment is not touched."""
         self._h = _vp()
         check(lib().glu_radix_sort_create(ctypes.byref(self._h)))
         if digit_bits is not None:
             check(lib().glu_radix_sort_set_digit_bits(self._h, digit_bits))
+        for name, value in (options or {}).items():
+            self.set_option(name, value)
+
+    def set_option(self, name, value):
+        check(lib().glu_radix_sort_set_option(self._h, str(name).encode(), int(value)))
 
     def set_digit_bits(self, bits):
         check(lib().glu_radix_sort_set_digit_bits(self._h, bits))

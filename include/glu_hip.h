@@ -235,6 +235,12 @@ GLU_API glu_status glu_radix_sort_plan_segments(const uint64_t* piece_begin, con
  * for 32-bit keys) or 8 (4 passes).  The sorted result is identical; see DESIGN.md. */
 GLU_API glu_status glu_radix_sort_set_digit_bits(glu_radix_sort sort, uint32_t bits);
 GLU_API glu_status glu_radix_sort_get_digit_bits(glu_radix_sort sort, uint32_t* bits);
+/* Switches of a sort object for tests, tuning and A/B runs (nothing the reference has: its only knob is num_steps,
+ * RadixSort.hpp:273): `name` is one of the options listed in gl-radix-sort_amd/csrc/glu_hip.hip (kSortOptions: SORT_LDS_FINISH,
+ * SORT_FINISH_MIN, SORT_PAIR_MIN, SORT_FORK, SORT_NO_LINES, ...), case-insensitive, with or without the prefix GLU_HIP_.  Takes effect from the
+ * object's next prepare / sort.  The process environment (GLU_HIP_<NAME>=value) supplies DEFAULTS, read when an object is
+ * created; a program never needs to touch it.  GLU_ERROR_INVALID_ARGUMENT for an unknown name. */
+GLU_API glu_status glu_radix_sort_set_option(glu_radix_sort sort, const char* name, long long value);
 /* Where the two large scratch arrays lie to each other decides between discrete speeds of every pass on this memory system,
  * so glu_radix_sort_prepare* places key + value scratch of 512 MiB of keys or more BY MEASUREMENT: the value array is
  * allocated behind spacers of 0, 0.5 .. 7.5 GiB (8 to 16 candidates; the search ends when one of them is 7 % faster

@@ -21,18 +21,9 @@ def G(built):
     return built
 
 
-def _sorter(G, **env):
-    """A sort object created under the given GLU_HIP_* switches (they are read by glu_radix_sort_create)."""
-    old = {k: os.environ.get(k) for k in env}
-    os.environ.update({k: str(v) for k, v in env.items()})
-    try:
-        return G.RadixSort()
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+def _sorter(G, **options):
+    """A sort object with the given switches set on it (glu_radix_sort_set_option; the process environment stays as it is)."""
+    return G.RadixSort(options=options)
 
 
 # small sizes: pair the passes and make the attempt from the smallest planned sort up (defaults: 2^26 elements)

@@ -1100,20 +1100,9 @@ def test_planned_sort_inside_a_captured_graph(G):
 # the data sends it back to its own count kernel.  glu_radix_sort_read_plan says what happened.
 
 def _sort_and_plan(G, keys, vals, passes, key_bytes=4, env=None, run=None, bits=8):
-    old = {}
     env = dict(env or {})
     env.setdefault("GLU_HIP_SORT_PAIR_MIN", "1")  # pair from the smallest planned sort up (default: from 2^28 bytes of keys)
-    for k, v in env.items():
-        old[k] = os.environ.get(k)
-        os.environ[k] = v
-    try:
-        sorter = G.RadixSort(digit_bits=bits)  # reads the environment switches
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+    sorter = G.RadixSort(digit_bits=bits, options=env)  # (switches set on the object: glu_radix_sort_set_option)
     kb = G.ShaderStorageBuffer(keys)
     vb = G.ShaderStorageBuffer(vals) if vals is not None else None
     if run is not None:
