@@ -554,6 +554,7 @@ struct glu_radix_sort_s
     uint32_t* finish_hint = nullptr;
     uint32_t finish_seq = 0, finish_seq_acted_on = 0, finish_wait = 0;
     uint32_t finish_last_geo = 0; // the tile geometry the device chose for the last sort whose outcome is known (0: none yet)
+    bool finish_last_refused = false; // the last attempt whose outcome is known was refused (see `side`)
     // The runs of a sort that ends in LDS are the values of the 16 key bits below `top`: the whole key's top 16 by default,
     // the top 16 of the bits that VARIED in this object's last attempt once that is known (keys below 2^28 make 4096 runs of the
     // whole key's top bits and 65536 of bits [12, 28)).  A guess: the plan kernel refuses if a bit from `top` up varies after all.
@@ -590,13 +591,18 @@ struct glu_radix_sort_s
     // end in LDS, 2 = its in-LDS pass (glu_radix_sort_read_profile books them by which of the two sequences ran); 3 = the
     // counting pass of a SEGMENTED sort that tries to end in LDS, 4 = an ordinary segmented pass enqueued behind such an attempt
     std::vector<uint8_t> pass_kinds;
+    // (round 6) which attempt a pass belongs to (finish_seq; 0: none): glu_radix_sort_read_profile books every sort of a window by
+    // ITS outcome -- the plan kernel notes them in a ring of 256 (finish_outcomes) -- not by the last sort's
+    std::vector<uint32_t> pass_seqs;
+    uint32_t cur_seq = 0;
+    Scratch finish_outcomes;
     uint8_t cur_kind = 0;
     bool cur_behind = false; // the pass being enqueued belongs to the sequence that is expected NOT to run
     // around_data_kernel: this mark is one of the two around the scatter kernel / the in-LDS pass
     void mark(hipStream_t stream, bool around_data_kernel = false)
     {
         if (!profiling) return;
-        if (slots.size() % 4 == 0) pass_kinds.push_back(cur_kind);
+        if (slots.size() % 4 == 0) pass_kinds.push_back(cur_kind), pass_seqs.push_back(cur_seq);
         hipEvent_t e = nullptr;
         if (profiling == 1 || (around_data_kernel && !cur_behind))
             if ((e = next_event()) != nullptr) (void) hipEventRecord(e, stream);
@@ -669,9 +675,9 @@ glu_status sort_prepare(glu_radix_sort_s* s, size_t count, size_t key_size, bool
             GLU_TRY(s->finish_lengths.reserve((size_t) kFinishRuns * sizeof(uint32_t)));
             GLU_TRY(s->finish_starts.reserve(((size_t) kFinishRuns + 1) * sizeof(uint32_t)));
             GLU_TRY(s->finish_crowded.reserve(crowded_list_words(kFinishRuns) * sizeof(uint32_t)));
-            if (key_size == 4 && with_vals)
+            GLU_TRY(s->finish_outcomes.reserve(256 * sizeof(uint32_t)));
             {
-                // runs longer than the in-LDS pass's tile are sorted by two segmented passes (radix_finish_long_runs_kernel)
+                // runs longer than the in-LDS pass's tile are sorted by segmented passes (radix_finish_long_runs_kernel)
                 GLU_TRY(s->long_image.reserve((size_t) LongRunsLayout((uint32_t) g_dev.num_cus).words * sizeof(uint32_t)));
                 GLU_TRY(s->long_hdr.reserve(64));
                 GLU_TRY(s->table.reserve(((size_t) kLongRunsMax + g_dev.num_cus) * 256 * sizeof(uint32_t)));
@@ -930,12 +936,13 @@ glu_status launch_pass_lines(glu_radix_sort_s* s, const KeyT* src_k, const uint3
         hipLaunchKernelGGL(radix_finish_lengths_kernel, dim3(kPairRadix), dim3(1024), 0, stream, (const uint32_t*) s->pair_t2.ptr, nb,
                            (uint32_t*) s->finish_lengths.ptr, (const PassPlan*) pa.plan, pa.pass);
         HIP_TRY(hipGetLastError());
+        const bool long_runs = pa.finish_long_ok && s->long_image.ptr;
         hipLaunchKernelGGL(radix_finish_plan_kernel, dim3(kFinishPlanBlocks), dim3(1024), 0, stream, (const uint32_t*) s->finish_lengths.ptr,
                            (uint32_t*) s->finish_starts.ptr, (uint32_t) count, pa.finish_geo_first, pa.finish_geo_last, pa.plan, pa.pass,
                            pa.finish_first_ordinary, pa.finish_num_ordinary, s->finish_hint, pa.finish_seq, pa.finish_top_bit,
-                           pa.finish_key_bits, pa.finish_long_ok ? 1u : 0u, (uint32_t*) s->finish_crowded.ptr);
+                           pa.finish_key_bits, long_runs ? 1u : 0u, (uint32_t*) s->finish_crowded.ptr, (uint32_t*) s->finish_outcomes.ptr);
         HIP_TRY(hipGetLastError());
-        if (pa.finish_long_ok)
+        if (long_runs)
         {
             hipLaunchKernelGGL(radix_finish_long_runs_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t*) s->finish_starts.ptr,
                                (const PassPlan*) pa.plan, usable_cus(s), (uint32_t*) s->long_image.ptr, (uint32_t*) s->long_hdr.ptr);
@@ -1174,8 +1181,10 @@ glu_status launch_finish(KeyT* keys_a, uint32_t* vals_a, KeyT* keys_b, uint32_t*
                          uint32_t pass, uint32_t key_xf, hipStream_t stream, uint32_t rank_bits, uint32_t* crowded)
 {
     constexpr uint32_t nruns = kFinishRuns;
+    // (order: the geometries that are not expected first -- they return at once in front of the long kernel instead of waiting
+    // behind it for room on the CUs; what follows the expected one is the launch that takes its crowded runs)
 #define GLU_FINISH(GEO_, THREADS_, KPT_)                                                                                          \
-    if (geo_first <= GEO_ && GEO_ <= geo_last)                                                                                    \
+    if (geo_first <= GEO_ && GEO_ <= geo_last && (GEO_ == geo_expected) == expected_turn)                                         \
     {                                                                                                                             \
         static_assert(finish_geometry_capacity(GEO_) == THREADS_ * KPT_, "geometry table");                                       \
         using Smem = BucketSmem<KeyT, THREADS_, KPT_, VALS>;                                                                      \
@@ -1207,25 +1216,35 @@ glu_status launch_finish(KeyT* keys_a, uint32_t* vals_a, KeyT* keys_b, uint32_t*
             lds_opt_in_result = hipFuncSetAttribute((const void*) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sizeof(Smem)); \
         });                                                                                                                       \
         HIP_TRY(lds_opt_in_result);                                                                                               \
-        hipLaunchKernelGGL(kern, dim3(8192), dim3(THREADS_), sizeof(Smem), stream, keys_a, vals_a, keys_b, vals_b, starts,        \
+        hipLaunchKernelGGL(kern, dim3(2048), dim3(THREADS_), sizeof(Smem), stream, keys_a, vals_a, keys_b, vals_b, starts,        \
                            low_bits, plan, pass, 0u, key_xf, nruns, (const uint32_t*) nullptr, 0u, rank_bits,                     \
                            (unsigned long long*) nullptr, (const uint32_t*) crowded);                                             \
         HIP_TRY(hipGetLastError());                                                                                               \
     }
-    GLU_FINISH(1, 256, 6)
-    GLU_FINISH(2, 256, 10)
+    for (int turn = 0; turn < 2; turn++)
+    {
+        const bool expected_turn = turn == 1;
+        GLU_FINISH(1, 256, 6)
+        GLU_FINISH(2, 256, 10)
+        if constexpr (sizeof(KeyT) == 4)
+        {
+            GLU_FINISH(3, 256, 18)
+            GLU_FINISH(4, 512, 18)
+        }
+        else
+        {
+            // 8-byte keys: twice the waves per workgroup (the word stage is 8 bytes per slot: two workgroups per CU)
+            GLU_FINISH(3, 512, 9)
+            GLU_FINISH(4, 1024, 9)
+        }
+    }
     if constexpr (sizeof(KeyT) == 4)
     {
-        GLU_FINISH(3, 256, 18)
-        GLU_FINISH(4, 512, 18)
         GLU_FINISH_ROUNDS(3, 256, 18)
         GLU_FINISH_ROUNDS(4, 512, 18)
     }
     else
     {
-        // 8-byte keys: twice the waves per workgroup (the word stage is 8 bytes per slot: two workgroups per CU)
-        GLU_FINISH(3, 512, 9)
-        GLU_FINISH(4, 1024, 9)
         GLU_FINISH_ROUNDS(3, 512, 9)
         GLU_FINISH_ROUNDS(4, 1024, 9)
     }
@@ -1234,16 +1253,21 @@ glu_status launch_finish(KeyT* keys_a, uint32_t* vals_a, KeyT* keys_b, uint32_t*
     return GLU_OK;
 }
 
-// The two segmented passes over the LONG runs of a whole-key sort that ends in LDS (radix_finish_long_runs_kernel built their
+// The segmented passes over the LONG runs of a whole-key sort that ends in LDS (radix_finish_long_runs_kernel built their
 // descriptors; hdr[0] = 0: there are none, or the sort was refused -- every kernel returns at once): key bits [0, 8) from the
-// arrays that hold the data (PassPlan::flip[2], known on the device) into the other pair, bits [8, 16) back.
-glu_status launch_long_run_passes(glu_radix_sort_s* s, uint32_t* a_k, uint32_t* a_v, uint32_t* b_k, uint32_t* b_v, size_t count, hipStream_t stream)
+// arrays that hold the data (PassPlan::flip[2], known on the device) into the other pair, bits [8, 16) back -- 4-byte keys.
+// Round 6: 8-byte keys (six passes: up to 48 bits are left below the runs' bits), keys-only sorts, typed keys (the last pass
+// decodes on store what the first top-bit pass encoded on load: the in-LDS pass, which does that for the other runs, leaves these alone).
+template<typename KeyT, bool VALS, bool XF>
+glu_status launch_long_run_passes(glu_radix_sort_s* s, KeyT* a_k, uint32_t* a_v, KeyT* b_k, uint32_t* b_v, size_t count, uint32_t key_xf,
+                                  hipStream_t stream)
 {
-    using G = SegLinesGeometry;
+    using G = typename std::conditional<sizeof(KeyT) == 4 && VALS, SegLinesGeometry, LinesGeometry<KeyT, 8, VALS>>::type;
     constexpr int RADIX = 256;
     constexpr int RS = (G::KPT + 2) / 3;
-    using Smem = LineSmem<uint32_t, 8, G::THREADS, G::KPT, true>;
-    auto scatter = radix_scatter_lines_kernel<uint32_t, 8, G::THREADS, G::KPT, false, true, 0, false, RS, true, true, 0, true>;
+    constexpr uint32_t kPasses = sizeof(KeyT) == 4 ? 2u : 6u; // (an even number: the runs come home)
+    using Smem = LineSmem<KeyT, 8, G::THREADS, G::KPT, VALS>;
+    auto scatter = radix_scatter_lines_kernel<KeyT, 8, G::THREADS, G::KPT, XF, VALS, 0, false, RS, true, true, 0, true>;
     static std::once_flag lds_opt_in;
     static hipError_t lds_opt_in_result = hipSuccess;
     std::call_once(lds_opt_in, [&] {
@@ -1256,20 +1280,30 @@ glu_status launch_long_run_passes(glu_radix_sort_s* s, uint32_t* a_k, uint32_t* 
     const uint32_t* hdr = (const uint32_t*) s->long_hdr.ptr;
     uint32_t* table = (uint32_t*) s->table.ptr;
     const PassPlan* plan = (const PassPlan*) s->plan.ptr;
-    for (uint32_t p = 0; p < 2; p++)
+    for (uint32_t p = 0; p < kPasses; p++)
     {
-        hipLaunchKernelGGL((radix_seg_count_kernel<8, 1024>), dim3(nwg), dim3(1024), 0, stream, (const uint32_t*) a_k, (const uint2*) image,
-                           image + lay.off_first, table, p * 8u, 255u, hdr, 0u, kSegGateIfNot, (const uint32_t*) b_k, plan, 2u, p);
+        hipLaunchKernelGGL((radix_seg_count_kernel<KeyT, 8, 1024>), dim3(nwg), dim3(1024), 0, stream, (const KeyT*) a_k, (const uint2*) image,
+                           image + lay.off_first, table, p * 8u, 255u, hdr, 0u, kSegGateIfNot, (const KeyT*) b_k, plan, 2u, p);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL((radix_seg_scan_kernel<RADIX>), dim3(512), dim3(RADIX), 0, stream, table, image + lay.off_list,
                            image + lay.off_start, hdr, 0u, kSegGateIfNot, hdr); // (workgroups loop over the device-counted segments)
         HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(scatter, dim3(nwg), dim3(G::THREADS), sizeof(Smem), stream, (const uint32_t*) a_k, (const uint32_t*) a_v, b_k, b_v,
-                           (const uint32_t*) table, (const uint32_t*) nullptr, (uint32_t) count, p * 8u, 255u, 0u, (unsigned long long*) nullptr, 0u,
-                           const_cast<PassPlan*>(plan), 2u, (const uint2*) image, p, image + lay.off_first, hdr, 0u, kSegGateIfNot);
+        hipLaunchKernelGGL(scatter, dim3(nwg), dim3(G::THREADS), sizeof(Smem), stream, (const KeyT*) a_k, (const uint32_t*) a_v, b_k, b_v,
+                           (const uint32_t*) table, (const uint32_t*) nullptr, (uint32_t) count, p * 8u, 255u, 0u, (unsigned long long*) nullptr,
+                           XF && p + 1 == kPasses ? key_xf << 2 : 0u, const_cast<PassPlan*>(plan), 2u, (const uint2*) image, p,
+                           image + lay.off_first, hdr, 0u, kSegGateIfNot);
         HIP_TRY(hipGetLastError());
     }
     return GLU_OK;
+}
+template<typename KeyT>
+glu_status launch_long_run_passes_any(glu_radix_sort_s* s, KeyT* a_k, uint32_t* a_v, KeyT* b_k, uint32_t* b_v, size_t count, uint32_t key_xf,
+                                      hipStream_t stream)
+{
+    if (a_v) return key_xf != KEY_XF_NONE ? launch_long_run_passes<KeyT, true, true>(s, a_k, a_v, b_k, b_v, count, key_xf, stream)
+                                          : launch_long_run_passes<KeyT, true, false>(s, a_k, a_v, b_k, b_v, count, key_xf, stream);
+    return key_xf != KEY_XF_NONE ? launch_long_run_passes<KeyT, false, true>(s, a_k, nullptr, b_k, nullptr, count, key_xf, stream)
+                                 : launch_long_run_passes<KeyT, false, false>(s, a_k, nullptr, b_k, nullptr, count, key_xf, stream);
 }
 
 // vals == nullptr: keys-only sort (no value traffic, no value scratch)
@@ -1300,6 +1334,8 @@ glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t cou
     uint32_t* vbuf[2] = {vals, vals ? (uint32_t*) s->vals.ptr : nullptr};
     int cur = 0;
     s->cur_kind = 0;
+    s->cur_behind = false; // (a call that failed half-way must not leave the next one's profile marks switched off)
+    s->cur_seq = 0;
     // large sorts: device-side pass plan (constant-digit passes are skipped, the arrays' roles follow on the device)
     const bool planned = count >= kPlanMinCount && !s->no_plan;
     s->last_planned = planned;
@@ -1344,6 +1380,7 @@ glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t cou
         if (s->finish_wait == 0 && s->finish_seq && (seen >> 3) == s->finish_seq) // the last attempt's outcome has arrived
         {
             if (seen & 7u) s->finish_last_geo = seen & 7u; // the tile it took
+            s->finish_last_refused = (seen & 7u) == 0u;
             if (s->finish_seq != s->finish_seq_acted_on)    // (acted on once)
             {
                 s->finish_seq_acted_on = s->finish_seq;
@@ -1373,6 +1410,7 @@ glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t cou
         if (s->finish_wait == 0 && s->finish_seq && (seen >> 3) == s->finish_seq) // the last attempt's outcome has arrived
         {
             if (seen & 7u) s->finish_last_geo = seen & 7u; // the tile it took
+            s->finish_last_refused = (seen & 7u) == 0u;
             if (s->finish_seq != s->finish_seq_acted_on)    // (acted on once)
             {
                 s->finish_seq_acted_on = s->finish_seq;
@@ -1401,6 +1439,7 @@ glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t cou
     if (finish_kpt)
     {
         s->finish_seq = s->finish_seq >= 0x0FFFFFFFu ? 1u : s->finish_seq + 1;
+        s->cur_seq = s->finish_seq;
         for (uint32_t i = num_passes; i-- > 0;) passes[i + 2] = passes[i];
         // (typed keys and sorts that do not collect which bits vary: the whole key's top bits)
         finish_top_bit = !device_top && key_xf == KEY_XF_NONE && !s->no_bit_shortcut && s->finish_top ? std::min<uint32_t>(s->finish_top, end_bit) : end_bit;
@@ -1409,8 +1448,9 @@ glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t cou
         num_passes += 2;
     }
     // runs longer than the tile: segmented passes over just them (4-byte untyped keys with values, all 16 low bits inside two digits)
-    const bool finish_long_ok = finish_kpt && sizeof(KeyT) == 4 && vals && key_xf == KEY_XF_NONE && s->long_runs && s->long_image.ptr &&
-                                finish_top_bit >= 16 && finish_top_bit - 16u <= 16u;
+    // (every key type since round 6; the passes cover 16 low bits of 4-byte keys, 48 of 8-byte keys)
+    const bool finish_long_ok = finish_kpt && s->long_runs && s->long_image.ptr && finish_top_bit >= 16 &&
+                                finish_top_bit - 16u <= (sizeof(KeyT) == 4 ? 16u : 48u);
     s->last_finish_long_ok = finish_long_ok;
     s->last_device_top = finish_kpt && device_top;
     s->last_finish_top = finish_kpt ? finish_top_bit : 0u;
@@ -1458,7 +1498,10 @@ glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t cou
     if (planned)
         for (uint32_t i = 0; i < (uint32_t) kPlanMaxPasses; i++) s->last_pair_roles[i] = i < num_passes ? (uint32_t) passes[i].pair_role : 0u;
     // (see glu_radix_sort_s::side)
-    const bool fork = planned && finish_kpt && s->fork_behind && s->ensure_side();
+    // Four cross-stream dependencies cost 0.1 ms that only long kernels hide: a sort whose attempt is refused and whose
+    // ordinary passes skip (2^28 all-zero keys, the reference's benchmark input: 0.22 ms on one queue, 0.35 forked) is
+    // better off on one queue -- so an object whose last known attempt was refused does not fork (the first sort of an object does).
+    const bool fork = planned && finish_kpt && s->fork_behind && !s->finish_last_refused && s->ensure_side();
     uint32_t pass = 0;
     for (; pass < num_passes; pass++)
     {
@@ -1524,9 +1567,8 @@ glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t cou
                     }
 #undef GLU_LAUNCH_FINISH
                     s->mark(stream, true);
-                    if constexpr (sizeof(KeyT) == 4)
-                        if (finish_long_ok && !fork)
-                            GLU_TRY(launch_long_run_passes(s, (uint32_t*) kbuf[0], vbuf[0], (uint32_t*) kbuf[1], vbuf[1], count, stream));
+                    if (finish_long_ok && !fork)
+                        GLU_TRY(launch_long_run_passes_any<KeyT>(s, kbuf[0], vbuf[0], kbuf[1], vbuf[1], count, key_xf, stream));
                 }
             }
         }
@@ -1542,9 +1584,7 @@ glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t cou
     {
         // the side stream: (behind the ordinary passes) the segmented passes over long runs, beside the in-LDS pass; then it joins
         HIP_TRY(hipStreamWaitEvent(s->side, s->ev_fork2, 0));
-        if constexpr (sizeof(KeyT) == 4)
-            if (finish_long_ok)
-                GLU_TRY(launch_long_run_passes(s, (uint32_t*) kbuf[0], vbuf[0], (uint32_t*) kbuf[1], vbuf[1], count, s->side));
+        if (finish_long_ok) GLU_TRY(launch_long_run_passes_any<KeyT>(s, kbuf[0], vbuf[0], kbuf[1], vbuf[1], count, key_xf, s->side));
         HIP_TRY(hipEventRecord(s->ev_join, s->side));
         HIP_TRY(hipStreamWaitEvent(stream, s->ev_join, 0));
     }
@@ -1959,7 +1999,7 @@ glu_status launch_seg_pass(glu_radix_sort_s* s, const uint32_t* src_k, const uin
     uint32_t* table = (uint32_t*) s->table.ptr;
     const uint2* subs = (const uint2*) image;
     s->mark(stream);
-    hipLaunchKernelGGL((radix_seg_count_kernel<8, 1024>), dim3(img.nwg), dim3(1024), 0, stream, src_k, subs, image + img.off_first, table,
+    hipLaunchKernelGGL((radix_seg_count_kernel<uint32_t, 8, 1024>), dim3(img.nwg), dim3(1024), 0, stream, src_k, subs, image + img.off_first, table,
                        shift, 255u, gate, gate_cap, gm_count, (const uint32_t*) nullptr, (const PassPlan*) nullptr, 0u, 0u);
     HIP_TRY(hipGetLastError());
     s->mark(stream);
@@ -2031,6 +2071,7 @@ glu_status seg_run_plan(glu_radix_sort_s* s, const SegPlan& plan, uint32_t* in_k
 {
     const size_t count = plan.count;
     const uint32_t passes = plan.passes, nseg = plan.nseg;
+    s->cur_kind = 0, s->cur_behind = false, s->cur_seq = 0; // (whatever an earlier call that failed half-way left)
     // (the scratch arrays are indexed like `out`: a plan with an origin -- a group of a sharded sort's rounds -- reaches further)
     GLU_TRY(sort_prepare(s, (plan.seg_start.empty() ? 0 : (size_t) plan.seg_start[0]) + count, sizeof(uint32_t), true));
     if (plan.by_copies)
@@ -2220,7 +2261,7 @@ glu_status glu_radix_sort_destroy(glu_radix_sort sort)
     // library queue, before its scratch goes away (RAII of the reference: RadixSort.hpp:194-200, gl_utils.hpp:184-188)
     (void) hipDeviceSynchronize();
     for (Scratch* sc : {&sort->keys, &sort->vals, &sort->table, &sort->plan, &sort->pair_t2, &sort->pair_table, &sort->pair_ranges,
-                        &sort->pair_sub, &sort->seg_desc, &sort->seg_zero, &sort->finish_lengths, &sort->finish_starts, &sort->finish_crowded, &sort->seg_gate, &sort->long_image, &sort->long_hdr})
+                        &sort->pair_sub, &sort->seg_desc, &sort->seg_zero, &sort->finish_lengths, &sort->finish_starts, &sort->finish_crowded, &sort->finish_outcomes, &sort->seg_gate, &sort->long_image, &sort->long_hdr})
         sc->release();
     if (sort->finish_hint) (void) hipHostFree(sort->finish_hint);
     for (hipEvent_t e : {sort->ev_fork, sort->ev_unit, sort->ev_fork2, sort->ev_join})
@@ -2524,7 +2565,7 @@ glu_status glu_radix_sort_set_profiling(glu_radix_sort sort, int enable)
     GLU_TRY(enter());
     if (!sort) return fail(GLU_ERROR_INVALID_ARGUMENT, "sort is NULL");
     sort->profiling = enable == 2 ? 2 : (enable != 0 ? 1 : 0);
-    if (!enable) sort->events_used = 0, sort->slots.clear(), sort->pass_kinds.clear();
+    if (!enable) sort->events_used = 0, sort->slots.clear(), sort->pass_kinds.clear(), sort->pass_seqs.clear();
     return GLU_OK;
 }
 
@@ -2638,6 +2679,11 @@ glu_status read_profile_impl(glu_radix_sort sort, double* count_ms, double* scan
         HIP_TRY(hipMemcpy(&host, sort->plan.ptr, sizeof(host), hipMemcpyDeviceToHost));
         accepted = host.finish != 0;
     }
+    // the outcome of every attempt of the window, by attempt number (a window of more than 256 sorts: the older ones by the last)
+    std::vector<uint32_t> ring(256, 0u);
+    const bool have_ring = sort->finish_outcomes.ptr != nullptr;
+    if (have_ring) HIP_TRY(hipMemcpy(ring.data(), sort->finish_outcomes.ptr, 256 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    const bool last_accepted = accepted;
     bool seg_accepted = false;
     if (sort->last_seg_finish_attempted && sort->seg_gate.ptr)
     {
@@ -2652,6 +2698,14 @@ glu_status read_profile_impl(glu_radix_sort sort, double* count_ms, double* scan
             if (sort->slots[p * 4 + k] && sort->slots[p * 4 + k + 1])
                 HIP_TRY(hipEventElapsedTime(&ms[k], sort->slots[p * 4 + k], sort->slots[p * 4 + k + 1]));
         const uint8_t kind = p < sort->pass_kinds.size() ? sort->pass_kinds[p] : 0;
+        const uint32_t seq = p < sort->pass_seqs.size() ? sort->pass_seqs[p] : 0u;
+        // (this pass's sort: accepted?  ring entry = attempt number << 3 | tile geometry)
+        accepted = last_accepted;
+        if (seq && have_ring && (ring[seq & 255u] >> 3) == seq) accepted = (ring[seq & 255u] & 7u) != 0u;
+        const bool attempted = seq != 0 || sort->last_finish_attempted;
+        // (light profiling records no events around the sequence the host expects not to run: such a pass is not a live pass with
+        // zero time, whatever the device then decided)
+        const bool timed = sort->slots[p * 4 + 2] && sort->slots[p * 4 + 3];
         if (kind == 2)
         {
             if (accepted || seg_accepted) fin += ms[2], fin_n++;
@@ -2668,13 +2722,15 @@ glu_status read_profile_impl(glu_radix_sort sort, double* count_ms, double* scan
             acc[0] += ms[0]; // the leader's count kernel ran before the device said no
             continue;
         }
-        if (kind == 0 && accepted && sort->last_finish_attempted) continue; // the sequence not taken
+        if (kind == 0 && accepted && attempted) continue; // the sequence not taken
+        if (!timed && sort->profiling == 2) continue;
         for (int k = 0; k < 3; k++) acc[k] += ms[k];
         live++;
     }
     sort->events_used = 0;
     sort->slots.clear();
     sort->pass_kinds.clear();
+    sort->pass_seqs.clear();
     if (count_ms) *count_ms = acc[0];
     if (scan_ms) *scan_ms = acc[1];
     if (scatter_ms) *scatter_ms = acc[2];

@@ -8,26 +8,34 @@
 // prices bytes, not passes:
 //
 //   1. the two counting passes on 16 TOP key bits first -- digit [top - 16, top - 8), then [top - 8, top), an ordinary pair
-//      of passes (radix_pair_passes.hpp); `top` is the key's width, or the highest key bit that varied in the object's last
-//      attempt (a guess, checked below).  After them the array is a sequence of 65536 RUNS, run r = the pairs whose key has
-//      the value r in those bits, in input order.  The leader's two-digit histogram T2 already holds every run's length:
-//      len[r] = sum over blocks b of T2[r & 255][b][r >> 8].
-//   2. if no run is longer than what one workgroup sorts in LDS (tiles of 1536 .. 9216 pairs: the device picks the smallest
-//      of the enqueued geometries that holds the longest run) and no key bit from `top` up varies, ONE pass finishes the
-//      sort in place: a workgroup per run orders it by the low top - 16 bits (rounds of 8 bits of rank / scan / re-stage, as
-//      in radix_sort_single_block_kernel: two for 32-bit keys, six for 64-bit keys) and writes it back where it was.  16 B
-//      per pair instead of the 2 x 20.5 of two more passes: 52.25 B per pair in all (64-bit keys: 80.25 instead of 225).
-//      Typed keys (signed, float) are encoded on load by the first top-bit pass and decoded on store by this one.
-//   3. otherwise (keys that crowd into few runs: small value ranges under the first guess, heavy duplicates) the top-bit
-//      passes are not run at all and the passes of the ordinary sort follow.  The decision is made on the device, after the
-//      leader's count kernel and before its scatter, from exact run lengths; the launch sequence is the same either way and
-//      the kernels of the path not taken return at once (PassPlan::off, PassPlan::skip).  A refused attempt costs one read
-//      of the keys (the leader's count kernel: 4 of 72.5 B per pair); its outcome and the key bits that varied reach the host
-//      through a pinned word that the next sort call reads without synchronising (glu_radix_sort_s::finish_hint).
+//      of passes (radix_pair_passes.hpp).  `top` is chosen ON THE DEVICE from a sample of the keys (radix_sample_top_kernel: the
+//      highest bit that varies, at least 16; typed keys: the key's width).  After them the array is a sequence of 65536 RUNS, run r =
+//      the pairs whose key has the value r in those bits, in input order.  The leader's two-digit histogram T2 already holds
+//      every run's length: len[r] = sum over blocks b of T2[r & 255][b][r >> 8].
+//   2. ONE pass then orders every run by the low top - 16 bits inside LDS, in place, and writes it back where it was: 16 B per pair
+//      instead of the 2 x 20.5 of two more passes -- 52.25 B per pair in all (64-bit keys: 80.25 instead of 225).  Since round 6
+//      that pass is radix_finish_bucket_kernel (radix_lds_bucket.hpp: one bucket round on unique words, whole 128-byte lines in
+//      and out); the ballot-ranked radix_finish_sort_kernel below (rounds of 8 bits of rank / scan / re-stage; 64-bit keys: two
+//      rounds on the top 16 of the remaining bits + exact tie repair) takes the runs that one lists as crowded, every run when
+//      fewer than nine bits are left to order (PassPlan::finish_rounds), and the runs of a SEGMENTED sort that ends in LDS.
+//      Typed keys (signed, float) are encoded on load by the first top-bit pass and decoded on store by the in-LDS pass.
+//   3. The decision is made on the device (radix_finish_plan_kernel, after the leader's count kernel and before its scatter, from
+//      exact run lengths): the tile is the smallest enqueued geometry that leaves at most 8192 runs and an eighth of the pairs
+//      longer than itself; those LONG runs are listed as segments and ordered by two segmented passes over just their elements
+//      (radix_seg_passes.hpp; 4-byte untyped keys with values), the in-LDS pass leaves them alone.  Keys that crowd into few runs
+//      (more than half of the pairs in long runs), a wrapped 16-bit counter of T2, or a key bit above `top` that varies after all
+//      refuse the attempt: the two top-bit passes are switched off and the passes of the ordinary sort, enqueued behind every
+//      attempt, run instead (PassPlan::off, PassPlan::skip).  One launch sequence either way -- the sort stays asynchronous and
+//      graph-capturable; the kernels of the sequence not taken return at once, on a stream of the sort object's own since round
+//      6 (glu_radix_sort_s::side).  A refused attempt costs one read of the keys; its outcome and the key bits that varied reach
+//      the host through a pinned word that the next sort call reads without synchronising (glu_radix_sort_s::finish_hint).
 //
+//   radix_sample_top_kernel       which 16 key bits make the runs                 (64 workgroups, 256 KiB of keys)
 //   radix_finish_lengths_kernel   len[r] from T2                                  (32 MiB of table, once per sort)
 //   radix_finish_plan_kernel      run starts, the longest run, the decision       (64 workgroups)
-//   radix_finish_sort_kernel      step 2                                         (a workgroup of 256 .. 1024 threads per run)
+//   radix_finish_long_runs_kernel the runs longer than the chosen tile, as segments of segmented passes
+//   radix_finish_sort_kernel      step 2 by ballot rounds                         (a workgroup of 256 .. 1024 threads per run)
+//   radix_finish_ranges_kernel    the same for runs longer than a tile / split runs of a segmented sort
 #pragma once
 
 #include "radix_pair_passes.hpp"
@@ -55,46 +63,16 @@ __device__ __forceinline__ void crowded_list_append(uint32_t* lists, uint32_t nr
     lists[kCrowdedLists * kCrowdedCountStride + k * crowded_list_capacity(nruns) + i] = run;
 }
 
-// lengths[e * 256 + d] = #keys with first top-bit digit d and second top-bit digit e: T2 rows (d, b) summed over the leader's nb
-// blocks.  One workgroup per d; thread (g, q) adds word q (counters e = 2q, 2q + 1) of the rows b = g, g + 8, ...
-__global__ __launch_bounds__(1024) void radix_finish_lengths_kernel(const uint32_t* __restrict__ t2, uint32_t nb,
-                                                                    uint32_t* __restrict__ lengths, const PassPlan* plan,
-                                                                    uint32_t pass)
-{
-    if (plan->off[pass] || plan->skip[pass] == kSkipWithoutCounting) return; // no tables (kernel-uniform)
-    __shared__ uint32_t part[8][kPairRadix];
-    const uint32_t tid = threadIdx.x, g = tid >> 7, q = tid & 127u, d = blockIdx.x;
-    uint32_t lo = 0, hi = 0;
-#pragma unroll 4
-    for (uint32_t b = g; b < nb; b += 8)
-    {
-        const uint32_t w = t2[((size_t) d * nb + b) * kPairRowWords + q];
-        lo += w & 0xFFFFu;
-        hi += w >> 16;
-    }
-    part[g][2 * q] = lo;
-    part[g][2 * q + 1] = hi;
-    __syncthreads();
-    if (tid < kPairRadix)
-    {
-        uint32_t c = 0;
-#pragma unroll
-        for (int k = 0; k < 8; k++) c += part[k][tid];
-        lengths[tid * kPairRadix + d] = c;
-    }
-}
-
-// starts[r] = exclusive scan of lengths (starts[65536] = n), and the decision: the sort ends in LDS if the lengths are
-// exact (they add up to n: a 16-bit counter of T2 that overflowed loses 65536) and the longest run fits the tile of one of the
-// in-LDS pass's geometries whose launches follow (numbered geo_first .. geo_last, finish_geometry_capacity; the host enqueues the
-// one that suits uniformly drawn keys of this count and the next larger ones: keys that leave some runs empty and the others
-// longer -- 31-bit keys, mild skew -- still end in LDS, in a larger tile).  PassPlan::finish = the geometry chosen.
+// The plan (radix_finish_plan_kernel below): starts[r] = exclusive scan of the run lengths (starts[65536] = n), and the decision:
+// the sort ends in LDS if the lengths are exact (they add up to n: a 16-bit counter of T2 that overflowed loses 65536) and the
+// longest run fits the tile of one of the in-LDS pass's geometries whose launches follow (numbered geo_first .. geo_last,
+// finish_geometry_capacity; the host enqueues the one that suits uniformly drawn keys of this count and the next larger ones:
+// keys that leave some runs empty and the others longer -- 31-bit keys, mild skew -- still end in LDS, in a larger tile).
+// PassPlan::finish = the geometry chosen.
 //   accepted: the ordinary passes [first_ordinary, first_ordinary + num_ordinary) are switched off;
 //   refused:  the two top-bit passes `pass`, `pass + 1` are switched off (the leader has counted already: its scatter
 //             sees skip = kSkipWithoutCounting, which leaves the arrays' roles as they are).
-// hint: see glu_radix_sort_s::finish_hint.  64 workgroups, each scans 1024 runs; every workgroup reads all 65536 lengths
-// (256 KiB, from L2) for the sum in front of its runs, the total and the longest run, so each reaches the same decision
-// without a second launch.
+// hint: see glu_radix_sort_s::finish_hint.
 constexpr uint32_t kFinishPlanBlocks = kFinishRuns / 1024;
 // tile geometries of the in-LDS pass: 1 = 256 threads x 6 pairs, 2 = 256 x 10, 3 = 256 x 18 (39 KiB of LDS: four workgroups per
 // CU), 4 = 512 x 18 (78 KiB: two per CU, the largest that still overlaps one run's memory time with another's ranking)
@@ -213,12 +191,170 @@ __global__ __launch_bounds__(256) void radix_sample_top_kernel(const KeyT* __res
 // if it leaves at most half of the pairs; failing that the sort is refused as before (keys crowded into few runs are better off
 // with the ordinary passes and their skipping of constant digits).
 constexpr uint32_t kLongRunsMax = 8192;
-__global__ __launch_bounds__(1024) void radix_finish_plan_kernel(const uint32_t* __restrict__ lengths, uint32_t* __restrict__ starts,
+
+// The runs longer than the tile the plan chose, as SEGMENTS of segmented passes (radix_seg_passes.hpp): the descriptor image
+// the host builds for the sharded sort's local sort (seg_build_image in glu_hip.hip), built on the device from the run starts.
+// The long runs laid end to end are cut into nwg equal shares, a sub-block is the part of one run inside one share:
+//   image + 0:          subs[kLongRunsMax + nwg] (begin, end) element ranges, in the order of the runs
+//   image + off_first:  seg_first[nwg + 1]       first sub-block of every workgroup's share
+//   image + off_list:   seg_list[kLongRunsMax + 1]  first sub-block of every long run
+//   image + off_start:  seg_start[kLongRunsMax]     where the run starts (it stays where it is)
+//   hdr[0] = number of long runs (0: none, or the sort does not end in LDS: the segmented kernels return at once), hdr[1] = sub-blocks,
+//   hdr[2] = pairs in long runs
+// One workgroup (radix_finish_long_runs_kernel, behind the plan kernel); thread t owns the runs [64 t, 64 t + 64).
+struct LongRunsLayout
+{
+    uint32_t nwg, off_first, off_list, off_start, words;
+    __host__ __device__ explicit LongRunsLayout(uint32_t nwg_) : nwg(nwg_)
+    {
+        off_first = 2u * (kLongRunsMax + nwg);
+        off_list = off_first + nwg + 1u;
+        off_start = off_list + kLongRunsMax + 1u;
+        words = off_start + kLongRunsMax;
+    }
+};
+__device__ __forceinline__ void finish_list_long_runs(const uint32_t* starts, uint32_t geo, uint32_t finish_longest, uint32_t nwg,
+                                                      uint32_t* __restrict__ image, uint32_t* __restrict__ hdr, uint32_t (&wsum)[2][16])
+{
+    const LongRunsLayout lay(nwg);
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t cap = finish_geometry_capacity(geo);
+    constexpr uint32_t PER = kFinishRuns / 1024;
+    auto ld = [&](uint32_t i) { return starts[i]; };
+    if (geo == 0 || finish_longest <= cap) // (workgroup-uniform) refused, or no run outgrows the tile: nothing to list
+    {
+        if (tid < 3) hdr[tid] = 0u;
+        return;
+    }
+    // (every workgroup's share starts empty; the sub-block that begins at a share's first position fills it in)
+    for (uint32_t w = tid; w <= nwg; w += 1024) image[lay.off_first + w] = 0xFFFFFFFFu;
+    uint32_t cnt = 0, len = 0;
+    {
+        uint32_t a = ld(tid * PER);
+        for (uint32_t j = 0; j < PER; j++)
+        {
+            const uint32_t e = ld(tid * PER + j + 1);
+            if (e - a > cap) cnt++, len += e - a;
+            a = e;
+        }
+    }
+    auto block_exclusive = [&](uint32_t v, int slot, uint32_t& total) -> uint32_t {
+        uint32_t wtotal;
+        uint32_t excl = wave_exclusive_sum(v, lane, wtotal);
+        __syncthreads(); // (the slot's last readers are done)
+        if (lane == 0) wsum[slot][wave] = wtotal;
+        __syncthreads();
+        total = 0;
+        for (uint32_t w = 0; w < 16; w++)
+        {
+            excl += w < wave ? wsum[slot][w] : 0u;
+            total += wsum[slot][w];
+        }
+        return excl;
+    };
+    uint32_t nseg, total;
+    uint32_t seg = block_exclusive(cnt, 0, nseg);
+    uint32_t pos = block_exclusive(len, 1, total);
+    // (the plan allowed at most kLongRunsMax long runs; a sort that did not ask for this has none that are not refused)
+    const bool active = nseg != 0 && nseg <= kLongRunsMax;
+    if (tid == 0)
+    {
+        hdr[0] = active ? nseg : 0u;
+        hdr[2] = active ? total : 0u;
+    }
+    if (!active) // (workgroup-uniform)
+    {
+        if (tid == 0) hdr[1] = 0u;
+        return;
+    }
+    const uint32_t share = (total + nwg - 1) / nwg; // >= cap / nwg > 0
+    // sub-blocks of this thread's long runs, then their numbers
+    uint32_t subs = 0;
+    {
+        uint32_t a = ld(tid * PER), p = pos;
+        for (uint32_t j = 0; j < PER; j++)
+        {
+            const uint32_t e = ld(tid * PER + j + 1), l = e - a;
+            if (l > cap)
+            {
+                subs += (p + l - 1) / share - p / share + 1;
+                p += l;
+            }
+            a = e;
+        }
+    }
+    uint32_t nsb;
+    uint32_t sb = block_exclusive(subs, 0, nsb);
+    {
+        uint32_t a = ld(tid * PER), p = pos, g = seg;
+        for (uint32_t j = 0; j < PER; j++)
+        {
+            const uint32_t e = ld(tid * PER + j + 1), l = e - a;
+            if (l > cap)
+            {
+                image[lay.off_list + g] = sb;
+                image[lay.off_start + g] = a;
+                for (uint32_t w = p / share; w <= (p + l - 1) / share; w++)
+                {
+                    const uint32_t b0 = max(p, w * share), b1 = min(p + l, (w + 1) * share);
+                    image[2 * sb] = a + (b0 - p);
+                    image[2 * sb + 1] = a + (b1 - p);
+                    if (b0 == w * share) image[lay.off_first + w] = sb; // (this sub-block begins workgroup w's share)
+                    sb++;
+                }
+                p += l;
+                g++;
+            }
+            a = e;
+        }
+    }
+    __syncthreads();
+    if (tid == 0)
+    {
+        hdr[1] = nsb;
+        image[lay.off_list + nseg] = nsb;
+    }
+    // shares behind the last pair (total < nwg * share) are empty: they begin and end at nsb
+    for (uint32_t w = tid; w <= nwg; w += 1024)
+        if (image[lay.off_first + w] == 0xFFFFFFFFu) image[lay.off_first + w] = nsb;
+}
+
+// lengths[e * 256 + d] = #keys with first top-bit digit d and second top-bit digit e: T2 rows (d, b) summed over the leader's nb
+// blocks.  One workgroup per d; thread (g, q) adds word q (counters e = 2q, 2q + 1) of the rows b = g, g + 8, ...
+__global__ __launch_bounds__(1024) void radix_finish_lengths_kernel(const uint32_t* __restrict__ t2, uint32_t nb,
+                                                                    uint32_t* __restrict__ lengths, const PassPlan* plan,
+                                                                    uint32_t pass)
+{
+    if (plan->off[pass] || plan->skip[pass] == kSkipWithoutCounting) return; // no tables (kernel-uniform)
+    __shared__ uint32_t part[8][kPairRadix];
+    const uint32_t tid = threadIdx.x, g = tid >> 7, q = tid & 127u, d = blockIdx.x;
+    uint32_t lo = 0, hi = 0;
+#pragma unroll 4
+    for (uint32_t b = g; b < nb; b += 8)
+    {
+        const uint32_t w = t2[((size_t) d * nb + b) * kPairRowWords + q];
+        lo += w & 0xFFFFu;
+        hi += w >> 16;
+    }
+    part[g][2 * q] = lo;
+    part[g][2 * q + 1] = hi;
+    __syncthreads();
+    if (tid < kPairRadix)
+    {
+        uint32_t c = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) c += part[k][tid];
+        lengths[tid * kPairRadix + d] = c;
+    }
+}
+
+__global__ __launch_bounds__(1024) void radix_finish_plan_kernel(const uint32_t* __restrict__ lengths, uint32_t* starts,
                                                                  uint32_t n, uint32_t geo_first, uint32_t geo_last, PassPlan* plan,
                                                                  uint32_t pass,
                                                                  uint32_t first_ordinary, uint32_t num_ordinary,
                                                                  uint32_t* hint, uint32_t attempt, uint32_t top_bit,
-                                                                 uint32_t key_bits, uint32_t long_ok, uint32_t* crowded_lists = nullptr)
+                                                                 uint32_t key_bits, uint32_t long_ok, uint32_t* crowded_lists,
+                                                                 uint32_t* outcomes = nullptr)
 {
     __shared__ uint32_t tmp[3][16];
     __shared__ uint32_t over_tmp[2][kFinishGeometries][16];
@@ -319,6 +455,7 @@ __global__ __launch_bounds__(1024) void radix_finish_plan_kernel(const uint32_t*
     {
         plan->finish = accept ? geo : 0u;
         plan->finish_longest = tables ? longest : 0xFFFFFFFFu;
+        if (outcomes) outcomes[attempt & 255u] = (attempt << 3) | (accept ? geo : 0u); // (glu_radix_sort_read_profile: per sort of a window)
         // which kernel orders the runs: with fewer than nine bits left to order -- or varying, where that is known -- one ballot
         // round beats the bucket round (whose buckets such keys crowd)
         {
@@ -327,18 +464,18 @@ __global__ __launch_bounds__(1024) void radix_finish_plan_kernel(const uint32_t*
             const uint32_t to_order = plan->bits_valid ? (uint32_t) __popcll(varying & low_mask) : low_bits;
             plan->finish_rounds = to_order < 9u ? 1u : 0u;
         }
-        // for the host, which reads it without synchronising: the outcome of attempt number `attempt` (pinned host memory)
-        // (attempt << 3 | the geometry chosen, 0 = refused; and which key bits vary, for the next sort's choice of top_bit:
-        // words 1, 2, valid for attempt number word 3)
+        // for the host, which reads it without synchronising (pinned host memory): the outcome of attempt number `attempt` --
+        // attempt << 3 | the geometry chosen, 0 = refused, stored LAST and with release: the host reads it first, then which key
+        // bits vary (words 1, 2, valid for attempt number word 3) and the top bit this attempt used (word 4)
         if (hint)
         {
             if (plan->bits_valid)
             {
                 __hip_atomic_store(hint + 1, (uint32_t) varying, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 __hip_atomic_store(hint + 2, (uint32_t) (varying >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                __hip_atomic_store(hint + 3, attempt, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(hint + 3, attempt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
-            __hip_atomic_store(hint + 4, top_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); // (the top bit this attempt used)
+            __hip_atomic_store(hint + 4, top_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(hint, (attempt << 3) | (accept ? geo : 0u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         if (!accept)
@@ -352,133 +489,14 @@ __global__ __launch_bounds__(1024) void radix_finish_plan_kernel(const uint32_t*
     if (b == 0 && accept && tid < num_ordinary) plan->off[first_ordinary + tid] = 1;
 }
 
-// The runs longer than the tile the plan chose, as SEGMENTS of segmented passes (radix_seg_passes.hpp): the descriptor image
-// the host builds for the sharded sort's local sort (seg_build_image in glu_hip.hip), built on the device from the run starts.
-// The long runs laid end to end are cut into nwg equal shares, a sub-block is the part of one run inside one share:
-//   image + 0:          subs[kLongRunsMax + nwg] (begin, end) element ranges, in the order of the runs
-//   image + off_first:  seg_first[nwg + 1]       first sub-block of every workgroup's share
-//   image + off_list:   seg_list[kLongRunsMax + 1]  first sub-block of every long run
-//   image + off_start:  seg_start[kLongRunsMax]     where the run starts (it stays where it is)
-//   hdr[0] = number of long runs (0: none, or the sort does not end in LDS: the segmented kernels return at once), hdr[1] = sub-blocks,
-//   hdr[2] = pairs in long runs
-// One workgroup; thread t owns the runs [64 t, 64 t + 64).
-struct LongRunsLayout
-{
-    uint32_t nwg, off_first, off_list, off_start, words;
-    __host__ __device__ explicit LongRunsLayout(uint32_t nwg_) : nwg(nwg_)
-    {
-        off_first = 2u * (kLongRunsMax + nwg);
-        off_list = off_first + nwg + 1u;
-        off_start = off_list + kLongRunsMax + 1u;
-        words = off_start + kLongRunsMax;
-    }
-};
+
+// (Folding this into the plan kernel -- its last workgroup to finish -- was measured: the fences of the ticket cost the plan kernel
+// 10 us more than this launch does, profiles/r06/last_sort_kernels_2p28_plan_merged.txt.)
 __global__ __launch_bounds__(1024) void radix_finish_long_runs_kernel(const uint32_t* __restrict__ starts, const PassPlan* plan,
                                                                       uint32_t nwg, uint32_t* __restrict__ image, uint32_t* __restrict__ hdr)
 {
-    const LongRunsLayout lay(nwg);
     __shared__ uint32_t wsum[2][16];
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t geo = plan->finish;
-    const uint32_t cap = finish_geometry_capacity(geo);
-    constexpr uint32_t PER = kFinishRuns / 1024;
-    if (geo == 0 || plan->finish_longest <= cap) // (kernel-uniform) refused, or no run outgrows the tile: nothing to list
-    {
-        if (tid < 3) hdr[tid] = 0u;
-        return;
-    }
-    // (every workgroup's share starts empty; the sub-block that begins at a share's first position fills it in)
-    for (uint32_t w = tid; w <= nwg; w += 1024) image[lay.off_first + w] = 0xFFFFFFFFu;
-    uint32_t cnt = 0, len = 0;
-    if (geo != 0)
-    {
-        uint32_t a = starts[tid * PER];
-        for (uint32_t j = 0; j < PER; j++)
-        {
-            const uint32_t e = starts[tid * PER + j + 1];
-            if (e - a > cap) cnt++, len += e - a;
-            a = e;
-        }
-    }
-    auto block_exclusive = [&](uint32_t v, int slot, uint32_t& total) -> uint32_t {
-        uint32_t wtotal;
-        uint32_t excl = wave_exclusive_sum(v, lane, wtotal);
-        if (lane == 0) wsum[slot][wave] = wtotal;
-        __syncthreads();
-        total = 0;
-        for (uint32_t w = 0; w < 16; w++)
-        {
-            excl += w < wave ? wsum[slot][w] : 0u;
-            total += wsum[slot][w];
-        }
-        return excl;
-    };
-    uint32_t nseg, total;
-    uint32_t seg = block_exclusive(cnt, 0, nseg);
-    uint32_t pos = block_exclusive(len, 1, total);
-    // (the plan kernel allowed at most kLongRunsMax long runs; a sort that did not ask for this has none that are not refused)
-    const bool active = geo != 0 && nseg != 0 && nseg <= kLongRunsMax;
-    if (tid == 0)
-    {
-        hdr[0] = active ? nseg : 0u;
-        hdr[2] = active ? total : 0u;
-    }
-    __syncthreads();
-    if (!active) // (workgroup-uniform)
-    {
-        if (tid == 0) hdr[1] = 0u;
-        return;
-    }
-    const uint32_t share = (total + nwg - 1) / nwg; // >= cap / nwg > 0
-    // sub-blocks of this thread's long runs, then their numbers
-    uint32_t subs = 0;
-    {
-        uint32_t a = starts[tid * PER], p = pos;
-        for (uint32_t j = 0; j < PER; j++)
-        {
-            const uint32_t e = starts[tid * PER + j + 1], l = e - a;
-            if (l > cap)
-            {
-                subs += (p + l - 1) / share - p / share + 1;
-                p += l;
-            }
-            a = e;
-        }
-    }
-    uint32_t nsb;
-    uint32_t sb = block_exclusive(subs, 0, nsb);
-    {
-        uint32_t a = starts[tid * PER], p = pos, g = seg;
-        for (uint32_t j = 0; j < PER; j++)
-        {
-            const uint32_t e = starts[tid * PER + j + 1], l = e - a;
-            if (l > cap)
-            {
-                image[lay.off_list + g] = sb;
-                image[lay.off_start + g] = a;
-                for (uint32_t w = p / share; w <= (p + l - 1) / share; w++)
-                {
-                    const uint32_t b0 = max(p, w * share), b1 = min(p + l, (w + 1) * share);
-                    image[2 * sb] = a + (b0 - p);
-                    image[2 * sb + 1] = a + (b1 - p);
-                    if (b0 == w * share) image[lay.off_first + w] = sb; // (this sub-block begins workgroup w's share)
-                    sb++;
-                }
-                p += l;
-                g++;
-            }
-            a = e;
-        }
-    }
-    __syncthreads();
-    if (tid == 0)
-    {
-        hdr[1] = nsb;
-        image[lay.off_list + nseg] = nsb;
-    }
-    // shares behind the last pair (total < nwg * share) are empty: they begin and end at nsb
-    for (uint32_t w = tid; w <= nwg; w += 1024)
-        if (image[lay.off_first + w] == 0xFFFFFFFFu) image[lay.off_first + w] = nsb;
+    finish_list_long_runs(starts, plan->finish, plan->finish_longest, nwg, image, hdr, wsum);
 }
 
 // The stage of 64-bit keys: only the low 48 key bits differ inside a run (the bits above are the run's, or constant over the

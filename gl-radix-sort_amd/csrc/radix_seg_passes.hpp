@@ -49,6 +49,7 @@ __global__ __launch_bounds__(1024) void radix_seg_runs_kernel(const uint32_t* __
         return row == seg_list[g + 1] ? seg_start[g] : table[(size_t) row * RADIX + d]; // (a segment without elements has no rows)
     };
     uint32_t longest = 0;
+#pragma unroll 8 // (two dependent loads per run: eight runs' chains in flight instead of one -- 2^18 runs are 256 iterations per thread)
     for (uint32_t i = tid; i < nruns; i += 1024)
     {
         const uint32_t a = start_of(i), b = start_of(i + 1);
@@ -72,14 +73,14 @@ __global__ __launch_bounds__(1024) void radix_seg_runs_kernel(const uint32_t* __
 // workgroup w of the scatter kernel moves.  (One workgroup per sub-block, the first version, ran 125 us where the plain
 // count kernel takes 86 us for the same 2^27 keys: sub-blocks come in all sizes, two share a CU, and the CU that draws two
 // large ones sets the kernel time.)
-template<int BITS, int THREADS>
-__global__ __launch_bounds__(THREADS) void radix_seg_count_kernel(const uint32_t* __restrict__ keys,
+template<typename KeyT, int BITS, int THREADS>
+__global__ __launch_bounds__(THREADS) void radix_seg_count_kernel(const KeyT* __restrict__ keys,
                                                                   const uint2* __restrict__ subs,
                                                                   const uint32_t* __restrict__ seg_first,
                                                                   uint32_t* __restrict__ table, uint32_t shift, uint32_t mask,
                                                                   const uint32_t* gate = nullptr, uint32_t gate_cap = 0,
                                                                   uint32_t gate_mode = kSegGateNone,
-                                                                  const uint32_t* __restrict__ keys_alt = nullptr,
+                                                                  const KeyT* __restrict__ keys_alt = nullptr,
                                                                   const PassPlan* plan = nullptr, uint32_t flip_pass = 0, uint32_t swap = 0)
 {
     if (seg_gate_closed(gate, gate_cap, gate_mode)) return; // (kernel-uniform)
@@ -87,15 +88,23 @@ __global__ __launch_bounds__(THREADS) void radix_seg_count_kernel(const uint32_t
     if (plan && ((plan->flip[flip_pass] ^ swap) & 1u)) keys = keys_alt;
     constexpr int RADIX = 1 << BITS;
     constexpr int WAVES = THREADS / kWave;
+    constexpr uint32_t EPV = 16 / sizeof(KeyT); // keys per 16-byte piece (8-byte keys: round 6, the long runs of 64-bit sorts)
     __shared__ uint32_t hist[WAVES][RADIX];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t* my_hist = hist[wave];
-    auto dig = [&](uint32_t k) { return digit_of<uint32_t>(k, shift, mask); };
+    auto dig = [&](KeyT k) { return digit_of<KeyT>(k, shift, mask); };
     // every lane of the wave is active when this runs (wave_tally: one add per group of equal digits when they are few)
     TallyRun run;
     auto add_count = [&](uint32_t dv, uint32_t c) { atomicAdd(&my_hist[dv], c); };
     auto tally = [&](auto peel, uint32_t d) { wave_tally_mode(peel, d, lane, run, add_count); };
-    auto tally_vec = [&](auto peel, const uint4& a) { tally(peel, dig(a.x)); tally(peel, dig(a.y)); tally(peel, dig(a.z)); tally(peel, dig(a.w)); };
+    auto key_at = [&](const uint4& a, int e) -> KeyT {
+        if constexpr (sizeof(KeyT) == 4) return (KeyT) (e == 0 ? a.x : e == 1 ? a.y : e == 2 ? a.z : a.w);
+        else return (KeyT) (e == 0 ? ((uint64_t) a.x | ((uint64_t) a.y << 32)) : ((uint64_t) a.z | ((uint64_t) a.w << 32)));
+    };
+    auto tally_vec = [&](auto peel, const uint4& a) {
+#pragma unroll
+        for (int e = 0; e < (int) EPV; e++) tally(peel, dig(key_at(a, e)));
+    };
     const uint32_t sb_first = seg_first[blockIdx.x], sb_last = seg_first[blockIdx.x + 1];
     for (int i = tid; i < WAVES * RADIX; i += THREADS) (&hist[0][0])[i] = 0;
     __syncthreads();
@@ -104,10 +113,10 @@ __global__ __launch_bounds__(THREADS) void radix_seg_count_kernel(const uint32_t
         const uint2 r = subs[sb];
         const uint64_t begin = r.x, end = r.y;
         // head: the elements in front of the first 16-byte boundary
-        uint64_t vstart = (begin + 3ull) & ~3ull;
+        uint64_t vstart = (begin + (EPV - 1)) & ~(uint64_t) (EPV - 1);
         if (vstart > end) vstart = end;
         if (begin + tid < vstart) atomicAdd(&my_hist[dig(keys[begin + tid])], 1u);
-        const uint64_t nvec = (end - vstart) / 4;
+        const uint64_t nvec = (end - vstart) / EPV;
         const uint4* vkeys = reinterpret_cast<const uint4*>(keys + vstart);
         uint64_t vbase = 0;
         auto main_loop = [&](auto peel) { // (twice, chosen once per wave and sub-block from its first keys: see wave_tally)
@@ -124,16 +133,14 @@ __global__ __launch_bounds__(THREADS) void radix_seg_count_kernel(const uint32_t
                 tally_vec(peel, d);
             }
         };
-        if (4 * THREADS <= nvec) wave_tally_dispatch(dig(vkeys[tid].x), lane, run, main_loop, add_count);
+        if (4 * THREADS <= nvec) wave_tally_dispatch(dig(key_at(vkeys[tid], 0)), lane, run, main_loop, add_count);
         for (uint64_t v = vbase + tid; v < nvec; v += THREADS) // lanes may be inactive: plain atomics
         {
             const uint4 a = vkeys[v];
-            atomicAdd(&my_hist[dig(a.x)], 1u);
-            atomicAdd(&my_hist[dig(a.y)], 1u);
-            atomicAdd(&my_hist[dig(a.z)], 1u);
-            atomicAdd(&my_hist[dig(a.w)], 1u);
+#pragma unroll
+            for (int e = 0; e < (int) EPV; e++) atomicAdd(&my_hist[dig(key_at(a, e))], 1u);
         }
-        const uint64_t tail = vstart + nvec * 4 + tid;
+        const uint64_t tail = vstart + nvec * EPV + tid;
         if (tail < end) atomicAdd(&my_hist[dig(keys[tail])], 1u);
         __syncthreads();
         // the sub-block's row, and the counters back to zero for the next one

@@ -132,7 +132,7 @@ def _with_one_run_of(n, length, seed, run=0x1234):
                                                       (2560, 1, 2560), (2561, 1, 4608), (4608, 1, 4608), (4609, 0, 4608),
                                                       (4608 + 5000, 0, 4608)])
 def test_the_longest_run_decides(G, length, accepted, capacity):
-    """Round-4 rule (GLU_HIP_SORT_LONG_RUNS=0; still the rule for 64-bit, typed and keys-only sorts): the in-LDS pass is enqueued
+    """Round-4 rule (GLU_HIP_SORT_LONG_RUNS=0): the in-LDS pass is enqueued
     in the tile geometry that suits uniform keys of this count (here 256 x 6 = 1536 pairs) and in the next two larger ones; the
     device runs the smallest whose tile holds the longest run.  A run of exactly a tile's capacity is sorted in that tile, one
     pair more takes the next, and one pair more than the largest enqueued tile sends the sort to the ordinary passes."""
@@ -155,6 +155,106 @@ def test_one_long_run_no_longer_refuses_the_sort(G, length):
     assert fin["attempted"] == 1 and fin["accepted"] == 1 and fin["longest_run"] == length and fin["capacity"] == CAP_SMALL, fin
     lr = s.read_long_runs()
     assert lr["runs"] == (1 if length > CAP_SMALL else 0) and lr["pairs"] == (length if length > CAP_SMALL else 0), lr
+
+
+# ---- round 6: the same for every kind of key -- keys only, 64-bit keys, signed and float keys (the long runs' last segmented pass
+# decodes what the in-LDS pass, which leaves those runs alone, would have decoded)
+
+def _sort_kind(G, s, kind, keys_u, vals):
+    """keys_u: unsigned bit patterns (np.uint32 / np.uint64) of the order the sort must produce for `kind`; returns (keys out as
+    unsigned patterns, values out or None, read_finish, read_long_runs)."""
+    name = {"u32_pairs": None, "u32_keys_only": None, "u64_pairs": None, "int32": "int32", "float64": "float64", "int64_keys_only": "int64"}[kind]
+    with_vals = not kind.endswith("keys_only")
+    if name is None:
+        stored = keys_u
+    else:
+        # the bit patterns whose natural order (as int / float) is the unsigned order of keys_u: invert the order-preserving code
+        top = keys_u.dtype.type(1) << keys_u.dtype.type(8 * keys_u.itemsize - 1)
+        stored = (keys_u ^ top) if name.startswith("int") else np.where(keys_u & top, keys_u ^ top, ~keys_u)
+    kb = G.ShaderStorageBuffer(stored)
+    vb = G.ShaderStorageBuffer(vals) if with_vals else None
+    if name is None and keys_u.itemsize == 4:
+        if with_vals:
+            s(kb, vb, keys_u.size)
+        else:
+            s.sort_keys_ptr(kb.device_ptr(), keys_u.size)
+    elif name is None:
+        s(kb, vb, keys_u.size, 0, key_bytes=8)
+    else:
+        s.sort_typed_ptr(kb.device_ptr(), vb.device_ptr() if with_vals else None, keys_u.size, name)
+    G.synchronize()
+    out = kb.get_data(keys_u.dtype)
+    if name is not None:
+        top = keys_u.dtype.type(1) << keys_u.dtype.type(8 * keys_u.itemsize - 1)
+        out = (out ^ top) if name.startswith("int") else np.where(out & top, ~out, out ^ top)
+    return out, (vb.get_data(np.uint32) if with_vals else None), s.read_finish(), s.read_long_runs()
+
+
+KINDS = ["u32_pairs", "u32_keys_only", "u64_pairs", "int32", "float64", "int64_keys_only"]
+
+
+def _kind_keys(kind, n, seed, long_runs):
+    """Uniform unsigned patterns of the kind's width with `long_runs` = [(run value of the top 16 bits, length)] planted."""
+    wide = kind in ("u64_pairs", "float64", "int64_keys_only")
+    dt = np.uint64 if wide else np.uint32
+    bits = 64 if wide else 32
+    rng = np.random.default_rng(seed)
+    keys = rng.integers(0, 2**bits, n, dtype=dt)
+    if kind == "float64":  # no NaN patterns in the order code: they would still sort, but numpy's view of them is not comparable
+        keys &= ~(dt(0x7FF) << dt(52)) | (dt(0x3FF) << dt(52))
+    sh = dt(bits - 16)
+    taken = np.zeros(n, dtype=bool)
+    for run, length in long_runs:
+        clash = ((keys >> sh) == dt(run)) & ~taken
+        keys[clash] ^= dt(1) << dt(bits - 2)
+        free = np.flatnonzero(~taken)
+        pos = rng.choice(free, size=length, replace=False)
+        low = rng.integers(0, 2**(bits - 16), length, dtype=dt)
+        if kind == "float64":
+            low &= ~(dt(0xF) << dt(44))
+        keys[pos] = (dt(run) << sh) | low
+        taken[pos] = True
+    return keys
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("length", [CAP_SMALL + 1, 4608 + 5000, 150_000])
+def test_long_runs_of_every_key_kind(G, kind, length):
+    n = N_SMALL if not kind.endswith("keys_only") or kind.startswith("int64") else (1 << 23) + 4321
+    keys = _kind_keys(kind, n, 5, [(0x1234 if kind != "float64" else 0x4234, length)])
+    vals = np.arange(n, dtype=np.uint32)
+    opts = dict(SMALL)
+    if kind == "u32_keys_only":
+        opts["GLU_HIP_SORT_LARGE_MIN"] = 1  # (keys-only sorts of 4-byte keys run the line kernel from 2^25 keys: forced here)
+    s = _sorter(G, **opts)
+    gk, gv, fin, lr = _sort_kind(G, s, kind, keys, vals)
+    order = np.argsort(keys, kind="stable")
+    assert (gk == keys[order]).all(), "keys differ at %s" % np.flatnonzero(gk != keys[order])[:5]
+    if gv is not None:
+        assert (gv == vals[order]).all(), "values differ at %s" % np.flatnonzero(gv != vals[order])[:5]
+    assert fin["attempted"] == 1 and fin["accepted"] == 1 and fin["longest_run"] >= length, fin
+    assert lr["runs"] == 1 and lr["pairs"] == fin["longest_run"], lr
+
+
+@pytest.mark.parametrize("kind", ["u64_pairs", "int32", "u32_keys_only", "float64"])
+def test_many_long_runs_and_one_percent_zeros_of_other_key_kinds(G, kind):
+    n = N_SMALL if kind != "u32_keys_only" else (1 << 23) + 4321
+    rng = np.random.default_rng(9)
+    runs = [(int(r), int(l)) for r, l in zip(rng.choice(30000, 40, replace=False) + 1000, rng.integers(1600, 9000, 40))]
+    keys = _kind_keys(kind, n, 6, runs)
+    keys[rng.choice(n, n // 100, replace=False)] = 0  # one run of a single key value, a percent of the input
+    vals = np.arange(n, dtype=np.uint32)
+    opts = dict(SMALL)
+    if kind == "u32_keys_only":
+        opts["GLU_HIP_SORT_LARGE_MIN"] = 1
+    s = _sorter(G, **opts)
+    for _ in range(2):  # (twice on one object)
+        gk, gv, fin, lr = _sort_kind(G, s, kind, keys, vals)
+        order = np.argsort(keys, kind="stable")
+        assert (gk == keys[order]).all()
+        if gv is not None:
+            assert (gv == vals[order]).all()
+        assert fin["accepted"] == 1 and lr["runs"] >= 41, (fin, lr)
 
 
 @pytest.mark.parametrize("shape", ["long_run_first", "long_run_last", "many_long_runs", "long_runs_of_equal_keys", "zeros_1_percent",
@@ -278,7 +378,7 @@ def test_one_object_alternates_between_the_two_sequences(G):
 
 
 @pytest.mark.parametrize("bits,garbage", [(28, 0), (28, 0xA0000000), (21, 0), (17, 0x00FE0000), (16, 0), (31, 0)])
-def test_keys_of_a_smaller_range_end_in_lds_from_the_second_sort_on(G, bits, garbage):
+def test_keys_of_a_smaller_range_with_the_host_side_guess(G, bits, garbage):
     """(Round-4 rule, GLU_HIP_SORT_DEVICE_TOP=0: the host takes the runs' key bits from the object's last attempt.)  Keys below 2^bits (with or without constant bits above) crowd into few runs of the whole key's top bits: the first sort is
     refused; it has noted which key bits vary, and the second takes its runs from the top 16 of those -- bits [bits - 16, bits)
     -- and orders the remaining low bits (12, 5, 1, none, 15) inside LDS."""
@@ -579,7 +679,8 @@ def test_u64_the_longest_run_decides(G, length, accepted, capacity):
     pos = rng.choice(N_SMALL, size=length, replace=False)
     keys[pos] = (run << np.uint64(48)) | rng.integers(0, 2**48, length, dtype=np.uint64)
     vals = np.arange(N_SMALL, dtype=np.uint32)
-    gk, gv, fin = _run64(G, _sorter(G, **SMALL), keys, vals)
+    # (the round-4 rule: since round 6 a long run of 64-bit keys goes to segmented passes too, see test_long_runs_of_every_key_kind)
+    gk, gv, fin = _run64(G, _sorter(G, GLU_HIP_SORT_LONG_RUNS=0, **SMALL), keys, vals)
     ek, ev = O.stable_sort_pairs(keys, vals)
     assert (gk == ek).all() and (gv == ev).all()
     assert fin["attempted"] == 1 and fin["accepted"] == accepted and fin["longest_run"] == length and fin["capacity"] == capacity

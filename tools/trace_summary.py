@@ -38,7 +38,7 @@ for r in rows:
         cur, other, t0, names, busy, t_end = [], 0.0, None, {}, 0.0, None
     elif "radix_scatter_lines" in n and d > 100:
         cur.append(("S", d))
-    elif "radix_finish_sort" in n and d > 100:
+    elif ("radix_finish_sort" in n or "radix_finish_bucket" in n) and d > 100:
         cur.append(("F", d))
     elif "pair_count" in n and d > 100:
         cur.append(("C", d))
