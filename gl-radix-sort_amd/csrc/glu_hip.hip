@@ -483,6 +483,7 @@ struct glu_radix_sort_s
     uint32_t seg_stage_next = 0;
     // a segmented sort that ends in LDS (seg_run_plan): the longest run its first pass found (device word), and what the host knows
     Scratch long_image, long_hdr; // the long runs of a whole-key sort that ends in LDS: their segment descriptors, built on the device
+    Scratch long_bits;            // ... and OR / AND of every sub-block's keys (a long run of one key value is left where it is)
     Scratch seg_gate;
     bool seg_finish = true;             // GLU_HIP_SEG_LDS_FINISH=0: always the ordinary segmented passes (tests / tuning)
     bool last_seg_finish_attempted = false;
@@ -680,6 +681,7 @@ glu_status sort_prepare(glu_radix_sort_s* s, size_t count, size_t key_size, bool
                 // runs longer than the in-LDS pass's tile are sorted by segmented passes (radix_finish_long_runs_kernel)
                 GLU_TRY(s->long_image.reserve((size_t) LongRunsLayout((uint32_t) g_dev.num_cus).words * sizeof(uint32_t)));
                 GLU_TRY(s->long_hdr.reserve(64));
+                GLU_TRY(s->long_bits.reserve(2 * ((size_t) kLongRunsMax + g_dev.num_cus) * sizeof(uint64_t)));
                 GLU_TRY(s->table.reserve(((size_t) kLongRunsMax + g_dev.num_cus) * 256 * sizeof(uint32_t)));
             }
             if (!s->finish_hint)
@@ -1280,14 +1282,31 @@ glu_status launch_long_run_passes(glu_radix_sort_s* s, KeyT* a_k, uint32_t* a_v,
     const uint32_t* hdr = (const uint32_t*) s->long_hdr.ptr;
     uint32_t* table = (uint32_t*) s->table.ptr;
     const PassPlan* plan = (const PassPlan*) s->plan.ptr;
+    // (the first pass's count kernel also notes OR / AND of every sub-block's keys, its scan kernel empties the segments whose keys
+    // agree on all the ordered bits: a long run of one key value -- every long run of a duplicate-heavy input -- stays where it is)
+    KeyT* const sub_or = (KeyT*) s->long_bits.ptr;
+    KeyT* const sub_and = sub_or + (kLongRunsMax + nwg);
     for (uint32_t p = 0; p < kPasses; p++)
     {
-        hipLaunchKernelGGL((radix_seg_count_kernel<KeyT, 8, 1024>), dim3(nwg), dim3(1024), 0, stream, (const KeyT*) a_k, (const uint2*) image,
-                           image + lay.off_first, table, p * 8u, 255u, hdr, 0u, kSegGateIfNot, (const KeyT*) b_k, plan, 2u, p);
-        HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL((radix_seg_scan_kernel<RADIX>), dim3(512), dim3(RADIX), 0, stream, table, image + lay.off_list,
-                           image + lay.off_start, hdr, 0u, kSegGateIfNot, hdr); // (workgroups loop over the device-counted segments)
-        HIP_TRY(hipGetLastError());
+        if (p == 0)
+        {
+            hipLaunchKernelGGL((radix_seg_count_kernel<KeyT, 8, 1024, true>), dim3(nwg), dim3(1024), 0, stream, (const KeyT*) a_k, (const uint2*) image,
+                               image + lay.off_first, table, 0u, 255u, hdr, 0u, kSegGateIfNot, (const KeyT*) b_k, plan, 2u, 0u, sub_or, sub_and);
+            HIP_TRY(hipGetLastError());
+            hipLaunchKernelGGL((radix_seg_scan_kernel<RADIX, KeyT>), dim3(512), dim3(RADIX), 0, stream, table, image + lay.off_list,
+                               image + lay.off_start, hdr, 0u, kSegGateIfNot, hdr, (uint2*) const_cast<uint32_t*>(image), (const KeyT*) sub_or,
+                               (const KeyT*) sub_and, plan, (uint32_t) (8 * sizeof(KeyT) - 16));
+            HIP_TRY(hipGetLastError());
+        }
+        else
+        {
+            hipLaunchKernelGGL((radix_seg_count_kernel<KeyT, 8, 1024>), dim3(nwg), dim3(1024), 0, stream, (const KeyT*) a_k, (const uint2*) image,
+                               image + lay.off_first, table, p * 8u, 255u, hdr, 0u, kSegGateIfNot, (const KeyT*) b_k, plan, 2u, p);
+            HIP_TRY(hipGetLastError());
+            hipLaunchKernelGGL((radix_seg_scan_kernel<RADIX>), dim3(512), dim3(RADIX), 0, stream, table, image + lay.off_list,
+                               image + lay.off_start, hdr, 0u, kSegGateIfNot, hdr); // (workgroups loop over the device-counted segments)
+            HIP_TRY(hipGetLastError());
+        }
         hipLaunchKernelGGL(scatter, dim3(nwg), dim3(G::THREADS), sizeof(Smem), stream, (const KeyT*) a_k, (const uint32_t*) a_v, b_k, b_v,
                            (const uint32_t*) table, (const uint32_t*) nullptr, (uint32_t) count, p * 8u, 255u, 0u, (unsigned long long*) nullptr,
                            XF && p + 1 == kPasses ? key_xf << 2 : 0u, const_cast<PassPlan*>(plan), 2u, (const uint2*) image, p,
@@ -2261,7 +2280,7 @@ glu_status glu_radix_sort_destroy(glu_radix_sort sort)
     // library queue, before its scratch goes away (RAII of the reference: RadixSort.hpp:194-200, gl_utils.hpp:184-188)
     (void) hipDeviceSynchronize();
     for (Scratch* sc : {&sort->keys, &sort->vals, &sort->table, &sort->plan, &sort->pair_t2, &sort->pair_table, &sort->pair_ranges,
-                        &sort->pair_sub, &sort->seg_desc, &sort->seg_zero, &sort->finish_lengths, &sort->finish_starts, &sort->finish_crowded, &sort->finish_outcomes, &sort->seg_gate, &sort->long_image, &sort->long_hdr})
+                        &sort->pair_sub, &sort->seg_desc, &sort->seg_zero, &sort->finish_lengths, &sort->finish_starts, &sort->finish_crowded, &sort->finish_outcomes, &sort->seg_gate, &sort->long_image, &sort->long_hdr, &sort->long_bits})
         sc->release();
     if (sort->finish_hint) (void) hipHostFree(sort->finish_hint);
     for (hipEvent_t e : {sort->ev_fork, sort->ev_unit, sort->ev_fork2, sort->ev_join})

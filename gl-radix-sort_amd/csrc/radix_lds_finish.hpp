@@ -51,16 +51,27 @@ constexpr uint32_t kFinishRuns = 65536; // runs = values of the 16 top-bit key b
 //   words [kCrowdedLists * kCrowdedCountStride + k * capacity + i]              the i-th of them
 // The counters are zeroed by radix_finish_plan_kernel.
 constexpr uint32_t kCrowdedLists = 256, kCrowdedCountStride = 32;
-__host__ __device__ constexpr uint32_t crowded_list_capacity(uint32_t nruns) { return (nruns + kCrowdedLists - 1u) / kCrowdedLists; }
+// (which list: the top bits of run * 0x9E3779B1 -- the run number's low bits put every 16th run, a pattern keys do produce, into 16
+// of the 256 lists.  Consecutive run numbers spread evenly under this hash: 254 .. 258 of 65536 per list, twice the mean at worst
+// for strided subsets; a list holds twice its mean, and a run that finds its list full takes the next one.)
+__host__ __device__ constexpr uint32_t crowded_list_capacity(uint32_t nruns) { return 2u * ((nruns + kCrowdedLists - 1u) / kCrowdedLists); }
 __host__ __device__ constexpr size_t crowded_list_words(uint32_t nruns)
 {
     return (size_t) kCrowdedLists * kCrowdedCountStride + (size_t) kCrowdedLists * crowded_list_capacity(nruns);
 }
 __device__ __forceinline__ void crowded_list_append(uint32_t* lists, uint32_t nruns, uint32_t run)
 {
-    const uint32_t k = run & (kCrowdedLists - 1u);
-    const uint32_t i = atomicAdd(&lists[k * kCrowdedCountStride], 1u);
-    lists[kCrowdedLists * kCrowdedCountStride + k * crowded_list_capacity(nruns) + i] = run;
+    const uint32_t cap = crowded_list_capacity(nruns);
+    for (uint32_t k = (run * 0x9E3779B1u) >> 24;; k = (k + 1u) & (kCrowdedLists - 1u))
+    {
+        const uint32_t i = atomicAdd(&lists[k * kCrowdedCountStride], 1u);
+        if (i < cap)
+        {
+            lists[kCrowdedLists * kCrowdedCountStride + k * cap + i] = run;
+            return;
+        }
+        // (full -- its count stays above the capacity, the reader clamps it -- the next list; all lists together hold 2 x nruns)
+    }
 }
 
 // The plan (radix_finish_plan_kernel below): starts[r] = exclusive scan of the run lengths (starts[65536] = n), and the decision:
@@ -430,7 +441,10 @@ __global__ __launch_bounds__(1024) void radix_finish_plan_kernel(const uint32_t*
             uint32_t ol = 0, oc = 0;
             for (int w = 0; w < 16; w++) ol += over_tmp[0][g - 1][w], oc += over_tmp[1][g - 1][w];
             const bool few = oc <= kLongRunsMax && ol <= n / 8u;
-            const bool tolerable = g == geo_last && oc <= kLongRunsMax && ol <= n / 2u;
+            // (round 6: however many pairs the long runs hold -- two segmented passes over them move no more bytes than the two
+            // ordinary passes they replace, and a long run of one key value, which is what fills long runs as a rule, is not moved at
+            // all.  Round 5 refused the sort when more than half of the pairs sat in long runs.)
+            const bool tolerable = g == geo_last && oc <= kLongRunsMax;
             if (few || (tolerable && pick == 0)) pick = g;
         }
         if (pick) geo = geo == 0 ? pick : min(geo, pick);
@@ -916,7 +930,7 @@ __global__ __launch_bounds__(THREADS, (sizeof(KeyT) == 8 && THREADS == 512 ? GLU
     const bool listed = run_list && !plan->finish_rounds;
     if (run_list && !listed && !LOOP) return; // (the launch for all runs is the looping one)
     const uint32_t list = blockIdx.x & (kCrowdedLists - 1u);
-    const uint32_t todo = listed ? run_list[list * kCrowdedCountStride] : nruns;
+    const uint32_t todo = listed ? min(run_list[list * kCrowdedCountStride], crowded_list_capacity(nruns)) : nruns;
     const uint32_t step = !LOOP ? todo : listed ? max(gridDim.x / kCrowdedLists, 1u) : gridDim.x;
     const uint32_t* const my_list = run_list + kCrowdedLists * kCrowdedCountStride + list * crowded_list_capacity(nruns);
     for (uint32_t it = listed ? blockIdx.x / kCrowdedLists : blockIdx.x; it < todo; it += step)

@@ -73,7 +73,10 @@ __global__ __launch_bounds__(1024) void radix_seg_runs_kernel(const uint32_t* __
 // workgroup w of the scatter kernel moves.  (One workgroup per sub-block, the first version, ran 125 us where the plain
 // count kernel takes 86 us for the same 2^27 keys: sub-blocks come in all sizes, two share a CU, and the CU that draws two
 // large ones sets the kernel time.)
-template<typename KeyT, int BITS, int THREADS>
+// BITS_OUT (round 6, the first pass over the long runs of a whole-key sort): also the OR and the AND of every sub-block's keys, for
+// radix_seg_scan_kernel to find the segments whose keys agree on every bit the passes order -- a long run of ONE key value, what
+// duplicate-heavy inputs are made of -- and take them out of both passes.
+template<typename KeyT, int BITS, int THREADS, bool BITS_OUT = false>
 __global__ __launch_bounds__(THREADS) void radix_seg_count_kernel(const KeyT* __restrict__ keys,
                                                                   const uint2* __restrict__ subs,
                                                                   const uint32_t* __restrict__ seg_first,
@@ -81,11 +84,13 @@ __global__ __launch_bounds__(THREADS) void radix_seg_count_kernel(const KeyT* __
                                                                   const uint32_t* gate = nullptr, uint32_t gate_cap = 0,
                                                                   uint32_t gate_mode = kSegGateNone,
                                                                   const KeyT* __restrict__ keys_alt = nullptr,
-                                                                  const PassPlan* plan = nullptr, uint32_t flip_pass = 0, uint32_t swap = 0)
+                                                                  const PassPlan* plan = nullptr, uint32_t flip_pass = 0, uint32_t swap = 0,
+                                                                  KeyT* __restrict__ sub_or = nullptr, KeyT* __restrict__ sub_and = nullptr)
 {
     if (seg_gate_closed(gate, gate_cap, gate_mode)) return; // (kernel-uniform)
     // (the long runs of a whole-key sort that ends in LDS: which pair of arrays holds the data is known on the device only)
     if (plan && ((plan->flip[flip_pass] ^ swap) & 1u)) keys = keys_alt;
+    __shared__ KeyT bits_tmp[2][THREADS / kWave];
     constexpr int RADIX = 1 << BITS;
     constexpr int WAVES = THREADS / kWave;
     constexpr uint32_t EPV = 16 / sizeof(KeyT); // keys per 16-byte piece (8-byte keys: round 6, the long runs of 64-bit sorts)
@@ -101,9 +106,17 @@ __global__ __launch_bounds__(THREADS) void radix_seg_count_kernel(const KeyT* __
         if constexpr (sizeof(KeyT) == 4) return (KeyT) (e == 0 ? a.x : e == 1 ? a.y : e == 2 ? a.z : a.w);
         else return (KeyT) (e == 0 ? ((uint64_t) a.x | ((uint64_t) a.y << 32)) : ((uint64_t) a.z | ((uint64_t) a.w << 32)));
     };
+    KeyT acc_or = 0, acc_and = (KeyT) ~(KeyT) 0;
+    auto note = [&](KeyT k) {
+        if (BITS_OUT) acc_or |= k, acc_and &= k;
+    };
     auto tally_vec = [&](auto peel, const uint4& a) {
 #pragma unroll
-        for (int e = 0; e < (int) EPV; e++) tally(peel, dig(key_at(a, e)));
+        for (int e = 0; e < (int) EPV; e++)
+        {
+            note(key_at(a, e));
+            tally(peel, dig(key_at(a, e)));
+        }
     };
     const uint32_t sb_first = seg_first[blockIdx.x], sb_last = seg_first[blockIdx.x + 1];
     for (int i = tid; i < WAVES * RADIX; i += THREADS) (&hist[0][0])[i] = 0;
@@ -115,7 +128,12 @@ __global__ __launch_bounds__(THREADS) void radix_seg_count_kernel(const KeyT* __
         // head: the elements in front of the first 16-byte boundary
         uint64_t vstart = (begin + (EPV - 1)) & ~(uint64_t) (EPV - 1);
         if (vstart > end) vstart = end;
-        if (begin + tid < vstart) atomicAdd(&my_hist[dig(keys[begin + tid])], 1u);
+        if (BITS_OUT) acc_or = 0, acc_and = (KeyT) ~(KeyT) 0;
+        if (begin + tid < vstart)
+        {
+            note(keys[begin + tid]);
+            atomicAdd(&my_hist[dig(keys[begin + tid])], 1u);
+        }
         const uint64_t nvec = (end - vstart) / EPV;
         const uint4* vkeys = reinterpret_cast<const uint4*>(keys + vstart);
         uint64_t vbase = 0;
@@ -138,10 +156,28 @@ __global__ __launch_bounds__(THREADS) void radix_seg_count_kernel(const KeyT* __
         {
             const uint4 a = vkeys[v];
 #pragma unroll
-            for (int e = 0; e < (int) EPV; e++) atomicAdd(&my_hist[dig(key_at(a, e))], 1u);
+            for (int e = 0; e < (int) EPV; e++)
+            {
+                note(key_at(a, e));
+                atomicAdd(&my_hist[dig(key_at(a, e))], 1u);
+            }
         }
         const uint64_t tail = vstart + nvec * EPV + tid;
-        if (tail < end) atomicAdd(&my_hist[dig(keys[tail])], 1u);
+        if (tail < end)
+        {
+            note(keys[tail]);
+            atomicAdd(&my_hist[dig(keys[tail])], 1u);
+        }
+        if (BITS_OUT)
+        {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1)
+            {
+                acc_or |= (KeyT) __shfl_xor((unsigned long long) acc_or, o);
+                acc_and &= (KeyT) __shfl_xor((unsigned long long) acc_and, o);
+            }
+            if (lane == 0) bits_tmp[0][wave] = acc_or, bits_tmp[1][wave] = acc_and;
+        }
         __syncthreads();
         // the sub-block's row, and the counters back to zero for the next one
         for (int d = tid; d < RADIX; d += THREADS)
@@ -155,6 +191,13 @@ __global__ __launch_bounds__(THREADS) void radix_seg_count_kernel(const KeyT* __
             }
             table[(size_t) sb * RADIX + d] = c;
         }
+        if (BITS_OUT && tid == 0)
+        {
+            KeyT o = 0, a = (KeyT) ~(KeyT) 0;
+            for (int w = 0; w < WAVES; w++) o |= bits_tmp[0][w], a &= bits_tmp[1][w];
+            sub_or[sb] = o;
+            sub_and[sb] = a;
+        }
         __syncthreads();
     }
 }
@@ -163,22 +206,55 @@ __global__ __launch_bounds__(THREADS) void radix_seg_count_kernel(const KeyT* __
 // turns the counts of digit d into running sums, scans the RADIX digit totals of the segment, and adds segment start +
 // digit offset to every entry.  (What BlellochScan + the reorder shader's 16-lane global scan do per pass in the
 // reference, BlellochScan.hpp:142-190, RadixSort.hpp:148-152 -- per segment.)
-template<int RADIX>
+// sub_or / sub_and (round 6, the first pass over the long runs of a whole-key sort; radix_seg_count_kernel<.., BITS_OUT> wrote
+// them): a segment whose keys agree on every bit of `ordered` -- the bits the passes order -- is in order as it stands (equal keys
+// in input order): its sub-blocks are made EMPTY in the descriptor image (subs[i].y = subs[i].x), and this pass's scatter and
+// every kernel of the passes behind it find nothing to do there.  A long run of one key value then costs the one read that found
+// that out instead of 2 x 20 bytes per pair.
+template<int RADIX, typename KeyT = uint32_t>
 __global__ __launch_bounds__(RADIX) void radix_seg_scan_kernel(uint32_t* __restrict__ table,
                                                                const uint32_t* __restrict__ seg_list,
                                                                const uint32_t* __restrict__ seg_start,
                                                                const uint32_t* gate = nullptr, uint32_t gate_cap = 0,
-                                                               uint32_t gate_mode = kSegGateNone, const uint32_t* nseg_dev = nullptr)
+                                                               uint32_t gate_mode = kSegGateNone, const uint32_t* nseg_dev = nullptr,
+                                                               uint2* subs = nullptr, const KeyT* __restrict__ sub_or = nullptr,
+                                                               const KeyT* __restrict__ sub_and = nullptr, const PassPlan* plan = nullptr,
+                                                               uint32_t ordered_bits = 0)
 {
     if (seg_gate_closed(gate, gate_cap, gate_mode)) return; // (kernel-uniform)
     constexpr int WAVES = (RADIX + kWave - 1) / kWave;
     __shared__ uint32_t wave_sums[WAVES];
+    __shared__ KeyT seg_bits[2][WAVES];
     const uint32_t d = threadIdx.x, lane = d & 63, wave = d >> 6;
+    // (the bits the long-run passes order: those below the runs' 16, which the device may have chosen -- PassPlan::top_bit)
+    if (plan && plan->top_bit) ordered_bits = plan->top_bit - 16u;
+    const KeyT ordered = ordered_bits >= 8u * sizeof(KeyT) ? (KeyT) ~(KeyT) 0 : (KeyT) ((((KeyT) 1) << ordered_bits) - 1);
     // (segments counted on the device -- nseg_dev: the workgroups loop over them; else a workgroup per segment)
     const uint32_t nseg = nseg_dev ? *nseg_dev : gridDim.x;
     for (uint32_t g = blockIdx.x; g < nseg; g += gridDim.x)
     {
     const uint32_t i0 = seg_list[g], i1 = seg_list[g + 1];
+    if (sub_or)
+    {
+        KeyT o = 0, a = (KeyT) ~(KeyT) 0;
+        for (uint32_t i = i0 + d; i < i1; i += RADIX) o |= sub_or[i], a &= sub_and[i];
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1)
+        {
+            o |= (KeyT) __shfl_xor((unsigned long long) o, s);
+            a &= (KeyT) __shfl_xor((unsigned long long) a, s);
+        }
+        if (lane == 0) seg_bits[0][wave] = o, seg_bits[1][wave] = a;
+        __syncthreads();
+        o = 0, a = (KeyT) ~(KeyT) 0;
+        for (int w = 0; w < WAVES; w++) o |= seg_bits[0][w], a &= seg_bits[1][w];
+        __syncthreads(); // (seg_bits is rewritten for the next segment)
+        if (((o ^ a) & ordered) == 0) // (workgroup-uniform) one value in the ordered bits: nothing to do for this segment, ever
+        {
+            for (uint32_t i = i0 + d; i < i1; i += RADIX) subs[i].y = subs[i].x;
+            continue;
+        }
+    }
     uint32_t run = 0;
     uint32_t i = i0;
     for (; i + 4 <= i1; i += 4) // 4 independent loads in flight

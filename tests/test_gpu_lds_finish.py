@@ -94,13 +94,19 @@ def test_duplicate_keys_inside_runs_keep_their_order(G):
     assert fin["accepted"] == 1
 
 
-def test_small_key_range_is_refused_and_sorted_by_the_ordinary_passes(G):
-    """(Round-4 rule, GLU_HIP_SORT_DEVICE_TOP=0: the host takes the runs' key bits from the object's last attempt.)  Keys below 2^20: sixteen runs hold everything -- the device says no after the first count kernel, the top-bit passes
-    move nothing, the ordinary passes follow (their two top-byte passes skipped as usual)."""
+def test_small_key_range_under_the_host_side_guess(G):
+    """20-bit keys with the round-4 rule for the runs' bits (GLU_HIP_SORT_DEVICE_TOP=0: a fresh object takes the whole key's top 16):
+    16 runs of a quarter million pairs each.  Round 5 refused (more than half of the pairs in long runs); since round 6 the
+    segmented passes take them, however many pairs they hold.  GLU_HIP_SORT_LONG_RUNS=0: refused, the ordinary passes run."""
     rng = np.random.default_rng(4)
     keys = rng.integers(0, 1 << 20, N_SMALL, dtype=np.uint32)
     vals = np.arange(N_SMALL, dtype=np.uint32)
     s = _sorter(G, GLU_HIP_SORT_DEVICE_TOP=0, **SMALL)
+    gk, gv, fin = _run(G, s, keys, vals)
+    _check(keys, vals, gk, gv)
+    assert fin["attempted"] == 1 and fin["accepted"] == 1 and fin["longest_run"] > CAP_SMALL
+    assert s.read_long_runs()["runs"] == 16
+    s = _sorter(G, GLU_HIP_SORT_DEVICE_TOP=0, GLU_HIP_SORT_LONG_RUNS=0, **SMALL)
     gk, gv, fin = _run(G, s, keys, vals)
     _check(keys, vals, gk, gv)
     assert fin["attempted"] == 1 and fin["accepted"] == 0 and fin["longest_run"] > CAP_SMALL
@@ -108,11 +114,17 @@ def test_small_key_range_is_refused_and_sorted_by_the_ordinary_passes(G):
     assert skipped[:3] == [0, 0, 0] and skipped[3] != 0 and roles == [1, 2, 1, 2]
 
 
-def test_all_keys_equal_is_refused(G):
-    """One run of n keys: the 16-bit counters of the two-digit table overflow, the lengths do not add up, refused."""
+def test_all_keys_equal(G):
+    """One run of n equal keys.  At this size no 16-bit counter of the two-digit table wraps (a block holds 16 Ki keys): the run
+    lengths are exact, the one run is a long run, and the first segmented pass finds it in order as it stands (round 5 refused the
+    sort: more than half of the pairs in long runs).  The round-4 rule still refuses."""
     keys = np.full(N_SMALL, 0xDEADBEEF, dtype=np.uint32)
     vals = np.arange(N_SMALL, dtype=np.uint32)
-    gk, gv, fin = _run(G, _sorter(G, **SMALL), keys, vals)
+    s = _sorter(G, **SMALL)
+    gk, gv, fin = _run(G, s, keys, vals)
+    _check(keys, vals, gk, gv)
+    assert fin["attempted"] == 1 and fin["accepted"] == 1 and s.read_long_runs()["pairs"] == N_SMALL
+    gk, gv, fin = _run(G, _sorter(G, GLU_HIP_SORT_LONG_RUNS=0, **SMALL), keys, vals)
     _check(keys, vals, gk, gv)
     assert fin["attempted"] == 1 and fin["accepted"] == 0
 
@@ -257,11 +269,34 @@ def test_many_long_runs_and_one_percent_zeros_of_other_key_kinds(G, kind):
         assert fin["accepted"] == 1 and lr["runs"] >= 41, (fin, lr)
 
 
+@pytest.mark.parametrize("distinct", [17, 100, 1000, 5000])
+@pytest.mark.parametrize("kind", ["u32_pairs", "u64_pairs", "int32"])
+def test_few_distinct_values_end_in_lds_and_their_runs_stay_put(G, kind, distinct):
+    """Every key is one of `distinct` values (scattered over the key space), a few thousand to a few hundred thousand copies each:
+    every run of equal top bits is a long run of ONE key value (or of a few: with 5000 values some share their top 16 bits) -- the
+    sort ends in LDS, and the segmented passes find the single-valued runs in order as they stand."""
+    wide = kind == "u64_pairs"
+    dt = np.uint64 if wide else np.uint32
+    rng = np.random.default_rng(1000 + distinct)
+    n = N_SMALL
+    pool = rng.integers(0, 2**(64 if wide else 32), distinct, dtype=dt)
+    keys = pool[rng.integers(0, distinct, n)]
+    vals = np.arange(n, dtype=np.uint32)
+    s = _sorter(G, **SMALL)
+    gk, gv, fin, lr = _sort_kind(G, s, kind, keys, vals)
+    order = np.argsort(keys, kind="stable")
+    assert (gk == keys[order]).all() and (gv == vals[order]).all()
+    assert fin["attempted"] == 1 and fin["accepted"] == 1, (fin, lr)
+    if distinct <= 100:  # (a value's copies outgrow every enqueued tile: each is a long run, and nothing but long runs is left)
+        assert lr["runs"] >= distinct * 0.95 and lr["pairs"] == n, (fin, lr)
+
+
 @pytest.mark.parametrize("shape", ["long_run_first", "long_run_last", "many_long_runs", "long_runs_of_equal_keys", "zeros_1_percent",
                                    "an_eighth_in_long_runs", "more_than_half_in_long_runs", "too_many_long_runs"])
 def test_mixed_long_and_short_runs(G, shape):
-    """Long runs at index 0 and 65535, hundreds of them, long runs of one key value, and the two ways out: more than half of the
-    pairs in long runs, or more than 8192 long runs, still send the sort to the ordinary passes."""
+    """Long runs at index 0 and 65535, hundreds of them, long runs of one key value (left where they are: their sub-blocks are emptied
+    by the first segmented pass's scan kernel), more than half of the pairs in long runs (accepted since round 6), and the way out
+    that is left: more than 8192 runs longer than every enqueued tile send the sort to the ordinary passes."""
     rng = np.random.default_rng(77)
     n = N_SMALL  # mean run 64; the tile for uniform keys holds 1536, the largest enqueued 4608
     keys = rng.integers(0, 2**32, n, dtype=np.uint32)
@@ -284,7 +319,7 @@ def test_mixed_long_and_short_runs(G, shape):
     elif shape == "more_than_half_in_long_runs":
         pos = rng.choice(n, n * 6 // 10, replace=False)
         keys[pos] = (rng.integers(0, 30, pos.size, dtype=np.uint32) << np.uint32(16)) | (keys[pos] & np.uint32(0xFFFF))
-        want = {"accepted": 0}
+        # (round 5 refused this; round 6: two segmented passes over the long runs move no more than the ordinary passes would)
     else:  # too_many_long_runs: 9000 runs of 1600 pairs need more than three segments' worth of ... 14.4 M pairs: a larger input
         n = 9000 * 1600 + (1 << 22)
         keys = rng.integers(0, 2**32, n, dtype=np.uint32)
@@ -660,14 +695,19 @@ def test_u64_keys_only_and_duplicates(G):
     assert (gk == ek).all() and (gv == ev).all() and fin["accepted"] == 1
 
 
-def test_u64_small_range_is_refused(G):
+def test_u64_small_range(G):
     keys = _uniform64(N_SMALL, 33) >> np.uint64(20)
     vals = np.arange(N_SMALL, dtype=np.uint32)
-    s = _sorter(G, GLU_HIP_SORT_DEVICE_TOP=0, **SMALL)
+    s = _sorter(G, GLU_HIP_SORT_DEVICE_TOP=0, GLU_HIP_SORT_LONG_RUNS=0, **SMALL)
     gk, gv, fin = _run64(G, s, keys, vals)
     ek, ev = O.stable_sort_pairs(keys, vals)
     assert (gk == ek).all() and (gv == ev).all()
     assert fin["attempted"] == 1 and fin["accepted"] == 0
+    # (the default since round 6: the few long runs go to the segmented passes)
+    s = _sorter(G, GLU_HIP_SORT_DEVICE_TOP=0, **SMALL)
+    gk, gv, fin = _run64(G, s, keys, vals)
+    assert (gk == ek).all() and (gv == ev).all()
+    assert fin["attempted"] == 1 and fin["accepted"] == 1 and s.read_long_runs()["runs"] > 0
 
 
 @pytest.mark.parametrize("length,accepted,capacity", [(1536, 1, 1536), (1537, 1, 2560), (4608, 1, 4608), (4609, 0, 4608)])
@@ -751,18 +791,19 @@ def test_typed_keys_end_in_lds(G, name, with_vals):
         assert (vb.get_data(np.uint32) == vals[order]).all()
 
 
-def test_typed_keys_of_a_small_range_are_refused(G):
+def test_typed_keys_of_a_small_range(G):
     n = N_SMALL
     keys = np.random.default_rng(42).integers(-5000, 5000, n, dtype=np.int32)
     vals = np.arange(n, dtype=np.uint32)
-    s = _sorter(G, **SMALL)
-    kb, vb = G.ShaderStorageBuffer(keys), G.ShaderStorageBuffer(vals)
-    s.sort_typed_ptr(kb.device_ptr(), vb.device_ptr(), n, "int32")
-    G.synchronize()
-    fin = s.read_finish()
-    assert fin["attempted"] == 1 and fin["accepted"] == 0
     order = np.argsort(keys, kind="stable")
-    assert (kb.get_data(np.int32) == keys[order]).all() and (vb.get_data(np.uint32) == vals[order]).all()
+    for long_runs, accepted in ((0, 0), (1, 1)):  # (the round-4 rule; the default since round 6: two long runs, the segmented passes')
+        s = _sorter(G, GLU_HIP_SORT_LONG_RUNS=long_runs, **SMALL)
+        kb, vb = G.ShaderStorageBuffer(keys), G.ShaderStorageBuffer(vals)
+        s.sort_typed_ptr(kb.device_ptr(), vb.device_ptr(), n, "int32")
+        G.synchronize()
+        fin = s.read_finish()
+        assert fin["attempted"] == 1 and fin["accepted"] == accepted, fin
+        assert (kb.get_data(np.int32) == keys[order]).all() and (vb.get_data(np.uint32) == vals[order]).all()
 
 
 @pytest.mark.parametrize("name", ["int32", "float64"])

@@ -3,7 +3,7 @@ many runs go to the segmented passes, how many bytes per pair move.  Every distr
 sort of such keys) and then six more times on the same object (restored input, back to back); the line holds the first sort's time and the median
 of the later ones.  The result of the last sort is checked for ascending keys on the host.
    python tools/measure_distributions_2p28.py [log2 pairs = 28]
-Record: profiles/r05/distributions_2p28.txt"""
+Record: profiles/r06/distributions_2p28.txt"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "gl-radix-sort_amd"))
@@ -54,6 +54,11 @@ dists = [
     ("sorted (uniform, ascending)", lambda: np.sort(uniform())),
     ("reversed (uniform, descending)", lambda: np.sort(uniform())[::-1].copy()),
     ("three values", lambda: rng.integers(0, 3, n, dtype=np.uint32) * np.uint32(0x55555555)),
+    ("100 distinct values, scattered over the key space", lambda: rng.integers(0, 2**32, 100, dtype=np.uint64).astype(np.uint32)[rng.integers(0, 100, n)]),
+    ("1000 distinct values, scattered", lambda: rng.integers(0, 2**32, 1000, dtype=np.uint64).astype(np.uint32)[rng.integers(0, 1000, n)]),
+    ("2^16 distinct values, scattered", lambda: rng.integers(0, 2**32, 65536, dtype=np.uint64).astype(np.uint32)[rng.integers(0, 65536, n)]),
+    ("2^20 distinct values, scattered (256 copies each)", lambda: rng.integers(0, 2**32, 1 << 20, dtype=np.uint64).astype(np.uint32)[rng.integers(0, 1 << 20, n)]),
+    ("uniform + 10 % zeros", lambda: with_zeros(10.0)),
     ("all zero (the reference README's benchmark input)", lambda: np.zeros(n, dtype=np.uint32)),
 ]
 vals = np.arange(n, dtype=np.uint32)
