@@ -1142,7 +1142,7 @@ glu_status launch_seg_finish_geo(const uint32_t* src_k, const uint32_t* src_v, u
     {
         hipLaunchKernelGGL(sort_kernel, dim3(nruns), dim3(THREADS), sizeof(Smem), stream, const_cast<uint32_t*>(src_k), const_cast<uint32_t*>(src_v),
                            dst_k, dst_v, starts, low_bits, (const PassPlan*) nullptr, 0u, geo, 0u, nruns, gate, gate_cap, rank_bits,
-                           (unsigned long long*) nullptr, (const uint32_t*) nullptr);
+                           (unsigned long long*) nullptr, (const uint32_t*) nullptr, 0u);
         HIP_TRY(hipGetLastError());
     }
     const uint64_t items = (((uint64_t) nruns + 7u) & ~7ull) << split_log2;
@@ -1206,9 +1206,12 @@ glu_status launch_finish(KeyT* keys_a, uint32_t* vals_a, KeyT* keys_b, uint32_t*
                            crowded);                                                                                              \
         HIP_TRY(hipGetLastError());                                                                                               \
     }
-    // (geometry 0 = whichever tile the device chose; the runs longer than THAT tile are the segmented passes')
-#define GLU_FINISH_ROUNDS(GEO_, THREADS_, KPT_)                                                                                   \
-    if (geo_last == GEO_)                                                                                                         \
+    // The runs the bucket kernel listed (or all of them: PassPlan::finish_rounds) by ballot rounds, 8192 workgroups that loop: one
+    // launch in the tile the sort is expected to take (four workgroups per CU for 256 x 18: 24-bit keys 3.15 -> 2.95 ms at 2^28
+    // against one launch in the largest tile), and one in the largest enqueued tile for whatever else the device chose (runs
+    // longer than the CHOSEN tile are the segmented passes' either way).
+#define GLU_FINISH_ROUNDS(GEO_, THREADS_, KPT_, FOR_EXPECTED_)                                                                    \
+    if (FOR_EXPECTED_ ? GEO_ == geo_expected : (GEO_ == geo_last && geo_first != geo_last))                                       \
     {                                                                                                                             \
         using Smem = FinishSmem<KeyT, THREADS_, KPT_, VALS>;                                                                      \
         auto kern = radix_finish_sort_kernel<KeyT, THREADS_, KPT_, VALS, true, XF>;                                               \
@@ -1218,9 +1221,10 @@ glu_status launch_finish(KeyT* keys_a, uint32_t* vals_a, KeyT* keys_b, uint32_t*
             lds_opt_in_result = hipFuncSetAttribute((const void*) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sizeof(Smem)); \
         });                                                                                                                       \
         HIP_TRY(lds_opt_in_result);                                                                                               \
-        hipLaunchKernelGGL(kern, dim3(2048), dim3(THREADS_), sizeof(Smem), stream, keys_a, vals_a, keys_b, vals_b, starts,        \
-                           low_bits, plan, pass, 0u, key_xf, nruns, (const uint32_t*) nullptr, 0u, rank_bits,                     \
-                           (unsigned long long*) nullptr, (const uint32_t*) crowded);                                             \
+        hipLaunchKernelGGL(kern, dim3(8192), dim3(THREADS_), sizeof(Smem), stream, keys_a, vals_a, keys_b, vals_b, starts,        \
+                           low_bits, plan, pass, FOR_EXPECTED_ ? (uint32_t) GEO_ : 0u, key_xf, nruns, (const uint32_t*) nullptr,  \
+                           0u, rank_bits, (unsigned long long*) nullptr, (const uint32_t*) crowded,                               \
+                           FOR_EXPECTED_ ? 0u : geo_expected);                                                                    \
         HIP_TRY(hipGetLastError());                                                                                               \
     }
     for (int turn = 0; turn < 2; turn++)
@@ -1240,15 +1244,22 @@ glu_status launch_finish(KeyT* keys_a, uint32_t* vals_a, KeyT* keys_b, uint32_t*
             GLU_FINISH(4, 1024, 9)
         }
     }
-    if constexpr (sizeof(KeyT) == 4)
+    // (first the launch for the expected tile, then -- if more than one tile is enqueued -- the one in the largest tile for every
+    // other choice of the device, the expected tile excepted: whatever the device chose, one of the two takes the listed runs)
+    for (int for_expected = 1; for_expected >= 0; for_expected--)
     {
-        GLU_FINISH_ROUNDS(3, 256, 18)
-        GLU_FINISH_ROUNDS(4, 512, 18)
-    }
-    else
-    {
-        GLU_FINISH_ROUNDS(3, 512, 9)
-        GLU_FINISH_ROUNDS(4, 1024, 9)
+        GLU_FINISH_ROUNDS(1, 256, 6, for_expected)
+        GLU_FINISH_ROUNDS(2, 256, 10, for_expected)
+        if constexpr (sizeof(KeyT) == 4)
+        {
+            GLU_FINISH_ROUNDS(3, 256, 18, for_expected)
+            GLU_FINISH_ROUNDS(4, 512, 18, for_expected)
+        }
+        else
+        {
+            GLU_FINISH_ROUNDS(3, 512, 9, for_expected)
+            GLU_FINISH_ROUNDS(4, 1024, 9, for_expected)
+        }
     }
 #undef GLU_FINISH
 #undef GLU_FINISH_ROUNDS
@@ -1288,7 +1299,8 @@ glu_status launch_long_run_passes(glu_radix_sort_s* s, KeyT* a_k, uint32_t* a_v,
     KeyT* const sub_and = sub_or + (kLongRunsMax + nwg);
     for (uint32_t p = 0; p < kPasses; p++)
     {
-        if (p == 0)
+        // (not typed keys: their long runs have to pass through the last pass, which decodes them)
+        if (p == 0 && !XF)
         {
             hipLaunchKernelGGL((radix_seg_count_kernel<KeyT, 8, 1024, true>), dim3(nwg), dim3(1024), 0, stream, (const KeyT*) a_k, (const uint2*) image,
                                image + lay.off_first, table, 0u, 255u, hdr, 0u, kSegGateIfNot, (const KeyT*) b_k, plan, 2u, 0u, sub_or, sub_and);

@@ -236,7 +236,7 @@ __global__ __launch_bounds__(THREADS, GLU_BUCKET_WAVES_PER_SIMD) void radix_fini
     bool crowded_seen = false;
     {
         // (before any atomic: a wave whose first words crowd into one bucket -- four lanes or more with the bucket of the first
-        // valid lane, 0.02 expected for uniformly drawn keys -- says so at once: the atomics of a run of a few distinct keys
+        // valid lane (eight in the small tiles), 0.02 expected for uniformly drawn keys -- says so at once: the atomics of a run of a few distinct keys
         // serialise 64-fold, 0.77 ms for 2^28 pairs of them where the loads alone take 0.3)
         const bool v0 = word[0] != INVALID;
         const uint64_t vm = __ballot(v0);
@@ -244,7 +244,10 @@ __global__ __launch_bounds__(THREADS, GLU_BUCKET_WAVES_PER_SIMD) void radix_fini
         {
             const uint32_t d0 = (uint32_t) (word[0] >> dsh);
             const uint32_t lead = (uint32_t) __builtin_amdgcn_readlane((int) d0, (int) __builtin_ctzll(vm));
-            if (__popcll(__ballot(v0 && d0 == lead)) >= 4)
+            // (fewer buckets, more chance meetings: 64 words in 1024 buckets put four into one bucket 4 x 10^-5 of the time -- a few
+            // runs of every 65536 -- and eight never)
+            constexpr int kSameBucket = NB >= 4096 ? 4 : NB >= 2048 ? 6 : 8;
+            if (__popcll(__ballot(v0 && d0 == lead)) >= kSameBucket)
             {
                 crowded_seen = true;
                 if (lane == 0) s.crowded = 1u;

@@ -904,7 +904,8 @@ __global__ __launch_bounds__(THREADS, (sizeof(KeyT) == 8 && THREADS == 512 ? GLU
                                                                     uint32_t nruns = kFinishRuns, const uint32_t* gate = nullptr,
                                                                     uint32_t gate_cap = 0, uint32_t rank_bits = 16,
                                                                     unsigned long long* stamps = nullptr,
-                                                                    const uint32_t* __restrict__ run_list = nullptr)
+                                                                    const uint32_t* __restrict__ run_list = nullptr,
+                                                                    uint32_t except_geometry = 0)
 {
     FinishClock<STAMPS> clock;
     if (plan && plan->top_bit) low_bits = plan->top_bit - 16u; // (the device chose the runs' bits: radix_sample_top_kernel)
@@ -912,8 +913,9 @@ __global__ __launch_bounds__(THREADS, (sizeof(KeyT) == 8 && THREADS == 512 ? GLU
     const uint32_t rank_from = low_bits > rank_bits ? ((low_bits - rank_bits) / 8u) * 8u : 0u;
     const KeyCodec<KeyT, XF> codec_out(key_xf);
     // (kernel-uniform: the device chose another geometry, or the ordinary passes)
-    // (geometry 0: whichever tile the device chose -- the launch behind radix_finish_bucket_kernel that takes the runs it flagged)
-    if (plan ? (geometry ? plan->finish != geometry : plan->finish == 0u) : *gate > gate_cap) return;
+    // (geometry 0: whichever tile the device chose, except except_geometry -- the launches behind radix_finish_bucket_kernel that
+    // take the runs it listed: one in the tile the sort is expected to take, one in the largest enqueued tile for any other choice)
+    if (plan ? (geometry ? plan->finish != geometry : (plan->finish == 0u || plan->finish == except_geometry)) : *gate > gate_cap) return;
     using Smem = FinishSmem<KeyT, THREADS, KPT, VALS>;
     constexpr int WAVES = Smem::WAVES;
 

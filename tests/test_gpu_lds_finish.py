@@ -354,15 +354,42 @@ def test_long_runs_on_one_object_back_to_back(G):
         keys = rng.integers(0, 2**32, n, dtype=np.uint32)
         if kind == "long":
             keys[rng.choice(n, 3000 + 4000 * it, replace=False)] &= np.uint32(0x0000FFFF)  # run 0 gets them
-        elif kind == "refused":  # (full-range keys, six in ten crowded into thirty runs: more than the long-run passes take)
+        elif kind == "refused":  # (full-range keys, six in ten crowded into thirty runs, and -- for this sort -- the round-4 rule: a
+            # run longer than every enqueued tile refuses the sort.  By default the long-run passes have taken such inputs since round 6.)
             crowd = rng.choice(n, n * 6 // 10, replace=False)
             keys[crowd] = (rng.integers(0, 30, crowd.size, dtype=np.uint32) * np.uint32(2001) << np.uint32(16)) | (keys[crowd] & np.uint32(0xFFFF))
+        s.set_option("SORT_LONG_RUNS", 0 if kind == "refused" else 1)
         vals = np.arange(n, dtype=np.uint32)
         gk, gv, fin = _run(G, s, keys, vals)
         _check(keys, vals, gk, gv)
         lr = s.read_long_runs()
         assert fin["accepted"] == (0 if kind == "refused" else 1), (kind, fin)
         assert (lr["runs"] > 0) == (kind == "long"), (kind, lr)
+
+
+def test_crowded_runs_in_a_tile_the_object_did_not_expect(G):
+    """An object whose last sort took the large tile expects it again; the next sort's runs fit the small one, and some of them are
+    crowded (four distinct keys): the small tile's kernel, launched with 8192 looping workgroups, lists them and the launch of
+    the ballot rounds for 'any tile but the expected one' takes them (found by test_u64_keys_of_a_smaller_range in round 6:
+    listed runs that no launch took came out unsorted)."""
+    rng = np.random.default_rng(123)
+    n = N_SMALL
+    vals = np.arange(n, dtype=np.uint32)
+    s = _sorter(G, GLU_HIP_SORT_LONG_RUNS=0, **SMALL)  # (the longest run decides the tile)
+    first = _with_one_run_of(n, 4000, 31)  # a run of 4000: the 4608 tile
+    gk, gv, fin = _run(G, s, first, vals)
+    _check(first, vals, gk, gv)
+    assert fin["accepted"] == 1 and fin["capacity"] == 4608
+    keys = _uniform(n, 32)
+    for run in (5, 600, 40000, 65535):  # a few runs of four distinct keys, 1200 pairs each: crowded, and short of the 1536 tile
+        clash = (keys >> 16) == run
+        keys[clash] ^= np.uint32(0x00010000)
+        pos = rng.choice(n, 1200, replace=False)
+        keys[pos] = (np.uint32(run) << np.uint32(16)) | (rng.integers(0, 4, 1200, dtype=np.uint32) * np.uint32(0x1111))
+    for _ in range(2):
+        gk, gv, fin = _run(G, s, keys, vals)
+        _check(keys, vals, gk, gv)
+        assert fin["accepted"] == 1 and fin["capacity"] == 1536, fin
 
 
 def test_empty_runs_and_runs_of_one(G):
@@ -396,7 +423,9 @@ def test_one_object_alternates_between_the_two_sequences(G):
     of the bits that varied in the attempt before (a guess the device checks): uniform keys end in LDS, 18-bit keys are refused
     under the first assumption and end in LDS under the second (runs = bits [2, 18)), full-range keys are then refused once --
     bits above 18 vary -- and end in LDS again.  A small sort (no plan) in between changes nothing."""
-    s = _sorter(G, GLU_HIP_SORT_DEVICE_TOP=0, GLU_HIP_SORT_FINISH_BACKOFF=0, **SMALL)
+    # (GLU_HIP_SORT_LONG_RUNS=0: with the long-run passes, the default, the four long runs of 18-bit keys under the first assumption
+    # end in LDS too -- test_small_key_range_under_the_host_side_guess)
+    s = _sorter(G, GLU_HIP_SORT_DEVICE_TOP=0, GLU_HIP_SORT_FINISH_BACKOFF=0, GLU_HIP_SORT_LONG_RUNS=0, **SMALL)
     vals = np.arange(N_SMALL, dtype=np.uint32)
     steps = [(8, False, 1, 32), (9, True, 0, 32), (10, True, 1, 18), (11, False, 0, 18), (12, False, 1, 32), (13, False, 1, 32)]
     for seed, small_range, accepted, top in steps:
@@ -417,7 +446,7 @@ def test_keys_of_a_smaller_range_with_the_host_side_guess(G, bits, garbage):
     """(Round-4 rule, GLU_HIP_SORT_DEVICE_TOP=0: the host takes the runs' key bits from the object's last attempt.)  Keys below 2^bits (with or without constant bits above) crowd into few runs of the whole key's top bits: the first sort is
     refused; it has noted which key bits vary, and the second takes its runs from the top 16 of those -- bits [bits - 16, bits)
     -- and orders the remaining low bits (12, 5, 1, none, 15) inside LDS."""
-    s = _sorter(G, GLU_HIP_SORT_DEVICE_TOP=0, **SMALL)
+    s = _sorter(G, GLU_HIP_SORT_LONG_RUNS=0, GLU_HIP_SORT_DEVICE_TOP=0, **SMALL)
     vals = np.arange(N_SMALL, dtype=np.uint32)
     for rep in range(3):
         keys = (_uniform(N_SMALL, 50 + rep) >> np.uint32(32 - bits)) | np.uint32(garbage)
@@ -454,8 +483,9 @@ def _crowded_and_wide():
 
 def test_every_sort_asks_whatever_the_object_sorted_before(G):
     """What a sort costs does not depend on the object's history: after refused attempts (crowded keys, all-zero keys) the next
-    sort of keys that fit ends in LDS at once."""
-    s = _sorter(G, **SMALL)
+    sort of keys that fit ends in LDS at once.  (GLU_HIP_SORT_LONG_RUNS=0: the round-4 rule makes the crowded keys a refusal; by
+    default their long runs go to the segmented passes.)"""
+    s = _sorter(G, GLU_HIP_SORT_LONG_RUNS=0, **SMALL)
     vals = np.arange(N_SMALL, dtype=np.uint32)
     narrow, wide = _crowded_and_wide()
     zeros = np.zeros(N_SMALL, dtype=np.uint32)
@@ -470,7 +500,7 @@ def test_every_sort_asks_whatever_the_object_sorted_before(G):
 def test_the_back_off_switch_skips_attempts_after_a_refusal(G):
     """GLU_HIP_SORT_FINISH_BACKOFF=8 (round 4's default): an object whose last attempt was refused skips the next eight attempts,
     then asks again (inputs that never fit pay for the refused attempt's read of the keys once in nine sorts)."""
-    s = _sorter(G, GLU_HIP_SORT_FINISH_BACKOFF=8, **SMALL)
+    s = _sorter(G, GLU_HIP_SORT_FINISH_BACKOFF=8, GLU_HIP_SORT_LONG_RUNS=0, **SMALL)  # (the round-4 rule: crowded keys are refused)
     vals = np.arange(N_SMALL, dtype=np.uint32)
     narrow, wide = _crowded_and_wide()
     seen = []
@@ -586,8 +616,8 @@ def test_beyond_the_largest_geometry_no_attempt_is_made(G):
 
 def test_profile_books_the_sequence_that_ran(G):
     """read_profile counts the passes that did the work: two counting passes + the in-LDS pass when accepted, the four
-    ordinary passes when refused."""
-    s = _sorter(G, **SMALL)
+    ordinary passes when refused (GLU_HIP_SORT_LONG_RUNS=0: the crowded keys below are a refusal under the round-4 rule)."""
+    s = _sorter(G, GLU_HIP_SORT_LONG_RUNS=0, **SMALL)
     s.set_profiling(True)
     vals = np.arange(N_SMALL, dtype=np.uint32)
     _run(G, s, _uniform(N_SMALL, 11), vals)
@@ -630,12 +660,17 @@ def test_one_captured_graph_serves_every_outcome(G):
     side = torch.cuda.Stream()
     graph = torch.cuda.CUDAGraph()
     vals = np.arange(n, dtype=np.uint32)
-    crowd = _uniform(n, 26)  # six keys in ten crowded into thirty runs: refused
+    crowd = _uniform(n, 26)  # six keys in ten crowded into thirty runs: thirty long runs
     pos = np.random.default_rng(26).choice(n, n * 6 // 10, replace=False)
     crowd[pos] = (np.random.default_rng(27).integers(0, 30, pos.size, dtype=np.uint32) * np.uint32(2001) << np.uint32(16)) | (crowd[pos] & np.uint32(0xFFFF))
     # (a long run goes to the segmented passes, 22-bit keys take their runs from bits [6, 22): both end in LDS in the small tile)
+    # (refused by default since round 6: only what the runs' bits cannot order -- 20-bit keys but for ONE key with bit 31 set, at an
+    # index the sample does not read; all-equal keys and the crowded keys are long runs for the segmented passes now)
+    missed = _uniform(n, 28) >> np.uint32(12)
+    missed[7] |= np.uint32(0x80000000)
     inputs = [(_uniform(n, 21), 1, 1536), (_with_one_run_of(n, 3000, 22), 1, 1536), (_uniform(n, 23) >> np.uint32(10), 1, 1536),
-              (np.full(n, 5, dtype=np.uint32), 0, 4608), (crowd, 0, 4608), (_with_one_run_of(n, 2000, 24), 1, 1536), (_uniform(n, 25), 1, 1536)]
+              (np.full(n, 5, dtype=np.uint32), 1, 4608), (crowd, 1, 4608), (missed, 0, 4608), (_with_one_run_of(n, 2000, 24), 1, 1536),
+              (_uniform(n, 25), 1, 1536)]
     with torch.cuda.stream(side):
         kt.copy_(torch.from_numpy(inputs[0][0].view(np.int32)))
         vt.copy_(torch.from_numpy(vals.view(np.int32)))
@@ -947,9 +982,9 @@ def test_a_key_the_sample_missed_refuses_once_and_is_remembered(G):
     gk, gv, fin = _run(G, s, keys, vals)
     _check(keys, vals, gk, gv)
     assert fin["attempted"] == 1 and fin["accepted"] == 0 and fin["top_bit"] == 20, fin
-    gk, gv, fin = _run(G, s, keys, vals)  # (under the whole key's top bits the 20-bit keys crowd into 16 runs: refused for its runs)
+    gk, gv, fin = _run(G, s, keys, vals)  # (under the whole key's top bits the 20-bit keys crowd into 16 long runs: the segmented passes')
     _check(keys, vals, gk, gv)
-    assert fin["attempted"] == 1 and fin["accepted"] == 0 and fin["top_bit"] == 32, fin
+    assert fin["attempted"] == 1 and fin["accepted"] == 1 and fin["top_bit"] == 32 and s.read_long_runs()["runs"] >= 16, fin
     small = keys & np.uint32(0x000FFFFF)
     gk, gv, fin = _run(G, s, small, vals)  # (still from the remembered top bit: the exact bits say 20)
     _check(small, vals, gk, gv)

@@ -118,7 +118,7 @@ void run(uint32_t log2n, uint32_t mode, uint32_t low_bits, uint32_t geo)
             if (which == 0)
                 hipLaunchKernelGGL(kern_old, dim3(nruns), dim3(THREADS), sizeof(SmemOld), 0, keys, vals, keys, vals, (const uint32_t*) d_starts,
                                    low_bits, (const PassPlan*) plan, 0u, geo, 0u, nruns, (const uint32_t*) nullptr, 0u, 16u,
-                                   (unsigned long long*) nullptr, (const uint32_t*) nullptr);
+                                   (unsigned long long*) nullptr, (const uint32_t*) nullptr, 0u);
             else
                 hipLaunchKernelGGL(kern_new, dim3(nruns), dim3(THREADS), sizeof(SmemNew), 0, keys, vals, keys, vals, (const uint32_t*) d_starts,
                                    low_bits, (const PassPlan*) plan, 0u, geo, 0u, nruns, d_flags);
@@ -126,7 +126,7 @@ void run(uint32_t log2n, uint32_t mode, uint32_t low_bits, uint32_t geo)
             if (which == 1) // the runs the bucket kernel listed: round 5's kernel, 8192 workgroups that loop over the list
                 hipLaunchKernelGGL(kern_crowded, dim3(8192), dim3(THREADS), sizeof(SmemOld), 0, keys, vals, keys, vals, (const uint32_t*) d_starts,
                                    low_bits, (const PassPlan*) plan, 0u, 0u, 0u, nruns, (const uint32_t*) nullptr, 0u, 16u,
-                                   (unsigned long long*) nullptr, (const uint32_t*) d_flags);
+                                   (unsigned long long*) nullptr, (const uint32_t*) d_flags, 0u);
             CK(hipEventRecord(e2, 0));
             CK(hipEventSynchronize(e2));
             CK(hipGetLastError());

@@ -107,7 +107,7 @@ void run(uint32_t log2n, uint32_t rank_bits)
             CK(hipEventRecord(e0, 0));
             hipLaunchKernelGGL(stamped ? kern : kern_plain, dim3(nruns), dim3(THREADS), sizeof(Smem), 0, keys, vals, keys, vals,
                                (const uint32_t*) d_starts, low_bits, (const PassPlan*) plan, 0u, geo, 0u, nruns, (const uint32_t*) nullptr, 0u,
-                               rank_bits, stamped ? d_stamps : (unsigned long long*) nullptr);
+                               rank_bits, stamped ? d_stamps : (unsigned long long*) nullptr, (const uint32_t*) nullptr, 0u);
             CK(hipEventRecord(e1, 0));
             CK(hipEventSynchronize(e1));
             float t;
