@@ -422,7 +422,13 @@ glu_status glu_dist_prepare(glu_dist d, size_t local_count, size_t recv_capacity
     // of arrays that were chosen, not drawn (place_pair_by_measurement; plain allocations for small arrays)
     GLU_TRY(place_pair_by_measurement(d->sorter, std::max<size_t>(local_count, 1), d->part_k, d->part_v));
     if (recv_capacity) GLU_TRY(place_pair_by_measurement(d->sorter, recv_capacity, d->recv_k, d->recv_v));
-    if (recv_capacity) GLU_TRY(place_pair_by_measurement(d->sorter, recv_capacity, d->land_k, d->land_v));
+    // (the landing pair only if a shard of this capacity, 256 / world buckets of equal size, would try to end in LDS)
+    {
+        uint32_t geo = 0, split_log2 = 0;
+        const uint64_t buckets = std::max<uint64_t>(1, (uint64_t) kDistBuckets / (uint64_t) std::max(d->world, 1));
+        if (recv_capacity && seg_finish_choice_for(d->sorter, 3u, 24u, buckets * 256u, recv_capacity / buckets, geo, split_log2))
+            GLU_TRY(place_pair_by_measurement(d->sorter, recv_capacity, d->land_k, d->land_v));
+    }
     // segmented local sort: one table row per sub-block (at most pieces + workgroups: world x buckets owned + CUs) and the
     // descriptor image of its two pass shapes
     const size_t rows = (size_t) kDistBuckets * (size_t) std::min(d->world, 16) + (size_t) g_dev.num_cus;
@@ -701,11 +707,23 @@ glu_status dist_sort_finish(glu_dist_s* d, uint32_t* recv_keys, uint32_t* recv_v
         const uint64_t tiles_per_wg = n_recv / LinesGeometry<uint32_t, 8, true>::TILE / usable_cus(d->sorter);
         segmented = !plan.by_copies && (d->seg_forced || plan.max_subs_per_wg() <= 2 + tiles_per_wg / 6);
     }
+    // A segmented sort that will try to end in LDS needs a third pair of arrays: the exchange lands in the object's landing pair,
+    // the sorter's scratch takes the counting pass, the caller's arrays the result.  A sort that will not try (eight ranks by
+    // default: runs of 16384 pairs fit no tile that shares a CU) lands in the sorter's scratch, as in round 4 -- no third pair
+    // of shard size is allocated or placed for it (1 GiB per rank at 2^27 pairs).
+    bool own_landing = false;
     if (segmented)
     {
-        // the landing arrays (grown here when glu_dist_prepare did not size them: an allocation, agreed on like every other)
-        note(d->land_k.reserve(n_recv * sizeof(uint32_t)));
-        note(d->land_v.reserve(n_recv * sizeof(uint32_t)));
+        uint32_t geo = 0, split_log2 = 0;
+        own_landing = seg_finish_choice(d->sorter, plan, geo, split_log2);
+        if (own_landing)
+        {
+            // (grown here when glu_dist_prepare did not size them: an allocation, agreed on like every other)
+            note(d->land_k.reserve(n_recv * sizeof(uint32_t)));
+            note(d->land_v.reserve(n_recv * sizeof(uint32_t)));
+        }
+        else
+            note(sort_prepare(d->sorter, n_recv, sizeof(uint32_t), true));
         if (local != GLU_OK) segmented = false;
     }
     d->last_local_sort = segmented ? 1u : 0u;
@@ -737,8 +755,8 @@ glu_status dist_sort_finish(glu_dist_s* d, uint32_t* recv_keys, uint32_t* recv_v
     // where the exchange delivers: the segmented sort reads the shard from the object's landing arrays and leaves its
     // result in the caller's (through the sorter's scratch arrays when it ends in LDS); the ordinary sort works in place in the
     // caller's
-    uint32_t* land_k = segmented ? (uint32_t*) d->land_k.ptr : recv_keys;
-    uint32_t* land_v = segmented ? (uint32_t*) d->land_v.ptr : recv_vals;
+    uint32_t* land_k = !segmented ? recv_keys : own_landing ? (uint32_t*) d->land_k.ptr : (uint32_t*) d->sorter->keys.ptr;
+    uint32_t* land_v = !segmented ? recv_vals : own_landing ? (uint32_t*) d->land_v.ptr : (uint32_t*) d->sorter->vals.ptr;
 
     // 4. the exchange.  One grouped exchange (ncclSend / ncclRecv to and from every peer between ncclGroupStart / End) per
     // ROUND.  With one round a rank's message to a peer is all of the peer's buckets and everything runs on `st`: partition

@@ -1180,8 +1180,11 @@ inline glu_status launch_seg_finish(const uint32_t* src_k, const uint32_t* src_v
 template<typename KeyT, bool VALS, bool XF>
 glu_status launch_finish(KeyT* keys_a, uint32_t* vals_a, KeyT* keys_b, uint32_t* vals_b, const uint32_t* starts,
                          uint32_t geo_first, uint32_t geo_last, uint32_t geo_expected, uint32_t low_bits, const PassPlan* plan,
-                         uint32_t pass, uint32_t key_xf, hipStream_t stream, uint32_t rank_bits, uint32_t* crowded)
+                         uint32_t pass, uint32_t key_xf, hipStream_t stream, uint32_t rank_bits, uint32_t* crowded,
+                         glu_radix_sort_s* marks)
 {
+    // (marks: the two profile marks of the in-LDS pass go around the launch of the EXPECTED tile, the one that does the work in
+    // a timed loop -- not around the launches beside it that return at once)
     constexpr uint32_t nruns = kFinishRuns;
     // (order: the geometries that are not expected first -- they return at once in front of the long kernel instead of waiting
     // behind it for room on the CUs; what follows the expected one is the launch that takes its crowded runs)
@@ -1201,9 +1204,11 @@ glu_status launch_finish(KeyT* keys_a, uint32_t* vals_a, KeyT* keys_b, uint32_t*
                     lds_opt_in_result = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sizeof(Smem));   \
         });                                                                                                                       \
         HIP_TRY(lds_opt_in_result);                                                                                               \
+        if (GEO_ == geo_expected) marks->mark(stream, true);                                                                      \
         hipLaunchKernelGGL(kern, dim3(GEO_ == geo_expected ? nruns : std::min(nruns, 8192u)), dim3(THREADS_), sizeof(Smem),       \
                            stream, keys_a, vals_a, keys_b, vals_b, starts, low_bits, plan, pass, (uint32_t) GEO_, key_xf, nruns,  \
                            crowded);                                                                                              \
+        if (GEO_ == geo_expected) marks->mark(stream, true);                                                                      \
         HIP_TRY(hipGetLastError());                                                                                               \
     }
     // The runs the bucket kernel listed (or all of them: PassPlan::finish_rounds) by ballot rounds, 8192 workgroups that loop: one
@@ -1580,12 +1585,11 @@ glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t cou
                     s->cur_behind = false;
                     s->mark(stream);
                     s->mark(stream);
-                    s->mark(stream, true);
 #define GLU_LAUNCH_FINISH(VALS_, XF_)                                                                                             \
     GLU_TRY((launch_finish<KeyT, VALS_, XF_>(kbuf[0], VALS_ ? vbuf[0] : nullptr, kbuf[1], VALS_ ? vbuf[1] : nullptr,              \
                                              (const uint32_t*) s->finish_starts.ptr, finish_kpt, finish_last, finish_expected,    \
                                              finish_top_bit - 16u, pa.plan, 2u, key_xf, stream, s->finish_rank_bits,              \
-                                             (uint32_t*) s->finish_crowded.ptr)))
+                                             (uint32_t*) s->finish_crowded.ptr, s)))
                     if (vals)
                     {
                         if (key_xf != KEY_XF_NONE) GLU_LAUNCH_FINISH(true, true);
@@ -1597,7 +1601,6 @@ glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t cou
                         else GLU_LAUNCH_FINISH(false, false);
                     }
 #undef GLU_LAUNCH_FINISH
-                    s->mark(stream, true);
                     if (finish_long_ok && !fork)
                         GLU_TRY(launch_long_run_passes_any<KeyT>(s, kbuf[0], vbuf[0], kbuf[1], vbuf[1], count, key_xf, stream));
                 }
@@ -2097,6 +2100,32 @@ void seg_make_plan(glu_radix_sort_s* s, std::vector<SegPiece>&& pieces, uint32_t
 }
 
 // Device half: enqueues the passes of `plan` on `stream`.
+// Will a segmented sort by this plan try to end in LDS (given a third pair of arrays to land its counting pass in)?  The tile and,
+// for long runs, the number of workgroups a run is split over follow from the run length uniformly drawn keys would give in the
+// LARGEST segment (segments may be of any sizes, empty ones included, and the host knows them).  Also asked by glu_dist, which
+// allocates the landing pair of the exchange only for sorts that will use it.
+bool seg_finish_choice_for(const glu_radix_sort_s* s, uint32_t passes, uint32_t bits, uint64_t nruns, uint64_t largest, uint32_t& geo,
+                           uint32_t& split_log2)
+{
+    geo = 0, split_log2 = 0;
+    if (!(s->seg_finish && s->lds_finish && passes >= 2 && bits == passes * 8 && nruns <= kSegFinishMaxRuns)) return false;
+    split_log2 = std::min(s->seg_split_min, s->seg_split_max);
+    for (; split_log2 <= s->seg_split_max && !geo; split_log2++)
+    {
+        geo = finish_geometry_for((size_t) (largest >> split_log2), 256u, std::min(s->seg_max_geo, kSegFinishGeometries));
+        if (split_log2 > 0 && geo > s->seg_split_geo) geo = 0; // (split runs take the tiles that share a CU four at a time)
+    }
+    if (!geo) return false;
+    split_log2--;
+    return true;
+}
+bool seg_finish_choice(const glu_radix_sort_s* s, const SegPlan& plan, uint32_t& geo, uint32_t& split_log2)
+{
+    uint64_t largest = 0;
+    for (uint32_t g = 0; g < plan.nseg; g++) largest = std::max<uint64_t>(largest, plan.seg_start[g + 1] - plan.seg_start[g]);
+    return seg_finish_choice_for(s, plan.passes, plan.bits, (uint64_t) plan.nseg * 256u, largest, geo, split_log2);
+}
+
 glu_status seg_run_plan(glu_radix_sort_s* s, const SegPlan& plan, uint32_t* in_k, uint32_t* in_v, uint32_t* out_k, uint32_t* out_v,
                         hipStream_t stream)
 {
@@ -2163,20 +2192,10 @@ glu_status seg_run_plan(glu_radix_sort_s* s, const SegPlan& plan, uint32_t* in_k
     const uint64_t nruns = (uint64_t) nseg * 256u;
     s->last_seg_finish_attempted = false;
     const bool third_pair = tmp_k != in_k && tmp_k != out_k && tmp_v != in_v && tmp_v != out_v;
-    if (s->seg_finish && s->lds_finish && passes >= 2 && plan.bits == passes * 8 && nruns <= kSegFinishMaxRuns && third_pair)
     {
-        // (the runs of the LARGEST segment: segments may be of any sizes, empty ones included, and the host knows them)
-        uint64_t largest = 0;
-        for (uint32_t g = 0; g < nseg; g++) largest = std::max<uint64_t>(largest, plan.seg_start[g + 1] - plan.seg_start[g]);
-        uint32_t geo = 0, split_log2 = std::min(s->seg_split_min, s->seg_split_max);
-        for (; split_log2 <= s->seg_split_max && !geo; split_log2++)
+        uint32_t geo = 0, split_log2 = 0;
+        if (third_pair && seg_finish_choice(s, plan, geo, split_log2))
         {
-            geo = finish_geometry_for((size_t) (largest >> split_log2), 256u, std::min(s->seg_max_geo, kSegFinishGeometries));
-            if (split_log2 > 0 && geo > s->seg_split_geo) geo = 0; // (split runs take the tiles that share a CU four at a time)
-        }
-        if (geo)
-        {
-            split_log2--;
             GLU_TRY(s->finish_starts.reserve(((size_t) std::max<uint64_t>(nruns, kFinishRuns) + 1) * sizeof(uint32_t)));
             GLU_TRY(s->seg_gate.reserve(64));
             gate_cap = (uint32_t) std::min<uint64_t>(0xFFFFFFFFull, (uint64_t) finish_geometry_capacity(geo) * 32u << split_log2);

@@ -412,8 +412,11 @@ GLU_API glu_status glu_dist_sort_begin(glu_dist dist, const uint32_t* keys, cons
 /* Second half: the grouped exchange into the caller's arrays (capacity >= the count glu_dist_sort_begin returned) and the
  * local sort, enqueued on `stream` (no host synchronisation). */
 GLU_API glu_status glu_dist_sort_finish(glu_dist dist, uint32_t* recv_keys, uint32_t* recv_vals, size_t capacity, void* stream);
-/* Both halves with receive arrays owned by `dist` (grown if the shard does not fit); *out_keys / *out_vals are device
- * pointers valid until the next sort on `dist` returns (arrays the next sort outgrows are freed by the sort after it). */
+/* Both halves with receive arrays owned by `dist` (grown if the shard does not fit).  LIFETIME of *out_keys / *out_vals: they
+ * point into arrays `dist` owns and are valid until the NEXT glu_dist_sort_ptr call on `dist` returns -- that call may overwrite
+ * them (same arrays) or outgrow them (the outgrown arrays stay allocated for exactly one more call, so a result that is still
+ * being read while the next sort is enqueued does not dangle; the call after that frees them).  Copy out what must live longer;
+ * glu_hip.dist.DistributedRadixSort.sort() returns tensors that alias these arrays under the same rule. */
 GLU_API glu_status glu_dist_sort_ptr(glu_dist dist, const uint32_t* keys, const uint32_t* vals, size_t local_count,
                                      void* stream, uint32_t** out_keys, uint32_t** out_vals, size_t* out_count);
 /* 1 if the local sort of the last sort on `dist` was the SEGMENTED sort of the low 24 bits per bucket (the shard arrives as one

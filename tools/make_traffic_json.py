@@ -29,6 +29,8 @@ def find(d, *subs):
 
 
 N = 1 << 28
+# (the in-LDS pass: round 6's bucket kernel, radix_lds_bucket.hpp; rounds 4 and 5: the ballot-ranked kernel)
+FINISH = "radix_finish_bucket_kernel" if ROUND >= "r06" else "radix_finish_sort_kernel"
 T2 = 256 * 256 * 512  # the two-digit table of a pair of passes: [256][workgroups][256] 16-bit counters
 T2_4 = 256 * 16 * 1024 + 16 * 256 * 16 * 4  # 4-bit digits: 16 x 16 counters per sub-block + the per-sub-block table
 rows = []
@@ -61,7 +63,7 @@ all_k = {
     "source": src, "corrections": corr,
     "kernels": [
         e8, e4,
-        entry(bench_f, bench_w, ("radix_finish_sort_kernel<unsigned int, 256, 18, true, false",), N * 16, "in-LDS pass of the headline sort (a workgroup per run of equal top 16 key bits; reads and writes every pair once)"),
+        entry(bench_f, bench_w, (FINISH + "<unsigned int, 256, 18, true, false",), N * 16, "in-LDS pass of the headline sort (a workgroup per run of equal top 16 key bits; reads and writes every pair once)"),
         entry(bench_f, bench_w, ("radix_pair_count_kernel<unsigned int",), N * 4 + T2, "count kernel of a pair of passes of the headline sort (reads the keys, writes the two-digit table)"),
         entry(bench_f, bench_w, ("radix_pair_unitsum_kernel",), T2, "count table of the second pass of a pair (reads the two-digit table)"),
         entry(bench_f, bench_w, ("radix_pair4_count_kernel<unsigned int",), N * 4 + T2_4, "count kernel of a pair of passes of the 4-bit sort (reads the keys -- the calibration of the FETCH_SIZE factor -- and writes 4.25 MiB of tables)"),
@@ -70,7 +72,7 @@ all_k = {
         entry(cfg_f, cfg_w, ("radix_scatter_lines_kernel<unsigned long, 4",), N * 24, "same, 4-bit digits"),
         entry(cfg_f, cfg_w, ("radix_pair_count_kernel<unsigned long",), N * 8 + T2, "count kernel of a pair of passes, 64-bit keys"),
         entry(cfg_f, cfg_w, ("radix_pair4_count_kernel<unsigned long",), N * 8 + T2_4, "count kernel of a pair of passes, 64-bit keys, 4-bit digits"),
-        entry(cfg_f, cfg_w, ("radix_finish_sort_kernel<unsigned long, 512, 9, true, false",), N * 24, "in-LDS pass of BASELINE.json configs[4] (2^28 u64 keys + u32 vals: two rounds on key bits [32, 48) + exact tie repair)"),
+        entry(cfg_f, cfg_w, (FINISH + "<unsigned long, 512, 9, true, false",), N * 24, "in-LDS pass of BASELINE.json configs[4] (2^28 u64 keys + u32 vals)"),
         entry(cfg_f, cfg_w, ("scan_chunks_kernel",), N * 8, "glu::BlellochScan 2^28 u32 (chained single pass)"),
     ],
 }

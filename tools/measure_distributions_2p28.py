@@ -11,6 +11,9 @@ import numpy as np
 import glu_hip as G
 
 log2n = int(sys.argv[1]) if len(sys.argv) > 1 else 28
+U64 = len(sys.argv) > 2 and sys.argv[2] == "u64"  # python tools/measure_distributions_2p28.py 28 u64: 64-bit keys (profiles/r06/distributions_2p28_u64.txt)
+KB = 8 if U64 else 4
+KT = np.uint64 if U64 else np.uint32
 n = 1 << log2n
 rng = np.random.default_rng(2028)
 print(G.device_info())
@@ -41,6 +44,35 @@ def zipf_small_integers():
     return np.floor(np.exp(rng.random(n) * np.log(float(1 << 20)))).astype(np.uint32)  # the ranks themselves: 20-bit keys, rank 1 the most frequent
 
 
+def uniform64(bits=64):
+    return rng.integers(0, 2 ** bits, n, dtype=np.uint64)
+
+
+def zipf64():
+    ranks = np.floor(np.exp(rng.random(n) * np.log(float(1 << 20)))).astype(np.uint64)
+    x = ranks * np.uint64(0x9E3779B97F4A7C15)
+    x ^= x >> np.uint64(29)
+    x *= np.uint64(0xBF58476D1CE4E5B9)
+    return x
+
+
+def zeros64(percent):
+    k = uniform64()
+    k[rng.random(n) < percent / 100.0] = 0
+    return k
+
+
+dists64 = [
+    ("uniform, full range", lambda: uniform64()),
+    ("uniform, 48-bit keys", lambda: uniform64(48)),
+    ("uniform, 40-bit keys", lambda: uniform64(40)),
+    ("uniform + 0.01 % zeros", lambda: zeros64(0.01)),
+    ("uniform + 1 % zeros", lambda: zeros64(1.0)),
+    ("Zipf(1.0) over 2^20 values, values scattered", zipf64),
+    ("sorted (uniform, ascending)", lambda: np.sort(uniform64())),
+    ("three values", lambda: rng.integers(0, 3, n, dtype=np.uint64) * np.uint64(0x5555555555555555)),
+    ("1000 distinct values, scattered", lambda: rng.integers(0, 2**64, 1000, dtype=np.uint64)[rng.integers(0, 1000, n)]),
+]
 dists = [
     ("uniform, full range", lambda: uniform()),
     ("uniform, 31-bit keys", lambda: uniform(31)),
@@ -61,32 +93,37 @@ dists = [
     ("uniform + 10 % zeros", lambda: with_zeros(10.0)),
     ("all zero (the reference README's benchmark input)", lambda: np.zeros(n, dtype=np.uint32)),
 ]
+if U64:
+    dists = dists64
 vals = np.arange(n, dtype=np.uint32)
 v0 = G.ShaderStorageBuffer(vals)
-k = G.ShaderStorageBuffer(size=4 * n)
+k = G.ShaderStorageBuffer(size=KB * n)
 v = G.ShaderStorageBuffer(size=4 * n)
 for name, make in dists:
     keys = make()
     k0 = G.ShaderStorageBuffer(keys)
     s = G.RadixSort()
-    s.prepare_internal_buffers(n)
+    s.prepare_internal_buffers(n, key_bytes=KB)
     times = []
     for rep in range(7):  # (back to back: a pause -- a host read-back -- lets the device clock down and costs the next sorts 8 %)
-        G.check(G.lib().glu_buffer_copy(k0.handle(), k.handle(), 4 * n, 0, 0))
+        G.check(G.lib().glu_buffer_copy(k0.handle(), k.handle(), KB * n, 0, 0))
         G.check(G.lib().glu_buffer_copy(v0.handle(), v.handle(), 4 * n, 0, 0))
-        times.append(G.measure_elapsed_time(lambda: s(k, v, n)) * 1e-6)
-    out = k.get_data(np.uint32)
+        times.append(G.measure_elapsed_time(lambda: s(k, v, n, 0, key_bytes=KB)) * 1e-6)
+    out = k.get_data(KT)
     assert bool((out[1:] >= out[:-1]).all()), name
     del out
     fin, lr = s.read_finish(), s.read_long_runs()
     later = sorted(times[1:])[len(times[1:]) // 2]
     if fin["accepted"]:
-        moved = 2 * 16 + 4 + (2 * 256 * 256 * 512 + 2 * 65536 * 4) / n + 16 * (1 - lr["pairs"] / n) + 2 * 20 * lr["pairs"] / n
+        PB = KB + 4  # bytes of a pair
+        lp = (2 if KB == 4 else 6) * (2 * PB + KB)  # what the segmented passes move per pair of a long run (less if the run is one key value)
+        moved = 2 * 2 * PB + KB + (2 * 256 * 256 * 512 + 2 * 65536 * 4) / n + 2 * PB * (1 - lr["pairs"] / n) + lp * lr["pairs"] / n
         what = "yes  bits [%2d,%2d)  tile %4d  long runs %5d (%9d pairs)" % (fin["top_bit"] - 16, fin["top_bit"], fin["capacity"], lr["runs"], lr["pairs"])
     else:
-        skipped, alone, roles = s.read_plan(4, roles=True)
-        reads = sum(1 for p in range(4) if skipped[p] != 2 and not (roles[p] == 2 and not alone[p])) + (1 if fin["attempted"] else 0)
-        moved = 16 * sum(1 for p in range(4) if not skipped[p]) + 4 * reads
-        what = "no   (%s; %d of 4 ordinary passes ran)" % ("refused" if fin["attempted"] else "not attempted", sum(1 for p in range(4) if not skipped[p]))
+        NP = KB  # ordinary passes of 8 bits
+        skipped, alone, roles = s.read_plan(NP, roles=True)
+        reads = sum(1 for p in range(NP) if skipped[p] != 2 and not (roles[p] == 2 and not alone[p])) + (1 if fin["attempted"] else 0)
+        moved = 2 * (KB + 4) * sum(1 for p in range(NP) if not skipped[p]) + KB * reads
+        what = "no   (%s; %d of %d ordinary passes ran)" % ("refused" if fin["attempted"] else "not attempted", sum(1 for p in range(NP) if not skipped[p]), NP)
     print("%-52s %7.3f | %7.3f | %-72s | %5.1f B | %6.1f" % (name, times[0], later, what, moved, n / later / 1e6), flush=True)
     del k0, keys, s
