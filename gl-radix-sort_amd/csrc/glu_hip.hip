@@ -467,6 +467,7 @@ struct glu_radix_sort_s
     Scratch pair_table;  // the follower's count table + digit totals,
     Scratch pair_ranges; // the element range of every follower workgroup,
     Scratch pair_sub;    // and (4-bit digits) the leader's table per sub-block: [16][num_blocks * 16]
+    Scratch pair_wide;   // the wide rows of a sort that tries to end in LDS: exact counts where 16-bit counters wrapped (kPairWideStride words per block)
     Scratch seg_desc;    // segmented passes (glu_dist's local sort): sub-block descriptors of the pass being enqueued
     Scratch seg_zero;    // and RADIX zero words (the digit totals a segmented scatter adds to its absolute table entries)
     bool last_planned = false; // the last sort on this object ran with a device-side plan (glu_radix_sort_read_plan)
@@ -677,6 +678,7 @@ glu_status sort_prepare(glu_radix_sort_s* s, size_t count, size_t key_size, bool
             GLU_TRY(s->finish_starts.reserve(((size_t) kFinishRuns + 1) * sizeof(uint32_t)));
             GLU_TRY(s->finish_crowded.reserve(crowded_list_words(kFinishRuns) * sizeof(uint32_t)));
             GLU_TRY(s->finish_outcomes.reserve(256 * sizeof(uint32_t)));
+            GLU_TRY(s->pair_wide.reserve((size_t) nb * kPairWideStride * sizeof(uint32_t)));
             {
                 // runs longer than the in-LDS pass's tile are sorted by segmented passes (radix_finish_long_runs_kernel)
                 GLU_TRY(s->long_image.reserve((size_t) LongRunsLayout((uint32_t) g_dev.num_cus).words * sizeof(uint32_t)));
@@ -863,9 +865,10 @@ glu_status launch_pass_lines(glu_radix_sort_s* s, const KeyT* src_k, const uint3
                 });
                 HIP_TRY(count2_opt_in_result);
                 auto count2 = (pa.flags & kPlanCollectBits) ? count2_collect : count2_plain;
+                // (the leader of an attempt to end in LDS puts wrapped 16-bit counters right: exact run lengths whatever the keys)
                 hipLaunchKernelGGL(count2, dim3(nb), dim3(1024), sizeof(PairCountSmem), stream, src_k, table, (uint32_t*) s->pair_t2.ptr,
                                    (uint32_t) count, shift, mask, pa.shift2, (1u << pa.bits2) - 1, tiles, xform, (const KeyT*) dst_k,
-                                   pa.plan, pa.pass, pa.flags, share);
+                                   pa.plan, pa.pass, pa.flags, share, pa.finish_geo_first ? (uint32_t*) s->pair_wide.ptr : (uint32_t*) nullptr);
             }
             else
             {
@@ -936,13 +939,14 @@ glu_status launch_pass_lines(glu_radix_sort_s* s, const KeyT* src_k, const uint3
     if (pa.finish_geo_first)
     {
         hipLaunchKernelGGL(radix_finish_lengths_kernel, dim3(kPairRadix), dim3(1024), 0, stream, (const uint32_t*) s->pair_t2.ptr, nb,
-                           (uint32_t*) s->finish_lengths.ptr, (const PassPlan*) pa.plan, pa.pass);
+                           (uint32_t*) s->finish_lengths.ptr, (const PassPlan*) pa.plan, pa.pass, (const uint32_t*) s->pair_wide.ptr);
         HIP_TRY(hipGetLastError());
         const bool long_runs = pa.finish_long_ok && s->long_image.ptr;
         hipLaunchKernelGGL(radix_finish_plan_kernel, dim3(kFinishPlanBlocks), dim3(1024), 0, stream, (const uint32_t*) s->finish_lengths.ptr,
                            (uint32_t*) s->finish_starts.ptr, (uint32_t) count, pa.finish_geo_first, pa.finish_geo_last, pa.plan, pa.pass,
                            pa.finish_first_ordinary, pa.finish_num_ordinary, s->finish_hint, pa.finish_seq, pa.finish_top_bit,
-                           pa.finish_key_bits, long_runs ? 1u : 0u, (uint32_t*) s->finish_crowded.ptr, (uint32_t*) s->finish_outcomes.ptr);
+                           pa.finish_key_bits, long_runs ? 1u : 0u, (uint32_t*) s->finish_crowded.ptr, (uint32_t*) s->finish_outcomes.ptr,
+                           (uint32_t) (sizeof(KeyT) + (VALS ? sizeof(uint32_t) : 0)));
         HIP_TRY(hipGetLastError());
         if (long_runs)
         {
@@ -2311,7 +2315,7 @@ glu_status glu_radix_sort_destroy(glu_radix_sort sort)
     // library queue, before its scratch goes away (RAII of the reference: RadixSort.hpp:194-200, gl_utils.hpp:184-188)
     (void) hipDeviceSynchronize();
     for (Scratch* sc : {&sort->keys, &sort->vals, &sort->table, &sort->plan, &sort->pair_t2, &sort->pair_table, &sort->pair_ranges,
-                        &sort->pair_sub, &sort->seg_desc, &sort->seg_zero, &sort->finish_lengths, &sort->finish_starts, &sort->finish_crowded, &sort->finish_outcomes, &sort->seg_gate, &sort->long_image, &sort->long_hdr, &sort->long_bits})
+                        &sort->pair_sub, &sort->pair_wide, &sort->seg_desc, &sort->seg_zero, &sort->finish_lengths, &sort->finish_starts, &sort->finish_crowded, &sort->finish_outcomes, &sort->seg_gate, &sort->long_image, &sort->long_hdr, &sort->long_bits})
         sc->release();
     if (sort->finish_hint) (void) hipHostFree(sort->finish_hint);
     for (hipEvent_t e : {sort->ev_fork, sort->ev_unit, sort->ev_fork2, sort->ev_join})

@@ -332,12 +332,15 @@ __device__ __forceinline__ void finish_list_long_runs(const uint32_t* starts, ui
 
 // lengths[e * 256 + d] = #keys with first top-bit digit d and second top-bit digit e: T2 rows (d, b) summed over the leader's nb
 // blocks.  One workgroup per d; thread (g, q) adds word q (counters e = 2q, 2q + 1) of the rows b = g, g + 8, ...
+// wide (round 6, radix_pair_passes.hpp): the counts >> 16 of the rows whose 16-bit counters wrapped, per block -- the lengths are exact
+// whatever share of the input one key value holds.
 __global__ __launch_bounds__(1024) void radix_finish_lengths_kernel(const uint32_t* __restrict__ t2, uint32_t nb,
                                                                     uint32_t* __restrict__ lengths, const PassPlan* plan,
-                                                                    uint32_t pass)
+                                                                    uint32_t pass, const uint32_t* __restrict__ wide = nullptr)
 {
     if (plan->off[pass] || plan->skip[pass] == kSkipWithoutCounting) return; // no tables (kernel-uniform)
     __shared__ uint32_t part[8][kPairRadix];
+    __shared__ uint32_t wide_list[1024], wide_n; // (block, wide row) pairs of this digit value: b << 8 | k
     const uint32_t tid = threadIdx.x, g = tid >> 7, q = tid & 127u, d = blockIdx.x;
     uint32_t lo = 0, hi = 0;
 #pragma unroll 4
@@ -349,12 +352,26 @@ __global__ __launch_bounds__(1024) void radix_finish_lengths_kernel(const uint32
     }
     part[g][2 * q] = lo;
     part[g][2 * q + 1] = hi;
+    if (tid == 0) wide_n = 0;
+    __syncthreads();
+    if (wide && tid < nb) // (thread b: has block b a wide row of this digit value?)
+    {
+        const uint32_t* hdr = wide + (size_t) tid * kPairWideStride;
+        const uint32_t nw = hdr[0] <= kPairWideRows ? hdr[0] : 0u; // (~0: more rows than the block could put right -- the lengths will not add up)
+        for (uint32_t k = 0; k < nw; k++)
+            if (hdr[1 + k] == d) wide_list[atomicAdd(&wide_n, 1u)] = (tid << 8) | k;
+    }
     __syncthreads();
     if (tid < kPairRadix)
     {
         uint32_t c = 0;
 #pragma unroll
         for (int k = 0; k < 8; k++) c += part[k][tid];
+        for (uint32_t i = 0; i < wide_n; i++)
+        {
+            const uint32_t bk = wide_list[i];
+            c += wide[(size_t) (bk >> 8) * kPairWideStride + 16 + (bk & 255u) * kPairRadix + tid] << 16;
+        }
         lengths[tid * kPairRadix + d] = c;
     }
 }
@@ -365,7 +382,7 @@ __global__ __launch_bounds__(1024) void radix_finish_plan_kernel(const uint32_t*
                                                                  uint32_t first_ordinary, uint32_t num_ordinary,
                                                                  uint32_t* hint, uint32_t attempt, uint32_t top_bit,
                                                                  uint32_t key_bits, uint32_t long_ok, uint32_t* crowded_lists,
-                                                                 uint32_t* outcomes = nullptr)
+                                                                 uint32_t* outcomes = nullptr, uint32_t pair_bytes = 8)
 {
     __shared__ uint32_t tmp[3][16];
     __shared__ uint32_t over_tmp[2][kFinishGeometries][16];
@@ -431,6 +448,25 @@ __global__ __launch_bounds__(1024) void radix_finish_plan_kernel(const uint32_t*
         longest = max(longest, tmp[2][w]);
         if ((uint32_t) w < wave) excl += wsum[w];
     }
+    // which key bits vary (exact: the leader's count kernel has looked at every key; typed keys: not collected, all of them may)
+    if (plan->top_bit) top_bit = plan->top_bit; // (chosen on the device from a sample of the keys: radix_sample_top_kernel)
+    uint64_t varying = ~0ull;
+    if (plan->bits_valid)
+        varying = (uint64_t) (plan->bits_or[0] & plan->bits_nor[0]) | ((uint64_t) (plan->bits_or[1] & plan->bits_nor[1]) << 32);
+    // What the two ways cost in bytes moved (round 6).  The ordinary sort: a counting pass (a read of the keys + both arrays read
+    // and written) for every key BYTE that varies -- the passes on constant bytes are skipped.  The sort that ends in LDS: the
+    // leader's read, two counting passes, the in-LDS pass over the short runs, and the segmented passes (2 for 4-byte keys, 6 for
+    // 8-byte keys) over the pairs of long runs -- priced as if no long run were one key value (those are not moved at all).
+    // Zipf-distributed small integers: 70 B/pair against 60, the ordinary passes win; three values: 76 against 80.
+    const uint32_t key_bytes = key_bits / 8u;
+    uint32_t varying_bytes = 0;
+    for (uint32_t kb = 0; kb < key_bytes; kb++) varying_bytes += ((varying >> (8u * kb)) & 0xFFull) != 0ull ? 1u : 0u;
+    const uint64_t pass_bytes = 2ull * pair_bytes + key_bytes;
+    const uint64_t ordinary_cost = (uint64_t) n * varying_bytes * pass_bytes;
+    auto attempt_cost = [&](uint32_t long_pairs) {
+        return (uint64_t) n * (key_bytes + 4ull * pair_bytes) + (uint64_t) (n - long_pairs) * 2ull * pair_bytes +
+               (uint64_t) long_pairs * (key_bytes == 4u ? 2ull : 6ull) * pass_bytes;
+    };
     uint32_t geo = finish_geometry_choice(longest, geo_first, geo_last);
     if (long_ok && b == 0 && geo != geo_first && geo_first >= 1)
     {
@@ -441,10 +477,10 @@ __global__ __launch_bounds__(1024) void radix_finish_plan_kernel(const uint32_t*
             uint32_t ol = 0, oc = 0;
             for (int w = 0; w < 16; w++) ol += over_tmp[0][g - 1][w], oc += over_tmp[1][g - 1][w];
             const bool few = oc <= kLongRunsMax && ol <= n / 8u;
-            // (round 6: however many pairs the long runs hold -- two segmented passes over them move no more bytes than the two
-            // ordinary passes they replace, and a long run of one key value, which is what fills long runs as a rule, is not moved at
-            // all.  Round 5 refused the sort when more than half of the pairs sat in long runs.)
-            const bool tolerable = g == geo_last && oc <= kLongRunsMax;
+            // (round 6: however many pairs the long runs hold -- a long run of one key value, which is what fills long runs as a
+            // rule, is not moved at all; round 5 refused the sort when more than half of the pairs sat in long runs --
+            // ... as long as that is not more than the ordinary passes would move.)
+            const bool tolerable = g == geo_last && oc <= kLongRunsMax && attempt_cost(ol) <= ordinary_cost;
             if (few || (tolerable && pick == 0)) pick = g;
         }
         if (pick) geo = geo == 0 ? pick : min(geo, pick);
@@ -452,14 +488,8 @@ __global__ __launch_bounds__(1024) void radix_finish_plan_kernel(const uint32_t*
     // The runs are the values of key bits [top_bit - 16, top_bit): that orders the keys only if no key bit from top_bit up
     // varies -- the host assumed so from what this object's last sort saw, the count kernel of this one has looked
     // (PassPlan::bits_or / bits_nor).  Typed keys and sorts that do not collect the bits are launched with top_bit = key_bits.
-    if (plan->top_bit) top_bit = plan->top_bit; // (chosen on the device from a sample of the keys: radix_sample_top_kernel)
     bool range_ok = top_bit >= key_bits;
-    uint64_t varying = ~0ull;
-    if (plan->bits_valid)
-    {
-        varying = (uint64_t) (plan->bits_or[0] & plan->bits_nor[0]) | ((uint64_t) (plan->bits_or[1] & plan->bits_nor[1]) << 32);
-        if (top_bit < key_bits) range_ok = (varying >> top_bit) == 0;
-    }
+    if (plan->bits_valid && top_bit < key_bits) range_ok = (varying >> top_bit) == 0;
     const bool accept = tables && all == n && geo != 0 && range_ok; // (workgroup 0's is the decision: only it knows of long runs)
     // (the run starts are written whatever the decision: nobody reads them unless plan->finish says so)
     starts[b * 1024u + tid] = before + excl;

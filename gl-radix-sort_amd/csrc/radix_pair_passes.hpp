@@ -45,6 +45,20 @@ struct PairCountSmem
     uint32_t hist2[kPairRadix * kPairRowWords]; // shared 16-bit counters of (digit p, digit p + 1)
 };
 
+// WIDE ROWS (round 6).  A 16-bit counter of T2 wraps when more than 65535 keys of one block share both digit values -- a key value
+// that holds more than 6 % of the input: three distinct values, 10 % zeros.  Round 5 could only notice (the row's counters do not add
+// up to T1) and the sort that tried to end in LDS was refused for want of exact run lengths.  With `wide` (the leader of such an
+// attempt) the block now puts its rows right: the rows that do not add up (at most kPairWideRows per block: a block of 2^20 keys has
+// at most 15 counters beyond 65535) are counted AGAIN with 32-bit counters -- a second read of the block's keys, 4 MiB from L2 /
+// HBM, only in blocks that have such a row --, the T2 row is rewritten with the low 16 bits of the exact counts and the high 16
+// bits go to the block's wide rows:
+//   wide[b * kPairWideStride]                  how many wide rows block b has (~0: more than kPairWideRows, left as they were)
+//   wide[b * kPairWideStride + 1 + k]          the first digit d of its k-th wide row
+//   wide[b * kPairWideStride + 16 + k * 256 + e]   count >> 16 of (d, e)
+// radix_finish_lengths_kernel adds 65536 x those.  The follower of the pair still counts for itself (its unit sums need whole rows).
+constexpr uint32_t kPairWideRows = 14;
+constexpr uint32_t kPairWideStride = 16 + kPairWideRows * 256;
+
 // t2 row of unit (d, b): words [(d * nb + b) * 128, + 128), counter e in the low (e even) / high (e odd) half of word e / 2
 template<typename KeyT, int TILE, bool XF = false, bool COLLECT = false>
 __global__ __launch_bounds__(1024) void radix_pair_count_kernel(const KeyT* __restrict__ keys_a, uint32_t* __restrict__ table,
@@ -52,7 +66,7 @@ __global__ __launch_bounds__(1024) void radix_pair_count_kernel(const KeyT* __re
                                                                 uint32_t mask, uint32_t shift2, uint32_t mask2,
                                                                 uint32_t tiles_total, uint32_t xform, const KeyT* keys_b,
                                                                 PassPlan* plan, uint32_t pass, uint32_t plan_flags = 0,
-                                                                uint32_t share = 0)
+                                                                uint32_t share = 0, uint32_t* __restrict__ wide = nullptr)
 {
     constexpr int THREADS = 1024;
     constexpr int WAVES = PairCountSmem::WAVES;
@@ -96,65 +110,67 @@ __global__ __launch_bounds__(1024) void radix_pair_count_kernel(const KeyT* __re
         const KeyT k = codec_in.encode(raw);
         return digit_of<KeyT>(k, shift, mask) | (digit_of<KeyT>(k, shift2, mask2) << 8);
     };
-    TallyRun run;
-    auto add_count = [&](uint32_t de, uint32_t c) {
-        atomicAdd(&my_hist[de & 255u], c);
-        atomicAdd(&s.hist2[pair_word(de & 255u, de >> 8)], c << (16u * ((de >> 8) & 1u)));
-    };
-    auto tally = [&](auto peel, KeyT raw) { wave_tally_mode(peel, both_digits(raw), lane, run, add_count); };
-    auto tally_one = [&](KeyT raw) { // lanes may be inactive
-        if (COLLECT) acc_or |= raw, acc_and &= raw;
-        const KeyT k = codec_in.encode(raw);
-        const uint32_t d = digit_of<KeyT>(k, shift, mask), e = digit_of<KeyT>(k, shift2, mask2);
-        atomicAdd(&my_hist[d], 1u);
-        atomicAdd(&s.hist2[pair_word(d, e)], 1u << (16u * (e & 1u)));
-    };
-
     constexpr int VEC = 16 / sizeof(KeyT);
     using VecT = typename std::conditional<sizeof(KeyT) == 4, uint4, ulonglong2>::type;
     const bool vec_ok = (reinterpret_cast<uintptr_t>(keys) & 15u) == 0;
     const uint64_t nvec = vec_ok ? (end - begin) / VEC : 0;
     const VecT* vkeys = reinterpret_cast<const VecT*>(keys + begin);
-    auto tally_vec = [&](auto peel, const VecT& a) {
-        if constexpr (sizeof(KeyT) == 4)
+    // The block's keys, every pair of digit values handed to add(d | e << 8, how many): groups of equal values with one call when few
+    // values dominate a wave (wave_tally).  Called once for the tables, and once more for the wide rows of a block that needs them.
+    auto count_keys = [&](auto&& add, auto collect) {
+        constexpr bool kCollect = decltype(collect)::value;
+        TallyRun run;
+        auto tally = [&](auto peel, KeyT raw) { wave_tally_mode(peel, both_digits(raw), lane, run, add); };
+        auto tally_one = [&](KeyT raw) { // lanes may be inactive
+            if (kCollect) acc_or |= raw, acc_and &= raw;
+            add(both_digits(raw), 1u);
+        };
+        auto tally_vec = [&](auto peel, const VecT& a) {
+            if constexpr (sizeof(KeyT) == 4)
+            {
+                if (kCollect) acc_or |= a.x | a.y | a.z | a.w, acc_and &= a.x & a.y & a.z & a.w;
+                tally(peel, a.x); tally(peel, a.y); tally(peel, a.z); tally(peel, a.w);
+            }
+            else
+            {
+                if (kCollect) acc_or |= a.x | a.y, acc_and &= a.x & a.y;
+                tally(peel, a.x); tally(peel, a.y);
+            }
+        };
+        uint64_t vbase = 0;
+        // (the loop twice, chosen once per wave from its first keys: see wave_tally.  An explicit prefetch of the next
+        // iteration's four vectors made the kernel 8 % slower)
+        auto main_loop = [&](auto peel) {
+            for (; vbase + 4 * THREADS <= nvec; vbase += 4 * THREADS) // block-uniform trip count, 4 x 16 B in flight per lane
+            {
+                if (wave_tally_gives_up(peel, run)) break; // (peel mode only; the wave comes back in the stateless mode)
+                VecT a = load_streaming(&vkeys[vbase + tid]);
+                VecT b = load_streaming(&vkeys[vbase + tid + THREADS]);
+                VecT c = load_streaming(&vkeys[vbase + tid + 2 * THREADS]);
+                VecT d = load_streaming(&vkeys[vbase + tid + 3 * THREADS]);
+                tally_vec(peel, a);
+                tally_vec(peel, b);
+                tally_vec(peel, c);
+                tally_vec(peel, d);
+            }
+        };
+        if (4 * THREADS <= nvec) wave_tally_dispatch(both_digits(vkeys[tid].x), lane, run, main_loop, add);
+        uint64_t i = begin + vbase * VEC + tid;
+        for (; i + 7ull * THREADS < end; i += 8ull * THREADS)
         {
-            if (COLLECT) acc_or |= a.x | a.y | a.z | a.w, acc_and &= a.x & a.y & a.z & a.w;
-            tally(peel, a.x); tally(peel, a.y); tally(peel, a.z); tally(peel, a.w);
-        }
-        else
-        {
-            if (COLLECT) acc_or |= a.x | a.y, acc_and &= a.x & a.y;
-            tally(peel, a.x); tally(peel, a.y);
-        }
-    };
-    uint64_t vbase = 0;
-    // (the loop twice, chosen once per wave from its first keys: see wave_tally.  An explicit prefetch of the next
-    // iteration's four vectors made the kernel 8 % slower)
-    auto main_loop = [&](auto peel) {
-        for (; vbase + 4 * THREADS <= nvec; vbase += 4 * THREADS) // block-uniform trip count, 4 x 16 B in flight per lane
-        {
-            if (wave_tally_gives_up(peel, run)) break; // (peel mode only; the wave comes back in the stateless mode)
-            VecT a = load_streaming(&vkeys[vbase + tid]);
-            VecT b = load_streaming(&vkeys[vbase + tid + THREADS]);
-            VecT c = load_streaming(&vkeys[vbase + tid + 2 * THREADS]);
-            VecT d = load_streaming(&vkeys[vbase + tid + 3 * THREADS]);
-            tally_vec(peel, a);
-            tally_vec(peel, b);
-            tally_vec(peel, c);
-            tally_vec(peel, d);
-        }
-    };
-    if (4 * THREADS <= nvec) wave_tally_dispatch(both_digits(vkeys[tid].x), lane, run, main_loop, add_count);
-    uint64_t i = begin + vbase * VEC + tid;
-    for (; i + 7ull * THREADS < end; i += 8ull * THREADS)
-    {
-        KeyT k[8];
+            KeyT k[8];
 #pragma unroll
-        for (int j = 0; j < 8; j++) k[j] = keys[i + (uint64_t) j * THREADS];
+            for (int j = 0; j < 8; j++) k[j] = keys[i + (uint64_t) j * THREADS];
 #pragma unroll
-        for (int j = 0; j < 8; j++) tally_one(k[j]);
-    }
-    for (; i < end; i += THREADS) tally_one(keys[i]);
+            for (int j = 0; j < 8; j++) tally_one(k[j]);
+        }
+        for (; i < end; i += THREADS) tally_one(keys[i]);
+    };
+    auto add_count = [&](uint32_t de, uint32_t c) {
+        atomicAdd(&my_hist[de & 255u], c);
+        atomicAdd(&s.hist2[pair_word(de & 255u, de >> 8)], c << (16u * ((de >> 8) & 1u)));
+    };
+    count_keys(add_count, std::integral_constant<bool, COLLECT>());
     __syncthreads();
     if (COLLECT && (plan_flags & kPlanCollectBits)) plan_publish_bits<KeyT>(plan, acc_or, acc_and, lane);
 
@@ -184,6 +200,75 @@ __global__ __launch_bounds__(1024) void radix_pair_count_kernel(const KeyT* __re
         row[64 + j0] = w1;
     }
     if (bad && lane == 0 && plan) plan->pair_fallback[pass + 1] = 1;
+    if (!wide) return; // (kernel-uniform)
+    // ---- wide rows: which rows did not add up (re-checked from T1 and the row in LDS, now that every T1 entry is in hist1[0])
+    __shared__ uint32_t nwide, wide_d[kPairWideRows];
+    uint32_t* const slot_of = s.hist1[1];              // [256]: 1 + the wide row of digit value d, 0: none
+    uint32_t* const wide_cnt = &s.hist1[2][0];         // [kPairWideRows][256] exact 32-bit counts (hist1 holds 16 rows of 256 words)
+    static_assert(2 + kPairWideRows <= PairCountSmem::WAVES, "the wide counters live in the wave-private T1 rows, which are done with");
+    __syncthreads(); // (every wave has read its T1 rows and checked its T2 rows)
+    for (uint32_t i = tid; i < (1u + kPairWideRows) * kPairRadix; i += THREADS) s.hist1[1][i] = 0u;
+    if (tid == 0) nwide = 0;
+    __syncthreads();
+    for (uint32_t d = wave; d < kPairRadix; d += WAVES)
+    {
+        const uint32_t w0 = s.hist2[d * kPairRowWords + lane], w1 = s.hist2[d * kPairRowWords + 64 + lane];
+        uint32_t sum = (w0 & 0xFFFFu) + (w0 >> 16) + (w1 & 0xFFFFu) + (w1 >> 16);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        if (sum != s.hist1[0][d] && lane == 0)
+        {
+            const uint32_t k = atomicAdd(&nwide, 1u);
+            if (k < kPairWideRows) slot_of[d] = k + 1u, wide_d[k] = d;
+        }
+    }
+    __syncthreads();
+    const uint32_t nw = nwide; // (workgroup-uniform)
+    uint32_t* const hdr = wide + (size_t) b * kPairWideStride;
+    // (a block whose keys are all ONE value -- all-zero keys, the reference's benchmark input: its row cannot be put right for less
+    // than a second read, and a sort of equal keys is better off refused: the ordinary passes then skip on the bits the first read
+    // collected, 0.31 ms for 2^28 keys.  Known where the key bits are collected: untyped keys.  The waves' OR / AND meet in LDS.)
+    bool one_value = false;
+    if (COLLECT && nw != 0)
+    {
+        KeyT o = acc_or, a = acc_and;
+#pragma unroll
+        for (int sh = 32; sh > 0; sh >>= 1)
+        {
+            o |= (KeyT) __shfl_xor((unsigned long long) o, sh);
+            a &= (KeyT) __shfl_xor((unsigned long long) a, sh);
+        }
+        KeyT* const wave_bits = reinterpret_cast<KeyT*>(&s.hist2[0]); // (the T2 rows have left for global memory)
+        __syncthreads();
+        if (lane == 0) wave_bits[2 * wave] = o, wave_bits[2 * wave + 1] = a;
+        __syncthreads();
+        o = 0, a = (KeyT) ~(KeyT) 0;
+        for (int w = 0; w < WAVES; w++) o |= wave_bits[2 * w], a &= wave_bits[2 * w + 1];
+        one_value = o == a;
+        __syncthreads();
+    }
+    if (nw == 0 || nw > kPairWideRows || one_value)
+    {
+        if (tid == 0) hdr[0] = nw == 0 ? 0u : 0xFFFFFFFFu;
+        return;
+    }
+    // the block's keys again, exact counts of the rows that wrapped
+    auto add_wide = [&](uint32_t de, uint32_t c) {
+        const uint32_t sl = slot_of[de & 255u];
+        if (sl) atomicAdd(&wide_cnt[(sl - 1u) * kPairRadix + (de >> 8)], c);
+    };
+    count_keys(add_wide, std::false_type());
+    __syncthreads();
+    if (tid == 0) hdr[0] = nw;
+    if (tid < nw) hdr[1 + tid] = wide_d[tid];
+    for (uint32_t k = 0; k < nw; k++)
+    {
+        const uint32_t d = wide_d[k];
+        if (tid < kPairRadix) hdr[16 + k * kPairRadix + tid] = wide_cnt[k * kPairRadix + tid] >> 16;
+        if (tid < kPairRowWords) // the T2 row with the low halves of the exact counts (a wrapped even counter had carried into its odd neighbour)
+            t2[((size_t) d * nb + b) * kPairRowWords + tid] =
+                (wide_cnt[k * kPairRadix + 2 * tid] & 0xFFFFu) | (wide_cnt[k * kPairRadix + 2 * tid + 1] << 16);
+    }
 }
 
 // ---- what the unit-sum kernels of both digit widths share ----------------------------------------------------------------

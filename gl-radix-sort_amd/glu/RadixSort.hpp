@@ -110,6 +110,9 @@ namespace glu
 
         /// Bits per counting pass: 4 = the reference's pass structure (8 passes), 8 = 4 passes; same output.
         void set_digit_bits(uint32_t bits) { GLU_CHECK_STATUS(glu_radix_sort_set_digit_bits(m_impl, bits)); }
+        /// A switch of this object for tests / tuning (glu_radix_sort_set_option in glu_hip.h: "SORT_LDS_FINISH", "SORT_FORK", ...);
+        /// the process environment only supplies defaults when an object is created.
+        void set_option(const char* name, long long value) { GLU_CHECK_STATUS(glu_radix_sort_set_option(m_impl, name, value)); }
         [[nodiscard]] uint32_t digit_bits() const
         {
             uint32_t bits = 0;

@@ -160,6 +160,36 @@ TEST_CASE("RadixSort-reuse-and-prepare")
     }
 }
 
+TEST_CASE("RadixSort-options-on-the-object")
+{
+    // switches are set on the object (glu_radix_sort_set_option), not through the process environment: the same sort by the small
+    // geometry, without the one-workgroup path, with 4-bit digits -- the results are the same, an unknown name is an error status
+    std::mt19937 gen(6);
+    const size_t n = 30000;
+    std::vector<GLuint> keys(n), vals(n);
+    for (auto& k : keys) k = gen();
+    std::iota(vals.begin(), vals.end(), 0u);
+    std::vector<GLuint> want_k, want_v;
+    for (int variant = 0; variant < 3; variant++)
+    {
+        RadixSort radix_sort;
+        if (variant == 1) radix_sort.set_option("SORT_SMALL", 1), radix_sort.set_option("GLU_HIP_SORT_NO_SINGLE_BLOCK", 1);
+        if (variant == 2) radix_sort.set_option("digit_bits", 4);
+        ShaderStorageBuffer kb(keys), vb(vals);
+        radix_sort(kb.handle(), vb.handle(), n);
+        std::vector<GLuint> sk = kb.get_data<GLuint>(), sv = vb.get_data<GLuint>();
+        check_sorted(sk);
+        if (variant == 0) want_k = sk, want_v = sv;
+        CHECK(sk == want_k);
+        CHECK(sv == want_v);
+        if (variant == 2) CHECK(radix_sort.digit_bits() == 4u);
+    }
+    glu_radix_sort raw = nullptr;
+    CHECK(glu_radix_sort_create(&raw) == GLU_OK);
+    CHECK(glu_radix_sort_set_option(raw, "NO_SUCH_SWITCH", 1) == GLU_ERROR_INVALID_ARGUMENT);
+    CHECK(glu_radix_sort_destroy(raw) == GLU_OK);
+}
+
 TEST_CASE("RadixSort-u64-keys")
 {
     // 64-bit keys + 32-bit values (BASELINE config 5; not in the reference): same stable contract

@@ -96,17 +96,13 @@ def test_duplicate_keys_inside_runs_keep_their_order(G):
 
 def test_small_key_range_under_the_host_side_guess(G):
     """20-bit keys with the round-4 rule for the runs' bits (GLU_HIP_SORT_DEVICE_TOP=0: a fresh object takes the whole key's top 16):
-    16 runs of a quarter million pairs each.  Round 5 refused (more than half of the pairs in long runs); since round 6 the
-    segmented passes take them, however many pairs they hold.  GLU_HIP_SORT_LONG_RUNS=0: refused, the ordinary passes run."""
+    16 runs of a quarter million pairs each.  Refused: the segmented passes over all of them would move 76 bytes per pair where three
+    ordinary passes -- the keys' top byte is constant -- move 60 (the plan's cost rule, round 6; round 5 refused for the share of the
+    pairs in long runs)."""
     rng = np.random.default_rng(4)
     keys = rng.integers(0, 1 << 20, N_SMALL, dtype=np.uint32)
     vals = np.arange(N_SMALL, dtype=np.uint32)
     s = _sorter(G, GLU_HIP_SORT_DEVICE_TOP=0, **SMALL)
-    gk, gv, fin = _run(G, s, keys, vals)
-    _check(keys, vals, gk, gv)
-    assert fin["attempted"] == 1 and fin["accepted"] == 1 and fin["longest_run"] > CAP_SMALL
-    assert s.read_long_runs()["runs"] == 16
-    s = _sorter(G, GLU_HIP_SORT_DEVICE_TOP=0, GLU_HIP_SORT_LONG_RUNS=0, **SMALL)
     gk, gv, fin = _run(G, s, keys, vals)
     _check(keys, vals, gk, gv)
     assert fin["attempted"] == 1 and fin["accepted"] == 0 and fin["longest_run"] > CAP_SMALL
@@ -114,17 +110,12 @@ def test_small_key_range_under_the_host_side_guess(G):
     assert skipped[:3] == [0, 0, 0] and skipped[3] != 0 and roles == [1, 2, 1, 2]
 
 
-def test_all_keys_equal(G):
-    """One run of n equal keys.  At this size no 16-bit counter of the two-digit table wraps (a block holds 16 Ki keys): the run
-    lengths are exact, the one run is a long run, and the first segmented pass finds it in order as it stands (round 5 refused the
-    sort: more than half of the pairs in long runs).  The round-4 rule still refuses."""
+def test_all_keys_equal_is_refused(G):
+    """One run of n equal keys: no key byte varies, so the ordinary passes are all identities and cost nothing -- the plan refuses
+    (round 6's cost rule; at 2^28 keys the blocks of the leader's count kernel would not even put their wrapped counters right)."""
     keys = np.full(N_SMALL, 0xDEADBEEF, dtype=np.uint32)
     vals = np.arange(N_SMALL, dtype=np.uint32)
-    s = _sorter(G, **SMALL)
-    gk, gv, fin = _run(G, s, keys, vals)
-    _check(keys, vals, gk, gv)
-    assert fin["attempted"] == 1 and fin["accepted"] == 1 and s.read_long_runs()["pairs"] == N_SMALL
-    gk, gv, fin = _run(G, _sorter(G, GLU_HIP_SORT_LONG_RUNS=0, **SMALL), keys, vals)
+    gk, gv, fin = _run(G, _sorter(G, **SMALL), keys, vals)
     _check(keys, vals, gk, gv)
     assert fin["attempted"] == 1 and fin["accepted"] == 0
 
@@ -289,6 +280,48 @@ def test_few_distinct_values_end_in_lds_and_their_runs_stay_put(G, kind, distinc
     assert fin["attempted"] == 1 and fin["accepted"] == 1, (fin, lr)
     if distinct <= 100:  # (a value's copies outgrow every enqueued tile: each is a long run, and nothing but long runs is left)
         assert lr["runs"] >= distinct * 0.95 and lr["pairs"] == n, (fin, lr)
+
+
+# ---- round 6: heavy hitters.  A key value that holds more than 6 % of a block of the leader's count kernel wraps a 16-bit counter of the
+# two-digit table; round 5 noticed and refused (no exact run lengths).  The block now counts such rows again with 32-bit counters
+# (radix_pair_passes.hpp, wide rows): the lengths are exact, the sort ends in LDS, the heavy hitters are long runs of one value.
+
+@pytest.mark.parametrize("shape", ["three_values", "ten_percent_zeros", "half_one_value_u64", "three_values_int32", "all_equal"])
+def test_heavy_hitters_that_wrap_the_16_bit_counters(G, shape):
+    n = (1 << 26) + 1234  # (256 blocks of 2^18 keys: a value holding a third of them wraps a 16-bit counter in every block)
+    rng = np.random.default_rng(606)
+    kind = "u32_pairs"
+    if shape == "three_values":
+        keys = np.array([0x00000000, 0x7F00FF01, 0xFFFFFFFF], dtype=np.uint32)[rng.integers(0, 3, n)]
+        want_runs = 3
+    elif shape == "ten_percent_zeros":
+        keys = rng.integers(0, 2**32, n, dtype=np.uint32)
+        keys[rng.random(n) < 0.35] = 0  # (35 %: 10 % would not wrap at this size, where a block is 2^18 keys)
+        want_runs = 1
+    elif shape == "half_one_value_u64":
+        kind = "u64_pairs"
+        keys = rng.integers(0, 2**64, n, dtype=np.uint64)
+        keys[rng.random(n) < 0.5] = np.uint64(0x0123456789ABCDEF)
+        want_runs = 1
+    elif shape == "three_values_int32":
+        kind = "int32"
+        keys = np.array([0x00000005, 0x80000000, 0xFFFFFFF0], dtype=np.uint32)[rng.integers(0, 3, n)]
+        want_runs = 3
+    else:
+        keys = np.full(n, 0x00C0FFEE, dtype=np.uint32)
+        want_runs = 0
+    vals = np.arange(n, dtype=np.uint32)
+    s = _sorter(G)
+    gk, gv, fin, lr = _sort_kind(G, s, kind, keys, vals)
+    order = np.argsort(keys, kind="stable")
+    assert (gk == keys[order]).all(), np.flatnonzero(gk != keys[order])[:5]
+    assert (gv == vals[order]).all(), np.flatnonzero(gv != vals[order])[:5]
+    if shape == "all_equal":
+        # (blocks of ONE key value do not put their row right: refused, and the ordinary passes skip on the collected bits)
+        assert fin["attempted"] == 1 and fin["accepted"] == 0, fin
+    else:
+        assert fin["attempted"] == 1 and fin["accepted"] == 1 and lr["runs"] >= want_runs, (fin, lr)
+        assert fin["longest_run"] == int(np.bincount((keys >> (keys.dtype.type(8 * keys.itemsize - 16))).astype(np.int64), minlength=65536).max()), fin
 
 
 @pytest.mark.parametrize("shape", ["long_run_first", "long_run_last", "many_long_runs", "long_runs_of_equal_keys", "zeros_1_percent",
@@ -664,12 +697,12 @@ def test_one_captured_graph_serves_every_outcome(G):
     pos = np.random.default_rng(26).choice(n, n * 6 // 10, replace=False)
     crowd[pos] = (np.random.default_rng(27).integers(0, 30, pos.size, dtype=np.uint32) * np.uint32(2001) << np.uint32(16)) | (crowd[pos] & np.uint32(0xFFFF))
     # (a long run goes to the segmented passes, 22-bit keys take their runs from bits [6, 22): both end in LDS in the small tile)
-    # (refused by default since round 6: only what the runs' bits cannot order -- 20-bit keys but for ONE key with bit 31 set, at an
-    # index the sample does not read; all-equal keys and the crowded keys are long runs for the segmented passes now)
+    # (refused: all-equal keys -- the ordinary passes are identities, nothing is cheaper -- and 20-bit keys but for ONE key with bit 31
+    # set, at an index the sample does not read; the crowded keys are thirty long runs for the segmented passes since round 6)
     missed = _uniform(n, 28) >> np.uint32(12)
     missed[7] |= np.uint32(0x80000000)
     inputs = [(_uniform(n, 21), 1, 1536), (_with_one_run_of(n, 3000, 22), 1, 1536), (_uniform(n, 23) >> np.uint32(10), 1, 1536),
-              (np.full(n, 5, dtype=np.uint32), 1, 4608), (crowd, 1, 4608), (missed, 0, 4608), (_with_one_run_of(n, 2000, 24), 1, 1536),
+              (np.full(n, 5, dtype=np.uint32), 0, 4608), (crowd, 1, 4608), (missed, 0, 4608), (_with_one_run_of(n, 2000, 24), 1, 1536),
               (_uniform(n, 25), 1, 1536)]
     with torch.cuda.stream(side):
         kt.copy_(torch.from_numpy(inputs[0][0].view(np.int32)))
@@ -738,11 +771,12 @@ def test_u64_small_range(G):
     ek, ev = O.stable_sort_pairs(keys, vals)
     assert (gk == ek).all() and (gv == ev).all()
     assert fin["attempted"] == 1 and fin["accepted"] == 0
-    # (the default since round 6: the few long runs go to the segmented passes)
+    # (the default: refused too -- six segmented passes over the one long run would move more than the six ordinary passes on the
+    # key bytes that vary; the plan's cost rule)
     s = _sorter(G, GLU_HIP_SORT_DEVICE_TOP=0, **SMALL)
     gk, gv, fin = _run64(G, s, keys, vals)
     assert (gk == ek).all() and (gv == ev).all()
-    assert fin["attempted"] == 1 and fin["accepted"] == 1 and s.read_long_runs()["runs"] > 0
+    assert fin["attempted"] == 1 and fin["accepted"] == 0
 
 
 @pytest.mark.parametrize("length,accepted,capacity", [(1536, 1, 1536), (1537, 1, 2560), (4608, 1, 4608), (4609, 0, 4608)])
