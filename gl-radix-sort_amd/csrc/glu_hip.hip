@@ -1,4 +1,5 @@
-// glu_hip.hip -- implementation of the C ABI in include/glu_hip.h (gfx950 only, no CPU fallback).
+// glu_hip.hip -- RadixSort and the sharded sort of libglu_hip.so: the C ABI of include/glu_hip.h (gfx950 only, no CPU fallback).
+// The library's other translation units: glu_core.hip, glu_sort_finish.hip, glu_scan_reduce.hip (glu_host.hpp).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -14,370 +15,16 @@
 #include <unordered_map>
 #include <vector>
 
-#define GLU_HIP_BUILD 1
-#include "glu_hip.h"
+#include "glu_host.hpp"
+#include "glu_sort_launch.hpp"
 #include "radix_sort_kernels.hpp"
 #include "radix_scatter_lines.hpp"
 #include "radix_pair_passes.hpp"
 #include "radix_seg_passes.hpp"
-#include "radix_lds_bucket.hpp"
-#include "scan_reduce_kernels.hpp"
+#include "radix_lds_plan.hpp"
 
 using namespace glu_hip;
-
-// ------------------------------------------------------------------------------------------------------------
-// errors
-// ------------------------------------------------------------------------------------------------------------
-namespace
-{
-thread_local std::string g_last_error;
-
-// GLU_VERBOSE=1: allocations and placement searches are narrated on stderr (read once per process)
-bool glu_verbose()
-{
-    static const bool on = getenv("GLU_VERBOSE") != nullptr;
-    return on;
-}
-
-// Every other environment variable the library reads goes through here: defaults of new sort objects (kSortOptions), the
-// tuning lists of the placement search / scan / reduce, and the test hooks of glu_dist (fault injection, the RCCL test double).
-const char* glu_env(const char* name) { return getenv(name); }
-
-glu_status fail(glu_status code, const char* fmt, ...)
-{
-    char buf[512];
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(buf, sizeof(buf), fmt, ap);
-    va_end(ap);
-    g_last_error = buf;
-    return code;
-}
-
-#define HIP_TRY(expr)                                                                                                  \
-    do                                                                                                                 \
-    {                                                                                                                  \
-        hipError_t e_ = (expr);                                                                                        \
-        if (e_ != hipSuccess)                                                                                          \
-            return fail(e_ == hipErrorOutOfMemory ? GLU_ERROR_OUT_OF_MEMORY : GLU_ERROR_DEVICE, "%s failed: %s", #expr, \
-                        hipGetErrorString(e_));                                                                        \
-    } while (0)
-
-#define GLU_TRY(expr)                                                                                                  \
-    do                                                                                                                 \
-    {                                                                                                                  \
-        glu_status s_ = (expr);                                                                                        \
-        if (s_ != GLU_OK) return s_;                                                                                   \
-    } while (0)
-
-// ------------------------------------------------------------------------------------------------------------
-// device / queue state (one device per process)
-// ------------------------------------------------------------------------------------------------------------
-struct Device
-{
-    std::mutex mutex;
-    bool ready = false;
-    int requested = -1;
-    int id = 0;
-    int num_cus = 256;
-    hipStream_t queue = nullptr;
-    hipDeviceProp_t props;
-};
-Device g_dev;
-
-glu_status ensure_device()
-{
-    std::lock_guard<std::mutex> lock(g_dev.mutex);
-    if (g_dev.ready) return GLU_OK;
-    int count = 0;
-    hipError_t e = hipGetDeviceCount(&count);
-    if (e != hipSuccess || count == 0)
-        return fail(GLU_ERROR_NO_DEVICE,
-                    "no HIP device visible (%s): libglu_hip has no CPU fallback, an MI355X (gfx950) is required",
-                    e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
-    int id = 0;
-    if (g_dev.requested >= 0)
-        id = g_dev.requested;
-    else
-        HIP_TRY(hipGetDevice(&id));
-    if (id >= count) return fail(GLU_ERROR_INVALID_ARGUMENT, "device %d does not exist (%d visible)", id, count);
-    HIP_TRY(hipSetDevice(id));
-    HIP_TRY(hipGetDeviceProperties(&g_dev.props, id));
-    if (strncmp(g_dev.props.gcnArchName, "gfx950", 6) != 0)
-        return fail(GLU_ERROR_NO_DEVICE, "device %d is %s; libglu_hip is built for gfx950 only", id,
-                    g_dev.props.gcnArchName);
-    g_dev.id = id;
-    g_dev.num_cus = g_dev.props.multiProcessorCount > 0 ? g_dev.props.multiProcessorCount : 256;
-    HIP_TRY(hipStreamCreateWithFlags(&g_dev.queue, hipStreamNonBlocking));
-    g_dev.ready = true;
-    return GLU_OK;
-}
-
-// Every public entry point runs this first: the device is initialised once per process, and the calling thread's
-// current HIP device is made the library's device (a new thread's current device is 0, and an application may switch
-// devices between two library calls -- torch.cuda.device(k), hipSetDevice -- so the current device is asked for every
-// time instead of being remembered per thread: without this, scratch would be allocated on one device and the kernels
-// launched on a stream of another).
-glu_status enter()
-{
-    GLU_TRY(ensure_device());
-    int current = -1;
-    if (hipGetDevice(&current) != hipSuccess || current != g_dev.id) HIP_TRY(hipSetDevice(g_dev.id));
-    return GLU_OK;
-}
-
-inline hipStream_t pick_stream(void* stream) { return stream ? (hipStream_t) stream : g_dev.queue; }
-
-// ------------------------------------------------------------------------------------------------------------
-// buffers
-// ------------------------------------------------------------------------------------------------------------
-struct Buffer
-{
-    void* ptr = nullptr;
-    size_t size = 0;
-    bool owned = true;
-};
-std::mutex g_buf_mutex;
-std::unordered_map<glu_buffer, Buffer> g_buffers;
-glu_buffer g_next_buffer = 1;
-
-glu_status lookup(glu_buffer h, Buffer& out, const char* what)
-{
-    if (h == 0) return fail(GLU_ERROR_INVALID_ARGUMENT, "Invalid %s", what);
-    std::lock_guard<std::mutex> lock(g_buf_mutex);
-    auto it = g_buffers.find(h);
-    if (it == g_buffers.end()) return fail(GLU_ERROR_INVALID_ARGUMENT, "Invalid %s (unknown handle %u)", what, h);
-    out = it->second;
-    return GLU_OK;
-}
-
-glu_buffer register_buffer(const Buffer& b)
-{
-    std::lock_guard<std::mutex> lock(g_buf_mutex);
-    glu_buffer h = g_next_buffer++;
-    if (g_next_buffer == 0) g_next_buffer = 1;
-    g_buffers[h] = b;
-    return h;
-}
-
-// grow-only device allocation owned by an operator object
-struct Scratch
-{
-    void* ptr = nullptr;
-    size_t size = 0;
-    glu_status reserve(size_t bytes)
-    {
-        if (bytes <= size) return GLU_OK;
-        if (ptr) HIP_TRY(hipFree(ptr));
-        ptr = nullptr;
-        size = 0;
-        HIP_TRY(hipMalloc(&ptr, bytes));
-        size = bytes;
-        if (glu_verbose()) fprintf(stderr, "[glu_hip] scratch reallocated to: %zu\n", bytes);
-        return GLU_OK;
-    }
-    void release()
-    {
-        if (ptr) (void) hipFree(ptr);
-        ptr = nullptr;
-        size = 0;
-    }
-};
-} // namespace
-
-// ------------------------------------------------------------------------------------------------------------
-// library / device
-// ------------------------------------------------------------------------------------------------------------
-extern "C" {
-
-const char* glu_last_error(void) { return g_last_error.c_str(); }
-const char* glu_version(void) { return "glu_hip 0.5.0 gfx950"; }
-
-glu_status glu_device_count(int* count)
-{
-    if (!count) return fail(GLU_ERROR_INVALID_ARGUMENT, "count is NULL");
-    int c = 0;
-    if (hipGetDeviceCount(&c) != hipSuccess) c = 0;
-    *count = c;
-    return GLU_OK;
-}
-
-glu_status glu_set_device(int device)
-{
-    {
-        std::lock_guard<std::mutex> lock(g_dev.mutex);
-        if (g_dev.ready)
-        {
-            if (device == g_dev.id) return GLU_OK;
-            return fail(GLU_ERROR_INVALID_STATE, "device already initialised to %d (one device per process)", g_dev.id);
-        }
-        g_dev.requested = device;
-    }
-    return ensure_device();
-}
-
-glu_status glu_device_info(char* out, size_t out_size)
-{
-    GLU_TRY(enter());
-    if (!out || out_size == 0) return fail(GLU_ERROR_INVALID_ARGUMENT, "out is NULL");
-    snprintf(out, out_size, "%s (%s), %d CUs, %.1f GiB, device %d", g_dev.props.name, g_dev.props.gcnArchName,
-             g_dev.num_cus, (double) g_dev.props.totalGlobalMem / (1024.0 * 1024.0 * 1024.0), g_dev.id);
-    return GLU_OK;
-}
-
-glu_status glu_device_synchronize(void)
-{
-    GLU_TRY(enter());
-    HIP_TRY(hipStreamSynchronize(g_dev.queue));
-    return GLU_OK;
-}
-
-glu_status glu_queue(void** stream)
-{
-    GLU_TRY(enter());
-    if (!stream) return fail(GLU_ERROR_INVALID_ARGUMENT, "stream is NULL");
-    *stream = (void*) g_dev.queue;
-    return GLU_OK;
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// buffers
-// ------------------------------------------------------------------------------------------------------------
-glu_status glu_buffer_create(size_t size, glu_buffer* out)
-{
-    GLU_TRY(enter());
-    if (!out) return fail(GLU_ERROR_INVALID_ARGUMENT, "out is NULL");
-    Buffer b;
-    b.size = size;
-    if (size > 0) HIP_TRY(hipMalloc(&b.ptr, size));
-    *out = register_buffer(b);
-    return GLU_OK;
-}
-
-glu_status glu_buffer_create_with_data(const void* data, size_t size, glu_buffer* out)
-{
-    GLU_TRY(enter());
-    if (!data) return fail(GLU_ERROR_INVALID_ARGUMENT, "data is NULL");
-    if (size == 0) return fail(GLU_ERROR_INVALID_ARGUMENT, "size is 0");
-    GLU_TRY(glu_buffer_create(size, out));
-    const glu_status st = glu_buffer_write(*out, data, size, 0);
-    if (st != GLU_OK)
-    {
-        const std::string message = g_last_error; // (the destroy below must not replace the reason)
-        (void) glu_buffer_destroy(*out);
-        *out = 0;
-        g_last_error = message;
-    }
-    return st;
-}
-
-glu_status glu_buffer_wrap(void* device_ptr, size_t size, glu_buffer* out)
-{
-    GLU_TRY(enter());
-    if (!out) return fail(GLU_ERROR_INVALID_ARGUMENT, "out is NULL");
-    if (!device_ptr && size > 0) return fail(GLU_ERROR_INVALID_ARGUMENT, "device_ptr is NULL");
-    Buffer b;
-    b.ptr = device_ptr;
-    b.size = size;
-    b.owned = false;
-    *out = register_buffer(b);
-    return GLU_OK;
-}
-
-glu_status glu_buffer_destroy(glu_buffer buffer)
-{
-    GLU_TRY(enter());
-    if (buffer == 0) return GLU_OK;
-    Buffer b;
-    {
-        std::lock_guard<std::mutex> lock(g_buf_mutex);
-        auto it = g_buffers.find(buffer);
-        if (it == g_buffers.end()) return fail(GLU_ERROR_INVALID_ARGUMENT, "unknown buffer handle %u", buffer);
-        b = it->second;
-        g_buffers.erase(it);
-    }
-    if (b.owned && b.ptr)
-    {
-        // queued work may still use it: free after the queue drains (hipFree synchronises the device anyway)
-        HIP_TRY(hipStreamSynchronize(g_dev.queue));
-        HIP_TRY(hipFree(b.ptr));
-    }
-    return GLU_OK;
-}
-
-glu_status glu_buffer_size(glu_buffer buffer, size_t* size)
-{
-    GLU_TRY(enter());
-    Buffer b;
-    GLU_TRY(lookup(buffer, b, "buffer"));
-    if (!size) return fail(GLU_ERROR_INVALID_ARGUMENT, "size is NULL");
-    *size = b.size;
-    return GLU_OK;
-}
-
-glu_status glu_buffer_device_ptr(glu_buffer buffer, void** device_ptr)
-{
-    GLU_TRY(enter());
-    Buffer b;
-    GLU_TRY(lookup(buffer, b, "buffer"));
-    if (!device_ptr) return fail(GLU_ERROR_INVALID_ARGUMENT, "device_ptr is NULL");
-    *device_ptr = b.ptr;
-    return GLU_OK;
-}
-
-glu_status glu_buffer_write(glu_buffer buffer, const void* data, size_t size, size_t offset)
-{
-    GLU_TRY(enter());
-    Buffer b;
-    GLU_TRY(lookup(buffer, b, "buffer"));
-    if (size == 0) return GLU_OK;
-    if (!data) return fail(GLU_ERROR_INVALID_ARGUMENT, "data is NULL");
-    if (offset > b.size || size > b.size - offset)
-        return fail(GLU_ERROR_INVALID_ARGUMENT, "write of %zu bytes at %zu exceeds buffer size %zu", size, offset, b.size);
-    // pageable host memory: the copy is staged before the call returns, ordered on the queue
-    HIP_TRY(hipMemcpyAsync((char*) b.ptr + offset, data, size, hipMemcpyHostToDevice, g_dev.queue));
-    HIP_TRY(hipStreamSynchronize(g_dev.queue));
-    return GLU_OK;
-}
-
-glu_status glu_buffer_read(glu_buffer buffer, void* data, size_t size, size_t offset)
-{
-    GLU_TRY(enter());
-    Buffer b;
-    GLU_TRY(lookup(buffer, b, "buffer"));
-    if (size == 0) return GLU_OK;
-    if (!data) return fail(GLU_ERROR_INVALID_ARGUMENT, "data is NULL");
-    if (offset > b.size || size > b.size - offset)
-        return fail(GLU_ERROR_INVALID_ARGUMENT, "read of %zu bytes at %zu exceeds buffer size %zu", size, offset, b.size);
-    HIP_TRY(hipMemcpyAsync(data, (const char*) b.ptr + offset, size, hipMemcpyDeviceToHost, g_dev.queue));
-    HIP_TRY(hipStreamSynchronize(g_dev.queue));
-    return GLU_OK;
-}
-
-glu_status glu_buffer_fill_u32(glu_buffer buffer, uint32_t value)
-{
-    GLU_TRY(enter());
-    Buffer b;
-    GLU_TRY(lookup(buffer, b, "buffer"));
-    if (b.size / 4 > 0) HIP_TRY(hipMemsetD32Async((hipDeviceptr_t) b.ptr, (int) value, b.size / 4, g_dev.queue));
-    return GLU_OK;
-}
-
-glu_status glu_buffer_copy(glu_buffer src, glu_buffer dst, size_t size, size_t src_offset, size_t dst_offset)
-{
-    GLU_TRY(enter());
-    Buffer s, d;
-    GLU_TRY(lookup(src, s, "source buffer"));
-    GLU_TRY(lookup(dst, d, "destination buffer"));
-    if (src_offset > s.size || size > s.size - src_offset || dst_offset > d.size || size > d.size - dst_offset)
-        return fail(GLU_ERROR_INVALID_ARGUMENT, "copy of %zu bytes out of range", size);
-    if (size > 0)
-        HIP_TRY(hipMemcpyAsync((char*) d.ptr + dst_offset, (const char*) s.ptr + src_offset, size,
-                               hipMemcpyDeviceToDevice, g_dev.queue));
-    return GLU_OK;
-}
-
-} // extern "C"
+using namespace glu_hip::host;
 
 // ------------------------------------------------------------------------------------------------------------
 // radix sort
@@ -1102,179 +749,6 @@ glu_status sort_single_block(KeyT* keys, uint32_t* vals, size_t count, uint32_t 
 }
 
 
-// A sort that ends in LDS (radix_lds_finish.hpp): the tile geometry of its last pass that suits uniformly drawn keys -- the
-// longest of 65536 runs stays below mean + 6 sigma.  The launches of that geometry and of the next larger ones are enqueued
-// and the device picks by the longest run it counted.  0: no geometry holds such runs (more than about 2^29 pairs).
-inline uint32_t finish_geometry_for(size_t count, size_t runs = kFinishRuns, uint32_t geometries = kFinishGeometries)
-{
-    const double mean = (double) count / (double) runs;
-    const double need = mean + 6.0 * std::sqrt(mean) + 8.0;
-    for (uint32_t g = 1; g <= geometries; g++)
-        if (need <= (double) finish_geometry_capacity(g)) return g;
-    return 0;
-}
-
-// More than 16 bits left to order (64-bit keys; a segmented sort by 32 bits): the rounds of the in-LDS pass rank the top 16 .. 23
-// of them and ties are repaired exactly (radix_lds_finish.hpp).  glu_radix_sort_s::finish_rank_bits.
-inline uint32_t finish_rank_from(uint32_t low_bits, uint32_t rank_bits)
-{
-    return low_bits > rank_bits ? ((low_bits - rank_bits) / 8u) * 8u : 0u;
-}
-
-// The in-LDS pass of a segmented sort, src -> dst over `nruns` runs (seg_run_plan): tile geometry `geo` (1 .. 4); split_log2 = 0: a
-// workgroup per run for the runs that fit the tile and radix_finish_ranges_kernel behind it for the longer ones; split_log2 > 0:
-// every run is split over 2^split_log2 workgroups of the ranges kernel.  Both return at once if the longest run (*gate) is
-// beyond gate_cap.
-template<int THREADS, int KPT>
-glu_status launch_seg_finish_geo(const uint32_t* src_k, const uint32_t* src_v, uint32_t* dst_k, uint32_t* dst_v, const uint32_t* starts,
-                                 uint32_t nruns, uint32_t geo, uint32_t split_log2, uint32_t low_bits, const uint32_t* gate, uint32_t gate_cap,
-                                 uint32_t rank_bits, hipStream_t stream)
-{
-    using Smem = FinishSmem<uint32_t, THREADS, KPT, true>;
-    auto sort_kernel = radix_finish_sort_kernel<uint32_t, THREADS, KPT, true, false, false>;
-    auto ranges_kernel = radix_finish_ranges_kernel<uint32_t, THREADS, KPT, true, false>;
-    static std::once_flag lds_opt_in;
-    static hipError_t lds_opt_in_result = hipSuccess;
-    std::call_once(lds_opt_in, [&] {
-        lds_opt_in_result = hipFuncSetAttribute((const void*) sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sizeof(Smem));
-        if (lds_opt_in_result == hipSuccess)
-            lds_opt_in_result = hipFuncSetAttribute((const void*) ranges_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sizeof(Smem));
-    });
-    HIP_TRY(lds_opt_in_result);
-    const uint32_t rank_from = finish_rank_from(low_bits, rank_bits);
-    if (split_log2 == 0)
-    {
-        hipLaunchKernelGGL(sort_kernel, dim3(nruns), dim3(THREADS), sizeof(Smem), stream, const_cast<uint32_t*>(src_k), const_cast<uint32_t*>(src_v),
-                           dst_k, dst_v, starts, low_bits, (const PassPlan*) nullptr, 0u, geo, 0u, nruns, gate, gate_cap, rank_bits,
-                           (unsigned long long*) nullptr, (const uint32_t*) nullptr, 0u);
-        HIP_TRY(hipGetLastError());
-    }
-    const uint64_t items = (((uint64_t) nruns + 7u) & ~7ull) << split_log2;
-    // (the long runs alone: workgroups that loop over the runs and skip the short ones)
-    const uint32_t grid = (uint32_t) (split_log2 == 0 ? std::min<uint64_t>(items, 2048u) : items);
-    hipLaunchKernelGGL(ranges_kernel, dim3(grid), dim3(THREADS), sizeof(Smem), stream, src_k, src_v, dst_k, dst_v, starts, nruns, low_bits,
-                       rank_from, split_log2, split_log2 == 0 ? (uint32_t) (THREADS * KPT) : 0u, gate, gate_cap, 0u);
-    HIP_TRY(hipGetLastError());
-    return GLU_OK;
-}
-
-inline glu_status launch_seg_finish(const uint32_t* src_k, const uint32_t* src_v, uint32_t* dst_k, uint32_t* dst_v, const uint32_t* starts,
-                                    uint32_t nruns, uint32_t geo, uint32_t split_log2, uint32_t low_bits, const uint32_t* gate, uint32_t gate_cap,
-                                    uint32_t rank_bits, hipStream_t stream)
-{
-#define GLU_SEG_FINISH(GEO_, THREADS_, KPT_)                                                                                                 \
-    if (geo == GEO_)                                                                                                                         \
-    {                                                                                                                                        \
-        static_assert(finish_geometry_capacity(GEO_) == THREADS_ * KPT_, "geometry table");                                                  \
-        return launch_seg_finish_geo<THREADS_, KPT_>(src_k, src_v, dst_k, dst_v, starts, nruns, geo, split_log2, low_bits, gate, gate_cap, rank_bits, stream); \
-    }
-    GLU_SEG_FINISH(1, 256, 6)
-    GLU_SEG_FINISH(2, 256, 10)
-    GLU_SEG_FINISH(3, 256, 18)
-    GLU_SEG_FINISH(4, 512, 18)
-    GLU_SEG_FINISH(5, 1024, 17)
-#undef GLU_SEG_FINISH
-    return fail(GLU_ERROR_INVALID_STATE, "no such tile geometry: %u", geo);
-}
-
-// The in-LDS pass of a whole-key sort (round 6): radix_finish_bucket_kernel for every enqueued tile geometry -- the one the sort is
-// expected to take gets a workgroup per run, the others 8192 workgroups that loop --, and behind them ONE launch of round 5's
-// ballot-ranked kernel in the largest enqueued tile for the runs the bucket kernel listed as crowded (or for all of them:
-// PassPlan::finish_rounds); it returns at once when the lists are empty.
-template<typename KeyT, bool VALS, bool XF>
-glu_status launch_finish(KeyT* keys_a, uint32_t* vals_a, KeyT* keys_b, uint32_t* vals_b, const uint32_t* starts,
-                         uint32_t geo_first, uint32_t geo_last, uint32_t geo_expected, uint32_t low_bits, const PassPlan* plan,
-                         uint32_t pass, uint32_t key_xf, hipStream_t stream, uint32_t rank_bits, uint32_t* crowded,
-                         glu_radix_sort_s* marks)
-{
-    // (marks: the two profile marks of the in-LDS pass go around the launch of the EXPECTED tile, the one that does the work in
-    // a timed loop -- not around the launches beside it that return at once)
-    constexpr uint32_t nruns = kFinishRuns;
-    // (order: the geometries that are not expected first -- they return at once in front of the long kernel instead of waiting
-    // behind it for room on the CUs; what follows the expected one is the launch that takes its crowded runs)
-#define GLU_FINISH(GEO_, THREADS_, KPT_)                                                                                          \
-    if (geo_first <= GEO_ && GEO_ <= geo_last && (GEO_ == geo_expected) == expected_turn)                                         \
-    {                                                                                                                             \
-        static_assert(finish_geometry_capacity(GEO_) == THREADS_ * KPT_, "geometry table");                                       \
-        using Smem = BucketSmem<KeyT, THREADS_, KPT_, VALS>;                                                                      \
-        auto kern = GEO_ == geo_expected ? radix_finish_bucket_kernel<KeyT, THREADS_, KPT_, VALS, false, XF>                      \
-                                         : radix_finish_bucket_kernel<KeyT, THREADS_, KPT_, VALS, true, XF>;                      \
-        static std::once_flag lds_opt_in;                                                                                         \
-        static hipError_t lds_opt_in_result = hipSuccess;                                                                         \
-        std::call_once(lds_opt_in, [&] {                                                                                          \
-            for (const void* k : {(const void*) radix_finish_bucket_kernel<KeyT, THREADS_, KPT_, VALS, false, XF>,                \
-                                  (const void*) radix_finish_bucket_kernel<KeyT, THREADS_, KPT_, VALS, true, XF>})                \
-                if (lds_opt_in_result == hipSuccess)                                                                              \
-                    lds_opt_in_result = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sizeof(Smem));   \
-        });                                                                                                                       \
-        HIP_TRY(lds_opt_in_result);                                                                                               \
-        if (GEO_ == geo_expected) marks->mark(stream, true);                                                                      \
-        hipLaunchKernelGGL(kern, dim3(GEO_ == geo_expected ? nruns : std::min(nruns, 8192u)), dim3(THREADS_), sizeof(Smem),       \
-                           stream, keys_a, vals_a, keys_b, vals_b, starts, low_bits, plan, pass, (uint32_t) GEO_, key_xf, nruns,  \
-                           crowded);                                                                                              \
-        if (GEO_ == geo_expected) marks->mark(stream, true);                                                                      \
-        HIP_TRY(hipGetLastError());                                                                                               \
-    }
-    // The runs the bucket kernel listed (or all of them: PassPlan::finish_rounds) by ballot rounds, 8192 workgroups that loop: one
-    // launch in the tile the sort is expected to take (four workgroups per CU for 256 x 18: 24-bit keys 3.15 -> 2.95 ms at 2^28
-    // against one launch in the largest tile), and one in the largest enqueued tile for whatever else the device chose (runs
-    // longer than the CHOSEN tile are the segmented passes' either way).
-#define GLU_FINISH_ROUNDS(GEO_, THREADS_, KPT_, FOR_EXPECTED_)                                                                    \
-    if (FOR_EXPECTED_ ? GEO_ == geo_expected : (GEO_ == geo_last && geo_first != geo_last))                                       \
-    {                                                                                                                             \
-        using Smem = FinishSmem<KeyT, THREADS_, KPT_, VALS>;                                                                      \
-        auto kern = radix_finish_sort_kernel<KeyT, THREADS_, KPT_, VALS, true, XF>;                                               \
-        static std::once_flag lds_opt_in;                                                                                         \
-        static hipError_t lds_opt_in_result = hipSuccess;                                                                         \
-        std::call_once(lds_opt_in, [&] {                                                                                          \
-            lds_opt_in_result = hipFuncSetAttribute((const void*) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sizeof(Smem)); \
-        });                                                                                                                       \
-        HIP_TRY(lds_opt_in_result);                                                                                               \
-        hipLaunchKernelGGL(kern, dim3(8192), dim3(THREADS_), sizeof(Smem), stream, keys_a, vals_a, keys_b, vals_b, starts,        \
-                           low_bits, plan, pass, FOR_EXPECTED_ ? (uint32_t) GEO_ : 0u, key_xf, nruns, (const uint32_t*) nullptr,  \
-                           0u, rank_bits, (unsigned long long*) nullptr, (const uint32_t*) crowded,                               \
-                           FOR_EXPECTED_ ? 0u : geo_expected);                                                                    \
-        HIP_TRY(hipGetLastError());                                                                                               \
-    }
-    for (int turn = 0; turn < 2; turn++)
-    {
-        const bool expected_turn = turn == 1;
-        GLU_FINISH(1, 256, 6)
-        GLU_FINISH(2, 256, 10)
-        if constexpr (sizeof(KeyT) == 4)
-        {
-            GLU_FINISH(3, 256, 18)
-            GLU_FINISH(4, 512, 18)
-        }
-        else
-        {
-            // 8-byte keys: twice the waves per workgroup (the word stage is 8 bytes per slot: two workgroups per CU)
-            GLU_FINISH(3, 512, 9)
-            GLU_FINISH(4, 1024, 9)
-        }
-    }
-    // (first the launch for the expected tile, then -- if more than one tile is enqueued -- the one in the largest tile for every
-    // other choice of the device, the expected tile excepted: whatever the device chose, one of the two takes the listed runs)
-    for (int for_expected = 1; for_expected >= 0; for_expected--)
-    {
-        GLU_FINISH_ROUNDS(1, 256, 6, for_expected)
-        GLU_FINISH_ROUNDS(2, 256, 10, for_expected)
-        if constexpr (sizeof(KeyT) == 4)
-        {
-            GLU_FINISH_ROUNDS(3, 256, 18, for_expected)
-            GLU_FINISH_ROUNDS(4, 512, 18, for_expected)
-        }
-        else
-        {
-            GLU_FINISH_ROUNDS(3, 512, 9, for_expected)
-            GLU_FINISH_ROUNDS(4, 1024, 9, for_expected)
-        }
-    }
-#undef GLU_FINISH
-#undef GLU_FINISH_ROUNDS
-    return GLU_OK;
-}
-
 // The segmented passes over the LONG runs of a whole-key sort that ends in LDS (radix_finish_long_runs_kernel built their
 // descriptors; hdr[0] = 0: there are none, or the sort was refused -- every kernel returns at once): key bits [0, 8) from the
 // arrays that hold the data (PassPlan::flip[2], known on the device) into the other pair, bits [8, 16) back -- 4-byte keys.
@@ -1589,11 +1063,12 @@ glu_status sort_bits(glu_radix_sort_s* s, KeyT* keys, uint32_t* vals, size_t cou
                     s->cur_behind = false;
                     s->mark(stream);
                     s->mark(stream);
+                    const FinishMarks finish_marks{[](void* object, hipStream_t st) { ((glu_radix_sort_s*) object)->mark(st, true); }, s};
 #define GLU_LAUNCH_FINISH(VALS_, XF_)                                                                                             \
     GLU_TRY((launch_finish<KeyT, VALS_, XF_>(kbuf[0], VALS_ ? vbuf[0] : nullptr, kbuf[1], VALS_ ? vbuf[1] : nullptr,              \
                                              (const uint32_t*) s->finish_starts.ptr, finish_kpt, finish_last, finish_expected,    \
                                              finish_top_bit - 16u, pa.plan, 2u, key_xf, stream, s->finish_rank_bits,              \
-                                             (uint32_t*) s->finish_crowded.ptr, s)))
+                                             (uint32_t*) s->finish_crowded.ptr, finish_marks)))
                     if (vals)
                     {
                         if (key_xf != KEY_XF_NONE) GLU_LAUNCH_FINISH(true, true);
@@ -2828,427 +2303,5 @@ glu_status glu_radix_sort_scratch_size(glu_radix_sort sort, size_t* bytes)
 
 } // extern "C"
 
-// ------------------------------------------------------------------------------------------------------------
-// scan / reduce: data-type dispatch
-// ------------------------------------------------------------------------------------------------------------
-namespace
-{
-size_t data_type_size(glu_data_type t)
-{
-    switch (t)
-    {
-    case GLU_DATA_TYPE_FLOAT: case GLU_DATA_TYPE_INT: case GLU_DATA_TYPE_UINT: return 4;
-    case GLU_DATA_TYPE_DOUBLE: case GLU_DATA_TYPE_VEC2: case GLU_DATA_TYPE_UVEC2: case GLU_DATA_TYPE_IVEC2: return 8;
-    case GLU_DATA_TYPE_VEC4: case GLU_DATA_TYPE_UVEC4: case GLU_DATA_TYPE_IVEC4: case GLU_DATA_TYPE_DVEC2: return 16;
-    case GLU_DATA_TYPE_DVEC4: return 32;
-    default: return 0;
-    }
-}
-
-// calls f.template operator()<S, N>() for the scalar type / component count of `t`
-template<typename F>
-glu_status dispatch_type(glu_data_type t, F&& f)
-{
-    switch (t)
-    {
-    case GLU_DATA_TYPE_FLOAT: return f.template operator()<float, 1>();
-    case GLU_DATA_TYPE_DOUBLE: return f.template operator()<double, 1>();
-    case GLU_DATA_TYPE_INT: return f.template operator()<int32_t, 1>();
-    case GLU_DATA_TYPE_UINT: return f.template operator()<uint32_t, 1>();
-    case GLU_DATA_TYPE_VEC2: return f.template operator()<float, 2>();
-    case GLU_DATA_TYPE_VEC4: return f.template operator()<float, 4>();
-    case GLU_DATA_TYPE_DVEC2: return f.template operator()<double, 2>();
-    case GLU_DATA_TYPE_DVEC4: return f.template operator()<double, 4>();
-    case GLU_DATA_TYPE_UVEC2: return f.template operator()<uint32_t, 2>();
-    case GLU_DATA_TYPE_UVEC4: return f.template operator()<uint32_t, 4>();
-    case GLU_DATA_TYPE_IVEC2: return f.template operator()<int32_t, 2>();
-    case GLU_DATA_TYPE_IVEC4: return f.template operator()<int32_t, 4>();
-    default: return fail(GLU_ERROR_INVALID_ARGUMENT, "Invalid data type: %d", (int) t);
-    }
-}
-} // namespace
-
-struct glu_scan_s
-{
-    glu_data_type type;
-    Scratch sums;
-    // chained (single-pass) scan state for 4-byte element types: one 64-bit word per chunk + a ticket counter
-    Scratch chain;
-    Scratch ticket;
-    uint32_t epoch = 0;
-    bool chained = true; // GLU_HIP_SCAN_CHAINED=0 falls back to reduce-then-scan
-    size_t chain_min_chunks = kChainMinChunks; // GLU_HIP_SCAN_CHAINED=2: chained from 2 chunks up (tests)
-};
-
-struct glu_reduce_s
-{
-    glu_data_type type;
-    glu_reduce_operator op;
-    Scratch partials;
-};
-
-namespace
-{
-constexpr int kReduceMaxBlocks = 8192;     // size of the partials buffer
-constexpr int kReduceDefaultBlocks = 512;  // first-stage grid for large inputs: 2 x 256 threads per CU, 64 B in flight
-                                           // per lane, measured 6.4 TB/s at 2^28 uint32 (1024-8192 workgroups: 5.3-5.6 TB/s)
-
-// number of chunk-sum elements over all recursion levels
-template<typename T>
-size_t scan_scratch_elems(size_t count, size_t partitions)
-{
-    size_t total = 0;
-    size_t c = count;
-    while (c > (size_t) ScanCfg<T>::CHUNK)
-    {
-        c = (c + ScanCfg<T>::CHUNK - 1) / ScanCfg<T>::CHUNK;
-        total += c * partitions;
-    }
-    return total;
-}
-
-// single-pass chained scan (4-byte element types, more than one chunk per partition)
-template<typename S, int N>
-glu_status scan_chained(glu_scan_s* scan, Elem<S, N>* data, size_t count, size_t partitions, hipStream_t stream)
-{
-    using T = Elem<S, N>;
-    using C = ScanCfg<T, kChainGroups, kChainThreads>;
-    const size_t chunks = (count + C::CHUNK - 1) / C::CHUNK;
-    const size_t words = chunks * partitions;
-    if (scan->chain.size < words * sizeof(unsigned long long))
-    {
-        GLU_TRY(scan->chain.reserve(words * sizeof(unsigned long long)));
-        HIP_TRY(hipMemsetAsync(scan->chain.ptr, 0, scan->chain.size, stream)); // epoch 0 = never ready
-        scan->epoch = 0;
-    }
-    GLU_TRY(scan->ticket.reserve(256));
-    if (++scan->epoch >= (1u << 30))
-    {
-        HIP_TRY(hipMemsetAsync(scan->chain.ptr, 0, scan->chain.size, stream));
-        scan->epoch = 1;
-    }
-    HIP_TRY(hipMemsetAsync(scan->ticket.ptr, 0, 16, stream));
-    const bool aligned = ((uintptr_t) data % 16 == 0) && (partitions == 1 || (count * sizeof(T)) % 16 == 0);
-    const dim3 grid((uint32_t) words);
-    if (aligned)
-        hipLaunchKernelGGL((scan_chunks_kernel<S, N, true, true>), grid, dim3(C::THREADS), 0, stream, data, (const T*) nullptr,
-                           (uint64_t) count, (uint32_t) chunks, (unsigned long long*) scan->chain.ptr,
-                           (uint32_t*) scan->ticket.ptr, scan->epoch);
-    else
-        hipLaunchKernelGGL((scan_chunks_kernel<S, N, false, true>), grid, dim3(C::THREADS), 0, stream, data, (const T*) nullptr,
-                           (uint64_t) count, (uint32_t) chunks, (unsigned long long*) scan->chain.ptr,
-                           (uint32_t*) scan->ticket.ptr, scan->epoch);
-    HIP_TRY(hipGetLastError());
-    return GLU_OK;
-}
-
-template<typename S, int N>
-glu_status scan_level(Elem<S, N>* data, size_t count, size_t partitions, Elem<S, N>* scratch, hipStream_t stream)
-{
-    using T = Elem<S, N>;
-    using C = ScanCfg<T>;
-    const size_t chunks = (count + C::CHUNK - 1) / C::CHUNK;
-    if (chunks * partitions > 0x7FFFFFFFull) return fail(GLU_ERROR_INVALID_ARGUMENT, "scan too large");
-    const bool aligned = ((uintptr_t) data % 16 == 0) && (partitions == 1 || (count * sizeof(T)) % 16 == 0);
-    const dim3 grid((uint32_t) (chunks * partitions));
-    // many small partitions: a workgroup takes CHUNK consecutive elements = several whole partitions (the array is one
-    // contiguous run of partitions, so only the array's own alignment matters)
-    if (partitions >= 2 && count <= (size_t) C::WAVE_ELEMS && (count & (count - 1)) == 0 && partitions * count > (size_t) C::CHUNK)
-    {
-        const uint64_t total = (uint64_t) partitions * count;
-        const dim3 sgrid((uint32_t) ((total + C::CHUNK - 1) / C::CHUNK));
-        if ((uintptr_t) data % 16 == 0)
-            hipLaunchKernelGGL((scan_small_partitions_kernel<S, N, true>), sgrid, dim3(C::THREADS), 0, stream, data, total, (uint32_t) count);
-        else
-            hipLaunchKernelGGL((scan_small_partitions_kernel<S, N, false>), sgrid, dim3(C::THREADS), 0, stream, data, total, (uint32_t) count);
-        HIP_TRY(hipGetLastError());
-        return GLU_OK;
-    }
-    if (chunks == 1)
-    {
-        if (aligned)
-            hipLaunchKernelGGL((scan_chunks_kernel<S, N, true>), grid, dim3(C::THREADS), 0, stream, data, (const T*) nullptr, (uint64_t) count, 1u);
-        else
-            hipLaunchKernelGGL((scan_chunks_kernel<S, N, false>), grid, dim3(C::THREADS), 0, stream, data, (const T*) nullptr, (uint64_t) count, 1u);
-        HIP_TRY(hipGetLastError());
-        return GLU_OK;
-    }
-    T* sums = scratch;
-    if (aligned)
-        hipLaunchKernelGGL((scan_chunk_sums_kernel<S, N, true>), grid, dim3(C::THREADS), 0, stream, (const T*) data, sums, (uint64_t) count, (uint32_t) chunks);
-    else
-        hipLaunchKernelGGL((scan_chunk_sums_kernel<S, N, false>), grid, dim3(C::THREADS), 0, stream, (const T*) data, sums, (uint64_t) count, (uint32_t) chunks);
-    HIP_TRY(hipGetLastError()); // every launch is checked where it happens
-    GLU_TRY((scan_level<S, N>(sums, chunks, partitions, scratch + chunks * partitions, stream)));
-    if (aligned)
-        hipLaunchKernelGGL((scan_chunks_kernel<S, N, true>), grid, dim3(C::THREADS), 0, stream, data, (const T*) sums, (uint64_t) count, (uint32_t) chunks);
-    else
-        hipLaunchKernelGGL((scan_chunks_kernel<S, N, false>), grid, dim3(C::THREADS), 0, stream, data, (const T*) sums, (uint64_t) count, (uint32_t) chunks);
-    HIP_TRY(hipGetLastError());
-    return GLU_OK;
-}
-
-struct ScanRunner
-{
-    glu_scan_s* scan;
-    void* data;
-    size_t count, partitions;
-    hipStream_t stream;
-    bool size_only;
-    template<typename S, int N>
-    glu_status operator()()
-    {
-        using T = Elem<S, N>;
-        if constexpr (sizeof(T) == 4)
-        {
-            const size_t chunks = (count + ScanCfg<T, kChainGroups, kChainThreads>::CHUNK - 1) / ScanCfg<T, kChainGroups, kChainThreads>::CHUNK;
-            // Below about one chunk per CU the ticket chain is latency-bound and the three-launch reduce-then-scan
-            // wins (measured crossover between 2^22 and 2^24 elements, tools/scan_probe.py).
-            // A captured launch would bake this call's epoch into the graph: every replay would accept the chain words of the
-            // replay before as ready.  Under stream capture the scan takes the reduce-then-scan path (capturable: no host state).
-            hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
-            if (!size_only) (void) hipStreamIsCapturing(stream, &capturing);
-            if (scan->chained && chunks > 1 && chunks * partitions >= scan->chain_min_chunks && chunks * partitions <= 0x7FFFFFFFull &&
-                capturing == hipStreamCaptureStatusNone)
-            {
-                if (size_only)
-                {
-                    GLU_TRY(scan->ticket.reserve(256));
-                    if (scan->chain.size < chunks * partitions * 8)
-                    {
-                        GLU_TRY(scan->chain.reserve(chunks * partitions * 8));
-                        HIP_TRY(hipMemset(scan->chain.ptr, 0, scan->chain.size));
-                        scan->epoch = 0;
-                    }
-                    // no return: a captured run of the same scan takes the other path and needs its scratch too
-                }
-                else
-                    return scan_chained<S, N>(scan, (T*) data, count, partitions, stream);
-            }
-        }
-        size_t need = scan_scratch_elems<T>(count, partitions) * sizeof(T);
-        if (need) GLU_TRY(scan->sums.reserve(need));
-        if (size_only) return GLU_OK;
-        return scan_level<S, N>((T*) data, count, partitions, (T*) scan->sums.ptr, stream);
-    }
-};
-
-template<int OP, typename S, int N>
-glu_status reduce_launch(glu_reduce_s* r, Elem<S, N>* data, size_t count, hipStream_t stream)
-{
-    using T = Elem<S, N>;
-    const bool aligned = ((uintptr_t) data % 16) == 0;
-    const size_t vec = (aligned && sizeof(T) < 16) ? 16 / sizeof(T) : 1;
-    const size_t packs = count / vec;
-    static const size_t max_blocks = [] {
-        const char* e = glu_env("GLU_HIP_REDUCE_BLOCKS"); // tuning override
-        const long v = e ? atol(e) : 0;
-        return (size_t) (v > 0 && v <= kReduceMaxBlocks ? v : kReduceDefaultBlocks);
-    }();
-    size_t blocks = std::max<size_t>(1, std::min<size_t>(packs / (256 * 4), max_blocks));
-    T* partials = (T*) r->partials.ptr;
-    if (blocks == 1)
-    {
-        if (aligned) hipLaunchKernelGGL((reduce_kernel<OP, S, N, true>), dim3(1), dim3(256), 0, stream, (const T*) data, data, (uint64_t) count);
-        else hipLaunchKernelGGL((reduce_kernel<OP, S, N, false>), dim3(1), dim3(256), 0, stream, (const T*) data, data, (uint64_t) count);
-    }
-    else
-    {
-        if (aligned) hipLaunchKernelGGL((reduce_kernel<OP, S, N, true>), dim3((uint32_t) blocks), dim3(256), 0, stream, (const T*) data, partials, (uint64_t) count);
-        else hipLaunchKernelGGL((reduce_kernel<OP, S, N, false>), dim3((uint32_t) blocks), dim3(256), 0, stream, (const T*) data, partials, (uint64_t) count);
-        hipLaunchKernelGGL((reduce_kernel<OP, S, N, true>), dim3(1), dim3(256), 0, stream, (const T*) partials, data, (uint64_t) blocks);
-    }
-    HIP_TRY(hipGetLastError());
-    return GLU_OK;
-}
-
-struct ReduceRunner
-{
-    glu_reduce_s* red;
-    void* data;
-    size_t count;
-    hipStream_t stream;
-    template<typename S, int N>
-    glu_status operator()()
-    {
-        using T = Elem<S, N>;
-        switch (red->op)
-        {
-        case GLU_REDUCE_SUM: return reduce_launch<OP_SUM, S, N>(red, (T*) data, count, stream);
-        case GLU_REDUCE_MUL: return reduce_launch<OP_MUL, S, N>(red, (T*) data, count, stream);
-        case GLU_REDUCE_MIN: return reduce_launch<OP_MIN, S, N>(red, (T*) data, count, stream);
-        case GLU_REDUCE_MAX: return reduce_launch<OP_MAX, S, N>(red, (T*) data, count, stream);
-        default: return fail(GLU_ERROR_INVALID_ARGUMENT, "Invalid reduction operator: %d", (int) red->op);
-        }
-    }
-};
-} // namespace
-
-extern "C" {
-
-glu_status glu_scan_create(glu_data_type data_type, glu_scan* out)
-{
-    GLU_TRY(enter());
-    if (!out) return fail(GLU_ERROR_INVALID_ARGUMENT, "out is NULL");
-    if ((int) data_type < 0 || data_type >= GLU_DATA_TYPE_COUNT_)
-        return fail(GLU_ERROR_INVALID_ARGUMENT, "Invalid data type: %d", (int) data_type);
-    glu_scan_s* s = new glu_scan_s();
-    s->type = data_type;
-    if (const char* e = glu_env("GLU_HIP_SCAN_CHAINED"))
-    {
-        s->chained = atoi(e) != 0;
-        if (atoi(e) == 2) s->chain_min_chunks = 2;
-    }
-    *out = s;
-    return GLU_OK;
-}
-
-glu_status glu_scan_destroy(glu_scan scan)
-{
-    GLU_TRY(enter());
-    if (!scan) return GLU_OK;
-    (void) hipDeviceSynchronize(); // (a caller stream may still run its kernels)
-    scan->sums.release();
-    scan->chain.release();
-    scan->ticket.release();
-    delete scan;
-    return GLU_OK;
-}
-
-glu_status glu_scan_prepare(glu_scan scan, size_t count, size_t num_partitions)
-{
-    GLU_TRY(enter());
-    if (!scan) return fail(GLU_ERROR_INVALID_ARGUMENT, "scan is NULL");
-    if (count == 0 || num_partitions == 0) return GLU_OK;
-    ScanRunner r{scan, nullptr, count, num_partitions, nullptr, true};
-    return dispatch_type(scan->type, r);
-}
-
-glu_status glu_scan_run_ptr(glu_scan scan, void* data, size_t count, size_t num_partitions, void* stream)
-{
-    GLU_TRY(enter());
-    if (!scan) return fail(GLU_ERROR_INVALID_ARGUMENT, "scan is NULL");
-    if (!data) return fail(GLU_ERROR_INVALID_ARGUMENT, "Invalid buffer");
-    if (count == 0) return fail(GLU_ERROR_INVALID_ARGUMENT, "Count must be greater than zero");
-    if (num_partitions < 1) return fail(GLU_ERROR_INVALID_ARGUMENT, "Num of partitions must be >= 1");
-    if (((uintptr_t) data % data_type_size(scan->type)) != 0)
-        return fail(GLU_ERROR_INVALID_ARGUMENT, "data is not aligned to its element size");
-    ScanRunner r{scan, data, count, num_partitions, pick_stream(stream), false};
-    return dispatch_type(scan->type, r);
-}
-
-glu_status glu_scan_run(glu_scan scan, glu_buffer buffer, size_t count, size_t num_partitions)
-{
-    GLU_TRY(enter());
-    if (!scan) return fail(GLU_ERROR_INVALID_ARGUMENT, "scan is NULL");
-    Buffer b;
-    GLU_TRY(lookup(buffer, b, "buffer"));                                                         // BlellochScan.hpp:132
-    if (count == 0) return fail(GLU_ERROR_INVALID_ARGUMENT, "Count must be greater than zero");    // :133
-    if ((count & (count - 1)) != 0) return fail(GLU_ERROR_INVALID_ARGUMENT, "Count must be a power of 2"); // :134
-    if (num_partitions < 1) return fail(GLU_ERROR_INVALID_ARGUMENT, "Num of partitions must be >= 1");      // :135
-    const size_t es = data_type_size(scan->type);
-    if (count > b.size / es / num_partitions)
-        return fail(GLU_ERROR_INVALID_ARGUMENT, "count * num_partitions exceeds the buffer size");
-    return glu_scan_run_ptr(scan, b.ptr, count, num_partitions, nullptr);
-}
-
-glu_status glu_reduce_create(glu_data_type data_type, glu_reduce_operator op, glu_reduce* out)
-{
-    GLU_TRY(enter());
-    if (!out) return fail(GLU_ERROR_INVALID_ARGUMENT, "out is NULL");
-    if ((int) data_type < 0 || data_type >= GLU_DATA_TYPE_COUNT_)
-        return fail(GLU_ERROR_INVALID_ARGUMENT, "Invalid data type: %d", (int) data_type);
-    if ((int) op < 0 || op >= GLU_REDUCE_COUNT_)
-        return fail(GLU_ERROR_INVALID_ARGUMENT, "Invalid reduction operator: %d", (int) op); // Reduce.hpp:94-97
-    glu_reduce_s* r = new glu_reduce_s();
-    r->type = data_type;
-    r->op = op;
-    glu_status st = r->partials.reserve((size_t) kReduceMaxBlocks * 32);
-    if (st != GLU_OK)
-    {
-        delete r;
-        return st;
-    }
-    *out = r;
-    return GLU_OK;
-}
-
-glu_status glu_reduce_destroy(glu_reduce reduce)
-{
-    GLU_TRY(enter());
-    if (!reduce) return GLU_OK;
-    (void) hipDeviceSynchronize();
-    reduce->partials.release();
-    delete reduce;
-    return GLU_OK;
-}
-
-glu_status glu_reduce_run_ptr(glu_reduce reduce, void* data, size_t count, void* stream)
-{
-    GLU_TRY(enter());
-    if (!reduce) return fail(GLU_ERROR_INVALID_ARGUMENT, "reduce is NULL");
-    if (!data) return fail(GLU_ERROR_INVALID_ARGUMENT, "Invalid buffer");
-    if (count == 0) return fail(GLU_ERROR_INVALID_ARGUMENT, "Count must be greater than zero");
-    if (((uintptr_t) data % std::min<size_t>(16, data_type_size(reduce->type))) != 0)
-        return fail(GLU_ERROR_INVALID_ARGUMENT, "data is not aligned to its element size");
-    ReduceRunner r{reduce, data, count, pick_stream(stream)};
-    return dispatch_type(reduce->type, r);
-}
-
-glu_status glu_reduce_run(glu_reduce reduce, glu_buffer buffer, size_t count)
-{
-    GLU_TRY(enter());
-    if (!reduce) return fail(GLU_ERROR_INVALID_ARGUMENT, "reduce is NULL");
-    Buffer b;
-    GLU_TRY(lookup(buffer, b, "buffer"));                                                      // Reduce.hpp:113
-    if (count == 0) return fail(GLU_ERROR_INVALID_ARGUMENT, "Count must be greater than zero"); // Reduce.hpp:114
-    if (count > b.size / data_type_size(reduce->type))
-        return fail(GLU_ERROR_INVALID_ARGUMENT, "count exceeds the buffer size");
-    return glu_reduce_run_ptr(reduce, b.ptr, count, nullptr);
-}
-
-} // extern "C"
 
 #include "glu_dist_impl.hpp"
-
-// ------------------------------------------------------------------------------------------------------------
-// timer
-// ------------------------------------------------------------------------------------------------------------
-struct glu_timer_s
-{
-    hipEvent_t start, stop;
-};
-
-extern "C" {
-
-glu_status glu_timer_begin(glu_timer* out)
-{
-    GLU_TRY(enter());
-    if (!out) return fail(GLU_ERROR_INVALID_ARGUMENT, "out is NULL");
-    glu_timer_s* t = new glu_timer_s();
-    if (hipEventCreate(&t->start) != hipSuccess || hipEventCreate(&t->stop) != hipSuccess)
-    {
-        delete t;
-        return fail(GLU_ERROR_DEVICE, "hipEventCreate failed");
-    }
-    HIP_TRY(hipEventRecord(t->start, g_dev.queue));
-    *out = t;
-    return GLU_OK;
-}
-
-glu_status glu_timer_end(glu_timer timer, uint64_t* elapsed_ns)
-{
-    GLU_TRY(enter());
-    if (!timer) return fail(GLU_ERROR_INVALID_ARGUMENT, "timer is NULL");
-    HIP_TRY(hipEventRecord(timer->stop, g_dev.queue));
-    HIP_TRY(hipEventSynchronize(timer->stop));
-    float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, timer->start, timer->stop));
-    if (elapsed_ns) *elapsed_ns = (uint64_t) ((double) ms * 1.0e6);
-    (void) hipEventDestroy(timer->start);
-    (void) hipEventDestroy(timer->stop);
-    delete timer;
-    return GLU_OK;
-}
-
-} // extern "C"

@@ -52,6 +52,13 @@ def test_the_makefile_tracks_every_header_of_the_library():
     import os
 
     csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gl-radix-sort_amd", "csrc")
-    rule = next(l for l in open(os.path.join(csrc, "Makefile")) if l.startswith("$(OUT)/libglu_hip.so:"))
+    text = open(os.path.join(csrc, "Makefile")).read().replace("\\\n", " ")
+    listed = set()
+    for var in ("KERNEL_HEADERS", "HOST_HEADERS"):
+        listed |= set(next(l for l in text.splitlines() if l.startswith(var + " :=")).split()[2:])
+    rule = next(l for l in text.splitlines() if l.startswith("$(OBJ)/%.o:"))
+    assert "$(KERNEL_HEADERS)" in rule and "$(HOST_HEADERS)" in rule  # (every translation unit depends on every header)
     for header in glob.glob(os.path.join(csrc, "*.hpp")):
-        assert os.path.basename(header) in rule.split(), os.path.basename(header)
+        assert os.path.basename(header) in listed, os.path.basename(header)
+    units = next(l for l in text.splitlines() if l.startswith("UNITS :=")).split()[2:]
+    assert sorted(units) == sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(csrc, "*.hip")))

@@ -35,6 +35,14 @@ def test_native_library_is_loaded(G):
     assert "libglu_hip.so" in maps
 
 
+def test_the_drivers_smoke_entry_passes(G):
+    """__graft_entry__.smoke() is what the driver runs on the GPU box before the bench; it asserts outcomes (ended in LDS / refused)
+    that a change of the plan's rules can flip (round 6: it did, and no test said so)."""
+    import __graft_entry__ as entry
+
+    entry.smoke()
+
+
 @pytest.mark.parametrize("bits", DIGIT_BITS)
 def test_reference_test_inputs_match_literal_oracle(G, golden, bits):
     """The reference's own test inputs (radix_sort_tests.cpp:88-158) with vals = iota: keys AND values must equal

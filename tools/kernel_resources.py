@@ -1,11 +1,9 @@
-"""Per-kernel VGPR / SGPR / LDS / scratch / occupancy table from hipcc -Rpass-analysis=kernel-resource-usage.
+"""Per-kernel VGPR / SGPR / LDS / scratch / occupancy table from hipcc -Rpass-analysis=kernel-resource-usage (the remarks the last
+`make -C gl-radix-sort_amd/csrc` left in gl-radix-sort_amd/lib/kernel_resources.log).
 usage: python tools/kernel_resources.py [substring]"""
 import os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(ROOT, "gl-radix-sort_amd", "csrc", "glu_hip.hip")
-cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-I", os.path.join(ROOT, "include"),
-       "-I", os.path.dirname(src), "-c", "-o", "/dev/null", src, "-Rpass-analysis=kernel-resource-usage"]
-out = subprocess.run(cmd, capture_output=True, text=True).stderr
+out = open(os.path.join(ROOT, "gl-radix-sort_amd", "lib", "kernel_resources.log")).read()
 sub = sys.argv[1] if len(sys.argv) > 1 else ""
 cur = None
 rows = []
