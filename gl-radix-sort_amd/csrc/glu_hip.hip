@@ -597,6 +597,8 @@ glu_status launch_pass_lines(glu_radix_sort_s* s, const KeyT* src_k, const uint3
         HIP_TRY(hipGetLastError());
         if (long_runs)
         {
+            // (on the caller's queue: on the side stream it finds no room beside the scatter's 1024-thread workgroups, finishes when that
+            // does, and holds up the follower's unit sums behind it -- measured: + 17 us)
             hipLaunchKernelGGL(radix_finish_long_runs_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t*) s->finish_starts.ptr,
                                (const PassPlan*) pa.plan, usable_cus(s), (uint32_t*) s->long_image.ptr, (uint32_t*) s->long_hdr.ptr);
             HIP_TRY(hipGetLastError());

@@ -96,12 +96,12 @@ glu_status launch_finish(KeyT* keys_a, uint32_t* vals_a, KeyT* keys_b, uint32_t*
         if (GEO_ == geo_expected) marks(stream);                                                                                    \
         HIP_TRY(hipGetLastError());                                                                                               \
     }
-    // The runs the bucket kernel listed (or all of them: PassPlan::finish_rounds) by ballot rounds, 8192 workgroups that loop: one
-    // launch in the tile the sort is expected to take (four workgroups per CU for 256 x 18: 24-bit keys 3.15 -> 2.95 ms at 2^28
-    // against one launch in the largest tile), and one in the largest enqueued tile for whatever else the device chose (runs
-    // longer than the CHOSEN tile are the segmented passes' either way).
-#define GLU_FINISH_ROUNDS(GEO_, THREADS_, KPT_, FOR_EXPECTED_)                                                                    \
-    if (FOR_EXPECTED_ ? GEO_ == geo_expected : (GEO_ == geo_last && geo_first != geo_last))                                       \
+    // The runs the bucket kernel listed (or all of them: PassPlan::finish_rounds) by ballot rounds, 8192 workgroups that loop, split
+    // by the runs' length over two launches: the tile the sort is expected to take (or the one below the largest, if that is the
+    // expected one) takes the runs that fit it -- four workgroups per CU for 256 x 18: 24-bit keys 3.15 -> 2.95 ms at 2^28 against
+    // one launch in the largest tile --, the largest enqueued tile takes the longer ones (runs longer than the tile the device
+    // CHOSE are the segmented passes' either way).
+#define GLU_FINISH_ROUNDS(GEO_, THREADS_, KPT_, LEN_ABOVE_)                                                                       \
     {                                                                                                                             \
         using Smem = FinishSmem<KeyT, THREADS_, KPT_, VALS>;                                                                      \
         auto kern = radix_finish_sort_kernel<KeyT, THREADS_, KPT_, VALS, true, XF>;                                               \
@@ -112,9 +112,8 @@ glu_status launch_finish(KeyT* keys_a, uint32_t* vals_a, KeyT* keys_b, uint32_t*
         });                                                                                                                       \
         HIP_TRY(lds_opt_in_result);                                                                                               \
         hipLaunchKernelGGL(kern, dim3(8192), dim3(THREADS_), sizeof(Smem), stream, keys_a, vals_a, keys_b, vals_b, starts,        \
-                           low_bits, plan, pass, FOR_EXPECTED_ ? (uint32_t) GEO_ : 0u, key_xf, nruns, (const uint32_t*) nullptr,  \
-                           0u, rank_bits, (unsigned long long*) nullptr, (const uint32_t*) crowded,                               \
-                           FOR_EXPECTED_ ? 0u : geo_expected);                                                                    \
+                           low_bits, plan, pass, 0u, key_xf, nruns, (const uint32_t*) nullptr, 0u, rank_bits,                     \
+                           (unsigned long long*) nullptr, (const uint32_t*) crowded, (uint32_t) (LEN_ABOVE_));                    \
         HIP_TRY(hipGetLastError());                                                                                               \
     }
     for (int turn = 0; turn < 2; turn++)
@@ -134,21 +133,23 @@ glu_status launch_finish(KeyT* keys_a, uint32_t* vals_a, KeyT* keys_b, uint32_t*
             GLU_FINISH(4, 1024, 9)
         }
     }
-    // (first the launch for the expected tile, then -- if more than one tile is enqueued -- the one in the largest tile for every
-    // other choice of the device, the expected tile excepted: whatever the device chose, one of the two takes the listed runs)
-    for (int for_expected = 1; for_expected >= 0; for_expected--)
+    // (the tile for the shorter runs, then -- if more than one tile is enqueued -- the largest for the runs that one leaves)
+    const uint32_t geo_lo = geo_expected < geo_last ? geo_expected : std::max(geo_first, geo_last - 1u);
+    for (uint32_t turn = 0; turn < (geo_lo < geo_last ? 2u : 1u); turn++)
     {
-        GLU_FINISH_ROUNDS(1, 256, 6, for_expected)
-        GLU_FINISH_ROUNDS(2, 256, 10, for_expected)
+        const uint32_t g = turn == 0 ? geo_lo : geo_last;
+        const uint32_t len_above = turn == 0 ? 0u : finish_geometry_capacity(geo_lo);
+        if (g == 1) GLU_FINISH_ROUNDS(1, 256, 6, len_above)
+        if (g == 2) GLU_FINISH_ROUNDS(2, 256, 10, len_above)
         if constexpr (sizeof(KeyT) == 4)
         {
-            GLU_FINISH_ROUNDS(3, 256, 18, for_expected)
-            GLU_FINISH_ROUNDS(4, 512, 18, for_expected)
+            if (g == 3) GLU_FINISH_ROUNDS(3, 256, 18, len_above)
+            if (g == 4) GLU_FINISH_ROUNDS(4, 512, 18, len_above)
         }
         else
         {
-            GLU_FINISH_ROUNDS(3, 512, 9, for_expected)
-            GLU_FINISH_ROUNDS(4, 1024, 9, for_expected)
+            if (g == 3) GLU_FINISH_ROUNDS(3, 512, 9, len_above)
+            if (g == 4) GLU_FINISH_ROUNDS(4, 1024, 9, len_above)
         }
     }
 #undef GLU_FINISH

@@ -495,7 +495,7 @@ __global__ __launch_bounds__(THREADS, (sizeof(KeyT) == 8 && THREADS == 512 ? GLU
                                                                     uint32_t gate_cap = 0, uint32_t rank_bits = 16,
                                                                     unsigned long long* stamps = nullptr,
                                                                     const uint32_t* __restrict__ run_list = nullptr,
-                                                                    uint32_t except_geometry = 0)
+                                                                    uint32_t len_above = 0)
 {
     FinishClock<STAMPS> clock;
     if (plan && plan->top_bit) low_bits = plan->top_bit - 16u; // (the device chose the runs' bits: radix_sample_top_kernel)
@@ -503,9 +503,12 @@ __global__ __launch_bounds__(THREADS, (sizeof(KeyT) == 8 && THREADS == 512 ? GLU
     const uint32_t rank_from = low_bits > rank_bits ? ((low_bits - rank_bits) / 8u) * 8u : 0u;
     const KeyCodec<KeyT, XF> codec_out(key_xf);
     // (kernel-uniform: the device chose another geometry, or the ordinary passes)
-    // (geometry 0: whichever tile the device chose, except except_geometry -- the launches behind radix_finish_bucket_kernel that
-    // take the runs it listed: one in the tile the sort is expected to take, one in the largest enqueued tile for any other choice)
-    if (plan ? (geometry ? plan->finish != geometry : (plan->finish == 0u || plan->finish == except_geometry)) : *gate > gate_cap) return;
+    // (geometry 0: whichever tile the device chose -- the launches behind radix_finish_bucket_kernel that take the runs it listed,
+    // split by the runs' LENGTH: one in the tile the sort is expected to take for the runs that fit it, one in the largest enqueued
+    // tile for the runs of more than len_above pairs, i.e. those the first one leaves.  A run is ordered in the smallest of the
+    // two tiles that holds it, whatever tile the device chose for the bucket kernel: 2^20 distinct values at 2^28 -- runs of 4096
+    // +- 1024 pairs, every one crowded, the 512 x 18 tile chosen -- took 1.56 ms in that tile alone.)
+    if (plan ? (geometry ? plan->finish != geometry : plan->finish == 0u) : *gate > gate_cap) return;
     using Smem = FinishSmem<KeyT, THREADS, KPT, VALS>;
     constexpr int WAVES = Smem::WAVES;
 
@@ -533,8 +536,9 @@ __global__ __launch_bounds__(THREADS, (sizeof(KeyT) == 8 && THREADS == 512 ? GLU
     if (len == 0 || (plan && !XF && len == 1)) continue; // (workgroup-uniform; a single typed key still has to be decoded)
     // (a run longer than the tile: radix_finish_ranges_kernel's in a segmented sort, the segmented passes' in a whole-key sort)
     if (len > (uint32_t) Smem::TILE) continue;
-    // (launched for whichever tile the device chose: the runs longer than THAT tile are the segmented passes' too)
-    if (plan && geometry == 0u && len > finish_geometry_capacity(plan->finish)) continue;
+    // (launched for whichever tile the device chose: the runs longer than THAT tile are the segmented passes' too; the runs of at
+    // most len_above pairs are the launch's in the smaller tile)
+    if (plan && geometry == 0u && (len > finish_geometry_capacity(plan->finish) || len <= len_above)) continue;
     // (64-bit keys: the key bits from 48 up, the same for every pair of the run -- and of a pad that comes back from the stage)
     const KeyT run_top = sizeof(KeyT) == 8 ? (KeyT) (keys[begin] & (KeyT) 0xFFFF000000000000ull) : (KeyT) 0;
     const uint32_t share = ((len + WAVES * kWave - 1) / (WAVES * kWave)) * kWave; // slots per wave: <= kWave * KPT

@@ -115,6 +115,7 @@ __global__ __launch_bounds__(256) void radix_sample_top_kernel(const KeyT* __res
 // the sort is refused (keys crowded into few runs of few varying bytes are better off with the ordinary passes and their
 // skipping of constant digits).
 constexpr uint32_t kLongRunsMax = 8192;
+constexpr uint32_t kLongRunsMinShare = 4096;  // pairs: the least one workgroup of the segmented passes is given (radix_finish_long_runs_kernel)
 
 // The runs longer than the tile the plan chose, as SEGMENTS of segmented passes (radix_seg_passes.hpp): the descriptor image
 // the host builds for the sharded sort's local sort (seg_build_image in glu_hip.hip), built on the device from the run starts.
@@ -191,7 +192,10 @@ __device__ __forceinline__ void finish_list_long_runs(const uint32_t* starts, ui
         if (tid == 0) hdr[1] = 0u;
         return;
     }
-    const uint32_t share = (total + nwg - 1) / nwg; // >= cap / nwg > 0
+    // (a share is what one workgroup of a segmented pass works on; a few long runs of a few thousand pairs cut 256 ways made 256
+    // sub-blocks of a hundred pairs, every one a row of 256 counts for the scan kernel to walk: 0.01 % zeros cost 0.15 ms more
+    // than 0 %.  Shares behind the last pair are empty.)
+    const uint32_t share = max((total + nwg - 1) / nwg, kLongRunsMinShare);
     // sub-blocks of this thread's long runs, then their numbers
     uint32_t subs = 0;
     {

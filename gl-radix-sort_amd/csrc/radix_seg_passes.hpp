@@ -255,17 +255,23 @@ __global__ __launch_bounds__(RADIX) void radix_seg_scan_kernel(uint32_t* __restr
             continue;
         }
     }
+    // (16 independent loads in flight, then the stores: a load behind a store that the compiler cannot tell apart from it is not
+    // moved up, and one row per load latency made 37 us of a segment of 256 sub-blocks)
+    constexpr int kRowsInFlight = 16;
     uint32_t run = 0;
     uint32_t i = i0;
-    for (; i + 4 <= i1; i += 4) // 4 independent loads in flight
+    for (; i + kRowsInFlight <= i1; i += kRowsInFlight)
     {
         uint32_t* row = table + (size_t) i * RADIX + d;
-        const uint32_t c0 = row[0], c1 = row[RADIX], c2 = row[2 * RADIX], c3 = row[3 * RADIX];
-        row[0] = run;
-        row[RADIX] = run + c0;
-        row[2 * RADIX] = run + c0 + c1;
-        row[3 * RADIX] = run + c0 + c1 + c2;
-        run += c0 + c1 + c2 + c3;
+        uint32_t c[kRowsInFlight];
+#pragma unroll
+        for (int k = 0; k < kRowsInFlight; k++) c[k] = row[k * RADIX];
+#pragma unroll
+        for (int k = 0; k < kRowsInFlight; k++)
+        {
+            row[k * RADIX] = run;
+            run += c[k];
+        }
     }
     for (; i < i1; i++)
     {
@@ -280,7 +286,16 @@ __global__ __launch_bounds__(RADIX) void radix_seg_scan_kernel(uint32_t* __restr
     __syncthreads();
     for (uint32_t w = 0; w < wave; w++) excl += wave_sums[w];
     const uint32_t add = seg_start[g] + excl;
-    for (i = i0; i < i1; i++) table[(size_t) i * RADIX + d] += add;
+    for (i = i0; i + kRowsInFlight <= i1; i += kRowsInFlight)
+    {
+        uint32_t* row = table + (size_t) i * RADIX + d;
+        uint32_t c[kRowsInFlight];
+#pragma unroll
+        for (int k = 0; k < kRowsInFlight; k++) c[k] = row[k * RADIX];
+#pragma unroll
+        for (int k = 0; k < kRowsInFlight; k++) row[k * RADIX] = c[k] + add;
+    }
+    for (; i < i1; i++) table[(size_t) i * RADIX + d] += add;
     __syncthreads(); // (wave_sums is rewritten for the next segment)
     }
 }
