@@ -23,7 +23,9 @@ def parse(path):
 def find(d, *subs):
     for k, v in d.items():
         # (not the copy of the line scatter that only differs in name: the passes enqueued behind an attempt to end in LDS)
-        if all(s in k for s in subs) and not k.split("(")[0].rstrip().endswith("false, false, true>"):
+        # (nor the segmented form, SEG = true: the passes over the long runs of a sort that ends in LDS, which return at once here)
+        name = k.split("(")[0].rstrip()
+        if all(s in k for s in subs) and not name.endswith("false, false, true>") and not ("radix_scatter_lines" in name and name.endswith("true, false, false>")):
             return k, v
     raise KeyError(subs)
 

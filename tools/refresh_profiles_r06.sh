@@ -38,8 +38,13 @@ tools/r06_trace_one.sh last_sort_kernels_2p28_u64.txt --log2 28 --key-bytes 8
 tools/r06_trace_one.sh refused_sort_kernels_three_values.txt --log2 28 --distinct 3
 tools/r06_trace_one.sh zipf_sort_kernels.txt --log2 28 --zipf
 tools/r06_trace_one.sh distinct_1000_sort_kernels.txt --log2 28 --distinct-scattered 1000
+tools/r06_trace_one.sh distinct_2p20_sort_kernels.txt --log2 28 --distinct-scattered 1048576
+tools/r06_trace_one.sh zeros_0p01_sort_kernels.txt --log2 28 --zeros 0.01
+tools/r06_trace_one.sh zeros_1_sort_kernels.txt --log2 28 --zeros 1
 python tools/measure_configs.py > $OUT/configs_single_gpu.txt 2>&1
 python tools/sort_loop.py --log2 28 --key-bytes 8 > $OUT/c5_loop.txt 2>&1
+python tools/caller_pairs_probe.py > $OUT/caller_pairs_probe.txt 2>&1
+python tools/caller_pairs_probe.py --key-bytes 8 --pairs 8 >> $OUT/caller_pairs_probe.txt 2>&1
 python tools/measure_distributions_2p28.py > $OUT/distributions_2p28.txt 2>&1
 python tools/measure_distributions_2p28.py 28 u64 > $OUT/distributions_2p28_u64.txt 2>&1
 python tools/size_ladder.py pairs 1000 300000000 > $OUT/size_ladder_pairs.txt 2>&1

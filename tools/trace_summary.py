@@ -11,6 +11,22 @@
        kernels by name, and the time between first kernel start and last kernel end that no kernel of the sort covers"""
 import csv, sys
 
+def targs(n):
+    """the template arguments of a kernel name"""
+    a = n.split("(")[0].rstrip()
+    return [x.strip() for x in a[a.index("<") + 1:a.rindex(">")].split(",")] if "<" in a else []
+
+
+def behind(n):  # (the last template argument is true)
+    t = targs(n)
+    return bool(t) and t[-1] == "true"
+
+
+def segmented(n):  # radix_scatter_lines_kernel<..., SEG = true, ...>: the long-run passes / a segmented sort (13 arguments, SEG the 13th)
+    t = targs(n)
+    return len(t) >= 13 and t[12] == "true"
+
+
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 bench = "--bench" in sys.argv
@@ -36,11 +52,15 @@ for r in rows:
         names[short] = names.get(short, 0.0) + d
         sorts.append((cur, other + d, (int(r["End_Timestamp"]) - t0) / 1e3, names, busy))
         cur, other, t0, names, busy, t_end = [], 0.0, None, {}, 0.0, None
-    elif "radix_scatter_lines" in n and d > 100:
+    # (round 6: the kernels of the sequence not taken run on the sort object's side stream and wait there for room on the CUs -- a
+    # launch that returns at once can show hundreds of microseconds beside a streaming kernel.  They are told apart by NAME: the
+    # scatter of the passes behind an attempt has BEHIND_ATTEMPT = true as its last template argument, the leader's count kernel
+    # is the instantiation that collects key bits.)
+    elif "radix_scatter_lines" in n and d > 100 and not behind(n) and not segmented(n):
         cur.append(("S", d))
     elif ("radix_finish_sort" in n or "radix_finish_bucket" in n) and d > 100:
         cur.append(("F", d))
-    elif "pair_count" in n and d > 100:
+    elif "pair_count" in n and d > 100 and behind(n):  # (<KeyT, TILE, XF, COLLECT = true>: the first pass's)
         cur.append(("C", d))
     else:
         other += d
@@ -54,10 +74,11 @@ if per_sorts:
     print("  scatter launches that moved data:   %s" % st([d for s in timed for k, d in s[0] if k == "S"]))
     print("  in-LDS pass (one per sort):         %s" % st([d for s in timed for k, d in s[0] if k == "F"]))
     print("  leader count kernel (one per sort): %s" % st([d for s in timed for k, d in s[0] if k == "C"]))
-    print("  every other kernel, summed per sort: %s" % st([s[1] for s in timed]))
     print("  first kernel start to last kernel end per sort: %s" % st([s[2] for s in timed]))
-    print("  of that, covered by no kernel (launch gaps): %s" % st([s[2] - s[4] for s in timed]))
-    print("  the other kernels by name, average us per sort (launch count per sort is not shown: most return at once):")
+    print("  of that, NOT under the leader's count, a scatter that moved data or the in-LDS pass: %s" % st([s[2] - sum(d for _, d in s[0]) for s in timed]))
+    print("  of that, covered by no kernel at all (launch gaps): %s" % st([s[2] - s[4] for s in timed]))
+    print("  the other kernels by name, average us per sort from launch to end -- side-stream kernels wait for room beside the streaming")
+    print("  kernels, so these overlap them and do not add up to the figure above:")
     agg = {}
     for s in timed:
         for k, d in s[3].items():
@@ -77,15 +98,15 @@ def stat(v):
 
 ended = [s for s in sorts if any(k == "F" for k, _ in s[0])]
 timed = ended[-last:]
-plain = [d for n, d in all_scatter8 if not n.rstrip().split("(")[0].rstrip().endswith("true>")]
-behind = [d for n, d in all_scatter8 if n.rstrip().split("(")[0].rstrip().endswith("true>")]
+plain = [d for n, d in all_scatter8 if not behind(n)]
+behind_launches = [d for n, d in all_scatter8 if behind(n)]
 print("radix_scatter_lines_kernel<u32, 8, ...> launches in the whole process (calibration sorts of prepare, warm-up, timed steps, the")
 print("four-pass comparison leg):  under its plain name %s" % stat(plain))
 print("  under the name of the passes enqueued behind an attempt to end in LDS (BEHIND_ATTEMPT = true; they return at once when the")
-print("  attempt was accepted): %s" % stat(behind))
+print("  attempt was accepted; on the side stream they wait for room beside the streaming kernels): %s" % stat(behind_launches))
 print("sorts that ended in LDS: %d; the last %d of them (bench.py's timed steps):" % (len(ended), len(timed)))
 print("  scatter launches (two per sort):  %s" % stat([d for s in timed for k, d in s[0] if k == "S"]))
 print("  in-LDS pass (one per sort):       %s" % stat([d for s in timed for k, d in s[0] if k == "F"]))
 print("  leader count kernel (one):        %s" % stat([d for s in timed for k, d in s[0] if k == "C"]))
-print("  every other kernel of the sort, summed per sort: %s" % stat([s[1] for s in timed]))
+print("  first start to last end NOT under the leader's count, a scatter that moved data or the in-LDS pass, per sort: %s" % stat([s[2] - sum(d for _, d in s[0]) for s in timed]))
 print("  first kernel start to last kernel end per sort:  %s" % stat([s[2] for s in timed]))
