@@ -9,7 +9,7 @@ os.makedirs(DST, exist_ok=True)
 keep = ["bench_n1.json", "bench_n1_default_flags.json", "bench_n1_under_rocprof.json", "bench_n1_kernel_stats.csv",
         "bench_n1_timed_region_from_trace.txt", "pmc_fetch_size_bench.txt", "pmc_write_size_bench.txt", "pmc_fetch_size_configs.txt",
         "pmc_write_size_configs.txt", "configs_single_gpu.txt", "c5_timed_region_from_trace.txt", "c5_kernel_stats.csv", "c5_loop.txt",
-        "last_sort_kernels_2p28.txt", "last_sort_kernels_2p28_u64.txt", "refused_sort_kernels_three_values.txt", "zipf_sort_kernels.txt",
+        "last_sort_kernels_2p28.txt", "last_sort_kernels_2p28_u64.txt", "refused_sort_kernels_three_values.txt", "three_values_sort_kernels.txt", "zipf_sort_kernels.txt",
         "distinct_1000_sort_kernels.txt", "distinct_2p20_sort_kernels.txt", "zeros_0p01_sort_kernels.txt", "zeros_1_sort_kernels.txt", "caller_pairs_probe.txt", "fuzz_heavy.txt", "distributions_2p28.txt", "distributions_2p28_u64.txt", "size_ladder_pairs.txt",
         "bench_ladder_reference_format.txt", "finish_bucket_bench.txt", "finish_midsize_any.txt",
         "smoke_head.txt", "pytest_gpu_head.txt", "fuzz_library.txt", "fuzz_library_large.txt", "fuzz_one_object.txt", "fuzz_segments.txt"]

@@ -35,7 +35,10 @@ python tools/trace_summary.py $(find $OUT/prof_c5 -name "*kernel_trace.csv" | he
 rm -rf $OUT/prof_bench $OUT/prof_c5 $OUT/pmc_bench_fetch $OUT/pmc_bench_write $OUT/pmc_cfg_fetch $OUT/pmc_cfg_write
 tools/r06_trace_one.sh last_sort_kernels_2p28.txt --log2 28
 tools/r06_trace_one.sh last_sort_kernels_2p28_u64.txt --log2 28 --key-bytes 8
-tools/r06_trace_one.sh refused_sort_kernels_three_values.txt --log2 28 --distinct 3
+# (a REFUSED sort, as round 5 refused every input like it: GLU_HIP_SORT_LONG_RUNS=0 takes the segmented passes over long runs away, three
+# key values then refuse the attempt on the device and the four ordinary passes run; then the same input with the library's defaults)
+GLU_HIP_SORT_LONG_RUNS=0 tools/r06_trace_one.sh refused_sort_kernels_three_values.txt --log2 28 --distinct 3
+tools/r06_trace_one.sh three_values_sort_kernels.txt --log2 28 --distinct 3
 tools/r06_trace_one.sh zipf_sort_kernels.txt --log2 28 --zipf
 tools/r06_trace_one.sh distinct_1000_sort_kernels.txt --log2 28 --distinct-scattered 1000
 tools/r06_trace_one.sh distinct_2p20_sort_kernels.txt --log2 28 --distinct-scattered 1048576
