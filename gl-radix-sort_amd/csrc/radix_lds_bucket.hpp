@@ -97,7 +97,6 @@ struct BucketSmem
     } a;
     alignas(16) WordT wstage[CAP + 12]; // the words in bucket order, then in order (positions shifted by front & 3)
     uint32_t scan_tmp[WAVES];
-    uint32_t votes[WAVES]; // every wave's reading of the crowded-world word (radix_lds_finish.hpp): any one raised, and the run goes to its list
     uint32_t crowded; // a wave met a bucket longer than kBucketMaxLen
     KeyT run_hi; // the key bits from low_bits up: the same for every pair of the run
 };
@@ -107,9 +106,6 @@ static_assert(sizeof(BucketSmem<uint64_t, 512, 9, true>) <= 80 * 1024, "64-bit k
 
 // A workgroup per run (LOOP = false) or every gridDim.x-th run (LOOP = true: the geometries enqueued besides the expected one).
 // XF: typed keys, encoded on load by the first top-bit pass, decoded on store here.
-#ifndef GLU_BUCKET_CROWDED_WORLD
-#define GLU_BUCKET_CROWDED_WORLD 1 // (tuning builds: 0 = every run looks for itself)
-#endif
 #ifndef GLU_BUCKET_WAVES_PER_SIMD
 #define GLU_BUCKET_WAVES_PER_SIMD 4 // (tuning builds)
 #endif
@@ -129,7 +125,6 @@ __global__ __launch_bounds__(THREADS, GLU_BUCKET_WAVES_PER_SIMD) void radix_fini
     constexpr uint32_t SMASK = (1u << SB) - 1u;
     constexpr WordT INVALID = (WordT) ~(WordT) 0;
     constexpr bool kBucketLateValues = bucket_late_values<KeyT>();
-    constexpr bool kWorld = !LOOP && GLU_BUCKET_CROWDED_WORLD != 0; // (the workgroups of the looping launches do not start in the order of their runs)
     if (plan->top_bit) low_bits = plan->top_bit - 16u; // (the device chose the runs' bits: radix_sample_top_kernel)
     const KeyCodec<KeyT, XF> codec_out(key_xf);
     if (plan->finish != geometry) return; // (kernel-uniform: the device chose another geometry, or the ordinary passes)
@@ -153,12 +148,7 @@ __global__ __launch_bounds__(THREADS, GLU_BUCKET_WAVES_PER_SIMD) void radix_fini
     if (len > (uint32_t) Smem::TILE) continue;   // (a run longer than the tile: the segmented passes')
     const uint32_t front = begin & 31u, f4 = front & 3u;
     const uint32_t abegin = begin - front;
-    // (a crowded world, kCrowdedWorldWord: this wave's reading of the word -- the waves of a workgroup may read it at either side of
-    // its change, so every wave votes, loads nothing if it read "crowded", and the workgroup goes by ANY such vote at the barrier
-    // below: no wave ever has to load late.  The read goes beside the loads of the run's bounds.)
-    const bool skip_vote = kWorld && __builtin_amdgcn_readfirstlane((int) __hip_atomic_load(&crowded[kCrowdedWorldWord], __ATOMIC_RELAXED,
-                                                                                           __HIP_MEMORY_SCOPE_AGENT)) != 0;
-    const uint32_t total = skip_vote ? 0u : front + len; // slots [front, total) hold the run (none for a wave that votes to skip: it loads nothing)
+    const uint32_t total = front + len; // slots [front, total) hold the run
 
     // ---- load: 16 bytes per lane and piece, keys and values into registers (the values wait there until the words are in order)
     u32x4_t kraw[KV];
@@ -238,19 +228,7 @@ __global__ __launch_bounds__(THREADS, GLU_BUCKET_WAVES_PER_SIMD) void radix_fini
             if (slot == front) s.run_hi = (KeyT) (t[e] & ~low_mask);
         }
     }
-    if (kWorld && lane == 0) s.votes[wave] = skip_vote ? 1u : 0u;
     __syncthreads(); // the counts are zero
-    if (kWorld)
-    {
-        uint32_t any = 0;
-#pragma unroll
-        for (int w = 0; w < WAVES; w++) any |= s.votes[w];
-        if (any != 0u) // (workgroup-uniform) radix_finish_sort_kernel's, as below
-        {
-            if (tid == 0) crowded_list_append(crowded, nruns, run);
-            continue;
-        }
-    }
     // ---- 1. count: a returning LDS atomic per word (its place among the words of its bucket, in no particular order).  A word
     // whose place is kBucketMaxLen or more proves the run crowded: the wave says so in LDS and stops counting, the others look
     // before their second and third piece (same-address atomics serialise: a crowded run's count is the expensive part of it).
@@ -305,12 +283,7 @@ __global__ __launch_bounds__(THREADS, GLU_BUCKET_WAVES_PER_SIMD) void radix_fini
     __syncthreads();
     if (s.crowded != 0u) // (workgroup-uniform) radix_finish_sort_kernel's, launched behind this kernel; nothing has been stored
     {
-        if (tid == 0)
-        {
-            const uint32_t listed = crowded_list_append(crowded, nruns, run);
-            if (kWorld && run >= kCrowdedWorldFrom && listed * kCrowdedLists * 4u >= (run - kCrowdedWorldLag) * 3u)
-                __hip_atomic_store(&crowded[kCrowdedWorldWord], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        if (tid == 0) crowded_list_append(crowded, nruns, run);
         if (LOOP) __syncthreads();
         continue;
     }

@@ -59,30 +59,20 @@ __host__ __device__ constexpr size_t crowded_list_words(uint32_t nruns)
 {
     return (size_t) kCrowdedLists * kCrowdedCountStride + (size_t) kCrowdedLists * crowded_list_capacity(nruns);
 }
-// (returns how many runs the run's own list -- the first one tried -- holds now)
-__device__ __forceinline__ uint32_t crowded_list_append(uint32_t* lists, uint32_t nruns, uint32_t run)
+__device__ __forceinline__ void crowded_list_append(uint32_t* lists, uint32_t nruns, uint32_t run)
 {
     const uint32_t cap = crowded_list_capacity(nruns);
-    uint32_t home = 0;
-    for (uint32_t k = (run * 0x9E3779B1u) >> 24, tries = 0;; k = (k + 1u) & (kCrowdedLists - 1u), tries++)
+    for (uint32_t k = (run * 0x9E3779B1u) >> 24;; k = (k + 1u) & (kCrowdedLists - 1u))
     {
         const uint32_t i = atomicAdd(&lists[k * kCrowdedCountStride], 1u);
-        if (tries == 0) home = i + 1u;
         if (i < cap)
         {
             lists[kCrowdedLists * kCrowdedCountStride + k * cap + i] = run;
-            return home;
+            return;
         }
         // (full -- its count stays above the capacity, the reader clamps it -- the next list; all lists together hold 2 x nruns)
     }
 }
-// A crowded WORLD (every key value a few hundred times over, say): every run of radix_finish_bucket_kernel bails out after its keys
-// have been loaded, 0.23-0.39 ms for 2^28 pairs.  The workgroups of that launch start in the order of their runs, about a
-// thousand at a time: a workgroup that bails out and finds that three quarters of the runs before it did -- counted in its own
-// list, one 256th of them -- raises this word of the lists (zeroed with the counters by the plan kernel), and the workgroups
-// that start afterwards go to their lists without a load.  A wrong guess costs a run the slower kernel, nothing else.
-constexpr uint32_t kCrowdedWorldWord = 1; // (in the line of list 0's counter)
-constexpr uint32_t kCrowdedWorldFrom = 6144, kCrowdedWorldLag = 2048; // runs
 
 // The plan (radix_finish_plan_kernel below): starts[r] = exclusive scan of the run lengths (starts[65536] = n), and the decision:
 // the sort ends in LDS if the lengths are exact (they add up to n: a 16-bit counter of T2 that overflowed loses 65536) and the

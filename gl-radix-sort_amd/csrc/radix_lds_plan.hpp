@@ -413,7 +413,6 @@ __global__ __launch_bounds__(1024) void radix_finish_plan_kernel(const uint32_t*
     starts[b * 1024u + tid] = before + excl;
     if (b == 0 && tid == 0) starts[kFinishRuns] = n;
     if (b == 0 && crowded_lists && tid < kCrowdedLists) crowded_lists[tid * kCrowdedCountStride] = 0u;
-    if (b == 0 && crowded_lists && tid == 0) crowded_lists[kCrowdedWorldWord] = 0u;
     if (b == 0 && tid == 0)
     {
         plan->finish = accept ? geo : 0u;
