@@ -328,10 +328,11 @@ glu_status sort_prepare(glu_radix_sort_s* s, size_t count, size_t key_size, bool
             GLU_TRY(s->pair_wide.reserve((size_t) nb * kPairWideStride * sizeof(uint32_t)));
             {
                 // runs longer than the in-LDS pass's tile are sorted by segmented passes (radix_finish_long_runs_kernel)
-                GLU_TRY(s->long_image.reserve((size_t) LongRunsLayout((uint32_t) g_dev.num_cus).words * sizeof(uint32_t)));
+                const uint32_t shares = (uint32_t) g_dev.num_cus * kLongRunsSharesPerWg;
+                GLU_TRY(s->long_image.reserve((size_t) LongRunsLayout(shares).words * sizeof(uint32_t)));
                 GLU_TRY(s->long_hdr.reserve(64));
-                GLU_TRY(s->long_bits.reserve(2 * ((size_t) kLongRunsMax + g_dev.num_cus) * sizeof(uint64_t)));
-                GLU_TRY(s->table.reserve(((size_t) kLongRunsMax + g_dev.num_cus) * 256 * sizeof(uint32_t)));
+                GLU_TRY(s->long_bits.reserve(2 * ((size_t) kLongRunsMax + shares) * sizeof(uint64_t)));
+                GLU_TRY(s->table.reserve(((size_t) kLongRunsMax + shares) * 256 * sizeof(uint32_t)));
             }
             if (!s->finish_hint)
             {
@@ -600,7 +601,7 @@ glu_status launch_pass_lines(glu_radix_sort_s* s, const KeyT* src_k, const uint3
             // (on the caller's queue: on the side stream it finds no room beside the scatter's 1024-thread workgroups, finishes when that
             // does, and holds up the follower's unit sums behind it -- measured: + 17 us)
             hipLaunchKernelGGL(radix_finish_long_runs_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t*) s->finish_starts.ptr,
-                               (const PassPlan*) pa.plan, usable_cus(s), (uint32_t*) s->long_image.ptr, (uint32_t*) s->long_hdr.ptr);
+                               (const PassPlan*) pa.plan, usable_cus(s) * kLongRunsSharesPerWg, (uint32_t*) s->long_image.ptr, (uint32_t*) s->long_hdr.ptr);
             HIP_TRY(hipGetLastError());
         }
         if (pa.fork_side) // the decision is made: the sequence that is expected not to run leaves the caller's queue here
@@ -618,7 +619,7 @@ glu_status launch_pass_lines(glu_radix_sort_s* s, const KeyT* src_k, const uint3
     }
     hipLaunchKernelGGL(scatter, dim3(nb), dim3(G::THREADS), sizeof(Smem), stream, src_k, src_v, dst_k, dst_v,
                        (const uint32_t*) table, (const uint32_t*) totals, (uint32_t) count, shift, mask, tiles,
-                       (unsigned long long*) nullptr, xform, pa.plan, pa.pass, ranges, share, (const uint32_t*) nullptr, (const uint32_t*) nullptr, 0u, 0u);
+                       (unsigned long long*) nullptr, xform, pa.plan, pa.pass, ranges, share, (const uint32_t*) nullptr, (const uint32_t*) nullptr, 0u, 0u, (const uint32_t*) nullptr);
     s->mark(stream, true);
     HIP_TRY(hipGetLastError());
     return GLU_OK;
@@ -772,8 +773,10 @@ glu_status launch_long_run_passes(glu_radix_sort_s* s, KeyT* a_k, uint32_t* a_v,
         lds_opt_in_result = hipFuncSetAttribute((const void*) scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sizeof(Smem));
     });
     HIP_TRY(lds_opt_in_result);
-    const uint32_t nwg = usable_cus(s);
-    const LongRunsLayout lay(nwg);
+    // (kLongRunsSharesPerWg shares per workgroup, dealt round-robin: what is left of the long runs once those of one key value have
+    // been emptied is spread over the chip)
+    const uint32_t nwg = usable_cus(s), shares = nwg * kLongRunsSharesPerWg;
+    const LongRunsLayout lay(shares);
     const uint32_t* image = (const uint32_t*) s->long_image.ptr;
     const uint32_t* hdr = (const uint32_t*) s->long_hdr.ptr;
     uint32_t* table = (uint32_t*) s->table.ptr;
@@ -781,14 +784,14 @@ glu_status launch_long_run_passes(glu_radix_sort_s* s, KeyT* a_k, uint32_t* a_v,
     // (the first pass's count kernel also notes OR / AND of every sub-block's keys, its scan kernel empties the segments whose keys
     // agree on all the ordered bits: a long run of one key value -- every long run of a duplicate-heavy input -- stays where it is)
     KeyT* const sub_or = (KeyT*) s->long_bits.ptr;
-    KeyT* const sub_and = sub_or + (kLongRunsMax + nwg);
+    KeyT* const sub_and = sub_or + (kLongRunsMax + shares);
     for (uint32_t p = 0; p < kPasses; p++)
     {
         // (not typed keys: their long runs have to pass through the last pass, which decodes them)
         if (p == 0 && !XF)
         {
             hipLaunchKernelGGL((radix_seg_count_kernel<KeyT, 8, 1024, true>), dim3(nwg), dim3(1024), 0, stream, (const KeyT*) a_k, (const uint2*) image,
-                               image + lay.off_first, table, 0u, 255u, hdr, 0u, kSegGateIfNot, (const KeyT*) b_k, plan, 2u, 0u, sub_or, sub_and);
+                               image + lay.off_first, table, 0u, 255u, hdr, 0u, kSegGateIfNot, (const KeyT*) b_k, plan, 2u, 0u, sub_or, sub_and, hdr + 3);
             HIP_TRY(hipGetLastError());
             hipLaunchKernelGGL((radix_seg_scan_kernel<RADIX, KeyT>), dim3(512), dim3(RADIX), 0, stream, table, image + lay.off_list,
                                image + lay.off_start, hdr, 0u, kSegGateIfNot, hdr, (uint2*) const_cast<uint32_t*>(image), (const KeyT*) sub_or,
@@ -798,7 +801,7 @@ glu_status launch_long_run_passes(glu_radix_sort_s* s, KeyT* a_k, uint32_t* a_v,
         else
         {
             hipLaunchKernelGGL((radix_seg_count_kernel<KeyT, 8, 1024>), dim3(nwg), dim3(1024), 0, stream, (const KeyT*) a_k, (const uint2*) image,
-                               image + lay.off_first, table, p * 8u, 255u, hdr, 0u, kSegGateIfNot, (const KeyT*) b_k, plan, 2u, p);
+                               image + lay.off_first, table, p * 8u, 255u, hdr, 0u, kSegGateIfNot, (const KeyT*) b_k, plan, 2u, p, (KeyT*) nullptr, (KeyT*) nullptr, hdr + 3);
             HIP_TRY(hipGetLastError());
             hipLaunchKernelGGL((radix_seg_scan_kernel<RADIX>), dim3(512), dim3(RADIX), 0, stream, table, image + lay.off_list,
                                image + lay.off_start, hdr, 0u, kSegGateIfNot, hdr); // (workgroups loop over the device-counted segments)
@@ -807,7 +810,7 @@ glu_status launch_long_run_passes(glu_radix_sort_s* s, KeyT* a_k, uint32_t* a_v,
         hipLaunchKernelGGL(scatter, dim3(nwg), dim3(G::THREADS), sizeof(Smem), stream, (const KeyT*) a_k, (const uint32_t*) a_v, b_k, b_v,
                            (const uint32_t*) table, (const uint32_t*) nullptr, (uint32_t) count, p * 8u, 255u, 0u, (unsigned long long*) nullptr,
                            XF && p + 1 == kPasses ? key_xf << 2 : 0u, const_cast<PassPlan*>(plan), 2u, (const uint2*) image, p,
-                           image + lay.off_first, hdr, 0u, kSegGateIfNot);
+                           image + lay.off_first, hdr, 0u, kSegGateIfNot, hdr + 3);
         HIP_TRY(hipGetLastError());
     }
     return GLU_OK;
@@ -1530,7 +1533,7 @@ glu_status launch_seg_pass(glu_radix_sort_s* s, const uint32_t* src_k, const uin
     s->mark(stream, true);
     hipLaunchKernelGGL(s->nt_stores ? scatter_nt : scatter_plain, dim3(img.nwg), dim3(G::THREADS), sizeof(Smem), stream, src_k, src_v,
                        dst_k, dst_v, (const uint32_t*) table, (const uint32_t*) nullptr, (uint32_t) count, shift, 255u, 0u,
-                       (unsigned long long*) nullptr, 0u, (PassPlan*) nullptr, 0u, subs, 0u, image + img.off_first, gate, gate_cap, gate_mode);
+                       (unsigned long long*) nullptr, 0u, (PassPlan*) nullptr, 0u, subs, 0u, image + img.off_first, gate, gate_cap, gate_mode, (const uint32_t*) nullptr);
     HIP_TRY(hipGetLastError());
     s->mark(stream, true);
     return GLU_OK;

@@ -116,16 +116,22 @@ __global__ __launch_bounds__(256) void radix_sample_top_kernel(const KeyT* __res
 // skipping of constant digits).
 constexpr uint32_t kLongRunsMax = 8192;
 constexpr uint32_t kLongRunsMinShare = 4096;  // pairs: the least one workgroup of the segmented passes is given (radix_finish_long_runs_kernel)
+// shares per workgroup of the segmented passes: the long runs laid end to end are cut into this many times the number of workgroups,
+// workgroup w works on the shares w, w + nwg, ...  With one share each, the runs of ONE key value -- emptied by the first pass's
+// scan kernel -- left whole workgroups idle and the few runs of two or three values to a few: 1000 distinct values at 2^28, seven
+// runs of two values, 0.37 ms per segmented scatter on seven workgroups (64-bit keys: six such passes).
+constexpr uint32_t kLongRunsSharesPerWg = 8;
 
 // The runs longer than the tile the plan chose, as SEGMENTS of segmented passes (radix_seg_passes.hpp): the descriptor image
 // the host builds for the sharded sort's local sort (seg_build_image in glu_hip.hip), built on the device from the run starts.
 // The long runs laid end to end are cut into nwg equal shares, a sub-block is the part of one run inside one share:
-//   image + 0:          subs[kLongRunsMax + nwg] (begin, end) element ranges, in the order of the runs
+//   image + 0:          subs[kLongRunsMax + nwg] (begin, end) element ranges, in the order of the runs  (nwg here and below: the number
+//                       of SHARES, kLongRunsSharesPerWg times the number of workgroups of the segmented passes)
 //   image + off_first:  seg_first[nwg + 1]       first sub-block of every workgroup's share
 //   image + off_list:   seg_list[kLongRunsMax + 1]  first sub-block of every long run
 //   image + off_start:  seg_start[kLongRunsMax]     where the run starts (it stays where it is)
 //   hdr[0] = number of long runs (0: none, or the sort does not end in LDS: the segmented kernels return at once), hdr[1] = sub-blocks,
-//   hdr[2] = pairs in long runs
+//   hdr[2] = pairs in long runs, hdr[3] = the number of shares the long runs are cut into (seg_first has that many + 1 entries in use)
 // One workgroup (radix_finish_long_runs_kernel, behind the plan kernel); thread t owns the runs [64 t, 64 t + 64).
 struct LongRunsLayout
 {
@@ -138,7 +144,7 @@ struct LongRunsLayout
         words = off_start + kLongRunsMax;
     }
 };
-__device__ __forceinline__ void finish_list_long_runs(const uint32_t* starts, uint32_t geo, uint32_t finish_longest, uint32_t nwg,
+__device__ __forceinline__ void finish_list_long_runs(const uint32_t* starts, uint32_t geo, uint32_t finish_longest, uint32_t nwg /* shares at most */,
                                                       uint32_t* __restrict__ image, uint32_t* __restrict__ hdr, uint32_t (&wsum)[2][16])
 {
     const LongRunsLayout lay(nwg);
@@ -148,7 +154,7 @@ __device__ __forceinline__ void finish_list_long_runs(const uint32_t* starts, ui
     auto ld = [&](uint32_t i) { return starts[i]; };
     if (geo == 0 || finish_longest <= cap) // (workgroup-uniform) refused, or no run outgrows the tile: nothing to list
     {
-        if (tid < 3) hdr[tid] = 0u;
+        if (tid < 4) hdr[tid] = tid < 3 ? 0u : nwg;
         return;
     }
     // (every workgroup's share starts empty; the sub-block that begins at a share's first position fills it in)
@@ -189,12 +195,21 @@ __device__ __forceinline__ void finish_list_long_runs(const uint32_t* starts, ui
     }
     if (!active) // (workgroup-uniform)
     {
-        if (tid == 0) hdr[1] = 0u;
+        if (tid == 0) hdr[1] = 0u, hdr[3] = nwg;
         return;
     }
     // (a share is what one workgroup of a segmented pass works on; a few long runs of a few thousand pairs cut 256 ways made 256
     // sub-blocks of a hundred pairs, every one a row of 256 counts for the scan kernel to walk: 0.01 % zeros cost 0.15 ms more
     // than 0 %.  Shares behind the last pair are empty.)
+    // How many shares: `nwg` is the most there may be, kLongRunsSharesPerWg per workgroup of the segmented passes.  Many shares
+    // spread what is left of the long runs, once those of one key value have been emptied, over the chip (1000 distinct values, seven
+    // runs of two values each: 0.37 -> 0.05 ms per segmented scatter; 64-bit keys 6.9 -> 4.6 ms) -- but every share boundary
+    // is a sub-block more in some run, a row more for the scan kernel's walk along that run and a partial tile more: one run of a
+    // tenth of the input cut 2048 ways cost 0.45 ms.  So: as many shares per workgroup as leave the LONGEST run about 64 sub-blocks.
+    const uint32_t wgs = nwg / kLongRunsSharesPerWg;
+    const uint32_t per_wg = (uint32_t) min<uint64_t>(kLongRunsSharesPerWg, max<uint64_t>(1ull, (uint64_t) total * 64ull / ((uint64_t) finish_longest * wgs)));
+    nwg = wgs * per_wg;
+    if (tid == 0) hdr[3] = nwg;
     const uint32_t share = max((total + nwg - 1) / nwg, kLongRunsMinShare);
     // sub-blocks of this thread's long runs, then their numbers
     uint32_t subs = 0;

@@ -98,7 +98,8 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
     uint32_t* __restrict__ vals_b, const uint32_t* __restrict__ table, const uint32_t* __restrict__ totals, uint32_t n,
     uint32_t shift, uint32_t mask, uint32_t tiles_total, unsigned long long* stamps = nullptr, uint32_t xform = 0,
     PassPlan* plan = nullptr, uint32_t pass = 0, const uint2* __restrict__ ranges = nullptr, uint32_t share = 0,
-    const uint32_t* __restrict__ seg_first = nullptr, const uint32_t* gate = nullptr, uint32_t gate_cap = 0, uint32_t gate_mode = 0)
+    const uint32_t* __restrict__ seg_first = nullptr, const uint32_t* gate = nullptr, uint32_t gate_cap = 0, uint32_t gate_mode = 0,
+    const uint32_t* seg_shares = nullptr)
 {
     // (SEG: a pass of a segmented sort that may end in LDS runs or returns by the longest run, radix_seg_passes.hpp)
     if (SEG && gate_mode != 0 && ((*gate <= gate_cap) != (gate_mode == 1))) return; // (kernel-uniform)
@@ -170,8 +171,15 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
 
     const uint32_t wave_off = wave * WAVE_TILE + lane; // wave-striped: item i of lane l of wave w = element w*64*KPT + i*64 + l
     // (readfirstlane: the values are workgroup-uniform; it keeps them and everything derived from them in scalar registers)
-    const uint32_t sb_first = SEG ? (uint32_t) __builtin_amdgcn_readfirstlane((int) seg_first[b]) : 0u;
-    const uint32_t sb_last = SEG ? (uint32_t) __builtin_amdgcn_readfirstlane((int) seg_first[b + 1]) : 1u;
+    // (SEG with seg_shares: more shares than workgroups, workgroup b takes the shares b, b + nb, ... -- radix_seg_count_kernel)
+    // (do ... while (SEG && ...): the unsegmented kernel keeps no loop around its body -- a loop the compiler could not see through
+    // cost every instantiation 36 bytes of scratch per lane)
+    const uint32_t seg_nshares = SEG ? (seg_shares ? (uint32_t) __builtin_amdgcn_readfirstlane((int) *seg_shares) : nb) : 0u;
+    uint32_t seg_sh = b;
+    do
+    {
+    const uint32_t sb_first = SEG ? (uint32_t) __builtin_amdgcn_readfirstlane((int) seg_first[seg_sh]) : 0u;
+    const uint32_t sb_last = SEG ? (uint32_t) __builtin_amdgcn_readfirstlane((int) seg_first[seg_sh + 1]) : 1u;
     for (uint32_t sb = sb_first; sb < sb_last; sb++)
     {
     // ---- prologue: exclusive scan of the digit totals (RadixSort.hpp:148-152) + this block's scanned table entry (:176)
@@ -652,6 +660,8 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_lines_kernel(
     }
     if (SEG) __syncthreads(); // the carry slots and the per-digit records are rewritten by the next sub-block
     } // sub-blocks
+    seg_sh += nb;
+    } while (SEG && seg_sh < seg_nshares); // shares
     if (STAMPS && lane == 0 && (wave == 0 || wave == WAVES - 1) && stamps)
     {
         // first and last wave of the workgroup: between them they show what a phase costs and what the barrier hides

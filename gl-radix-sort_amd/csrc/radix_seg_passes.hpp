@@ -85,7 +85,8 @@ __global__ __launch_bounds__(THREADS) void radix_seg_count_kernel(const KeyT* __
                                                                   uint32_t gate_mode = kSegGateNone,
                                                                   const KeyT* __restrict__ keys_alt = nullptr,
                                                                   const PassPlan* plan = nullptr, uint32_t flip_pass = 0, uint32_t swap = 0,
-                                                                  KeyT* __restrict__ sub_or = nullptr, KeyT* __restrict__ sub_and = nullptr)
+                                                                  KeyT* __restrict__ sub_or = nullptr, KeyT* __restrict__ sub_and = nullptr,
+                                                                  const uint32_t* seg_shares = nullptr)
 {
     if (seg_gate_closed(gate, gate_cap, gate_mode)) return; // (kernel-uniform)
     // (the long runs of a whole-key sort that ends in LDS: which pair of arrays holds the data is known on the device only)
@@ -118,9 +119,16 @@ __global__ __launch_bounds__(THREADS) void radix_seg_count_kernel(const KeyT* __
             tally(peel, dig(key_at(a, e)));
         }
     };
-    const uint32_t sb_first = seg_first[blockIdx.x], sb_last = seg_first[blockIdx.x + 1];
     for (int i = tid; i < WAVES * RADIX; i += THREADS) (&hist[0][0])[i] = 0;
     __syncthreads();
+    // (seg_shares, round 6, the long runs of a whole-key sort: more shares than workgroups, workgroup w takes the shares w, w +
+    // gridDim.x, ... -- the sub-blocks that are left once the runs of one key value have been emptied are then spread over the
+    // chip instead of sitting in a few workgroups' shares; how many: decided on the device, radix_finish_long_runs_kernel; nullptr: a
+    // share per workgroup)
+    const uint32_t nshares = seg_shares ? *seg_shares : gridDim.x;
+    for (uint32_t sh = blockIdx.x; sh < nshares; sh += gridDim.x)
+    {
+    const uint32_t sb_first = seg_first[sh], sb_last = seg_first[sh + 1];
     for (uint32_t sb = sb_first; sb < sb_last; sb++)
     {
         const uint2 r = subs[sb];
@@ -200,6 +208,7 @@ __global__ __launch_bounds__(THREADS) void radix_seg_count_kernel(const KeyT* __
         }
         __syncthreads();
     }
+    } // shares
 }
 
 // K2 per segment: thread d walks the segment's sub-blocks (rows of the table, RADIX consecutive words each: coalesced),
