@@ -173,7 +173,8 @@ constexpr uint32_t finish_capacity() { return (uint32_t) (THREADS * KPT); }
 // scan / re-stage as in radix_sort_single_block_kernel: ballot ranking against wave-private digit counters, one scan over
 // (digit, wave), staging in ranked order.
 //
-// rank_from > 0 (keys with more than 16 bits left to order: 64-bit keys, a segmented sort by 32 bits): the rounds rank only the
+// rank_from > 0 (64-bit keys: up to 48 bits are left to order.  4-byte keys -- a segmented sort by 32 bits leaves 24 -- run every
+// round instead, TIES = false below, whatever rank_from their launch passes): the rounds rank only the
 // key bits [rank_from, low_bits) -- the TOP of what is left, two rounds instead of six for 64-bit keys -- which orders the run
 // except where two keys agree on those bits (a TIE: for uniformly drawn keys a run of 4096 has some 128 tied neighbours on 16
 // ranked bits).  Ties are repaired exactly: every position compares itself with its successor in LDS; where both agree on the
