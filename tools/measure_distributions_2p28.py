@@ -78,6 +78,7 @@ dists = [
     ("uniform, 31-bit keys", lambda: uniform(31)),
     ("uniform, 30-bit keys", lambda: uniform(30)),
     ("uniform, 28-bit keys", lambda: uniform(28)),
+    ("uniform, 26-bit keys", lambda: uniform(26)),
     ("uniform, 24-bit keys", lambda: uniform(24)),
     ("uniform + 0.01 % zeros", lambda: with_zeros(0.01)),
     ("uniform + 1 % zeros", lambda: with_zeros(1.0)),
