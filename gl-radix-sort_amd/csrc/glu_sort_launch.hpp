@@ -22,8 +22,8 @@ inline uint32_t finish_geometry_for(size_t count, size_t runs = kFinishRuns, uin
     return 0;
 }
 
-// More than 16 bits left to order (64-bit keys; a segmented sort by 32 bits): the rounds of the in-LDS pass rank the top 16 .. 23
-// of them and ties are repaired exactly (radix_lds_finish.hpp).  glu_radix_sort_s::finish_rank_bits.
+// More than 16 bits left to order (64-bit keys): the rounds of the in-LDS pass rank the top 16 .. 23 of them and ties are repaired
+// exactly (radix_lds_finish.hpp; 4-byte keys run every round).  glu_radix_sort_s::finish_rank_bits.
 inline uint32_t finish_rank_from(uint32_t low_bits, uint32_t rank_bits)
 {
     return low_bits > rank_bits ? ((low_bits - rank_bits) / 8u) * 8u : 0u;
@@ -51,9 +51,10 @@ glu_status launch_seg_finish(const uint32_t* src_k, const uint32_t* src_v, uint3
                              uint32_t rank_bits, hipStream_t stream);
 
 // The in-LDS pass of a whole-key sort (round 6): radix_finish_bucket_kernel for every enqueued tile geometry -- the one the sort is
-// expected to take gets a workgroup per run, the others 8192 workgroups that loop --, and behind them ONE launch of round 5's
-// ballot-ranked kernel in the largest enqueued tile for the runs the bucket kernel listed as crowded (or for all of them:
-// PassPlan::finish_rounds); it returns at once when the lists are empty.
+// expected to take gets a workgroup per run, the others 8192 workgroups that loop --, and behind them round 5's ballot-ranked
+// kernel for the runs the bucket kernel listed as crowded (or for all of them: PassPlan::finish_rounds), two launches split by the
+// runs' length: the expected tile for the runs that fit it, the largest enqueued tile for the longer ones.  They return at once
+// when the lists are empty.
 template<typename KeyT, bool VALS, bool XF>
 glu_status launch_finish(KeyT* keys_a, uint32_t* vals_a, KeyT* keys_b, uint32_t* vals_b, const uint32_t* starts,
                          uint32_t geo_first, uint32_t geo_last, uint32_t geo_expected, uint32_t low_bits, const PassPlan* plan,

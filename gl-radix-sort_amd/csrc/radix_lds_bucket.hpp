@@ -30,6 +30,8 @@
 //     buckets with many words, and step 3 is made for buckets of a few.  A word that finds kBucketMaxLen others in its bucket
 //     proves the run crowded: the workgroup stops, stores nothing, and appends the run to a list (crowded_list_append,
 //     radix_lds_finish.hpp) that radix_finish_sort_kernel -- round 5's ballot-ranked kernel, launched behind this one -- works off.
+//     Keys of 25 .. 27 varying bits (9 .. 11 bits left to order, every key value a few times over in its run) are not crowded by
+//     that measure, but their buckets hold two to four words each: the pass takes 1.1 ms for 2^28 pairs instead of 0.81.
 //     (Both ways of ordering a crowded run inside this kernel were built and measured: the ballot rounds inlined cost the
 //     uncrowded path 9 % in registers and scalar spills, profiles/r06/finish_bucket_variants.txt.)
 //   * OUTPUT.  Lane j reads four consecutive ordered words (one 16-byte LDS load; the word positions are shifted by

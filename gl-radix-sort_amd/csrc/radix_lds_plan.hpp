@@ -411,7 +411,7 @@ __global__ __launch_bounds__(1024) void radix_finish_plan_kernel(const uint32_t*
             for (int w = 0; w < 16; w++) ol += over_tmp[0][g - 1][w], oc += over_tmp[1][g - 1][w];
             const bool few = oc <= kLongRunsMax && ol <= n / 8u;
             // (round 6: however many pairs the long runs hold -- a long run of one key value, which is what fills long runs as a
-            // rule, is not moved at all; round 5 refused the sort when more than half of the pairs sat in long runs --
+            // rule, is not moved at all; round 5 refused a sort with more than half of its pairs in long runs --
             // ... as long as that is not more than the ordinary passes would move.)
             const bool tolerable = g == geo_last && oc <= kLongRunsMax && attempt_cost(ol) <= ordinary_cost;
             if (few || (tolerable && pick == 0)) pick = g;
