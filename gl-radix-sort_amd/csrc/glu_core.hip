@@ -109,7 +109,7 @@ glu_buffer register_buffer(const Buffer& b)
 extern "C" {
 
 const char* glu_last_error(void) { return g_last_error.c_str(); }
-const char* glu_version(void) { return "glu_hip 0.5.0 gfx950"; }
+const char* glu_version(void) { return "glu_hip 0.6.0 gfx950"; }
 
 glu_status glu_device_count(int* count)
 {
