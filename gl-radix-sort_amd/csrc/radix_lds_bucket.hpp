@@ -25,7 +25,7 @@
 //          registers, a sorting network of min / max, back.  Exact, because words are unique.  (Round 6's first form let every
 //          word count the smaller words of its bucket in a loop: a chain of dependent LDS reads as long as the longest bucket
 //          any lane of the wave met -- slower than the ballots, profiles/r06/finish_bucket_first.txt.)
-//     About 40 vector instructions per pair instead of 130.
+//     67 vector instructions per pair instead of 130 (SQ_INSTS_VALU, profiles/r06/finish_bucket_what_bounds_it.txt).
 //   * CROWDED RUNS.  Keys whose low bits repeat (a run of a few distinct keys, keys that are multiples of 65536) fill few
 //     buckets with many words, and step 3 is made for buckets of a few.  A word that finds kBucketMaxLen others in its bucket
 //     proves the run crowded: the workgroup stops, stores nothing, and appends the run to a list (crowded_list_append,
