@@ -1,10 +1,12 @@
 // glu_host.hpp -- what the translation units of libglu_hip.so share on the HOST side: the error slot behind glu_last_error(), the
 // one device of the process and its queue, the buffer registry behind the glu_buffer handles, grow-only scratch allocations.
-// Defined in glu_core.hip.  The library is built from four translation units (round 6; it was one, a three-minute compile):
-//   glu_core.hip         errors, device, buffers, timer
-//   glu_hip.hip          RadixSort (every launch sequence but the in-LDS pass's) and the sharded sort (glu_dist_impl.hpp)
-//   glu_sort_finish.hip  the launches of the in-LDS pass (radix_lds_bucket.hpp, radix_lds_finish.hpp: a hundred kernel instantiations)
-//   glu_scan_reduce.hip  BlellochScan and Reduce
+// Defined in glu_core.hip.  The library is built from six translation units (round 6; it was one, a three-minute compile):
+//   glu_core.hip              errors, device, buffers, timer
+//   glu_hip.hip               RadixSort's launch sequences, the segmented sort and the sharded sort (glu_dist_impl.hpp)
+//   glu_sort_passes_u32.hip   the launchers of one counting pass for 4-byte keys (glu_sort_passes.hpp over glu_sort_object.hpp)
+//   glu_sort_passes_u64.hip   the same for 8-byte keys
+//   glu_sort_finish.hip       the launches of the in-LDS pass (radix_lds_bucket.hpp, radix_lds_finish.hpp: a hundred kernel instantiations)
+//   glu_scan_reduce.hip       BlellochScan and Reduce
 #pragma once
 #include <hip/hip_runtime.h>
 

@@ -6,8 +6,9 @@
 //   radix_finish_plan_kernel      run starts, the longest run, the decision       (64 workgroups)
 //   radix_finish_long_runs_kernel the runs longer than the chosen tile, as segments of segmented passes
 //
-// Included by glu_hip.hip only (these kernels are not templates: one translation unit may hold them); the kernels of the in-LDS
-// pass itself are launched from glu_sort_finish.hip.
+// Launched from glu_sort_passes.hpp (the kernels that are not templates are `static`: both of its translation units hold a copy);
+// glu_hip.hip takes the sample kernel and the layout of the long runs from here; the kernels of the in-LDS pass itself are launched
+// from glu_sort_finish.hip.
 #pragma once
 
 #include "radix_lds_finish.hpp"
@@ -266,7 +267,7 @@ __device__ __forceinline__ void finish_list_long_runs(const uint32_t* starts, ui
 // blocks.  One workgroup per d; thread (g, q) adds word q (counters e = 2q, 2q + 1) of the rows b = g, g + 8, ...
 // wide (round 6, radix_pair_passes.hpp): the counts >> 16 of the rows whose 16-bit counters wrapped, per block -- the lengths are exact
 // whatever share of the input one key value holds.
-__global__ __launch_bounds__(1024) void radix_finish_lengths_kernel(const uint32_t* __restrict__ t2, uint32_t nb,
+static __global__ __launch_bounds__(1024) void radix_finish_lengths_kernel(const uint32_t* __restrict__ t2, uint32_t nb,
                                                                     uint32_t* __restrict__ lengths, const PassPlan* plan,
                                                                     uint32_t pass, const uint32_t* __restrict__ wide = nullptr)
 {
@@ -308,7 +309,7 @@ __global__ __launch_bounds__(1024) void radix_finish_lengths_kernel(const uint32
     }
 }
 
-__global__ __launch_bounds__(1024) void radix_finish_plan_kernel(const uint32_t* __restrict__ lengths, uint32_t* starts,
+static __global__ __launch_bounds__(1024) void radix_finish_plan_kernel(const uint32_t* __restrict__ lengths, uint32_t* starts,
                                                                  uint32_t n, uint32_t geo_first, uint32_t geo_last, PassPlan* plan,
                                                                  uint32_t pass,
                                                                  uint32_t first_ordinary, uint32_t num_ordinary,
@@ -469,7 +470,7 @@ __global__ __launch_bounds__(1024) void radix_finish_plan_kernel(const uint32_t*
 
 // (Folding this into the plan kernel -- its last workgroup to finish -- was measured: the fences of the ticket cost the plan kernel
 // 10 us more than this launch does, profiles/r06/last_sort_kernels_2p28_plan_merged.txt.)
-__global__ __launch_bounds__(1024) void radix_finish_long_runs_kernel(const uint32_t* __restrict__ starts, const PassPlan* plan,
+static __global__ __launch_bounds__(1024) void radix_finish_long_runs_kernel(const uint32_t* __restrict__ starts, const PassPlan* plan,
                                                                       uint32_t nwg, uint32_t* __restrict__ image, uint32_t* __restrict__ hdr)
 {
     __shared__ uint32_t wsum[2][16];

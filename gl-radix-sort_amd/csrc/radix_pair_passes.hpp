@@ -339,7 +339,7 @@ __device__ __forceinline__ void pair_find_run(const uint32_t* __restrict__ scann
 // Follower pass `pass` (8-bit digits): workgroup w's run of units and its digit counts.  table_l / totals_l: the leader's
 // scanned table and digit totals; table_f: the follower's count table (as radix_count_kernel would write it); ranges[w] =
 // the element range of workgroup w.  Returns at once when the follower counts for itself.
-__global__ __launch_bounds__(1024) void radix_pair_unitsum_kernel(const uint32_t* __restrict__ t2,
+static __global__ __launch_bounds__(1024) void radix_pair_unitsum_kernel(const uint32_t* __restrict__ t2,
                                                                   const uint32_t* __restrict__ table_l,
                                                                   const uint32_t* __restrict__ totals_l,
                                                                   uint32_t* __restrict__ table_f, uint2* __restrict__ ranges,
@@ -542,7 +542,7 @@ __global__ __launch_bounds__(256) void radix_pair4_count_kernel(const KeyT* __re
 
 // Follower pass `pass` (4-bit digits): as radix_pair_unitsum_kernel, units = (digit value, sub-block).
 // sub_scanned: the leader's per-sub-block table after its row scan; totals_l: the leader's digit totals.
-__global__ __launch_bounds__(1024) void radix_pair4_unitsum_kernel(const uint32_t* __restrict__ t2,
+static __global__ __launch_bounds__(1024) void radix_pair4_unitsum_kernel(const uint32_t* __restrict__ t2,
                                                                    const uint32_t* __restrict__ sub_scanned,
                                                                    const uint32_t* __restrict__ totals_l,
                                                                    uint32_t* __restrict__ table_f, uint2* __restrict__ ranges,
