@@ -8,7 +8,7 @@ if [ "$1" = build ]; then
   for c in $CFGS; do
     t=${c%x*}; g=${c#*x}
     (cd $R/gl-radix-sort_amd/csrc && /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -fvisibility=hidden -Wno-unused-function \
-      -I$R/include -I. -DGLU_CHAIN_THREADS=$t -DGLU_CHAIN_GROUPS=$g -shared -o $R/gl-radix-sort_amd/lib/tuning_chain_$c.so glu_core.hip glu_hip.hip glu_sort_finish.hip glu_scan_reduce.hip) &
+      -I$R/include -I. -DGLU_CHAIN_THREADS=$t -DGLU_CHAIN_GROUPS=$g -shared -o $R/gl-radix-sort_amd/lib/tuning_chain_$c.so glu_core.hip glu_hip.hip glu_sort_passes_u32.hip glu_sort_passes_u64.hip glu_sort_finish.hip glu_scan_reduce.hip) &
     while [ $(jobs -r | wc -l) -ge 4 ]; do sleep 1; done
   done
   wait
